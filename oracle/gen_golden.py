@@ -1,0 +1,125 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by running the UNMODIFIED
+reference (/root/reference, imported through oracle/ref_shim.py) on CPU with the seeded
+synthetic checkpoints of perspectivefields_amd/synth.py.
+
+The reference cannot travel to the GPU box, so its outputs are committed as small
+fixtures.  Run from the repo root, in the build container only:
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+What is stored per zoo version (tag):
+  in_u8_i          (320,320,3) uint8   post-PIL-resize network input (BGR)
+  size_i           (2,) int            original (H, W)
+  grav_s2_i        (2,160,160) f32     pred_gravity[:, ::2, ::2]      (regression)
+  lat_s2_i         (1,160,160) f32     pred_latitude[:, ::2, ::2]     (regression)
+  grav_argmax_i    (320,320) u8        argmax of the 73 logits        (classification)
+  lat_argmax_i     (320,320) u8        argmax of the 180 logits       (classification)
+  grav_logit_g_i   (73,20,20) f32      logits on a 16-pixel grid      (classification)
+  lat_logit_g_i    (180,20,20) f32
+  grav_orig_i      (2,H,W) f32         pred_gravity_original
+  lat_orig_i       (H,W) f32           pred_latitude_original (degrees)
+  param_names      list of scalar keys;  params_i (n,) f32;  params64_i (n,) f64 (reference run in float64)
+  sums_i           (4,) f64            sum|pred_gravity|, sum pred_gravity, sum|pred_latitude|, sum pred_latitude (full res)
+  c1_s..c4_s, ll_s                     stage-boundary activations of image 0 (subsampled)
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim  # noqa: E402
+from perspectivefields_amd.synth import synthetic_image, synthetic_state_dict, to_torch  # noqa: E402
+
+CASES = {
+    "centered": ("Paramnet-360Cities-edina-centered", [(96, 128), (150, 100)]),
+    "persnet": ("PersNet-360Cities", [(96, 128), (80, 80)]),
+    "uncentered": ("Paramnet-360Cities-edina-uncentered", [(96, 128), (64, 200)]),
+}
+PARAM_KEYS = ["pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal", "pred_general_vfov", "pred_rel_cx", "pred_rel_cy"]
+SEED = 0
+
+
+def run(tag, version, sizes, out_dir):
+    torch.manual_seed(0)
+    sd = to_torch(synthetic_state_dict(version, SEED))
+    model = ref_shim.build_reference(version, sd)
+    imgs = [synthetic_image(h, w, seed=10 + i) for i, (h, w) in enumerate(sizes)]
+    with torch.no_grad():
+        preds = model.inference_batch(imgs)
+        singles = [model.inference(im) for im in imgs]
+    blob = {}
+    cls = preds[0]["pred_gravity"].shape[0] != 2
+    names = [k for k in PARAM_KEYS if k in preds[0]]
+    blob["param_names"] = np.array(names)
+    for i, (im, p, s) in enumerate(zip(imgs, preds, singles)):
+        # batch == single (images are independent; eval-mode BN) -- reference property
+        # The reference's own fp32 noise floor (different MKL/oneDNN blocking for B=1 vs B=2) is
+        # recorded, not asserted away: it bounds how tight any parity tolerance can honestly be.
+        noise = {k: float((p[k].double() - s[k].double()).abs().max()) for k in p if torch.is_tensor(p[k])}
+        print(f"  [{tag} img{i}] reference batch-vs-single max|diff|:", {k: f"{v:.2e}" for k, v in noise.items()})
+        blob[f"selfnoise_{i}"] = np.array([noise.get(k, 0.0) for k in sorted(noise)], dtype=np.float64)
+        blob["selfnoise_keys"] = np.array(sorted(noise))
+        blob[f"in_u8_{i}"] = model.aug.apply_image(im)
+        blob[f"size_{i}"] = np.array(im.shape[:2])
+        g, l = p["pred_gravity"], p["pred_latitude"]
+        if cls:
+            blob[f"grav_argmax_{i}"] = g.argmax(0).to(torch.uint8).numpy()
+            blob[f"lat_argmax_{i}"] = l.argmax(0).to(torch.uint8).numpy()
+            blob[f"grav_logit_g_{i}"] = g[:, 8::16, 8::16].numpy()
+            blob[f"lat_logit_g_{i}"] = l[:, 8::16, 8::16].numpy()
+        else:
+            blob[f"grav_s2_{i}"] = g[:, ::2, ::2].numpy()
+            blob[f"lat_s2_{i}"] = l[:, ::2, ::2].numpy()
+        blob[f"grav_orig_{i}"] = p["pred_gravity_original"].numpy()
+        blob[f"lat_orig_{i}"] = p["pred_latitude_original"].numpy()
+        blob[f"sums_{i}"] = np.array(
+            [g.double().abs().sum(), g.double().sum(), l.double().abs().sum(), l.double().sum()], dtype=np.float64
+        )
+        if names:
+            blob[f"params_{i}"] = np.array([float(p[k].reshape(-1)[0]) for k in names], dtype=np.float32)
+
+    # stage boundaries of image 0, through the reference's own modules
+    with torch.no_grad():
+        x = torch.as_tensor(blob["in_u8_0"].astype("float32").transpose(2, 0, 1))[None]
+        x = (x - model.pixel_mean) / model.pixel_std
+        feats = model.backbone(x)
+        ll = model.ll_enc(x)
+    for k, f in enumerate(feats):
+        st = (4, 2, 1, 1)[k]
+        blob[f"c{k + 1}_s"] = f[0, :, ::st, ::st].numpy()
+    blob["ll_s"] = ll[0, :, ::8, ::8].numpy()
+
+    # float64 run of the same reference (yardstick for the fp32 tolerances)
+    if names:
+        model64 = model.double()
+        with torch.no_grad():
+            preds64 = model64.inference_batch(imgs)
+        for i, p in enumerate(preds64):
+            blob[f"params64_{i}"] = np.array([float(p[k].reshape(-1)[0]) for k in names], dtype=np.float64)
+            if not cls:
+                blob[f"grav64_s8_{i}"] = p["pred_gravity"][:, ::8, ::8].numpy()
+                blob[f"lat64_s8_{i}"] = p["pred_latitude"][:, ::8, ::8].numpy()
+    path = os.path.join(out_dir, f"{tag}.npz")
+    np.savez_compressed(path, **blob)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB; params:",
+          {n: float(blob['params_0'][j]) for j, n in enumerate(names)} if names else "-")
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    only = sys.argv[1:]
+    for tag, (version, sizes) in CASES.items():
+        if only and tag not in only:
+            continue
+        run(tag, version, sizes, out_dir)
+
+
+if __name__ == "__main__":
+    main()

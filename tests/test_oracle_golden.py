@@ -1,0 +1,96 @@
+"""Pins the CPU oracle (oracle/pf_oracle.py) against golden vectors produced by the
+unmodified reference (oracle/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pf_oracle
+from perspectivefields_amd.config import arch_of, get_cfg
+from perspectivefields_amd.synth import synthetic_state_dict, to_torch
+from tests.parity import TOL_PARAM, assert_fields_close, l1
+
+CASES = {
+    "centered": "Paramnet-360Cities-edina-centered",
+    "persnet": "PersNet-360Cities",
+    "uncentered": "Paramnet-360Cities-edina-uncentered",
+}
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def case(request, golden_dir):
+    tag = request.param
+    version = CASES[tag]
+    g = np.load(os.path.join(golden_dir, f"{tag}.npz"))
+    arch = arch_of(get_cfg(version))
+    sd = to_torch(synthetic_state_dict(version, 0))
+    x = np.stack([g["in_u8_0"], g["in_u8_1"]])
+    sizes = [tuple(int(v) for v in g["size_0"]), tuple(int(v) for v in g["size_1"])]
+    with torch.no_grad():
+        res, stages = pf_oracle.forward(sd, arch, x, sizes, stages=True)
+    return tag, g, arch, res, stages
+
+
+def test_stage_boundaries(case):
+    tag, g, arch, res, stages = case
+    for k, st in enumerate((4, 2, 1, 1)):
+        got = stages["feats"][k][0, :, ::st, ::st].numpy()
+        ref = g[f"c{k + 1}_s"]
+        assert got.shape == ref.shape
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 2e-4 * scale, (k, np.abs(got - ref).max(), scale)
+    got = stages["ll"][0, :, ::8, ::8].numpy()
+    assert np.abs(got - g["ll_s"]).max() <= 1e-4 * max(1.0, np.abs(g["ll_s"]).max())
+
+
+def test_fields(case):
+    tag, g, arch, res, _ = case
+    for i in range(2):
+        r = res[i]
+        if arch["gravity_cls"]:
+            ga = r["pred_gravity"].argmax(0).numpy()
+            la = r["pred_latitude"].argmax(0).numpy()
+            # argmax is discontinuous: report mismatching-pixel fraction
+            assert (ga != g[f"grav_argmax_{i}"]).mean() <= 2e-3
+            assert (la != g[f"lat_argmax_{i}"]).mean() <= 2e-3
+            np.testing.assert_allclose(r["pred_gravity"][:, 8::16, 8::16].numpy(), g[f"grav_logit_g_{i}"], atol=2e-4, rtol=1e-4)
+            np.testing.assert_allclose(r["pred_latitude"][:, 8::16, 8::16].numpy(), g[f"lat_logit_g_{i}"], atol=2e-4, rtol=1e-4)
+            # decoded fields: allow the rare flipped-argmax pixel
+            d = np.abs(r["pred_latitude_original"].numpy() - g[f"lat_orig_{i}"])
+            assert np.mean(d > 1e-3) <= 5e-3
+        else:
+            assert_fields_close(
+                r["pred_gravity"][:, ::2, ::2].numpy(), g[f"grav_s2_{i}"],
+                r["pred_latitude"][:, ::2, ::2].numpy(), g[f"lat_s2_{i}"], f"{tag} img{i} 320^2",
+            )
+            assert_fields_close(
+                r["pred_gravity_original"].numpy(), g[f"grav_orig_{i}"],
+                r["pred_latitude_original"].numpy(), g[f"lat_orig_{i}"], f"{tag} img{i} original",
+            )
+            sums = g[f"sums_{i}"]
+            assert abs(float(r["pred_gravity"].double().abs().sum()) - sums[0]) <= 1e-4 * sums[0]
+            assert abs(float(r["pred_latitude"].double().abs().sum()) - sums[2]) <= 1e-4 * sums[2]
+
+
+def test_param_scalars(case):
+    tag, g, arch, res, _ = case
+    names = [str(n) for n in g["param_names"]]
+    if not names:
+        assert "pred_roll" not in res[0]
+        assert list(res[0].keys()) == [
+            "pred_gravity", "pred_gravity_original", "pred_latitude", "pred_latitude_original", "pred_latitude_original_mode",
+        ]
+        return
+    for i in range(2):
+        got = np.array([float(res[i][n]) for n in names])
+        np.testing.assert_allclose(got, g[f"params_{i}"], atol=TOL_PARAM, rtol=0)
+        # the fp32 reference itself sits this far from its float64 run:
+        assert np.abs(g[f"params_{i}"] - g[f"params64_{i}"]).max() < TOL_PARAM
+
+
+def test_output_keys_centered(golden_dir):
+    """Key order of the 12-key dict printed in notebooks/predict_perspective_fields.ipynb:63."""
+    version = CASES["centered"]
+    arch = arch_of(get_cfg(version))
+    assert arch["param_net"] == "ParamNet" and arch["param_out"] == 5
