@@ -1,0 +1,201 @@
+"""bench.py -- images/sec of the PerspectiveFields hot path on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch: 320x320 uint8 network inputs already resident
+in HBM -> MiT-B3 + both decoders + ParamNet (pf_forward_u8) -> post-process of every image to its
+original 640x640 size (pf_postprocess) -> per-image ParamNet scalars (+ all-gather of the
+scalars over RCCL when N > 1).  Workload = BASELINE.json configs[2]: batch 32, 640x640,
+Paramnet-360Cities-edina-centered, random-init (seeded synthetic) weights, synthetic images.
+The host-side PIL resize (reference perspectivefields.py:201) happens before the timed region;
+its inclusive rate is reported separately (never as `value`).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
+GFLOP_PER_IMAGE_REF = 213.44   # contraction FLOPs of the reference graph, Paramnet-centered
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=640, help="original image height = width")
+    ap.add_argument("--version", default="Paramnet-360Cities-edina-centered")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--events-in-timed", type=int, default=1, help="bracket the dominant kernel with HIP events inside the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(version, size, budget_s=12.0, max_images=12):
+    """The oracle (CPU port of the reference algorithm) timed on this host's cores on a bounded sample
+    of the same workload.  The unmodified reference cannot travel to the GPU box (kind = "port")."""
+    from oracle import pf_oracle
+    from perspectivefields_amd.config import arch_of, get_cfg
+    from perspectivefields_amd.synth import synthetic_image, synthetic_state_dict, to_torch
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = to_torch(synthetic_state_dict(version, 0))
+    arch = arch_of(get_cfg(version))
+    with torch.no_grad():
+        pf_oracle.inference_batch(sd, arch, [synthetic_image(size, size, 900)])  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < max_images and time.perf_counter() - t0 < budget_s:
+            pf_oracle.inference_batch(sd, arch, [synthetic_image(size, size, 901 + n + i) for i in range(2)])
+            n += 2
+        dt = time.perf_counter() - t0
+    return {
+        "value": round(n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{n} synthetic {size}x{size} images through oracle/pf_oracle.py inference_batch (PIL resize + fp32 forward + post-process), batches of 2, {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from perspectivefields_amd import PerspectiveFields
+    from perspectivefields_amd.dist import gather_params
+    from perspectivefields_amd.synth import synthetic_image
+
+    model = PerspectiveFields(args.version, weights="synthetic:0").eval().to(dev)
+    B, S = args.batch, args.size
+    # per-rank shard of the global batch: synthetic images, host resize (outside the timed region)
+    imgs = [synthetic_image(S, S, seed=1000 + rank * B + i) for i in range(min(B, 4))]
+    t_resize = time.perf_counter()
+    resized4 = [model.aug.apply_image(im) for im in imgs]
+    t_resize = (time.perf_counter() - t_resize) / len(imgs)
+    resized = np.stack([resized4[i % len(resized4)] for i in range(B)])
+    batch = torch.from_numpy(resized).to(dev)
+    sizes = [(S, S)] * B
+    eng = model._get_engine()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        pg, pl, params = eng.forward(batch)
+        outs = [eng.postprocess(pg[i], pl[i], h, w) for i, (h, w) in enumerate(sizes)]
+        allp = gather_params(params) if (params is not None and world > 1) else params
+        return pg, pl, outs, allp
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    use_events = bool(args.events_in_timed) and not args.no_roofline
+    if use_events:
+        eng.profile_begin(classes=("igemm", "dwconv3x3_gelu"))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_end() if use_events else None
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    total_images = B * world * args.steps
+    value = total_images / dt
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+        return
+
+    line = {
+        "metric": "images/sec (640x640, Paramnet-360Cities)",
+        "value": round(value, 2),
+        "unit": "images/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * dt / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[2]: batch {B}/GPU {S}x{S} {args.version}, fields + ParamNet, 320x320 network inputs resident in HBM, post-process to {S}x{S}",
+            "global_batch": B * world, "image_size": [S, S], "parallelism": f"dp{world} (images sharded, all-gather of ParamNet scalars)",
+            "weights": "seeded synthetic checkpoint (no network for the trained .pth)",
+        },
+    }
+    if prof is not None:
+        ig = prof["igemm"]
+        if ig["ms"] > 0:
+            ach = ig["work"] / (ig["ms"] * 1e-3) / 1e12
+            line["roofline"] = {
+                "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": "pf::igemm_kernel (implicit-GEMM conv/GEMM, v_mfma_f32_32x32x2_f32)",
+                "launches_per_step": ig["launches"] // args.steps,
+                "avg_launch_us": round(1000.0 * ig["ms"] / max(ig["launches"], 1), 2),
+                "algorithmic_gflop_per_step": round(ig["work"] / args.steps / 1e9, 2),
+                "share_of_step_time": round(ig["ms"] / (1000.0 * dt), 4),
+            }
+        dw = prof["dwconv3x3_gelu"]
+        if dw["ms"] > 0:
+            gbps = dw["work"] / (dw["ms"] * 1e-3) / 1e9
+            line["roofline_dwconv3x3"] = {
+                "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                "traffic": None, "kernel": "pf::dwconv3x3_gelu_kernel", "launches_per_step": dw["launches"] // args.steps,
+                "algorithmic_mb_per_step": round(dw["work"] / args.steps / 1e6, 1),
+            }
+        line["achieved_tflops_ref_graph"] = round(value / world * GFLOP_PER_IMAGE_REF / 1e3, 2)
+    line["host_resize_ms_per_image"] = round(1000.0 * t_resize, 3)
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(args.version, S)
+        except Exception as e:  # the checker failing must not hide the measurement
+            line["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+/* pf_hip.h -- C ABI of libpf_hip.so, the MI355X (gfx950) implementation of the
+ * PerspectiveFields dense-field + ParamNet inference path.
+ *
+ * The reference (jinlinyi/PerspectiveFields) has no FFI layer: its boundary for this
+ * path is the Python method PerspectiveFields.forward (perspective2d/perspectivefields.py:
+ * 223-272), reached from .inference() (:194-205) and .inference_batch() (:207-221).
+ * The entry points below are what a ctypes binding inside that class binds instead of
+ * running the nn.Module tree:
+ *
+ *   pf_create / pf_load_tensor / pf_finalize_weights   <- PerspectiveFields.__init__ + _init_weights
+ *                                                         (perspectivefields.py:122-192): build the
+ *                                                         network for a zoo architecture and load
+ *                                                         the {"model": state_dict} checkpoint
+ *   pf_forward_u8 / pf_forward_f32                     <- forward() up to `results`
+ *                                                         (perspectivefields.py:234-254,258): normalise,
+ *                                                         backbone (mix_transformers.py:449-485), ll_enc
+ *                                                         (:70-83), persformer_heads.inference
+ *                                                         (persformer_heads.py:73-81), param_net
+ *                                                         (param_network.py:46-69 / 193-221)
+ *   pf_postprocess                                     <- persformer_heads.postprocess
+ *                                                         (persformer_heads.py:83-101 ->
+ *                                                         gravity_head.py:237-261, latitude_head.py:195-219,
+ *                                                         utils/utils.py:483-507,114-130,148-162)
+ *
+ * Conventions: plain pointers and sizes only.  Every `d_` pointer is a DEVICE pointer owned
+ * by the caller; `h_` pointers are host memory.  All work is enqueued on the given
+ * hipStream_t (passed as void*) and never synchronises.  Return value 0 = success,
+ * negative = pf_status; pf_last_error() gives the message.  A handle is bound to one
+ * device and is not thread-safe.  There is no CPU fallback: every entry point fails with
+ * PF_ERR_DEVICE when no gfx950 device is usable.
+ */
+#ifndef PF_HIP_H
+#define PF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pf_engine* pf_handle;
+
+enum pf_status {
+  PF_OK = 0,
+  PF_ERR_ARG = -1,      /* bad argument (null pointer, bad shape, unknown arch) */
+  PF_ERR_DEVICE = -2,   /* no usable HIP device / HIP runtime error */
+  PF_ERR_WEIGHTS = -3,  /* missing / unexpected / mis-shaped checkpoint tensor, or forward before finalize */
+  PF_ERR_WORKSPACE = -4 /* workspace too small */
+};
+
+/* architectures = the three module trees the reference zoo instantiates (perspectivefields.py:86-118) */
+enum pf_arch {
+  PF_ARCH_PARAMNET_CENTERED = 0,   /* regression heads (2 / 1 ch) + ParamNet (ConvNeXt-T, 5 raw outputs) */
+  PF_ARCH_PERSNET_CLS = 1,         /* classification heads (73 / 180 logits), no ParamNet */
+  PF_ARCH_PARAMNET_UNCENTERED = 2  /* regression heads + ParamNetConvNextRegress (64x64 input, 5 outputs) */
+};
+
+#define PF_NET_SIZE 320  /* the network always runs at 320x320 (every reference YAML: DATALOADER.RESIZE) */
+#define PF_PARAMS_STRIDE 8
+
+const char* pf_version(void);
+const char* pf_last_error(pf_handle h); /* h may be NULL: error of the last failed pf_create on this thread */
+
+int pf_create(pf_handle* out, int device, int arch);
+int pf_destroy(pf_handle h);
+
+/* Checkpoint tensors by their reference state_dict key (schema: SURVEY.md appendix B), fp32, C-contiguous.
+ * `ll_enc.bn1.num_batches_tracked` is accepted and ignored. */
+int pf_load_tensor(pf_handle h, const char* key, const float* h_data, const int64_t* shape, int rank);
+/* Strict validation (all keys of the architecture present, none unknown), BatchNorm / layer-scale folding,
+ * repack to the kernels' layouts, upload. */
+int pf_finalize_weights(pf_handle h);
+
+/* channel counts of the API-visible 320x320 maps and number of raw ParamNet outputs (0 if none) */
+int pf_output_info(pf_handle h, int* gravity_channels, int* latitude_channels, int* param_raw_outputs);
+
+/* bytes of scratch pf_forward_* needs for a batch of `batch` images */
+size_t pf_workspace_bytes(pf_handle h, int batch);
+
+/* Forward pass for `batch` images already resized to 320x320.
+ *   d_images_u8   : [batch][320][320][3] uint8, BGR (what ResizeTransform.apply_image returns, :201)
+ *   d_images_f32  : [batch][3][320][320] fp32 BGR 0..255 (the "image" entries forward() receives, :234)
+ *   d_pred_gravity : [batch][Cg][320][320] fp32 -- unit up-vectors (Cg=2) or 73 logits
+ *   d_pred_latitude: [batch][Cl][320][320] fp32 -- sin(latitude) in [-1,1] (Cl=1) or 180 logits
+ *   d_params       : [batch][PF_PARAMS_STRIDE] fp32 or NULL when the arch has no ParamNet:
+ *                    CENTERED  : roll, pitch, vfov (deg), rel_focal, raw x0..x3   (param_network.py:62-67)
+ *                    UNCENTERED: raw x0..x4 (roll/90, pitch/90, general_vfov/90, rel_cx, rel_cy), 0, 0, 0
+ */
+int pf_forward_u8(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_pred_gravity, float* d_pred_latitude,
+                  float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
+int pf_forward_f32(pf_handle h, int batch, const float* d_images_f32, float* d_pred_gravity, float* d_pred_latitude,
+                   float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Post-process ONE image's 320x320 predictions to its original size (H, W):
+ *   d_up_out  : [2][H][W] unit up-vectors (x right, y down), d_lat_out : [H][W] degrees.
+ * For the classification arch d_workspace must hold 3*320*320 floats (decoded fields). */
+int pf_postprocess(pf_handle h, const float* d_pred_gravity, const float* d_pred_latitude, int H, int W,
+                   float* d_up_out, float* d_lat_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-kernel-class timing with HIP events on the launch stream (bench.py `roofline`) ----
+ * classes: 0 implicit-GEMM conv/GEMM (work = algorithmic FLOPs, 2*M*Cout*KH*KW*Cin), 1 attention (FLOPs),
+ * 2 LayerNorm, 3 depthwise3x3+GELU, 4 depthwise7x7, 5 bilinear x2 (work = algorithmic bytes in+out), 6 other.
+ * Between begin and end every launch of a class whose bit is set in class_mask is bracketed by an
+ * event pair; pf_profile_end synchronises those events and sums elapsed ms / work / launches per class. */
+#define PF_PROFILE_CLASSES 7
+int pf_profile_begin(pf_handle h, unsigned class_mask);
+int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n);
+
+/* ---- kernel-level entry points (used by the parity tests; same kernels pf_forward runs) ----
+ * NHWC fp32 device activations; weights are HOST pointers in the reference's layouts. */
+int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, int W, int C1, int C2,
+                 const float* h_weight /*[Cout][C1+C2][KH][KW]*/, const float* h_bias /*[Cout] or NULL*/,
+                 int Cout, int KH, int KW, int stride, int pad, int act /*0 none 1 relu 2 gelu*/,
+                 const float* d_res1, const float* d_res2, int post_relu, int nchw_out, int tile_id /*-1 auto*/,
+                 float* d_y, void* stream);
+int pf_op_layernorm(int device, const float* d_x, const float* h_gamma, const float* h_beta, float* d_y, long rows, int C, float eps, void* stream);
+int pf_op_dwconv3x3_gelu(int device, const float* d_x, const float* h_weight /*[C][1][3][3]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);
+int pf_op_dwconv7x7(int device, const float* d_x, const float* h_weight /*[C][1][7][7]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);
+int pf_op_sr_attention(int device, const float* d_q, const float* d_kv, float* d_out, int B, int N, int M, int heads, void* stream);
+int pf_op_upsample2x(int device, const float* d_x, float* d_y, int B, int H, int W, int C, void* stream);
+int pf_op_num_conv_tiles(void);
+const char* pf_op_conv_tile_name(int tile_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PF_HIP_H */

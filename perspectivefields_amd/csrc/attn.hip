@@ -1,0 +1,138 @@
+// Spatial-reduction attention core of MiT-B3 for gfx950, fp32 MFMA, softmax in registers.
+//
+// Reference: Attention.forward, mix_transformers.py:108-141 -- attn = softmax(q k^T * d^-0.5) v
+// with head_dim d = 64 in every stage and kv_len = 100 always (sr 8/4/2/1 on 80^2..10^2 maps).
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); K and V of that head
+// (100 x 64 fp32 each) live in LDS for the whole block.  Each wave owns 32 query rows and
+// computes the TRANSPOSED score tile S^T = K Q^T with v_mfma_f32_32x32x2_f32, so a query
+// row's scores sit in ONE lane pair (l, l^32): row max / sum are register reductions plus a
+// single cross-half shuffle, and P^T in the accumulator layout is *already* the B operand
+// of the second product O^T = V^T P^T (k-pair = the two kv rows held by the half-waves).
+#include "pf_kernels.h"
+
+namespace pf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int HD = 64;        // head dim
+static constexpr int KV_PAD = 128;   // kv rows padded to 4 MFMA row blocks
+static constexpr int K_ROW = HD + 4; // 68 floats: 68*i mod 64 = 4i -> conflict-free ds_read_b128 over 16 rows
+
+__global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                           float* __restrict__ out, int N, int M, int heads) {
+  __shared__ __attribute__((aligned(16))) float Ks[KV_PAD * K_ROW];
+  __shared__ __attribute__((aligned(16))) float Vs[KV_PAD * HD];
+  const int C = heads * HD;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // stage K, V (rows >= M zero-filled so masked columns contribute exact zeros)
+  const float* kvb = kv + (long)b * M * 2 * C + h * HD;
+  for (int i = tid; i < KV_PAD * (HD / 4); i += 256) {
+    const int row = i / (HD / 4), c4 = i % (HD / 4);
+    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+    if (row < M) {
+      kk = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * C + c4 * 4);
+      vv = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * C + C + c4 * 4);
+    }
+    *reinterpret_cast<float4*>(Ks + row * K_ROW + c4 * 4) = kk;
+    *reinterpret_cast<float4*>(Vs + row * HD + c4 * 4) = vv;
+  }
+
+  // this lane's query row (clamped; out-of-range rows are computed but not stored)
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = q0 + l31;
+  const int qr = qrow < N ? qrow : N - 1;
+  const float* qp = q + ((long)b * N + qr) * C + h * HD + 4 * hi;
+  float4 qf[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float4 v = *reinterpret_cast<const float4*>(qp + 8 * t);
+    qf[t] = make_float4(v.x * 0.125f, v.y * 0.125f, v.z * 0.125f, v.w * 0.125f);  // d^-0.5, exact
+  }
+  __syncthreads();
+
+  // ---- S^T[kv][q] = sum_d K[kv][d] * Q[q][d]; 4 kv blocks of 32 rows
+  f32x16 sacc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[c][e] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    float4 kf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const float4*>(Ks + (c * 32 + l31) * K_ROW + 8 * t + 4 * hi);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].x, qf[t].x, sacc[c], 0, 0, 0);
+      sacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].y, qf[t].y, sacc[c], 0, 0, 0);
+      sacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].z, qf[t].z, sacc[c], 0, 0, 0);
+      sacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].w, qf[t].w, sacc[c], 0, 0, 0);
+    }
+  }
+
+  // ---- softmax over kv for query column (lane & 31); rows held by this lane:
+  //      kv = 32 c + (r & 3) + 8 (r >> 2) + 4 hi
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (kvi < M) mx = fmaxf(mx, sacc[c][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float pexp = kvi < M ? expf(sacc[c][r] - mx) : 0.f;
+      sacc[c][r] = pexp;
+      sum += pexp;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+
+  // ---- O^T[d][q] = sum_kv V[kv][d] * P^T[kv][q]; A operand = V row (kv chosen per half-wave), B = P register
+  f32x16 oacc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[j][e] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (32 * c + (r & 3) + 8 * (r >> 2) < M) {  // block-uniform skip of fully masked k-pairs (kv >= M in both halves => p = 0)
+        const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float v0 = Vs[kvi * HD + l31];
+        const float v1 = Vs[kvi * HD + 32 + l31];
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[c][r], oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sacc[c][r], oacc[1], 0, 0, 0);
+      }
+    }
+
+  // ---- store: lane holds O[q = lane&31][d = 32 j + (r & 3) + 8 (r >> 2) + 4 hi]; 4 consecutive d per float4
+  if (qrow < N) {
+    float* op = out + ((long)b * N + qrow) * C + h * HD;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = make_float4(oacc[j][4 * g] * inv, oacc[j][4 * g + 1] * inv, oacc[j][4 * g + 2] * inv, oacc[j][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + 32 * j + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+void launch_sr_attention(const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s) {
+  const dim3 grid((N + 127) / 128, heads, B);
+  hipLaunchKernelGGL(sr_attention_kernel, grid, dim3(256), 0, s, q, kv, out, N, M, heads);
+}
+
+}  // namespace pf

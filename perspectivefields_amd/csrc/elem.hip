@@ -1,0 +1,492 @@
+// HBM-bound kernels of the PerspectiveFields path for gfx950: LayerNorm, depthwise
+// 3x3(+GELU) / 7x7 with LDS-staged halo tiles, bilinear x2, prediction heads,
+// post-process, input normalisation, ConvNeXt tail.  All NHWC fp32, 16-byte accesses.
+#include "pf_kernels.h"
+
+namespace pf {
+
+__device__ __forceinline__ float gelu_erf_e(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+// Reference: nn.LayerNorm in mix_transformers.py:89,160,172,224,327-387 (eps 1e-5 / 1e-6) and
+// convnext.py:155-182 (both data formats reduce over C, which is the NHWC row here).
+// LPR lanes cooperate on one row (wave-shuffle reductions); two-pass mean / centred variance.
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* __restrict__ y, long rows, int C, float eps) {
+  constexpr int RPB = 256 / LPR;
+  const int sub = threadIdx.x % LPR;
+  const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+  const int nv = C >> 2;
+  const bool rok = row < rows;
+  float4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = sub + i * LPR;
+    if (rok && c < nv) {
+      v[i] = reinterpret_cast<const float4*>(x + row * C)[c];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    } else {
+      v[i] = f4(0.f);
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, LPR);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = sub + i * LPR;
+    if (c < nv) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, LPR);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = sub + i * LPR;
+    if (rok && c < nv) {
+      const float4 gg = reinterpret_cast<const float4*>(g)[c];
+      const float4 bb = reinterpret_cast<const float4*>(b)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gg.x + bb.x;
+      o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+      o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
+      o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+      reinterpret_cast<float4*>(y + row * C)[c] = o;
+    }
+  }
+}
+
+void launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps, hipStream_t s) {
+  const int nv = C / 4;
+  if (nv <= 16) {
+    hipLaunchKernelGGL((layernorm_kernel<16, 1>), dim3((rows + 15) / 16), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+  } else if (nv <= 32) {
+    hipLaunchKernelGGL((layernorm_kernel<32, 1>), dim3((rows + 7) / 8), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+  } else if (nv <= 64) {
+    hipLaunchKernelGGL((layernorm_kernel<64, 1>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+  } else if (nv <= 128) {
+    hipLaunchKernelGGL((layernorm_kernel<64, 2>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+  } else {
+    hipLaunchKernelGGL((layernorm_kernel<64, 4>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+  }
+}
+
+// -------------------------------------------------------------------- depthwise 3x3 + GELU
+// Reference: DWConv + nn.GELU inside Mlp (mix_transformers.py:49-56,497-508).
+// Block = 8x8 output pixels x 128 channels.  The 10x10x128 input tile (with halo) is staged
+// in LDS once (51.2 KB); thread (q = channel quad, y = row) then marches along x keeping a
+// 3x3 window of float4 in registers: 3 ds_read_b128 + 9 fma4 + erf per output float4.
+static constexpr int DW3_T = 8;
+static constexpr int DW3_CQ = 32;  // channel quads per block (128 channels)
+
+__global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int B, int H, int W, int C) {
+  __shared__ __attribute__((aligned(16))) float4 tile[(DW3_T + 2) * (DW3_T + 2) * DW3_CQ];
+  const int tilesX = (W + DW3_T - 1) / DW3_T, tilesY = (H + DW3_T - 1) / DW3_T;
+  const int slabs = C / (DW3_CQ * 4);
+  int bid = blockIdx.x;
+  const int slab = bid % slabs; bid /= slabs;
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY; bid /= tilesY;
+  const int b = bid;
+  const int x0 = tx * DW3_T, y0 = ty * DW3_T, cq0 = slab * DW3_CQ;
+  const int CQ = C >> 2;
+  const float4* xin = reinterpret_cast<const float4*>(x) + (long)b * H * W * CQ;
+  for (int i = threadIdx.x; i < (DW3_T + 2) * (DW3_T + 2) * DW3_CQ; i += 256) {
+    const int q = i % DW3_CQ, pix = i / DW3_CQ;
+    const int py = pix / (DW3_T + 2), px = pix % (DW3_T + 2);
+    const int iy = y0 + py - 1, ix = x0 + px - 1;
+    float4 v = f4(0.f);
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xin[((long)iy * W + ix) * CQ + cq0 + q];
+    tile[i] = v;
+  }
+  const int q = threadIdx.x % DW3_CQ, ry = threadIdx.x / DW3_CQ;  // ry in 0..7
+  float4 wk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const float4*>(w9c)[(long)k * CQ + cq0 + q];
+  const float4 bv = reinterpret_cast<const float4*>(bias)[cq0 + q];
+  __syncthreads();
+  const int oy = y0 + ry;
+  if (oy >= H) return;
+  float4 win[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    win[r][1] = tile[((ry + r) * (DW3_T + 2) + 0) * DW3_CQ + q];
+    win[r][2] = tile[((ry + r) * (DW3_T + 2) + 1) * DW3_CQ + q];
+  }
+  float4* yout = reinterpret_cast<float4*>(y) + ((long)b * H + oy) * W * CQ + cq0 + q;
+#pragma unroll
+  for (int ox = 0; ox < DW3_T; ++ox) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      win[r][0] = win[r][1];
+      win[r][1] = win[r][2];
+      win[r][2] = tile[((ry + r) * (DW3_T + 2) + ox + 2) * DW3_CQ + q];
+    }
+    float4 a = bv;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a = fma4(win[r][c], wk[r * 3 + c], a);
+    a.x = gelu_erf_e(a.x); a.y = gelu_erf_e(a.y); a.z = gelu_erf_e(a.z); a.w = gelu_erf_e(a.w);
+    if (x0 + ox < W) yout[(long)(x0 + ox) * CQ] = a;
+  }
+}
+
+void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+  const int tilesX = (W + DW3_T - 1) / DW3_T, tilesY = (H + DW3_T - 1) / DW3_T;
+  const long blocks = (long)B * tilesY * tilesX * (C / (DW3_CQ * 4));
+  hipLaunchKernelGGL(dwconv3x3_gelu_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+}
+
+// ------------------------------------------------------------------------- depthwise 7x7
+// Reference: ConvNeXt Block.dwconv (convnext.py:30-32,48).  Block = 8x8 outputs x 96 channels
+// (24 quads; all ConvNeXt-T widths are multiples of 96), 192 threads.  14x14x96 halo tile in
+// LDS (75 KB) + the 49x96 weights (18.8 KB); thread (q, row) accumulates its 8 outputs while
+// streaming the 7 input rows: each staged value is read once per thread and reused for up
+// to 7 outputs.
+static constexpr int DW7_T = 8;
+static constexpr int DW7_CQ = 24;
+static constexpr int DW7_IN = DW7_T + 6;
+
+__global__ __launch_bounds__(192) void dwconv7x7_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int B, int H, int W, int C) {
+  __shared__ __attribute__((aligned(16))) float4 tile[DW7_IN * DW7_IN * DW7_CQ];
+  __shared__ __attribute__((aligned(16))) float4 wt[49 * DW7_CQ];
+  const int tilesX = (W + DW7_T - 1) / DW7_T, tilesY = (H + DW7_T - 1) / DW7_T;
+  const int slabs = C / (DW7_CQ * 4);
+  int bid = blockIdx.x;
+  const int slab = bid % slabs; bid /= slabs;
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY; bid /= tilesY;
+  const int b = bid;
+  const int x0 = tx * DW7_T, y0 = ty * DW7_T, cq0 = slab * DW7_CQ;
+  const int CQ = C >> 2;
+  const float4* xin = reinterpret_cast<const float4*>(x) + (long)b * H * W * CQ;
+  for (int i = threadIdx.x; i < DW7_IN * DW7_IN * DW7_CQ; i += 192) {
+    const int q = i % DW7_CQ, pix = i / DW7_CQ;
+    const int py = pix / DW7_IN, px = pix % DW7_IN;
+    const int iy = y0 + py - 3, ix = x0 + px - 3;
+    float4 v = f4(0.f);
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xin[((long)iy * W + ix) * CQ + cq0 + q];
+    tile[i] = v;
+  }
+  for (int i = threadIdx.x; i < 49 * DW7_CQ; i += 192) {
+    const int q = i % DW7_CQ, k = i / DW7_CQ;
+    wt[i] = reinterpret_cast<const float4*>(w49c)[(long)k * CQ + cq0 + q];
+  }
+  __syncthreads();
+  const int q = threadIdx.x % DW7_CQ, ry = threadIdx.x / DW7_CQ;  // ry 0..7
+  const int oy = y0 + ry;
+  if (oy >= H) return;
+  const float4 bv = reinterpret_cast<const float4*>(bias)[cq0 + q];
+  float4 acc[DW7_T];
+#pragma unroll
+  for (int o = 0; o < DW7_T; ++o) acc[o] = bv;
+#pragma unroll 1
+  for (int ky = 0; ky < 7; ++ky) {  // rolled: keeps only one weight row (7 float4) live
+    float4 wr[7];
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) wr[kx] = wt[(ky * 7 + kx) * DW7_CQ + q];
+#pragma unroll
+    for (int ix = 0; ix < DW7_IN; ++ix) {
+      const float4 v = tile[((ry + ky) * DW7_IN + ix) * DW7_CQ + q];
+#pragma unroll
+      for (int o = 0; o < DW7_T; ++o) {
+        const int kx = ix - o;
+        if (kx >= 0 && kx < 7) acc[o] = fma4(v, wr[kx], acc[o]);
+      }
+    }
+  }
+  float4* yout = reinterpret_cast<float4*>(y) + ((long)b * H + oy) * W * CQ + cq0 + q;
+#pragma unroll
+  for (int o = 0; o < DW7_T; ++o)
+    if (x0 + o < W) yout[(long)(x0 + o) * CQ] = acc[o];
+}
+
+void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+  const int tilesX = (W + DW7_T - 1) / DW7_T, tilesY = (H + DW7_T - 1) / DW7_T;
+  const long blocks = (long)B * tilesY * tilesX * (C / (DW7_CQ * 4));
+  hipLaunchKernelGGL(dwconv7x7_kernel, dim3((unsigned)blocks), dim3(192), 0, s, x, w49c, bias, y, B, H, W, C);
+}
+
+// --------------------------------------------------------------------------- bilinear x2
+// Reference: F.interpolate(scale_factor=2, mode="bilinear", align_corners=False)
+// (decode_head.py:284-286; gravity_head.py:172).  src = (dst + 0.5) * 0.5 - 0.5 clamped at 0.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float4* __restrict__ x, float4* __restrict__ y, int B, int H, int W, int CQ) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * Ho * Wo * CQ;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int q = (int)(i % CQ);
+    long r = i / CQ;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float sy = ((float)oy + 0.5f) * 0.5f - 0.5f; sy = sy < 0.f ? 0.f : sy;
+    float sx = ((float)ox + 0.5f) * 0.5f - 0.5f; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float4* base = x + (long)b * H * W * CQ + q;
+    const float4 v00 = base[((long)y0 * W + x0) * CQ], v01 = base[((long)y0 * W + x1) * CQ];
+    const float4 v10 = base[((long)y1 * W + x0) * CQ], v11 = base[((long)y1 * W + x1) * CQ];
+    float4 o;
+    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    y[i] = o;
+  }
+}
+
+void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s) {
+  const long total = (long)B * 4 * H * W * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                     reinterpret_cast<float4*>(y), B, H, W, C / 4);
+}
+
+// ---------------------------------------------------------------------- input normalise
+// Reference: (x - pixel_mean) / pixel_std then stack (perspectivefields.py:234-236); BGR order.
+__global__ __launch_bounds__(256) void prep_u8_kernel(const uint8_t* __restrict__ in, float4* __restrict__ out, long npix,
+                                                      float m0, float m1, float m2, float s0, float s1, float s2) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const uint8_t* p = in + i * 3;
+    out[i] = make_float4(((float)p[0] - m0) / s0, ((float)p[1] - m1) / s1, ((float)p[2] - m2) / s2, 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void prep_f32_nchw_kernel(const float* __restrict__ in, float4* __restrict__ out, int B, int HW,
+                                                            float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long npix = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const long b = i / HW, pix = i - b * HW;
+    const float* p = in + b * 3 * HW + pix;
+    out[i] = make_float4((p[0] - m0) / s0, (p[HW] - m1) / s1, (p[2L * HW] - m2) / s2, 0.f);
+  }
+}
+static unsigned grid_for(long n) { long b = (n + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+void launch_prep_u8(const uint8_t* in, float* out, long npix, const float* mean3, const float* std3, hipStream_t s) {
+  hipLaunchKernelGGL(prep_u8_kernel, dim3(grid_for(npix)), dim3(256), 0, s, in, reinterpret_cast<float4*>(out), npix,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+}
+void launch_prep_f32_nchw(const float* in, float* out, int B, int HW, const float* mean3, const float* std3, hipStream_t s) {
+  hipLaunchKernelGGL(prep_f32_nchw_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, s, in, reinterpret_cast<float4*>(out), B, HW,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+}
+
+// -------------------------------------------------------------- regression prediction heads
+// Reference: linear_pred_gravity (1x1, 32->2) + F.normalize(dim=1) (gravity_head.py:117,190-193);
+// linear_pred_latitude (1x1, 32->1) + clamp(-1,1) (latitude_head.py:118,189-192).
+// 8 lanes per pixel, one float4 of the 32 channels each, xor-shuffle reduction.
+__global__ __launch_bounds__(256) void pred_regression_kernel(const float4* __restrict__ tg, const float4* __restrict__ tl,
+                                                              const float4* __restrict__ wg, const float* __restrict__ bg,
+                                                              const float4* __restrict__ wl, const float* __restrict__ bl,
+                                                              float* __restrict__ pg, float* __restrict__ pl, float4* __restrict__ pn,
+                                                              int B, int HW) {
+  const long npix = (long)B * HW;
+  const int sub = threadIdx.x & 7;
+  const float4 wg0 = wg[sub], wg1 = wg[8 + sub], wl0 = wl[sub];
+  const float bg0 = bg[0], bg1 = bg[1], bl0 = bl[0];
+  for (long pix = ((long)blockIdx.x * 256 + threadIdx.x) >> 3; pix < npix; pix += ((long)gridDim.x * 256) >> 3) {
+    const float4 a = tg[pix * 8 + sub], c = tl[pix * 8 + sub];
+    float g0 = (a.x * wg0.x + a.y * wg0.y) + (a.z * wg0.z + a.w * wg0.w);
+    float g1 = (a.x * wg1.x + a.y * wg1.y) + (a.z * wg1.z + a.w * wg1.w);
+    float l0 = (c.x * wl0.x + c.y * wl0.y) + (c.z * wl0.z + c.w * wl0.w);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      g0 += __shfl_xor(g0, o, 8);
+      g1 += __shfl_xor(g1, o, 8);
+      l0 += __shfl_xor(l0, o, 8);
+    }
+    if (sub == 0) {
+      g0 += bg0; g1 += bg1; l0 += bl0;
+      const float nrm = fmaxf(sqrtf(g0 * g0 + g1 * g1), 1e-12f);  // F.normalize eps
+      g0 /= nrm; g1 /= nrm;
+      l0 = fminf(fmaxf(l0, -1.f), 1.f);
+      const long b = pix / HW, r = pix - b * HW;
+      pg[(b * 2) * HW + r] = g0;
+      pg[(b * 2 + 1) * HW + r] = g1;
+      pl[pix] = l0;
+      if (pn) pn[pix] = make_float4(g0, g1, l0, 0.f);
+    }
+  }
+}
+
+void launch_pred_regression(const float* tg, const float* tl, const float* wg, const float* bg, const float* wl, const float* bl,
+                            float* pred_g_nchw, float* pred_l_nchw, float* pn_in_nhwc4, int B, int HW, hipStream_t s) {
+  const long threads = (long)B * HW * 8;
+  hipLaunchKernelGGL(pred_regression_kernel, dim3(grid_for(threads)), dim3(256), 0, s, reinterpret_cast<const float4*>(tg),
+                     reinterpret_cast<const float4*>(tl), reinterpret_cast<const float4*>(wg), bg, reinterpret_cast<const float4*>(wl), bl,
+                     pred_g_nchw, pred_l_nchw, reinterpret_cast<float4*>(pn_in_nhwc4), B, HW);
+}
+
+// --------------------------------------------------------------------- classification decode
+// Reference: argmax(dim=0) then decode_bin (utils/utils.py:114-130) / decode_bin_latitude (:148-162).
+__global__ __launch_bounds__(256) void decode_cls_kernel(const float* __restrict__ lg, int ng, const float* __restrict__ ll, int nl,
+                                                         float* __restrict__ dg, float* __restrict__ dl, int B, int HW) {
+  const long npix = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const long b = i / HW, r = i - b * HW;
+    const float* pgp = lg + b * ng * HW + r;
+    int best = 0; float bv = pgp[0];
+    for (int c = 1; c < ng; ++c) { const float v = pgp[(long)c * HW]; if (v > bv) { bv = v; best = c; } }  // first max wins, as torch.argmax
+    float cx = 0.f, sy = 0.f;
+    if (best != ng - 1) {
+      const double ang = ((double)best * (360.0 / (double)(ng - 1)) - 180.0) / 180.0 * 3.14159265358979323846;
+      cx = (float)cos(ang); sy = (float)sin(ang);
+    }
+    dg[(b * 2) * HW + r] = cx;
+    dg[(b * 2 + 1) * HW + r] = sy;
+    const float* plp = ll + b * nl * HW + r;
+    best = 0; bv = plp[0];
+    for (int c = 1; c < nl; ++c) { const float v = plp[(long)c * HW]; if (v > bv) { bv = v; best = c; } }
+    const float size = 180.f / (float)nl;
+    dl[i] = (-90.f + (float)best * size) + size * 0.5f;
+  }
+}
+void launch_decode_cls(const float* logit_g, int ng, const float* logit_l, int nl, float* dec_g, float* dec_l, int B, int HW, hipStream_t s) {
+  hipLaunchKernelGGL(decode_cls_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, s, logit_g, ng, logit_l, nl, dec_g, dec_l, B, HW);
+}
+
+// ------------------------------------------------------------------------------ post-process
+// Reference: GravityDecoder.postprocess (gravity_head.py:237-261), LatitudeDecoder.postprocess
+// (latitude_head.py:195-219), pf_postprocess (utils/utils.py:483-507): bilinear (align_corners
+// False, scale = in/out in fp32) of the (2,h,w)*[W/w, H/h] field then L2-normalise; latitude:
+// bilinear then asin -> degrees (regression) or degrees directly (classification).
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ g2, const float* __restrict__ l1, int h, int w,
+                                                          float* __restrict__ up, float* __restrict__ lat, int H, int W,
+                                                          float sx_scale, float sy_scale, float rh, float rw, int lat_is_sin) {
+  const long total = (long)H * W;
+  const long hw = (long)h * w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int oy = (int)(i / W), ox = (int)(i - (long)oy * W);
+    float sy = rh * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+    float sx = rw * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+    int y0 = (int)sy, x0 = (int)sx;
+    y0 = y0 > h - 1 ? h - 1 : y0; x0 = x0 > w - 1 ? w - 1 : x0;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    float ly = sy - (float)y0, lx = sx - (float)x0;
+    ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const long i00 = (long)y0 * w + x0, i01 = (long)y0 * w + x1, i10 = (long)y1 * w + x0, i11 = (long)y1 * w + x1;
+    float gx = hy * (hx * (g2[i00] * sx_scale) + lx * (g2[i01] * sx_scale)) + ly * (hx * (g2[i10] * sx_scale) + lx * (g2[i11] * sx_scale));
+    float gy = hy * (hx * (g2[hw + i00] * sy_scale) + lx * (g2[hw + i01] * sy_scale)) +
+               ly * (hx * (g2[hw + i10] * sy_scale) + lx * (g2[hw + i11] * sy_scale));
+    const float nrm = fmaxf(sqrtf(gx * gx + gy * gy), 1e-12f);
+    up[i] = gx / nrm;
+    up[total + i] = gy / nrm;
+    float lv = hy * (hx * l1[i00] + lx * l1[i01]) + ly * (hx * l1[i10] + lx * l1[i11]);
+    if (lat_is_sin) lv = asinf(lv) * 57.295779513082320876798f;  // torch.rad2deg
+    lat[i] = lv;
+  }
+}
+void launch_postprocess(const float* g2, const float* l1, int h, int w, float* up_out, float* lat_out, int H, int W, int lat_is_sin, hipStream_t s) {
+  const float rh = (float)h / (float)H, rw = (float)w / (float)W;  // area_pixel_compute_scale, fp32
+  const float sxs = (float)((double)W / (double)w), sys = (float)((double)H / (double)h);  // python float -> float32 tensor
+  hipLaunchKernelGGL(postprocess_kernel, dim3(grid_for((long)H * W)), dim3(256), 0, s, g2, l1, h, w, up_out, lat_out, H, W, sxs, sys, rh, rw, lat_is_sin);
+}
+
+// --------------------------------------------------------------------------- nearest resize
+// Reference: F.interpolate(images, (S,S)) default 'nearest' (param_network.py:197): src = floor(dst * in/out).
+__global__ __launch_bounds__(256) void nearest_nhwc4_kernel(const float4* __restrict__ x, float4* __restrict__ y, int B, int H, int W, int Ho, int Wo,
+                                                            float sh, float sw) {
+  const long total = (long)B * Ho * Wo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    long r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    int iy = (int)floorf((float)oy * sh), ix = (int)floorf((float)ox * sw);
+    iy = iy > H - 1 ? H - 1 : iy; ix = ix > W - 1 ? W - 1 : ix;
+    y[i] = x[((long)b * H + iy) * W + ix];
+  }
+}
+void launch_nearest_nhwc4(const float* x, float* y, int B, int H, int W, int Ho, int Wo, hipStream_t s) {
+  hipLaunchKernelGGL(nearest_nhwc4_kernel, dim3(grid_for((long)B * Ho * Wo)), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                     reinterpret_cast<float4*>(y), B, H, W, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo);
+}
+
+// ------------------------------------------------------------------------------ ConvNeXt tail
+// Reference: x.mean([-2,-1]) -> nn.LayerNorm(768, eps 1e-6) -> head Linear (convnext.py:144-151).
+// One block per image.
+__global__ __launch_bounds__(256) void gap_ln_head_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                          const float* __restrict__ w, const float* __restrict__ hb, float* __restrict__ out,
+                                                          int HW, int C, int nout, float eps) {
+  __shared__ float pooled[1024];
+  __shared__ float red[256];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const float* xi = x + (long)img * HW * C;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += xi[(long)p * C + c];
+    pooled[c] = s / (float)HW;
+  }
+  __syncthreads();
+  auto block_sum = [&](float v) {
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  float s = 0.f;
+  for (int c = tid; c < C; c += 256) s += pooled[c];
+  const float mean = block_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = tid; c < C; c += 256) { const float d = pooled[c] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(block_sum(q) / (float)C + eps);
+  for (int c = tid; c < C; c += 256) pooled[c] = (pooled[c] - mean) * rstd * g[c] + b[c];
+  __syncthreads();
+  for (int o = 0; o < nout; ++o) {
+    float d = 0.f;
+    for (int c = tid; c < C; c += 256) d += pooled[c] * w[(long)o * C + c];
+    const float r = block_sum(d);
+    if (tid == 0) out[(long)img * nout + o] = r + hb[o];
+  }
+}
+void launch_gap_ln_head(const float* x, const float* g, const float* b, const float* w, const float* hb, float* out, int B, int HW, int C, int nout, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(gap_ln_head_kernel, dim3(B), dim3(256), 0, s, x, g, b, w, hb, out, HW, C, nout, eps);
+}
+
+// Reference: ParamNet.forward eval branch (param_network.py:62-67).  out is [B][8]:
+// mode 0 (centered): roll, pitch, vfov (deg), rel_focal = 1/(2 tan x2), raw x0..x3
+// mode 1 (uncentered): raw x0..x(n-1), zero padded (host applies the factors / fsolve, param_network.py:204-220)
+__global__ void paramnet_scalars_kernel(const float* __restrict__ raw, int nraw, float* __restrict__ out8, int B, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const float* r = raw + (long)i * nraw;
+  float* o = out8 + (long)i * 8;
+  if (mode == 0) {
+    o[0] = r[0] * 90.0f;
+    o[1] = r[1] * 90.0f;
+    o[2] = r[2] * 90.0f;
+    o[3] = 1.0f / 2.0f / tanf(r[2]);
+    o[4] = r[0]; o[5] = r[1]; o[6] = r[2]; o[7] = r[3];
+  } else {
+    for (int k = 0; k < 8; ++k) o[k] = k < nraw ? r[k] : 0.f;
+  }
+}
+void launch_paramnet_scalars(const float* raw, int nraw, float* out8, int B, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(paramnet_scalars_kernel, dim3((B + 63) / 64), dim3(64), 0, s, raw, nraw, out8, B, mode);
+}
+
+}  // namespace pf

@@ -1,0 +1,806 @@
+// libpf_hip.so: weight store, layer graph and C ABI of the MI355X PerspectiveFields path.
+// Host-side C++ here only *orchestrates* hand-written gfx950 kernels (igemm.hip, attn.hip,
+// elem.hip); there is no CPU or library (MIOpen / hipBLASLt) fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pf_hip.h"
+#include "pf_kernels.h"
+
+using namespace pf;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+std::string fmt(const char* f, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof buf, f, ap);
+  va_end(ap);
+  return buf;
+}
+
+// ---- architecture constants (reference: mix_transformers.py:511-524, gravity_head.py:121-137, convnext.py:78-79)
+constexpr int NET = PF_NET_SIZE;
+const int MIT_DIMS[4] = {64, 128, 320, 512};
+const int MIT_HEADS[4] = {1, 2, 5, 8};
+const int MIT_DEPTHS[4] = {3, 4, 18, 3};
+const int MIT_SR[4] = {8, 4, 2, 1};
+const int MIT_PK[4] = {7, 3, 3, 3}, MIT_PS[4] = {4, 2, 2, 2}, MIT_PP[4] = {3, 1, 1, 1};
+constexpr int DEC_EMBED = 768, DEC_FEAT = 256, LL_CH = 64;
+const int CNX_DEPTHS[4] = {3, 3, 9, 3};
+const int CNX_DIMS[4] = {96, 192, 384, 768};
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  bool used = false;
+};
+
+struct ConvW {
+  float* w = nullptr;
+  float* b = nullptr;
+  int Cout = 0, Cin = 0 /*padded*/, CinReal = 0, KH = 1, KW = 1, stride = 1, pad = 0, KWC = 0, KWCp = 0;
+};
+struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-6f; };
+struct DwW { float* w = nullptr; float* b = nullptr; int C = 0; };
+
+struct MitBlock { LNW n1, n2, srn; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; };
+struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
+struct Head {
+  ConvW lin[4], proc[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
+  float* predw = nullptr; float* predb = nullptr; int nout = 0;
+};
+struct CnxBlock { DwW dw; LNW n; ConvW pw1, pw2; };
+struct Cnx { ConvW stem, ds[3]; LNW stemn, dsn[3], norm; std::vector<CnxBlock> blocks[4]; float* headw = nullptr; float* headb = nullptr; int nout = 0; };
+
+struct Profiler;
+struct Ctx {
+  hipStream_t s;
+  uintptr_t base;
+  size_t off = 0, peak = 0;
+  bool dry;
+  Profiler* prof = nullptr;
+  float* alloc(size_t nfloats) {
+    const size_t bytes = (nfloats * 4 + 255) & ~(size_t)255;
+    const size_t o = off;
+    off += bytes;
+    if (off > peak) peak = off;
+    return reinterpret_cast<float*>(base + o);
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+};
+
+int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+// Per-kernel-class timing with HIP events on the launch stream (bench.py's `roofline` object):
+// every launch of a class is bracketed by an event pair; work = algorithmic FLOPs or bytes.
+enum ProfCat { PC_IGEMM = 0, PC_ATTN, PC_LAYERNORM, PC_DW3, PC_DW7, PC_UPSAMPLE, PC_OTHER, PC_COUNT };
+struct Profiler {
+  struct Rec { int cat; double work; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  bool on = false;
+  unsigned mask = 0xffffffffu;
+  hipEvent_t get() {
+    if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+    return pool[used++];
+  }
+  void reset() { recs.clear(); used = 0; }
+  ~Profiler() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+struct ProfScope {
+  Profiler* p; hipStream_t s; hipEvent_t b = nullptr;
+  ProfScope(Profiler* pr, hipStream_t st, int cat, double work) : p(pr), s(st) {
+    if (!p || !p->on || !((p->mask >> cat) & 1u)) { p = nullptr; return; }
+    hipEvent_t a = p->get(); b = p->get();
+    if (!a || !b) { p = nullptr; return; }
+    (void)hipEventRecord(a, s);
+    p->recs.push_back({cat, work, a, b});
+  }
+  ~ProfScope() { if (p) (void)hipEventRecord(b, s); }
+};
+
+std::vector<float> pack_conv(const float* w, int Cout, int Cin, int KH, int KW, int CinP, const double* out_scale, int* KWC, int* KWCp) {
+  *KWC = KW * CinP;
+  *KWCp = roundup(*KWC, 32);
+  std::vector<float> o((size_t)Cout * KH * *KWCp, 0.f);
+  for (int n = 0; n < Cout; ++n)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+          double v = w[(((size_t)n * Cin + ci) * KH + ky) * KW + kx];
+          if (out_scale) v *= out_scale[n];
+          o[((size_t)n * KH + ky) * *KWCp + kx * CinP + ci] = (float)v;
+        }
+  return o;
+}
+
+std::vector<float> pack_dw(const float* w, int C, int K) {  // [C][1][K][K] -> [K*K][C]
+  std::vector<float> o((size_t)K * K * C);
+  for (int c = 0; c < C; ++c)
+    for (int k = 0; k < K * K; ++k) o[(size_t)k * C + c] = w[(size_t)c * K * K + k];
+  return o;
+}
+
+}  // namespace
+
+struct pf_engine {
+  int device = 0;
+  int arch = 0;
+  bool finalized = false;
+  std::string err;
+  std::unordered_map<std::string, HostTensor> host;
+  std::vector<void*> dev_allocs;
+  std::map<int, size_t> ws_cache;
+  Profiler prof;
+
+  MitStage stages[4];
+  ConvW ll;
+  Head heads[2];  // 0 gravity, 1 latitude
+  Cnx cnx;
+  bool has_param = false;
+  int param_in = NET;  // ParamNet input resolution
+  float mean3[3] = {103.53f, 116.28f, 123.675f};
+  float std3[3] = {1.f, 1.f, 1.f};
+
+  int fail(int code, const std::string& m) { err = m; return code; }
+
+  // ------------------------------------------------------------------ weights
+  float* upload(const std::vector<float>& v) {
+    void* d = nullptr;
+    if (hipMalloc(&d, v.size() * sizeof(float)) != hipSuccess) throw std::string("hipMalloc failed for weights");
+    if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) throw std::string("hipMemcpy H2D failed for weights");
+    dev_allocs.push_back(d);
+    return static_cast<float*>(d);
+  }
+  const HostTensor& get(const std::string& key, std::initializer_list<int64_t> shape) {
+    auto it = host.find(key);
+    if (it == host.end()) throw fmt("missing checkpoint tensor '%s'", key.c_str());
+    HostTensor& t = it->second;
+    if (t.shape != std::vector<int64_t>(shape)) {
+      std::string got, want;
+      for (auto d : t.shape) got += std::to_string(d) + ",";
+      for (auto d : shape) want += std::to_string(d) + ",";
+      throw fmt("shape mismatch for '%s': got (%s) expected (%s)", key.c_str(), got.c_str(), want.c_str());
+    }
+    t.used = true;
+    return t;
+  }
+  ConvW make_conv(const std::string& wkey, const std::string& bkey, int Cout, int Cin, int K, int stride, int pad,
+                  const double* out_scale = nullptr, const std::vector<float>* bias_override = nullptr) {
+    ConvW c;
+    const int CinP = roundup(Cin, 4);
+    const HostTensor& w = get(wkey, {Cout, Cin, K, K});
+    c.w = upload(pack_conv(w.data.data(), Cout, Cin, K, K, CinP, out_scale, &c.KWC, &c.KWCp));
+    if (bias_override) c.b = upload(*bias_override);
+    else if (!bkey.empty()) {
+      std::vector<float> b = get(bkey, {Cout}).data;
+      if (out_scale) for (int n = 0; n < Cout; ++n) b[n] = (float)(b[n] * out_scale[n]);
+      c.b = upload(b);
+    }
+    c.Cout = Cout; c.Cin = CinP; c.CinReal = Cin; c.KH = c.KW = K; c.stride = stride; c.pad = pad;
+    return c;
+  }
+  ConvW make_linear(const std::string& pfx, int N, int K, const double* out_scale = nullptr) {
+    ConvW c;
+    const HostTensor& w = get(pfx + ".weight", {N, K});
+    c.w = upload(pack_conv(w.data.data(), N, K, 1, 1, K, out_scale, &c.KWC, &c.KWCp));
+    std::vector<float> b = get(pfx + ".bias", {N}).data;
+    if (out_scale) for (int n = 0; n < N; ++n) b[n] = (float)(b[n] * out_scale[n]);
+    c.b = upload(b);
+    c.Cout = N; c.Cin = K; c.CinReal = K; c.KH = c.KW = 1; c.stride = 1; c.pad = 0;
+    return c;
+  }
+  LNW make_ln(const std::string& pfx, int C, float eps) {
+    LNW l;
+    l.g = upload(get(pfx + ".weight", {C}).data);
+    l.b = upload(get(pfx + ".bias", {C}).data);
+    l.C = C; l.eps = eps;
+    return l;
+  }
+  DwW make_dw(const std::string& pfx, int C, int K) {
+    DwW d;
+    d.w = upload(pack_dw(get(pfx + ".weight", {C, 1, K, K}).data.data(), C, K));
+    d.b = upload(get(pfx + ".bias", {C}).data);
+    d.C = C;
+    return d;
+  }
+
+  void build_head(Head& hd, const std::string& name, int nout, bool cls) {
+    const std::string p = "persformer_heads." + name + "_head.";
+    for (int k = 0; k < 4; ++k) {
+      const std::string ks = std::to_string(k + 1);
+      hd.lin[k] = make_linear(p + "linear_c" + ks + ".proj", DEC_EMBED, MIT_DIMS[k]);
+      hd.proc[k] = make_conv(p + "linear_c" + ks + "_proc.weight", p + "linear_c" + ks + "_proc.bias", DEC_FEAT, DEC_EMBED, 3, 1, 1);
+      const std::string f = p + "fusion" + ks + ".";
+      if (k < 3) {
+        hd.r1c1[k] = make_conv(f + "resConfUnit1.conv1.weight", f + "resConfUnit1.conv1.bias", DEC_FEAT, DEC_FEAT, 3, 1, 1);
+        hd.r1c2[k] = make_conv(f + "resConfUnit1.conv2.weight", f + "resConfUnit1.conv2.bias", DEC_FEAT, DEC_FEAT, 3, 1, 1);
+      }
+      hd.r2c1[k] = make_conv(f + "resConfUnit2.conv1.weight", f + "resConfUnit2.conv1.bias", DEC_FEAT, DEC_FEAT, 3, 1, 1);
+      hd.r2c2[k] = make_conv(f + "resConfUnit2.conv2.weight", f + "resConfUnit2.conv2.bias", DEC_FEAT, DEC_FEAT, 3, 1, 1);
+    }
+    hd.conv0 = make_conv(p + "conv_fuse_conv0.conv.weight", p + "conv_fuse_conv0.conv.bias", 64, DEC_FEAT + LL_CH, 3, 1, 1);
+    hd.conv1 = make_conv(p + "conv_fuse_conv1.conv.weight", p + "conv_fuse_conv1.conv.bias", 32, 64, 3, 1, 1);
+    hd.nout = nout;
+    const std::string pk = p + "linear_pred_" + name;
+    if (cls) {
+      hd.predcls = make_conv(pk + ".weight", pk + ".bias", nout, 32, 1, 1, 0);
+    } else {
+      hd.predw = upload(get(pk + ".weight", {nout, 32, 1, 1}).data);
+      hd.predb = upload(get(pk + ".bias", {nout}).data);
+    }
+  }
+
+  void build() {
+    // MiT-B3
+    int cin = 3;
+    for (int s = 0; s < 4; ++s) {
+      const int C = MIT_DIMS[s];
+      const std::string pe = "backbone.patch_embed" + std::to_string(s + 1);
+      stages[s].pe = make_conv(pe + ".proj.weight", pe + ".proj.bias", C, cin, MIT_PK[s], MIT_PS[s], MIT_PP[s]);
+      stages[s].pen = make_ln(pe + ".norm", C, 1e-5f);  // nn.LayerNorm default eps (mix_transformers.py:224)
+      for (int i = 0; i < MIT_DEPTHS[s]; ++i) {
+        const std::string b = "backbone.block" + std::to_string(s + 1) + "." + std::to_string(i);
+        MitBlock mb;
+        mb.n1 = make_ln(b + ".norm1", C, 1e-6f);  // mit_b3 norm_layer eps (:519)
+        mb.n2 = make_ln(b + ".norm2", C, 1e-6f);
+        mb.q = make_linear(b + ".attn.q", C, C);
+        mb.kv = make_linear(b + ".attn.kv", 2 * C, C);
+        mb.proj = make_linear(b + ".attn.proj", C, C);
+        if (MIT_SR[s] > 1) {
+          mb.sr = make_conv(b + ".attn.sr.weight", b + ".attn.sr.bias", C, C, MIT_SR[s], MIT_SR[s], 0);
+          mb.srn = make_ln(b + ".attn.norm", C, 1e-5f);  // Attention.norm default eps (:89)
+        }
+        mb.fc1 = make_linear(b + ".mlp.fc1", 4 * C, C);
+        mb.dw = make_dw(b + ".mlp.dwconv.dwconv", 4 * C, 3);
+        mb.fc2 = make_linear(b + ".mlp.fc2", C, 4 * C);
+        stages[s].blocks.push_back(mb);
+      }
+      stages[s].norm = make_ln("backbone.norm" + std::to_string(s + 1), C, 1e-6f);
+      cin = C;
+    }
+    // low-level encoder with eval BatchNorm folded (perspectivefields.py:70-83; BN eps 1e-5)
+    {
+      const std::vector<float>& g = get("ll_enc.bn1.weight", {LL_CH}).data;
+      const std::vector<float>& be = get("ll_enc.bn1.bias", {LL_CH}).data;
+      const std::vector<float>& mu = get("ll_enc.bn1.running_mean", {LL_CH}).data;
+      const std::vector<float>& var = get("ll_enc.bn1.running_var", {LL_CH}).data;
+      std::vector<double> sc(LL_CH);
+      std::vector<float> bias(LL_CH);
+      for (int n = 0; n < LL_CH; ++n) {
+        sc[n] = (double)g[n] / std::sqrt((double)var[n] + 1e-5);
+        bias[n] = (float)((double)be[n] - (double)mu[n] * sc[n]);
+      }
+      ll = make_conv("ll_enc.conv1.weight", "", LL_CH, 3, 7, 2, 3, sc.data(), &bias);
+      auto it = host.find("ll_enc.bn1.num_batches_tracked");
+      if (it != host.end()) it->second.used = true;
+    }
+    const bool cls = arch == PF_ARCH_PERSNET_CLS;
+    build_head(heads[0], "gravity", cls ? 73 : 2, cls);
+    build_head(heads[1], "latitude", cls ? 180 : 1, cls);
+    has_param = arch != PF_ARCH_PERSNET_CLS;
+    param_in = arch == PF_ARCH_PARAMNET_UNCENTERED ? 64 : NET;
+    if (has_param) {
+      const std::string p = "param_net.backbone.";
+      cnx.nout = 5;
+      cnx.stem = make_conv(p + "downsample_layers.0.0.weight", p + "downsample_layers.0.0.bias", CNX_DIMS[0], 3, 4, 4, 0);
+      cnx.stemn = make_ln(p + "downsample_layers.0.1", CNX_DIMS[0], 1e-6f);
+      for (int i = 1; i < 4; ++i) {
+        const std::string d = p + "downsample_layers." + std::to_string(i);
+        cnx.dsn[i - 1] = make_ln(d + ".0", CNX_DIMS[i - 1], 1e-6f);
+        cnx.ds[i - 1] = make_conv(d + ".1.weight", d + ".1.bias", CNX_DIMS[i], CNX_DIMS[i - 1], 2, 2, 0);
+      }
+      for (int s = 0; s < 4; ++s) {
+        const int C = CNX_DIMS[s];
+        for (int j = 0; j < CNX_DEPTHS[s]; ++j) {
+          const std::string b = p + "stages." + std::to_string(s) + "." + std::to_string(j);
+          CnxBlock cb;
+          cb.dw = make_dw(b + ".dwconv", C, 7);
+          cb.n = make_ln(b + ".norm", C, 1e-6f);
+          cb.pw1 = make_linear(b + ".pwconv1", 4 * C, C);
+          // layer scale gamma folded into pwconv2 (convnext.py:54-55: x = gamma * x)
+          const std::vector<float>& gm = get(b + ".gamma", {C}).data;
+          std::vector<double> sc(gm.begin(), gm.end());
+          cb.pw2 = make_linear(b + ".pwconv2", C, 4 * C, sc.data());
+          cnx.blocks[s].push_back(cb);
+        }
+      }
+      cnx.norm = make_ln(p + "norm", CNX_DIMS[3], 1e-6f);
+      cnx.headw = upload(get(p + "head.weight", {cnx.nout, CNX_DIMS[3]}).data);
+      cnx.headb = upload(get(p + "head.bias", {cnx.nout}).data);
+    }
+    for (auto& kv : host)
+      if (!kv.second.used) throw fmt("unexpected checkpoint tensor '%s' for this architecture", kv.first.c_str());
+    host.clear();
+  }
+
+  // ------------------------------------------------------------------ layer helpers
+  void conv(Ctx& c, const ConvW& w, const float* x, int B, int H, int W, float* y, int act = ACT_NONE, const float* res1 = nullptr,
+            const float* res2 = nullptr, int post_relu = 0, const float* x2 = nullptr, int C1 = -1, int nchw = 0) {
+    if (c.dry) return;
+    ConvParams p;
+    p.x = x; p.x2 = x2; p.w = w.w; p.bias = w.b; p.res1 = res1; p.res2 = res2; p.y = y;
+    p.B = B; p.H = H; p.W = W;
+    p.C1 = C1 < 0 ? w.Cin : C1; p.C2 = w.Cin - p.C1; p.Cin = w.Cin;
+    p.KH = w.KH; p.KW = w.KW; p.stride = w.stride; p.pad = w.pad;
+    p.Ho = (H + 2 * w.pad - w.KH) / w.stride + 1;
+    p.Wo = (W + 2 * w.pad - w.KW) / w.stride + 1;
+    p.Cout = w.Cout; p.KWC = w.KWC; p.KWCp = w.KWCp;
+    p.M = B * p.Ho * p.Wo;
+    p.act = act; p.post_relu = post_relu; p.ldy = w.Cout; p.nchw_out = nchw;
+    ProfScope ps(c.prof, c.s, PC_IGEMM, 2.0 * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal);
+    launch_conv(p, c.s);
+  }
+  void gemm(Ctx& c, const ConvW& w, const float* x, long rows, float* y, int act = ACT_NONE, const float* res1 = nullptr) {
+    conv(c, w, x, 1, (int)rows, 1, y, act, res1);
+  }
+  void ln(Ctx& c, const LNW& l, const float* x, float* y, long rows) {
+    if (c.dry) return;
+    ProfScope ps(c.prof, c.s, PC_LAYERNORM, 8.0 * rows * l.C);
+    launch_layernorm(x, l.g, l.b, y, rows, l.C, l.eps, c.s);
+  }
+
+  // MiT-B3 forward_features (mix_transformers.py:449-485); feats[s] = NHWC stage outputs
+  void mit(Ctx& c, int B, const float* x0, float* feats[4]) {
+    const float* cur = x0;
+    int H = NET, W = NET;
+    for (int s = 0; s < 4; ++s) {
+      MitStage& st = stages[s];
+      const int C = MIT_DIMS[s], heads_n = MIT_HEADS[s], sr = MIT_SR[s];
+      const int Ho = (H + 2 * MIT_PP[s] - MIT_PK[s]) / MIT_PS[s] + 1, Wo = (W + 2 * MIT_PP[s] - MIT_PK[s]) / MIT_PS[s] + 1;
+      const long N = (long)Ho * Wo, M = (long)B * N;
+      float* x = c.alloc(M * C);  // token stream, updated in place by the residual epilogues
+      conv(c, st.pe, cur, B, H, W, x);
+      ln(c, st.pen, x, x, M);
+      const size_t mk = c.mark();
+      const int kvh = Ho / sr, kvw = Wo / sr;
+      const long Mkv = (long)B * kvh * kvw;
+      float* xn = c.alloc(M * C);
+      float* qb = c.alloc(M * C);
+      float* ab = c.alloc(M * C);
+      float* srb = c.alloc(Mkv * C);
+      float* kvb = c.alloc(Mkv * 2 * C);
+      float* hb = c.alloc(M * 4 * C);
+      float* h2 = c.alloc(M * 4 * C);
+      for (MitBlock& mb : st.blocks) {
+        // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
+        ln(c, mb.n1, x, xn, M);
+        gemm(c, mb.q, xn, M, qb);
+        if (sr > 1) {
+          conv(c, mb.sr, xn, B, Ho, Wo, srb);
+          ln(c, mb.srn, srb, srb, Mkv);
+          gemm(c, mb.kv, srb, Mkv, kvb);
+        } else {
+          gemm(c, mb.kv, xn, M, kvb);
+        }
+        if (!c.dry) {
+          ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
+          launch_sr_attention(qb, kvb, ab, B, (int)N, kvh * kvw, heads_n, c.s);
+        }
+        gemm(c, mb.proj, ab, M, x, ACT_NONE, x);
+        // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
+        ln(c, mb.n2, x, xn, M);
+        gemm(c, mb.fc1, xn, M, hb);
+        if (!c.dry) {
+          ProfScope ps(c.prof, c.s, PC_DW3, 8.0 * M * 4 * C);  // read + write of the hidden map
+          launch_dwconv3x3_gelu(hb, mb.dw.w, mb.dw.b, h2, B, Ho, Wo, 4 * C, c.s);
+        }
+        gemm(c, mb.fc2, h2, M, x, ACT_NONE, x);
+      }
+      c.release(mk);
+      ln(c, st.norm, x, x, M);  // stage norm; the normalised map is both the output and the next stage's input (:457-462)
+      feats[s] = x;
+      cur = x;
+      H = Ho; W = Wo;
+    }
+  }
+
+  // decoder head up to the 32-channel 320x320 map (gravity_head.py:139-173 / latitude_head.py:138-172).
+  // Stored tensors are post-ReLU wherever every consumer applies ReLU first (ResidualConvUnit's in-place
+  // ReLU, decode_head.py:242-256): RCU(x) = conv2(relu(conv1(relu x))) + relu x.
+  void head(Ctx& c, Head& hd, int B, float* feats[4], const float* llf, float* t32) {
+    float* up[4];
+    for (int k = 3; k >= 0; --k) {
+      const int h = NET >> (k + 2);
+      up[k] = c.alloc((size_t)B * 4 * h * h * DEC_FEAT);
+    }
+    for (int k = 3; k >= 0; --k) {
+      const int h = NET >> (k + 2);
+      const long M = (long)B * h * h;
+      const size_t mk = c.mark();
+      float* e = c.alloc(M * DEC_EMBED);
+      gemm(c, hd.lin[k], feats[k], M, e);                                   // MLP (decode_head.py:49-53)
+      float* p = c.alloc(M * DEC_FEAT);
+      conv(c, hd.proc[k], e, B, h, h, p, ACT_NONE, nullptr, nullptr, 1);     // relu(_ck)
+      float* o = p;
+      if (k < 3) {                                                           // o = relu(up(prev) + RCU1(_ck))
+        float* t = c.alloc(M * DEC_FEAT);
+        conv(c, hd.r1c1[k], p, B, h, h, t, ACT_RELU);
+        o = c.alloc(M * DEC_FEAT);
+        conv(c, hd.r1c2[k], t, B, h, h, o, ACT_NONE, p, up[k + 1], 1);
+      }
+      float* t2 = c.alloc(M * DEC_FEAT);
+      conv(c, hd.r2c1[k], o, B, h, h, t2, ACT_RELU);
+      float* o2 = c.alloc(M * DEC_FEAT);
+      conv(c, hd.r2c2[k], t2, B, h, h, o2, ACT_NONE, o);                     // RCU2 output, raw
+      if (!c.dry) {                                                          // decode_head.py:284-286
+        ProfScope ps(c.prof, c.s, PC_UPSAMPLE, 20.0 * M * DEC_FEAT);
+        launch_upsample2x(o2, up[k], B, h, h, DEC_FEAT, c.s);
+      }
+      c.release(mk);
+    }
+    const int h = NET / 2;
+    float* z = c.alloc((size_t)B * h * h * 64);
+    conv(c, hd.conv0, up[0], B, h, h, z, ACT_RELU, nullptr, nullptr, 0, llf, DEC_FEAT);  // cat fused into the A gather (:170-171)
+    float* zu = c.alloc((size_t)B * NET * NET * 64);
+    if (!c.dry) {
+      ProfScope ps(c.prof, c.s, PC_UPSAMPLE, 20.0 * B * h * h * 64);
+      launch_upsample2x(z, zu, B, h, h, 64, c.s);
+    }
+    conv(c, hd.conv1, zu, B, NET, NET, t32, ACT_RELU);
+  }
+
+  // ConvNeXt-T + heads of the ParamNets (convnext.py:140-152)
+  void paramnet(Ctx& c, int B, const float* pn_in, float* d_params) {
+    const float* src = pn_in;
+    int H = NET;
+    if (param_in != NET) {
+      float* small = c.alloc((size_t)B * param_in * param_in * 4);
+      if (!c.dry) launch_nearest_nhwc4(pn_in, small, B, NET, NET, param_in, param_in, c.s);
+      src = small;
+      H = param_in;
+    }
+    int h = H / 4;
+    float* y = c.alloc((size_t)B * h * h * CNX_DIMS[0]);
+    conv(c, cnx.stem, src, B, H, H, y);
+    ln(c, cnx.stemn, y, y, (long)B * h * h);
+    for (int s = 0; s < 4; ++s) {
+      const int C = CNX_DIMS[s];
+      if (s > 0) {
+        const long Mi = (long)B * h * h;
+        ln(c, cnx.dsn[s - 1], y, y, Mi);
+        float* yn = c.alloc((size_t)B * (h / 2) * (h / 2) * C);
+        conv(c, cnx.ds[s - 1], y, B, h, h, yn);
+        y = yn;
+        h /= 2;
+      }
+      const long M = (long)B * h * h;
+      const size_t mk = c.mark();
+      float* d = c.alloc(M * C);
+      float* hb = c.alloc(M * 4 * C);
+      for (CnxBlock& cb : cnx.blocks[s]) {
+        if (!c.dry) {
+          ProfScope ps(c.prof, c.s, PC_DW7, 8.0 * M * C);
+          launch_dwconv7x7(y, cb.dw.w, cb.dw.b, d, B, h, h, C, c.s);
+        }
+        ln(c, cb.n, d, d, M);
+        gemm(c, cb.pw1, d, M, hb, ACT_GELU);
+        gemm(c, cb.pw2, hb, M, y, ACT_NONE, y);  // y += gamma * pwconv2(...)  (gamma folded)
+      }
+      c.release(mk);
+    }
+    float* raw = c.alloc((size_t)B * 8);
+    if (!c.dry) {
+      launch_gap_ln_head(y, cnx.norm.g, cnx.norm.b, cnx.headw, cnx.headb, raw, B, h * h, CNX_DIMS[3], cnx.nout, cnx.norm.eps, c.s);
+      launch_paramnet_scalars(raw, cnx.nout, d_params, B, arch == PF_ARCH_PARAMNET_CENTERED ? 0 : 1, c.s);
+    }
+  }
+
+  void run(Ctx& c, int B, const void* in, bool is_u8, float* pg, float* pl, float* params) {
+    float* x0 = c.alloc((size_t)B * NET * NET * 4);
+    if (!c.dry) {
+      if (is_u8) launch_prep_u8(static_cast<const uint8_t*>(in), x0, (long)B * NET * NET, mean3, std3, c.s);
+      else launch_prep_f32_nchw(static_cast<const float*>(in), x0, B, NET * NET, mean3, std3, c.s);
+    }
+    float* feats[4];
+    mit(c, B, x0, feats);
+    float* llf = c.alloc((size_t)B * (NET / 2) * (NET / 2) * LL_CH);
+    conv(c, ll, x0, B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
+    float* tg = c.alloc((size_t)B * NET * NET * 32);
+    float* tl = c.alloc((size_t)B * NET * NET * 32);
+    float* pn = has_param ? c.alloc((size_t)B * NET * NET * 4) : nullptr;
+    const size_t mk = c.mark();
+    head(c, heads[0], B, feats, llf, tg);
+    c.release(mk);
+    head(c, heads[1], B, feats, llf, tl);
+    c.release(mk);
+    if (arch == PF_ARCH_PERSNET_CLS) {
+      // 1x1 convs to 73 / 180 logits, stored NCHW because the logits are API-visible (gravity_head.py:259)
+      conv(c, heads[0].predcls, tg, B, NET, NET, pg, ACT_NONE, nullptr, nullptr, 0, nullptr, -1, 1);
+      conv(c, heads[1].predcls, tl, B, NET, NET, pl, ACT_NONE, nullptr, nullptr, 0, nullptr, -1, 1);
+      return;
+    }
+    if (!c.dry)
+      launch_pred_regression(tg, tl, heads[0].predw, heads[0].predb, heads[1].predw, heads[1].predb, pg, pl, pn, B, NET * NET, c.s);
+    if (has_param) paramnet(c, B, pn, params);
+  }
+
+  size_t workspace_bytes(int B) {
+    auto it = ws_cache.find(B);
+    if (it != ws_cache.end()) return it->second;
+    Ctx c{nullptr, 4096, 0, 0, true, nullptr};
+    run(c, B, nullptr, true, nullptr, nullptr, nullptr);
+    const size_t need = c.peak + 4096;
+    ws_cache[B] = need;
+    return need;
+  }
+
+  int forward(int B, const void* in, bool is_u8, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!finalized) return fail(PF_ERR_WEIGHTS, "pf_forward called before pf_finalize_weights");
+    if (B <= 0 || !in || !pg || !pl || !ws) return fail(PF_ERR_ARG, "pf_forward: null pointer or batch <= 0");
+    if (has_param && !params) return fail(PF_ERR_ARG, "pf_forward: d_params is required for a ParamNet architecture");
+    if ((long)B * NET * NET * 64 * 4 > 0x7fffffffL * 4L) return fail(PF_ERR_ARG, "pf_forward: batch too large for 32-bit tile indexing (max 81)");
+    const size_t need = workspace_bytes(B);
+    if (ws_bytes < need) return fail(PF_ERR_WORKSPACE, fmt("workspace too small: %zu < %zu bytes", ws_bytes, need));
+    if (hipSetDevice(device) != hipSuccess) return fail(PF_ERR_DEVICE, "hipSetDevice failed");
+    uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255;
+    Ctx c{s, base, 0, 0, false, nullptr};
+    c.prof = prof.on ? &prof : nullptr;
+    run(c, B, in, is_u8, pg, pl, params);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+    return PF_OK;
+  }
+};
+
+// =========================================================================== C ABI
+namespace {
+int check_device(int device, std::string* err) {
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) { *err = fmt("no HIP device available (%s); libpf_hip has no CPU fallback", hipGetErrorString(e)); return PF_ERR_DEVICE; }
+  if (device < 0 || device >= n) { *err = fmt("device %d out of range (have %d)", device, n); return PF_ERR_ARG; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { *err = "hipGetDeviceProperties failed"; return PF_ERR_DEVICE; }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { *err = fmt("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName); return PF_ERR_DEVICE; }
+  if (hipSetDevice(device) != hipSuccess) { *err = "hipSetDevice failed"; return PF_ERR_DEVICE; }
+  return PF_OK;
+}
+
+struct TmpDev {  // test-entry-point helper: upload host weights, free on scope exit
+  std::vector<void*> p;
+  float* up(const float* h, size_t n) {
+    if (!h) return nullptr;
+    void* d = nullptr;
+    if (hipMalloc(&d, n * 4) != hipSuccess) return nullptr;
+    hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice);
+    p.push_back(d);
+    return static_cast<float*>(d);
+  }
+  float* up(const std::vector<float>& v) { return up(v.data(), v.size()); }
+  void sync_free(hipStream_t s) { hipStreamSynchronize(s); for (void* d : p) hipFree(d); p.clear(); }
+};
+}  // namespace
+
+extern "C" {
+
+const char* pf_version(void) { return "pf_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+const char* pf_last_error(pf_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pf_create(pf_handle* out, int device, int arch) {
+  if (!out) { g_create_error = "pf_create: out is NULL"; return PF_ERR_ARG; }
+  *out = nullptr;
+  if (arch < 0 || arch > 2) { g_create_error = fmt("pf_create: unknown arch %d", arch); return PF_ERR_ARG; }
+  const int rc = check_device(device, &g_create_error);
+  if (rc != PF_OK) return rc;
+  pf_engine* e = new pf_engine();
+  e->device = device;
+  e->arch = arch;
+  *out = e;
+  return PF_OK;
+}
+
+int pf_destroy(pf_handle h) {
+  if (!h) return PF_ERR_ARG;
+  hipSetDevice(h->device);
+  for (void* d : h->dev_allocs) hipFree(d);
+  delete h;
+  return PF_OK;
+}
+
+int pf_load_tensor(pf_handle h, const char* key, const float* data, const int64_t* shape, int rank) {
+  if (!h || !key || (!data && rank > 0) || rank < 0 || rank > 4) return h ? h->fail(PF_ERR_ARG, "pf_load_tensor: bad argument") : PF_ERR_ARG;
+  if (h->finalized) return h->fail(PF_ERR_WEIGHTS, "pf_load_tensor after pf_finalize_weights");
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < rank; ++i) { if (shape[i] <= 0) return h->fail(PF_ERR_ARG, "pf_load_tensor: non-positive dim"); t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  if (data) t.data.assign(data, data + n);
+  h->host[key] = std::move(t);
+  return PF_OK;
+}
+
+int pf_finalize_weights(pf_handle h) {
+  if (!h) return PF_ERR_ARG;
+  if (h->finalized) return h->fail(PF_ERR_WEIGHTS, "weights already finalized");
+  if (hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
+  try {
+    h->build();
+  } catch (const std::string& m) {
+    return h->fail(PF_ERR_WEIGHTS, m);
+  }
+  h->finalized = true;
+  return PF_OK;
+}
+
+int pf_output_info(pf_handle h, int* g, int* l, int* p) {
+  if (!h) return PF_ERR_ARG;
+  const bool cls = h->arch == PF_ARCH_PERSNET_CLS;
+  if (g) *g = cls ? 73 : 2;
+  if (l) *l = cls ? 180 : 1;
+  if (p) *p = cls ? 0 : 5;
+  return PF_OK;
+}
+
+size_t pf_workspace_bytes(pf_handle h, int batch) {
+  if (!h || batch <= 0) return 0;
+  const bool was = h->has_param;
+  if (!h->finalized) {  // architecture-only estimate is allowed before weights are loaded
+    h->has_param = h->arch != PF_ARCH_PERSNET_CLS;
+    h->param_in = h->arch == PF_ARCH_PARAMNET_UNCENTERED ? 64 : NET;
+    for (int s = 0; s < 4; ++s)
+      if (h->stages[s].blocks.empty()) h->stages[s].blocks.resize(MIT_DEPTHS[s]);
+    if (h->has_param)
+      for (int s = 0; s < 4; ++s)
+        if (h->cnx.blocks[s].empty()) h->cnx.blocks[s].resize(CNX_DEPTHS[s]);
+  }
+  const size_t n = h->workspace_bytes(batch);
+  if (!h->finalized) {
+    h->has_param = was;
+    for (int s = 0; s < 4; ++s) { h->stages[s].blocks.clear(); h->cnx.blocks[s].clear(); }
+    h->ws_cache.clear();
+  }
+  return n;
+}
+
+int pf_forward_u8(pf_handle h, int batch, const uint8_t* in, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return PF_ERR_ARG;
+  return h->forward(batch, in, true, pg, pl, params, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+int pf_forward_f32(pf_handle h, int batch, const float* in, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return PF_ERR_ARG;
+  return h->forward(batch, in, false, pg, pl, params, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int pf_postprocess(pf_handle h, const float* pg, const float* pl, int H, int W, float* up, float* lat, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return PF_ERR_ARG;
+  if (!pg || !pl || !up || !lat || H <= 0 || W <= 0) return h->fail(PF_ERR_ARG, "pf_postprocess: bad argument");
+  if (hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->arch == PF_ARCH_PERSNET_CLS) {
+    const size_t need = (size_t)3 * NET * NET * 4 + 256;
+    if (!ws || ws_bytes < need) return h->fail(PF_ERR_WORKSPACE, fmt("pf_postprocess: classification needs %zu workspace bytes", need));
+    float* dg = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    float* dl = dg + 2 * NET * NET;
+    launch_decode_cls(pg, 73, pl, 180, dg, dl, 1, NET * NET, s);
+    launch_postprocess(dg, dl, NET, NET, up, lat, H, W, 0, s);
+  } else {
+    launch_postprocess(pg, pl, NET, NET, up, lat, H, W, 1, s);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return h->fail(PF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+  return PF_OK;
+}
+
+int pf_profile_begin(pf_handle h, unsigned class_mask) {
+  if (!h) return PF_ERR_ARG;
+  h->prof.reset();
+  h->prof.mask = class_mask;
+  h->prof.on = true;
+  return PF_OK;
+}
+
+int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n) {
+  if (!h || n < PC_COUNT) return h ? h->fail(PF_ERR_ARG, "pf_profile_end: arrays must hold PF_PROFILE_CLASSES entries") : PF_ERR_ARG;
+  h->prof.on = false;
+  for (int i = 0; i < n; ++i) { ms[i] = 0; work[i] = 0; launches[i] = 0; }
+  if (hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
+  for (auto& r : h->prof.recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipEventSynchronize failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipEventElapsedTime failed");
+    ms[r.cat] += t; work[r.cat] += r.work; launches[r.cat] += 1;
+  }
+  h->prof.reset();
+  return PF_OK;
+}
+
+// ---- kernel-level entry points -------------------------------------------------------------
+int pf_op_num_conv_tiles(void) { return conv_num_tiles(); }
+const char* pf_op_conv_tile_name(int id) { return conv_tile_name(id); }
+
+int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int W, int C1, int C2, const float* hw, const float* hb,
+                 int Cout, int KH, int KW, int stride, int pad, int act, const float* res1, const float* res2, int post_relu,
+                 int nchw_out, int tile_id, float* y, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  const int Cin = C1 + C2;
+  if (Cin % 4 != 0 || (C2 > 0 && C1 % 32 != 0)) { g_create_error = "pf_op_conv2d: Cin must be a multiple of 4 (pad on the host), C1 of 32 when concatenating"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  ConvParams p;
+  std::vector<float> packed = pack_conv(hw, Cout, Cin, KH, KW, Cin, nullptr, &p.KWC, &p.KWCp);
+  p.w = tmp.up(packed);
+  p.bias = tmp.up(hb, Cout);
+  p.x = x; p.x2 = x2; p.res1 = res1; p.res2 = res2; p.y = y;
+  p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.Cin = Cin;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.Ho = (H + 2 * pad - KH) / stride + 1; p.Wo = (W + 2 * pad - KW) / stride + 1;
+  p.Cout = Cout; p.M = B * p.Ho * p.Wo; p.act = act; p.post_relu = post_relu; p.ldy = Cout; p.nchw_out = nchw_out;
+  launch_conv_tile(p, tile_id, s);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_layernorm(int device, const float* x, const float* hg, const float* hbeta, float* y, long rows, int C, float eps, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  launch_layernorm(x, tmp.up(hg, C), tmp.up(hbeta, C), y, rows, C, eps, s);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_dwconv3x3_gelu(int device, const float* x, const float* hw, const float* hb, float* y, int B, int H, int W, int C, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (C % 128 != 0) { g_create_error = "pf_op_dwconv3x3_gelu: C must be a multiple of 128"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  launch_dwconv3x3_gelu(x, tmp.up(pack_dw(hw, C, 3)), tmp.up(hb, C), y, B, H, W, C, s);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_dwconv7x7(int device, const float* x, const float* hw, const float* hb, float* y, int B, int H, int W, int C, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (C % 96 != 0) { g_create_error = "pf_op_dwconv7x7: C must be a multiple of 96"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  launch_dwconv7x7(x, tmp.up(pack_dw(hw, C, 7)), tmp.up(hb, C), y, B, H, W, C, s);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_sr_attention(int device, const float* q, const float* kv, float* out, int B, int N, int M, int heads, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (M <= 0 || M > 128) { g_create_error = "pf_op_sr_attention: kv length must be in 1..128"; return PF_ERR_ARG; }
+  launch_sr_attention(q, kv, out, B, N, M, heads, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+}
+
+int pf_op_upsample2x(int device, const float* x, float* y, int B, int H, int W, int C, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  launch_upsample2x(x, y, B, H, W, C, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+}
+
+}  // extern "C"

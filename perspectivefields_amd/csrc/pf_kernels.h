@@ -1,0 +1,80 @@
+// Internal kernel-launcher interface of libpf_hip.so (gfx950 / CDNA4 only).
+// All activations are NHWC fp32 in HBM; "tokens (B,N,C)" of the reference's MiT
+// blocks are the same memory as NHWC maps, so none of the reference's ~200
+// NCHW<->NLC round trips (mix_transformers.py:117-118,246,458,504-506) exist here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pf {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+// Implicit-GEMM convolution / GEMM on v_mfma_f32_32x32x2_f32.
+//   y[m][n] = post( act( sum_k A[m][k] * Wp[n][k] + bias[n] ) + res1[m][n] + res2[m][n] )
+// m = (b, oy, ox) output pixel, k = (ky, kx, ci) with ci fastest, A gathered on the fly
+// from one NHWC tensor or from the channel-concat of two (x: C1 channels, x2: C2).
+struct ConvParams {
+  const float* x;
+  const float* x2;    // nullptr unless channel-concat input
+  const float* w;     // packed [Cout][KH][KWCp], KWCp = roundup(KW*Cin, 32), zero padded
+  const float* bias;  // [Cout] or nullptr
+  const float* res1;  // [M][Cout] or nullptr (may alias y)
+  const float* res2;  // [M][Cout] or nullptr
+  float* y;           // [M][ldy] rows, written at column offset 0..Cout-1
+  int B, H, W, C1, C2, Cin;
+  int KH, KW, stride, pad;
+  int Ho, Wo, Cout;
+  int KWC, KWCp;
+  int M;
+  int act;        // Act applied to (acc + bias)
+  int post_relu;  // relu after the residual adds
+  int ldy;        // row stride of y / res1 / res2 in floats (normally Cout)
+  int nchw_out;   // 1: store y as [B][Cout][Ho*Wo] (API-visible logits), residuals unsupported
+};
+
+void launch_conv(const ConvParams& p, hipStream_t s);
+// tile choice is exposed for tests / tuning: -1 = auto
+void launch_conv_tile(const ConvParams& p, int tile_id, hipStream_t s);
+int conv_num_tiles();
+const char* conv_tile_name(int tile_id);
+
+// rows x C LayerNorm (biased variance), y may alias x
+void launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps, hipStream_t s);
+
+// depthwise 3x3 (pad 1) + bias + exact-erf GELU, NHWC, w packed [9][C]
+void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
+// depthwise 7x7 (pad 3) + bias, NHWC, w packed [49][C]
+void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
+
+// spatial-reduction attention: q [B][N][C], kv [B][M][2C] (k | v), out [B][N][C]; head_dim 64, M <= 128
+void launch_sr_attention(const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s);
+
+// bilinear x2 (align_corners=False), NHWC
+void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
+
+// input normalisation: uint8 NHWC BGR [B][320][320][3] or fp32 NCHW [B][3][320][320] -> fp32 NHWC4 (x-mean)/std, ch3=0
+void launch_prep_u8(const uint8_t* in, float* out, long npix, const float* mean3, const float* std3, hipStream_t s);
+void launch_prep_f32_nchw(const float* in, float* out, int B, int HW, const float* mean3, const float* std3, hipStream_t s);
+
+// regression prediction heads: 1x1 (32->2) + L2-normalise, 1x1 (32->1) + clamp; writes NCHW API outputs and the NHWC4 ParamNet input
+void launch_pred_regression(const float* tg, const float* tl, const float* wg, const float* bg, const float* wl, const float* bl,
+                            float* pred_g_nchw, float* pred_l_nchw, float* pn_in_nhwc4, int B, int HW, hipStream_t s);
+
+// classification decode: argmax over channels of NCHW logits -> decoded fields (gravity (2,HW), latitude degrees (1,HW))
+void launch_decode_cls(const float* logit_g, int ng, const float* logit_l, int nl, float* dec_g, float* dec_l, int B, int HW, hipStream_t s);
+
+// post-process one image: gravity (2,h,w)*scale -> bilinear (H,W) -> normalise; latitude bilinear -> (asin->deg)
+void launch_postprocess(const float* g2, const float* l1, int h, int w, float* up_out, float* lat_out, int H, int W, int lat_is_sin, hipStream_t s);
+
+// nearest resize NHWC4 (ParamNetConvNextRegress input, param_network.py:197)
+void launch_nearest_nhwc4(const float* x, float* y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
+
+// ConvNeXt tail: global average pool -> LN(C) -> Linear(C->nout); out [B][nout]
+void launch_gap_ln_head(const float* x, const float* g, const float* b, const float* w, const float* hb, float* out, int B, int HW, int C, int nout, float eps, hipStream_t s);
+
+// ParamNet scalar formulas (param_network.py:62-67): raw [B][nraw] -> [B][8] (layout: include/pf_hip.h)
+void launch_paramnet_scalars(const float* raw, int nraw, float* out8, int B, int mode, hipStream_t s);
+
+}  // namespace pf

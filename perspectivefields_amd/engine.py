@@ -1,0 +1,225 @@
+"""ctypes binding of libpf_hip.so (include/pf_hip.h) -- the only compute path.
+
+PyTorch is used for device memory and stream ownership only: tensors are allocated with
+torch, their raw device pointers and torch's current HIP stream are handed to the C ABI.
+There is NO fallback: a missing library, a missing GPU or a non-gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpf_hip.so")
+NET = 320
+PARAMS_STRIDE = 8
+
+PF_OK = 0
+_STATUS = {0: "PF_OK", -1: "PF_ERR_ARG", -2: "PF_ERR_DEVICE", -3: "PF_ERR_WEIGHTS", -4: "PF_ERR_WORKSPACE"}
+
+# every symbol include/pf_hip.h declares: name -> (restype, argtypes)
+_c = ctypes
+_P = _c.c_void_p
+_SIGNATURES = {
+    "pf_version": (_c.c_char_p, []),
+    "pf_last_error": (_c.c_char_p, [_P]),
+    "pf_create": (_c.c_int, [_c.POINTER(_P), _c.c_int, _c.c_int]),
+    "pf_destroy": (_c.c_int, [_P]),
+    "pf_load_tensor": (_c.c_int, [_P, _c.c_char_p, _P, _c.POINTER(_c.c_int64), _c.c_int]),
+    "pf_finalize_weights": (_c.c_int, [_P]),
+    "pf_output_info": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "pf_workspace_bytes": (_c.c_size_t, [_P, _c.c_int]),
+    "pf_forward_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_forward_f32": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_postprocess": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_profile_begin": (_c.c_int, [_P, _c.c_uint]),
+    "pf_profile_end": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.c_int]),
+    "pf_op_conv2d": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P,
+                                _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_int,
+                                _c.c_int, _c.c_int, _P, _P]),
+    "pf_op_layernorm": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_long, _c.c_int, _c.c_float, _P]),
+    "pf_op_dwconv3x3_gelu": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "pf_op_dwconv7x7": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "pf_op_sr_attention": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "pf_op_upsample2x": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "pf_op_num_conv_tiles": (_c.c_int, []),
+    "pf_op_conv_tile_name": (_c.c_char_p, [_c.c_int]),
+}
+
+_lib = None
+
+
+class PfError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libpf_hip.so and bind every declared symbol.  Raises if the library has
+    not been built (run `python -m perspectivefields_amd.build` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise PfError(
+            f"{p} not found: the HIP extension is not built and there is no CPU fallback. "
+            "Build it with `python -m perspectivefields_amd.build` (needs hipcc)."
+        )
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI drift between header and library
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def declared_symbols():
+    return list(_SIGNATURES)
+
+
+def _stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(rc: int, handle=None, what: str = ""):
+    if rc != PF_OK:
+        lib = load_library()
+        msg = lib.pf_last_error(handle)
+        raise PfError(f"{what}: {_STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+
+def _dev_index(device) -> int:
+    import torch
+
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise PfError(f"the PerspectiveFields HIP engine needs a GPU device, got '{d}' (no CPU fallback)")
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+class Engine:
+    """One network (architecture + weights) resident on one GPU."""
+
+    def __init__(self, arch_id: int, device):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise PfError("no GPU visible to PyTorch-ROCm: the HIP engine cannot run (no CPU fallback)")
+        self.lib = load_library()
+        self.device = torch.device("cuda", _dev_index(device))
+        self.arch_id = arch_id
+        self._h = ctypes.c_void_p()
+        _check(self.lib.pf_create(ctypes.byref(self._h), self.device.index, arch_id), None, "pf_create")
+        self._ws = None
+        self._finalized = False
+        g, l, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.lib.pf_output_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(p))
+        self.gravity_channels, self.latitude_channels, self.param_outputs = g.value, l.value, p.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self.lib.pf_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- weights
+    def load_state_dict(self, state_dict: Dict[str, object]):
+        """Strict load of a reference-format state_dict (values: numpy arrays or torch tensors)."""
+        for key, val in state_dict.items():
+            arr = val.detach().cpu().numpy() if hasattr(val, "detach") else np.asarray(val)
+            if key.endswith("num_batches_tracked"):
+                arr = np.zeros((), dtype=np.float32)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (ctypes.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            _check(
+                self.lib.pf_load_tensor(self._h, key.encode(), arr.ctypes.data_as(ctypes.c_void_p), shape, arr.ndim),
+                self._h, f"pf_load_tensor({key})",
+            )
+        _check(self.lib.pf_finalize_weights(self._h), self._h, "pf_finalize_weights")
+        self._finalized = True
+
+    # ---------------------------------------------------------------- forward
+    def workspace_bytes(self, batch: int) -> int:
+        return int(self.lib.pf_workspace_bytes(self._h, batch))
+
+    def _workspace(self, nbytes: int):
+        import torch
+
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, images) -> Tuple[object, object, Optional[object]]:
+        """images: uint8 (B,320,320,3) BGR or float32 (B,3,320,320) BGR 0..255, on self.device.
+        Returns (pred_gravity (B,Cg,320,320), pred_latitude (B,Cl,320,320), params (B,8) or None)."""
+        import torch
+
+        if images.device != self.device:
+            raise PfError(f"input on {images.device}, engine on {self.device}")
+        images = images.contiguous()
+        B = images.shape[0]
+        if images.dtype == torch.uint8:
+            if tuple(images.shape[1:]) != (NET, NET, 3):
+                raise PfError(f"uint8 input must be (B,{NET},{NET},3), got {tuple(images.shape)}")
+            fn = self.lib.pf_forward_u8
+        elif images.dtype == torch.float32:
+            if tuple(images.shape[1:]) != (3, NET, NET):
+                raise PfError(f"float32 input must be (B,3,{NET},{NET}), got {tuple(images.shape)}")
+            fn = self.lib.pf_forward_f32
+        else:
+            raise PfError(f"unsupported input dtype {images.dtype}")
+        with torch.cuda.device(self.device):
+            pg = torch.empty((B, self.gravity_channels, NET, NET), dtype=torch.float32, device=self.device)
+            pl = torch.empty((B, self.latitude_channels, NET, NET), dtype=torch.float32, device=self.device)
+            params = torch.empty((B, PARAMS_STRIDE), dtype=torch.float32, device=self.device) if self.param_outputs else None
+            need = self.workspace_bytes(B)
+            ws = self._workspace(need)
+            rc = fn(
+                self._h, B, images.data_ptr(), pg.data_ptr(), pl.data_ptr(),
+                params.data_ptr() if params is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr(),
+            )
+        _check(rc, self._h, "pf_forward")
+        return pg, pl, params
+
+    PROFILE_CLASSES = ("igemm", "attention", "layernorm", "dwconv3x3_gelu", "dwconv7x7", "upsample2x", "other")
+
+    def profile_begin(self, classes=None):
+        mask = 0
+        for i, n in enumerate(self.PROFILE_CLASSES):
+            if classes is None or n in classes:
+                mask |= 1 << i
+        _check(self.lib.pf_profile_begin(self._h, mask), self._h, "pf_profile_begin")
+
+    def profile_end(self) -> Dict[str, dict]:
+        n = len(self.PROFILE_CLASSES)
+        ms, work, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_long * n)()
+        _check(self.lib.pf_profile_end(self._h, ms, work, cnt, n), self._h, "pf_profile_end")
+        return {name: {"ms": ms[i], "work": work[i], "launches": cnt[i]} for i, name in enumerate(self.PROFILE_CLASSES)}
+
+    def postprocess(self, pred_gravity_i, pred_latitude_i, height: int, width: int):
+        """One image: (Cg,320,320), (Cl,320,320) -> (2,H,W) unit up-vectors, (H,W) degrees."""
+        import torch
+
+        with torch.cuda.device(self.device):
+            up = torch.empty((2, height, width), dtype=torch.float32, device=self.device)
+            lat = torch.empty((height, width), dtype=torch.float32, device=self.device)
+            ws_ptr, ws_n = None, 0
+            if self.gravity_channels != 2:
+                ws = self._workspace(max(3 * NET * NET * 4 + 512, self._ws.numel() if self._ws is not None else 0))
+                ws_ptr, ws_n = ws.data_ptr(), ws.numel()
+            rc = self.lib.pf_postprocess(
+                self._h, pred_gravity_i.data_ptr(), pred_latitude_i.data_ptr(), int(height), int(width),
+                up.data_ptr(), lat.data_ptr(), ws_ptr, ws_n, _stream_ptr(),
+            )
+        _check(rc, self._h, "pf_postprocess")
+        return up, lat

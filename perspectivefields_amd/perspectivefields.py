@@ -1,0 +1,214 @@
+"""Drop-in replacement for `perspective2d.PerspectiveFields` on MI355X.
+
+Same surface as the reference class (perspective2d/perspectivefields.py:121-272):
+`PerspectiveFields(version).eval().cuda()`, `.inference(img_bgr)`,
+`.inference_batch(img_bgr_list)`, `.forward(batched_inputs)`, `.versions()`, attributes
+`.version`, `.param_on`, `.cfg`, `.device`, module-level `model_zoo`; both entry points
+run under no_grad and never mutate their inputs; the returned dicts have the reference's
+keys, key order, shapes, dtypes (fp32) and units.
+
+What differs by design: the nn.Module tree is replaced by one HIP engine (libpf_hip.so
+through include/pf_hip.h); the checkpoint is validated strictly (the reference loads with
+strict=False, :185,192); there is no network, so weights come from a local file, a
+state_dict, or the seeded synthetic generator.  No CPU path exists: forward() on a CPU
+device raises.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import torch
+from PIL import Image
+from torch import nn
+
+from . import config as _config
+from .config import NET_H, NET_W, arch_of, get_cfg, model_zoo
+from .engine import Engine, PfError
+from .schema import checkpoint_schema, validate_state_dict
+from .synth import synthetic_state_dict
+
+
+class ResizeTransform:
+    """uint8 HxWx3 -> 320x320x3 with PIL's antialiased BILINEAR, aspect ratio not kept
+    (reference: ResizeTransform.apply_image, perspectivefields.py:34-46)."""
+
+    def __init__(self, new_h: int, new_w: int, interp=None):
+        self.new_h, self.new_w = new_h, new_w
+        self.interp = Image.BILINEAR if interp is None else interp
+
+    def apply_image(self, img: np.ndarray, interp=None) -> np.ndarray:
+        if img.dtype != np.uint8:
+            raise TypeError("PerspectiveFields expects uint8 BGR images (as cv2.imread returns)")
+        method = interp if interp is not None else self.interp
+        return np.asarray(Image.fromarray(img).resize((self.new_w, self.new_h), method))
+
+
+def _resolve_weights(version: str, weights) -> Dict[str, np.ndarray]:
+    """weights: None | 'synthetic' | 'synthetic:<seed>' | path | state_dict | {'model': state_dict}."""
+    if isinstance(weights, str) and weights.startswith("synthetic"):
+        seed = int(weights.split(":", 1)[1]) if ":" in weights else 0
+        return synthetic_state_dict(version, seed)
+    if isinstance(weights, dict):
+        sd = weights["model"] if "model" in weights and isinstance(weights["model"], dict) else weights
+        return OrderedDict(sd)
+    path = weights
+    if path is None:
+        fname = os.path.basename(model_zoo[version]["weights"])
+        candidates = []
+        if os.environ.get("PF_WEIGHTS_DIR"):
+            candidates.append(os.path.join(os.environ["PF_WEIGHTS_DIR"], fname))
+        candidates.append(os.path.join(torch.hub.get_dir(), "checkpoints", fname))
+        path = next((c for c in candidates if os.path.exists(c)), None)
+        if path is None:
+            raise FileNotFoundError(
+                f"no local checkpoint for '{version}' (looked for {candidates}); this build has no network access. "
+                f"Download {model_zoo[version]['weights']} elsewhere and point PF_WEIGHTS_DIR at it, pass weights=<path|state_dict>, "
+                "or weights='synthetic' for the seeded random checkpoint used by tests and benchmarks."
+            )
+    ckpt = torch.load(path, map_location="cpu")
+    return OrderedDict(ckpt["model"] if "model" in ckpt else ckpt)
+
+
+class PerspectiveFields(nn.Module):
+    def __init__(self, version: str = "Paramnet-360Cities-edina-centered", weights=None):
+        super().__init__()
+        cfg = get_cfg(version)  # KeyError on an unknown version, as the reference (:127)
+        self.version = version
+        self.param_on = model_zoo[version]["param"]
+        self.cfg = cfg
+        self.arch = arch_of(cfg)
+        self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
+        self.input_format = cfg.INPUT.FORMAT
+        self.aug = ResizeTransform(cfg.DATALOADER.RESIZE[0], cfg.DATALOADER.RESIZE[1])
+        self._engine: Optional[Engine] = None
+        self._state: Dict[str, np.ndarray] = OrderedDict()
+        self._init_weights(weights)
+
+    # -------------------------------------------------------------- reference surface
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    @staticmethod
+    def versions():
+        for key in model_zoo:
+            print(f"{key}")
+            print(f"   - {model_zoo[key]['description']}")
+
+    def _init_weights(self, weights=None):
+        sd = _resolve_weights(self.version, weights)
+        self.load_state_dict(sd)
+
+    def state_dict(self, *args, **kwargs):  # checkpoint-format view (host copies)
+        return OrderedDict((k, torch.as_tensor(np.asarray(v))) for k, v in self._state.items())
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        sd = state_dict["model"] if "model" in state_dict and isinstance(state_dict["model"], dict) else state_dict
+        host = OrderedDict()
+        for k, v in sd.items():
+            host[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        validate_state_dict(self.version, host)  # always strict: silent partial loads are a reference bug source
+        self._state = host
+        self._engine = None
+        return self
+
+    def _get_engine(self) -> Engine:
+        dev = self.device
+        if dev.type != "cuda":
+            raise PfError(
+                f"PerspectiveFields is on '{dev}': the MI355X engine has no CPU path. Call .cuda() / .to('cuda:N') first."
+            )
+        if self._engine is None or self._engine.device != dev:
+            eng = Engine(self.arch["arch_id"], dev)
+            eng.load_state_dict(self._state)
+            self._engine = eng
+        return self._engine
+
+    @torch.no_grad()
+    def inference(self, img_bgr: np.ndarray) -> dict:
+        return self.inference_batch([img_bgr])[0]
+
+    @torch.no_grad()
+    def inference_batch(self, img_bgr_list: List[np.ndarray]) -> List[dict]:
+        sizes, resized = [], []
+        for img_bgr in img_bgr_list:
+            original = img_bgr  # never mutated: apply_image returns a new array (reference copies, :196,211)
+            if self.input_format == "RGB":
+                original = original[:, :, ::-1]
+            sizes.append(tuple(int(v) for v in original.shape[:2]))
+            resized.append(self.aug.apply_image(np.ascontiguousarray(original)))
+        batch = torch.from_numpy(np.stack(resized)).to(self.device, non_blocking=False)  # uint8 (B,320,320,3)
+        return self._run(batch, sizes)
+
+    def forward(self, batched_inputs) -> List[dict]:
+        """batched_inputs: list of {"image": (3,320,320) float BGR 0..255, "height", "width"} (reference :223-272)."""
+        with torch.no_grad():
+            imgs = torch.stack([x["image"].to(self.device, dtype=torch.float32) for x in batched_inputs])
+            sizes = [(int(x.get("height")), int(x.get("width"))) for x in batched_inputs]
+            return self._run(imgs, sizes)
+
+    # -------------------------------------------------------------------- engine path
+    def _run(self, batch, sizes) -> List[dict]:
+        eng = self._get_engine()
+        pg, pl, params = eng.forward(batch)
+        results = []
+        for i, (h, w) in enumerate(sizes):
+            up, lat = eng.postprocess(pg[i], pl[i], h, w)
+            results.append(
+                {
+                    "pred_gravity": pg[i],
+                    "pred_gravity_original": up,
+                    "pred_latitude": pl[i],
+                    "pred_latitude_original": lat,
+                    "pred_latitude_original_mode": "deg",
+                }
+            )
+        if params is not None:
+            for i, extra in enumerate(self._param_dicts(params)):
+                results[i].update(extra)
+        return results
+
+    def _param_dicts(self, params) -> List[dict]:
+        """(B,8) engine output -> the reference's per-image scalar dict entries
+        (param_network.py:54-69 / 199-221 and perspectivefields.py:260-271)."""
+        B = params.shape[0]
+        if self.arch["param_net"] == "ParamNet":
+            zeros = torch.zeros(B, dtype=torch.float32, device=params.device)
+            cols = OrderedDict(
+                pred_roll=params[:, 0], pred_pitch=params[:, 1], pred_vfov=params[:, 2], pred_rel_focal=params[:, 3],
+                pred_general_vfov=params[:, 2], pred_rel_cx=zeros, pred_rel_cy=zeros,
+            )
+            return [{k: v[i] for k, v in cols.items()} for i in range(B)]
+        # ParamNetConvNextRegress: factors per predicted parameter, then rel_focal from general_vfov on the host
+        factors = {"roll": 90.0, "pitch": 90.0, "vfov": 90.0, "rel_focal": 1.0, "rel_cx": 1.0, "rel_cy": 1.0, "general_vfov": 90.0}
+        cols = OrderedDict()
+        for j, key in enumerate(self.arch["predict_params"]):
+            cols["pred_" + key] = params[:, j] * factors[key]
+        if "pred_rel_focal" not in cols:
+            cols["pred_rel_focal"] = torch.from_numpy(
+                general_vfov_to_focal(
+                    cols["pred_rel_cx"].double().cpu().numpy(), cols["pred_rel_cy"].double().cpu().numpy(),
+                    cols["pred_general_vfov"].double().cpu().numpy(),
+                ).astype(np.float32)
+            )
+        return [{k: v[i] for k, v in cols.items()} for i in range(B)]
+
+
+def general_vfov_to_focal(rel_cx, rel_cy, gvfov_deg):
+    """Relative focal length from the general vertical FoV (reference: utils/utils.py:47-91 with h=1,
+    degree=True).  With u = f^2 + cx^2 + cy^2 + 1/4 the reference's equation
+    cos(gvfov) = (u - 1/2) / sqrt(u^2 - cy^2) is a quadratic in u, solved here in closed form
+    (the reference runs scipy.fsolve from 1.5 on the same equation and returns |f|)."""
+    cx = np.asarray(rel_cx, dtype=np.float64)
+    cy = np.asarray(rel_cy, dtype=np.float64)
+    c = np.cos(np.radians(np.asarray(gvfov_deg, dtype=np.float64)))
+    s2 = 1.0 - c * c
+    disc = np.sqrt(np.maximum(1.0 - 4.0 * s2 * (c * c * cy * cy + 0.25), 0.0))
+    # root selection: cos > 0 needs u > 1/2 -> '+' root; cos < 0 (gvfov > 90 deg) -> '-' root
+    u = np.where(c >= 0, (1.0 + disc), (1.0 - disc)) / (2.0 * s2)
+    f2 = u - cy * cy - 0.25 - cx * cx
+    return np.sqrt(np.abs(f2))

@@ -1,0 +1,152 @@
+"""End-to-end parity (-m gpu): the drop-in PerspectiveFields class on the HIP engine against
+(a) golden vectors of the unmodified reference, (b) the CPU oracle run live on the same inputs.
+Tolerances are BASELINE.json's: up-vector 1-cos <= 1e-3, latitude L1 <= 1e-3, ParamNet |delta| <= 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pf_oracle
+from perspectivefields_amd.config import arch_of, get_cfg
+from perspectivefields_amd.synth import synthetic_image, synthetic_state_dict, to_torch
+from tests.parity import TOL_PARAM, assert_fields_close, l1, one_minus_cos
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "centered": "Paramnet-360Cities-edina-centered",
+    "persnet": "PersNet-360Cities",
+    "uncentered": "Paramnet-360Cities-edina-uncentered",
+}
+_models = {}
+
+
+def model(tag):
+    if tag not in _models:
+        from perspectivefields_amd import PerspectiveFields
+
+        _models[tag] = PerspectiveFields(CASES[tag], weights="synthetic:0").eval().cuda()
+    return _models[tag]
+
+
+def _golden_inputs(g):
+    batched = []
+    for i in range(2):
+        img = torch.as_tensor(g[f"in_u8_{i}"].astype("float32").transpose(2, 0, 1))
+        h, w = (int(v) for v in g[f"size_{i}"])
+        batched.append({"image": img, "height": h, "width": w})
+    return batched
+
+
+@pytest.mark.parametrize("tag", ["centered", "uncentered"])
+def test_regression_vs_golden(tag, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"{tag}.npz"))
+    m = model(tag)
+    res = m.forward(_golden_inputs(g))
+    names = [str(n) for n in g["param_names"]]
+    for i, r in enumerate(res):
+        pg, pl = r["pred_gravity"].cpu().numpy(), r["pred_latitude"].cpu().numpy()
+        assert pg.shape == (2, 320, 320) and pl.shape == (1, 320, 320)
+        c, e = assert_fields_close(pg[:, ::2, ::2], g[f"grav_s2_{i}"], pl[:, ::2, ::2], g[f"lat_s2_{i}"], f"{tag} img{i} 320^2")
+        c2, e2 = assert_fields_close(
+            r["pred_gravity_original"].cpu().numpy(), g[f"grav_orig_{i}"],
+            r["pred_latitude_original"].cpu().numpy(), g[f"lat_orig_{i}"], f"{tag} img{i} original",
+        )
+        got = np.array([float(r[n]) for n in names])
+        d = np.abs(got - g[f"params_{i}"])
+        print(f"[{tag} img{i}] 1-cos {c:.2e}/{c2:.2e} latL1 {e:.2e}/{e2:.2e} param max|d| {d.max():.2e}")
+        assert d.max() <= TOL_PARAM, dict(zip(names, d))
+        assert r["pred_latitude_original_mode"] == "deg"
+
+
+def test_key_order_and_types():
+    m = model("centered")
+    r = m.inference(synthetic_image(120, 90, 3))
+    assert list(r.keys()) == [
+        "pred_gravity", "pred_gravity_original", "pred_latitude", "pred_latitude_original", "pred_latitude_original_mode",
+        "pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal", "pred_general_vfov", "pred_rel_cx", "pred_rel_cy",
+    ]
+    assert r["pred_gravity_original"].shape == (2, 120, 90) and r["pred_latitude_original"].shape == (120, 90)
+    assert r["pred_roll"].dim() == 0 and r["pred_roll"].dtype == torch.float32 and r["pred_roll"].is_cuda
+    assert float(r["pred_rel_cx"]) == 0.0 and float(r["pred_general_vfov"]) == float(r["pred_vfov"])
+
+
+def test_persnet_vs_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "persnet.npz"))
+    m = model("persnet")
+    res = m.forward(_golden_inputs(g))
+    for i, r in enumerate(res):
+        assert list(r.keys()) == ["pred_gravity", "pred_gravity_original", "pred_latitude", "pred_latitude_original", "pred_latitude_original_mode"]
+        pg, pl = r["pred_gravity"], r["pred_latitude"]
+        assert pg.shape == (73, 320, 320) and pl.shape == (180, 320, 320)
+        np.testing.assert_allclose(pg[:, 8::16, 8::16].cpu().numpy(), g[f"grav_logit_g_{i}"], atol=3e-4, rtol=2e-4)
+        np.testing.assert_allclose(pl[:, 8::16, 8::16].cpu().numpy(), g[f"lat_logit_g_{i}"], atol=3e-4, rtol=2e-4)
+        fg = float((pg.argmax(0).cpu().numpy() != g[f"grav_argmax_{i}"]).mean())
+        fl = float((pl.argmax(0).cpu().numpy() != g[f"lat_argmax_{i}"]).mean())
+        print(f"[persnet img{i}] argmax mismatch fraction gravity {fg:.2e} latitude {fl:.2e}")
+        assert fg <= 2e-3 and fl <= 2e-3
+        d = np.abs(r["pred_latitude_original"].cpu().numpy() - g[f"lat_orig_{i}"])
+        assert np.mean(d > 1e-3) <= 5e-3
+        c = one_minus_cos(r["pred_gravity_original"].cpu().numpy(), g[f"grav_orig_{i}"])
+        assert np.mean(c > 1e-3) <= 5e-3
+
+
+def test_vs_live_oracle_u8_path():
+    """inference_batch (PIL resize + uint8 entry point) vs the oracle on mixed-resolution inputs."""
+    tag = "centered"
+    m = model(tag)
+    imgs = [synthetic_image(h, w, seed=40 + i) for i, (h, w) in enumerate([(64, 64), (48, 80), (100, 60)])]
+    keep = [im.copy() for im in imgs]
+    res = m.inference_batch(imgs)
+    assert all((a == b).all() for a, b in zip(imgs, keep)), "inputs must not be mutated"
+    arch = arch_of(get_cfg(CASES[tag]))
+    with torch.no_grad():
+        ref = pf_oracle.inference_batch(to_torch(synthetic_state_dict(CASES[tag], 0)), arch, imgs)
+    for i, (r, o) in enumerate(zip(res, ref)):
+        assert_fields_close(r["pred_gravity"].cpu().numpy(), o["pred_gravity"].numpy(), r["pred_latitude"].cpu().numpy(), o["pred_latitude"].numpy(), f"img{i} 320")
+        assert_fields_close(r["pred_gravity_original"].cpu().numpy(), o["pred_gravity_original"].numpy(),
+                            r["pred_latitude_original"].cpu().numpy(), o["pred_latitude_original"].numpy(), f"img{i} orig")
+        for k in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"):
+            assert abs(float(r[k]) - float(o[k])) <= TOL_PARAM, (k, float(r[k]), float(o[k]))
+
+
+def test_full_size_properties():
+    """BASELINE-size batch (B=8, 640x640): size-independent properties instead of an oracle run."""
+    m = model("centered")
+    imgs = [synthetic_image(640, 640, seed=60 + i) for i in range(8)]
+    res = m.inference_batch(imgs)
+    res2 = m.inference_batch(imgs)
+    single = m.inference(imgs[3])
+    for i, r in enumerate(res):
+        up, lat = r["pred_gravity_original"], r["pred_latitude_original"]
+        assert up.shape == (2, 640, 640) and lat.shape == (640, 640)
+        nrm = torch.linalg.vector_norm(up, dim=0)
+        assert float((nrm - 1).abs().max()) < 1e-5, "up-vectors must be unit norm"
+        assert float(lat.abs().max()) <= 90.0 + 1e-4
+        assert torch.isfinite(up).all() and torch.isfinite(lat).all()
+        assert float((torch.linalg.vector_norm(r["pred_gravity"], dim=0) - 1).abs().max()) < 1e-5
+        assert float(r["pred_latitude"].abs().max()) <= 1.0
+        # determinism: same launch sequence, same bits
+        assert torch.equal(up, res2[i]["pred_gravity_original"]) and torch.equal(lat, res2[i]["pred_latitude_original"])
+        assert float(r["pred_roll"]) == float(res2[i]["pred_roll"])
+    # batch independence (images are independent units; the multi-GPU sharding relies on it)
+    c = one_minus_cos(res[3]["pred_gravity_original"].cpu().numpy(), single["pred_gravity_original"].cpu().numpy())
+    assert c.max() <= 1e-6
+    assert l1(res[3]["pred_latitude_original"].cpu().numpy(), single["pred_latitude_original"].cpu().numpy()) <= 1e-5
+    assert abs(float(res[3]["pred_roll"]) - float(single["pred_roll"])) <= 1e-5
+
+
+def test_errors_are_loud():
+    from perspectivefields_amd import PerspectiveFields
+    from perspectivefields_amd.engine import PfError
+
+    with pytest.raises(KeyError):
+        PerspectiveFields("no-such-version", weights="synthetic")
+    bad = synthetic_state_dict(CASES["centered"], 0)
+    bad.pop("backbone.block3.7.attn.sr.bias")
+    with pytest.raises(ValueError):
+        PerspectiveFields(CASES["centered"], weights=bad)
+    cpu_model = PerspectiveFields(CASES["centered"], weights="synthetic")
+    with pytest.raises(PfError):
+        cpu_model.inference(synthetic_image(32, 32, 1))

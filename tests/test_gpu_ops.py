@@ -1,0 +1,192 @@
+"""Kernel-level parity (-m gpu): every HIP kernel of libpf_hip.so, called through the C ABI
+(pf_op_*), against the CPU oracle's formulation of the same op in float64.
+Tolerance: fp32 accumulation error, |err| <= 2e-5 * (1 + |ref|) * sqrt(K/64)-ish; stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import pf_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from perspectivefields_amd import ops as _ops
+
+    return _ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float32) * scale)
+
+
+def _close(got, ref, tol, what):
+    got = got.double().cpu()
+    ref = ref.double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs()
+    bound = tol * (1.0 + ref.abs())
+    worst = float((err / bound).max())
+    assert worst <= 1.0, f"{what}: max err {float(err.max()):.3e} (ratio to bound {worst:.2f}), ref scale {float(ref.abs().max()):.3e}"
+
+
+def _ref_conv(x_nhwc, w, b, stride, pad, x2=None):
+    x = x_nhwc if x2 is None else torch.cat([x_nhwc, x2], dim=-1)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), None if b is None else b.double(), stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+CONV_CASES = [
+    # name, B, H, W, C1, C2, Cout, K, stride, pad
+    ("head3x3_64_32", 2, 20, 24, 64, 0, 32, 3, 1, 1),
+    ("rcu3x3_256", 1, 10, 10, 256, 0, 256, 3, 1, 1),
+    ("proc3x3_768", 1, 10, 12, 768, 0, 256, 3, 1, 1),
+    ("cat3x3_256+64", 1, 16, 16, 256, 64, 64, 3, 1, 1),
+    ("patch7x7s4_c4", 2, 64, 64, 4, 0, 64, 7, 4, 3),
+    ("ll7x7s2_c4", 1, 40, 40, 4, 0, 64, 7, 2, 3),
+    ("patch3x3s2", 1, 20, 20, 64, 0, 128, 3, 2, 1),
+    ("sr8x8s8", 1, 80, 80, 64, 0, 64, 8, 8, 0),
+    ("sr2x2s2_320", 1, 20, 20, 320, 0, 320, 2, 2, 0),
+    ("stem4x4s4_c4", 1, 32, 32, 4, 0, 96, 4, 4, 0),
+    ("ds2x2s2_96", 1, 20, 20, 96, 0, 192, 2, 2, 0),
+    ("odd_sizes", 3, 7, 5, 32, 0, 40, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_all_tiles(ops, case):
+    name, B, H, W, C1, C2, Cout, K, stride, pad = case
+    x = _rand((B, H, W, C1), 1)
+    x2 = _rand((B, H, W, C2), 2) if C2 else None
+    if C1 == 4:
+        x[..., 3] = 0  # padded channel of the 3-channel inputs
+    w = _rand((Cout, C1 + C2, K, K), 3, 1.0 / math.sqrt((C1 + C2) * K * K))
+    b = _rand((Cout,), 4, 0.1)
+    ref = _ref_conv(x, w, b, stride, pad, x2)
+    xd = x.cuda()
+    x2d = x2.cuda() if x2 is not None else None
+    for tile in [-1] + list(range(len(ops.conv_tiles()))):
+        got = ops.conv2d(xd, w, b, stride=stride, pad=pad, x2=x2d, tile=tile)
+        _close(got, ref, 2e-5, f"{name} tile {tile}")
+
+
+def test_conv2d_epilogues(ops):
+    B, H, W, C = 2, 12, 12, 256
+    x = _rand((B, H, W, C), 5)
+    w = _rand((C, C, 3, 3), 6, 1.0 / math.sqrt(C * 9))
+    b = _rand((C,), 7, 0.1)
+    r1 = _rand((B, H, W, C), 8)
+    r2 = _rand((B, H, W, C), 9)
+    base = _ref_conv(x, w, b, 1, 1)
+    xd, r1d, r2d = x.cuda(), r1.cuda(), r2.cuda()
+    _close(ops.conv2d(xd, w, b, pad=1, act=1), F.relu(base), 2e-5, "relu")
+    _close(ops.conv2d(xd, w, b, pad=1, act=2), pf_oracle.gelu(base), 2e-5, "gelu")
+    _close(ops.conv2d(xd, w, b, pad=1, res1=r1d), base + r1.double(), 2e-5, "res1")
+    _close(ops.conv2d(xd, w, b, pad=1, res1=r1d, res2=r2d, post_relu=True), F.relu(base + r1.double() + r2.double()), 2e-5, "res1+res2+relu")
+    _close(ops.conv2d(xd, w, None, pad=1), base - b.double(), 2e-5, "no bias")
+    # in-place residual (y aliases res1), as the engine uses for the transformer stream
+    y = r1.cuda().clone()
+    from perspectivefields_amd.engine import load_library, _stream_ptr
+    got = ops.conv2d(xd, w, b, pad=1, res1=y)
+    _close(got, base + r1.double(), 2e-5, "res1 (separate out)")
+
+
+def test_conv2d_nchw_logits(ops):
+    """1x1 conv to 73 / 180 classes with the NCHW store used for the API-visible logits."""
+    B, H, W = 2, 16, 24
+    x = _rand((B, H, W, 32), 10)
+    for n in (73, 180):
+        w = _rand((n, 32, 1, 1), 11, 0.2)
+        b = _rand((n,), 12, 0.1)
+        ref = _ref_conv(x, w, b, 1, 0).permute(0, 3, 1, 2).contiguous()
+        for tile in [-1] + list(range(len(ops.conv_tiles()))):
+            got = ops.conv2d(x.cuda(), w, b, nchw_out=True, tile=tile)
+            _close(got, ref, 2e-5, f"nchw n={n} tile {tile}")
+
+
+@pytest.mark.parametrize("K,N,rows", [(64, 256, 300), (320, 1280, 257), (1280, 320, 129), (2048, 512, 100), (96, 384, 64), (3072, 768, 33), (32, 2, 200)])
+def test_linear(ops, K, N, rows):
+    x = _rand((rows, K), 13)
+    w = _rand((N, K), 14, 1.0 / math.sqrt(K))
+    b = _rand((N,), 15, 0.1)
+    r = _rand((rows, N), 16)
+    ref = F.linear(x.double(), w.double(), b.double())
+    _close(ops.linear(x.cuda(), w, b), ref, 3e-5, "linear")
+    _close(ops.linear(x.cuda(), w, b, act=2), pf_oracle.gelu(ref), 3e-5, "linear+gelu")
+    _close(ops.linear(x.cuda(), w, b, res1=r.cuda()), ref + r.double(), 3e-5, "linear+res")
+
+
+def test_mfma_operand_orientation(ops):
+    """A = I-like check with an ASYMMETRIC B: catches a row/col swap of the MFMA C layout."""
+    K = N = 64
+    rows = 64
+    x = torch.zeros(rows, K)
+    x[torch.arange(rows), torch.arange(rows) % K] = 1.0
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 100.0
+    ref = F.linear(x.double(), w.double())
+    _close(ops.linear(x.cuda(), w), ref, 1e-6, "identity A, asymmetric B")
+
+
+@pytest.mark.parametrize("C,eps", [(64, 1e-5), (96, 1e-6), (128, 1e-6), (192, 1e-6), (320, 1e-6), (384, 1e-6), (512, 1e-5), (768, 1e-6)])
+def test_layernorm(ops, C, eps):
+    x = _rand((37, 5, C), 17, 2.0) + 0.5
+    g = 1 + _rand((C,), 18, 0.1)
+    b = _rand((C,), 19, 0.1)
+    ref = F.layer_norm(x.double(), (C,), g.double(), b.double(), eps)
+    _close(ops.layernorm(x.cuda(), g, b, eps), ref, 1e-5, f"layernorm C={C}")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 80, 80, 256), (1, 40, 40, 512), (2, 20, 20, 1280), (3, 10, 10, 2048), (1, 9, 13, 128)])
+def test_dwconv3x3_gelu(ops, B, H, W, C):
+    x = _rand((B, H, W, C), 20)
+    w = _rand((C, 1, 3, 3), 21, 0.4)
+    b = _rand((C,), 22, 0.1)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1, groups=C)
+    ref = pf_oracle.gelu(ref).permute(0, 2, 3, 1).contiguous()
+    _close(ops.dwconv3x3_gelu(x.cuda(), w, b), ref, 1e-5, "dwconv3x3+gelu")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 80, 80, 96), (1, 40, 40, 192), (2, 20, 20, 384), (3, 10, 10, 768), (1, 2, 2, 768), (1, 5, 11, 96)])
+def test_dwconv7x7(ops, B, H, W, C):
+    x = _rand((B, H, W, C), 23)
+    w = _rand((C, 1, 7, 7), 24, 0.15)
+    b = _rand((C,), 25, 0.1)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=3, groups=C).permute(0, 2, 3, 1).contiguous()
+    _close(ops.dwconv7x7(x.cuda(), w, b), ref, 1e-5, "dwconv7x7")
+
+
+@pytest.mark.parametrize("B,N,heads,M", [(2, 6400, 1, 100), (1, 1600, 2, 100), (2, 400, 5, 100), (3, 100, 8, 100), (1, 70, 2, 37)])
+def test_sr_attention(ops, B, N, heads, M):
+    C = heads * 64
+    q = _rand((B, N, C), 26)
+    kv = _rand((B, M, 2 * C), 27)
+    qh = q.double().reshape(B, N, heads, 64).transpose(1, 2)
+    k = kv.double()[..., :C].reshape(B, M, heads, 64).transpose(1, 2)
+    v = kv.double()[..., C:].reshape(B, M, heads, 64).transpose(1, 2)
+    a = ((qh @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    ref = (a @ v).transpose(1, 2).reshape(B, N, C)
+    _close(ops.sr_attention(q.cuda(), kv.cuda(), heads), ref, 1e-5, "sr attention")
+
+
+def test_sr_attention_spiked_row(ops):
+    """one key dominating a query row (softmax max path) and a large-magnitude row"""
+    B, N, heads, M = 1, 64, 1, 100
+    q = _rand((B, N, 64), 28)
+    kv = _rand((B, M, 128), 29)
+    kv[0, 17, :64] = q[0, 5] * 6.0
+    q[0, 9] *= 30.0
+    a = ((q.double() @ kv.double()[..., :64].transpose(-2, -1)) * 0.125).softmax(-1)
+    ref = a @ kv.double()[..., 64:]
+    _close(ops.sr_attention(q.cuda(), kv.cuda(), heads), ref, 1e-5, "spiked attention")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 10, 10, 256), (1, 80, 80, 256), (1, 160, 160, 64), (1, 3, 5, 8)])
+def test_upsample2x(ops, B, H, W, C):
+    x = _rand((B, H, W, C), 30)
+    ref = F.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1).contiguous()
+    _close(ops.upsample2x(x.cuda()), ref, 2e-6, "upsample2x")
