@@ -106,6 +106,9 @@ int pf_postprocess(pf_handle h, const float* d_pred_gravity, const float* d_pred
 #define PF_PROFILE_CLASSES 7
 int pf_profile_begin(pf_handle h, unsigned class_mask);
 int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n);
+/* per-launch records of the last begin/end window (valid until the next pf_profile_begin); returns the
+ * total number of records, fills at most max_records entries; mnk = GEMM view [M, N, K, KH] for class 0 */
+int pf_profile_records(pf_handle h, int max_records, int* cat, double* work, float* ms, int* mnk);
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels pf_forward runs) ----
  * NHWC fp32 device activations; weights are HOST pointers in the reference's layouts. */

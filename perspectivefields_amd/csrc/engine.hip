@@ -3,6 +3,7 @@
 // elem.hip); there is no CPU or library (MIOpen / hipBLASLt) fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -88,7 +89,7 @@ int roundup(int v, int m) { return (v + m - 1) / m * m; }
 // every launch of a class is bracketed by an event pair; work = algorithmic FLOPs or bytes.
 enum ProfCat { PC_IGEMM = 0, PC_ATTN, PC_LAYERNORM, PC_DW3, PC_DW7, PC_UPSAMPLE, PC_OTHER, PC_COUNT };
 struct Profiler {
-  struct Rec { int cat; double work; hipEvent_t a, b; };
+  struct Rec { int cat; double work; hipEvent_t a, b; int m, n, k, kh; float ms; };
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
@@ -103,12 +104,12 @@ struct Profiler {
 };
 struct ProfScope {
   Profiler* p; hipStream_t s; hipEvent_t b = nullptr;
-  ProfScope(Profiler* pr, hipStream_t st, int cat, double work) : p(pr), s(st) {
+  ProfScope(Profiler* pr, hipStream_t st, int cat, double work, int m = 0, int n = 0, int k = 0, int kh = 0) : p(pr), s(st) {
     if (!p || !p->on || !((p->mask >> cat) & 1u)) { p = nullptr; return; }
     hipEvent_t a = p->get(); b = p->get();
     if (!a || !b) { p = nullptr; return; }
     (void)hipEventRecord(a, s);
-    p->recs.push_back({cat, work, a, b});
+    p->recs.push_back({cat, work, a, b, m, n, k, kh, 0.f});
   }
   ~ProfScope() { if (p) (void)hipEventRecord(b, s); }
 };
@@ -342,7 +343,7 @@ struct pf_engine {
     p.Cout = w.Cout; p.KWC = w.KWC; p.KWCp = w.KWCp;
     p.M = B * p.Ho * p.Wo;
     p.act = act; p.post_relu = post_relu; p.ldy = w.Cout; p.nchw_out = nchw;
-    ProfScope ps(c.prof, c.s, PC_IGEMM, 2.0 * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal);
+    ProfScope ps(c.prof, c.s, PC_IGEMM, 2.0 * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal, p.M, w.Cout, w.KH * w.KW * w.CinReal, w.KH);
     launch_conv(p, c.s);
   }
   void gemm(Ctx& c, const ConvW& w, const float* x, long rows, float* y, int act = ACT_NONE, const float* res1 = nullptr) {
@@ -713,10 +714,23 @@ int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n)
     if (hipEventSynchronize(r.b) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipEventSynchronize failed");
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipEventElapsedTime failed");
+    r.ms = t;
     ms[r.cat] += t; work[r.cat] += r.work; launches[r.cat] += 1;
   }
-  h->prof.reset();
-  return PF_OK;
+  return PF_OK;  // records stay readable through pf_profile_records until the next pf_profile_begin
+}
+
+int pf_profile_records(pf_handle h, int max_records, int* cat, double* work, float* ms, int* mnk /*[max][4]: M, N, K, KH*/) {
+  if (!h) return PF_ERR_ARG;
+  const int n = (int)std::min<size_t>(h->prof.recs.size(), (size_t)(max_records < 0 ? 0 : max_records));
+  for (int i = 0; i < n; ++i) {
+    const auto& r = h->prof.recs[i];
+    if (cat) cat[i] = r.cat;
+    if (work) work[i] = r.work;
+    if (ms) ms[i] = r.ms;
+    if (mnk) { mnk[4 * i] = r.m; mnk[4 * i + 1] = r.n; mnk[4 * i + 2] = r.k; mnk[4 * i + 3] = r.kh; }
+  }
+  return (int)h->prof.recs.size();
 }
 
 // ---- kernel-level entry points -------------------------------------------------------------

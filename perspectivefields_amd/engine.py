@@ -37,6 +37,7 @@ _SIGNATURES = {
     "pf_postprocess": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
     "pf_profile_begin": (_c.c_int, [_P, _c.c_uint]),
     "pf_profile_end": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.c_int]),
+    "pf_profile_records": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double), _c.POINTER(_c.c_float), _c.POINTER(_c.c_int)]),
     "pf_op_conv2d": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P,
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_int,
                                 _c.c_int, _c.c_int, _P, _P]),
@@ -205,6 +206,13 @@ class Engine:
         ms, work, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_long * n)()
         _check(self.lib.pf_profile_end(self._h, ms, work, cnt, n), self._h, "pf_profile_end")
         return {name: {"ms": ms[i], "work": work[i], "launches": cnt[i]} for i, name in enumerate(self.PROFILE_CLASSES)}
+
+    def profile_records(self):
+        """Per-launch records of the last profile window: list of (class, work, ms, (M, N, K, KH))."""
+        n = self.lib.pf_profile_records(self._h, 0, None, None, None, None)
+        cat, work, ms, mnk = (ctypes.c_int * n)(), (ctypes.c_double * n)(), (ctypes.c_float * n)(), (ctypes.c_int * (4 * n))()
+        self.lib.pf_profile_records(self._h, n, cat, work, ms, mnk)
+        return [(self.PROFILE_CLASSES[cat[i]], work[i], ms[i], tuple(mnk[4 * i : 4 * i + 4])) for i in range(n)]
 
     def postprocess(self, pred_gravity_i, pred_latitude_i, height: int, width: int):
         """One image: (Cg,320,320), (Cl,320,320) -> (2,H,W) unit up-vectors, (H,W) degrees."""
