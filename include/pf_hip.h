@@ -117,6 +117,8 @@ int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, 
                  int Cout, int KH, int KW, int stride, int pad, int act /*0 none 1 relu 2 gelu*/,
                  const float* d_res1, const float* d_res2, int post_relu, int nchw_out, int tile_id /*-1 auto*/,
                  float* d_y, void* stream);
+/* times `iters` launches of one conv shape on random data with tile config `tile_id` (-1 auto); avg ms per launch */
+int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, float* ms_out);
 int pf_op_layernorm(int device, const float* d_x, const float* h_gamma, const float* h_beta, float* d_y, long rows, int C, float eps, void* stream);
 int pf_op_dwconv3x3_gelu(int device, const float* d_x, const float* h_weight /*[C][1][3][3]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);
 int pf_op_dwconv7x7(int device, const float* d_x, const float* h_weight /*[C][1][7][7]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -51,6 +52,7 @@ struct HostTensor {
 struct ConvW {
   float* w = nullptr;
   float* b = nullptr;
+  float* btab = nullptr;  // [9][Cout] border-case biases of a folded Linear->3x3 pair
   int Cout = 0, Cin = 0 /*padded*/, CinReal = 0, KH = 1, KW = 1, stride = 1, pad = 0, KWC = 0, KWCp = 0;
 };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-6f; };
@@ -59,7 +61,7 @@ struct DwW { float* w = nullptr; float* b = nullptr; int C = 0; };
 struct MitBlock { LNW n1, n2, srn; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; };
 struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
 struct Head {
-  ConvW lin[4], proc[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
+  ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
   float* predw = nullptr; float* predb = nullptr; int nout = 0;
 };
 struct CnxBlock { DwW dw; LNW n; ConvW pw1, pw2; };
@@ -147,6 +149,7 @@ struct pf_engine {
   std::vector<void*> dev_allocs;
   std::map<int, size_t> ws_cache;
   Profiler prof;
+  bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
 
   MitStage stages[4];
   ConvW ll;
@@ -205,6 +208,53 @@ struct pf_engine {
     c.Cout = N; c.Cin = K; c.CinReal = K; c.KH = c.KW = 1; c.stride = 1; c.pad = 0;
     return c;
   }
+  // Linear(C -> 768) followed (no nonlinearity) by a zero-padded conv3x3(768 -> 256) is one conv3x3(C -> 256):
+  //   W'[o][ci][ky][kx] = sum_e Wp[o][e][ky][kx] * Wl[e][ci]
+  // and the Linear bias reaches an output pixel only through the taps that fall inside the map:
+  //   bias(y,x)[o] = bp[o] + sum_{valid (ky,kx)} T[o][ky][kx],   T[o][ky][kx] = sum_e Wp[o][e][ky][kx] * bl[e]
+  // -> a 9-entry table indexed by the 3x3 border case.  Folded in fp64 (reference: decode_head.py:49-53 +
+  // gravity_head.py:70-97,145-166).  8.2x fewer FLOPs for these layers (30.1 -> 3.7 GFLOP per head).
+  ConvW make_folded(const std::string& lin, const std::string& proc, int C) {
+    const HostTensor& wl = get(lin + ".weight", {DEC_EMBED, C});
+    const HostTensor& bl = get(lin + ".bias", {DEC_EMBED});
+    const HostTensor& wp = get(proc + ".weight", {DEC_FEAT, DEC_EMBED, 3, 3});
+    const HostTensor& bp = get(proc + ".bias", {DEC_FEAT});
+    std::vector<float> wf((size_t)DEC_FEAT * C * 9);
+    std::vector<double> T((size_t)DEC_FEAT * 9), acc(C);
+    std::vector<double> wld(wl.data.begin(), wl.data.end());
+    for (int o = 0; o < DEC_FEAT; ++o)
+      for (int t = 0; t < 9; ++t) {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        double tb = 0.0;
+        for (int e = 0; e < DEC_EMBED; ++e) {
+          const double a = wp.data[((size_t)o * DEC_EMBED + e) * 9 + t];
+          const double* row = &wld[(size_t)e * C];
+          for (int ci = 0; ci < C; ++ci) acc[ci] += a * row[ci];
+          tb += a * (double)bl.data[e];
+        }
+        for (int ci = 0; ci < C; ++ci) wf[((size_t)o * C + ci) * 9 + t] = (float)acc[ci];
+        T[(size_t)o * 9 + t] = tb;
+      }
+    ConvW c;
+    c.w = upload(pack_conv(wf.data(), DEC_FEAT, C, 3, 3, C, nullptr, &c.KWC, &c.KWCp));
+    std::vector<float> tab((size_t)9 * DEC_FEAT);
+    for (int cy = 0; cy < 3; ++cy)
+      for (int cx = 0; cx < 3; ++cx)
+        for (int o = 0; o < DEC_FEAT; ++o) {
+          double b = bp.data[o];
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+              const bool vy = !((cy == 0 && ky == 0) || (cy == 2 && ky == 2));  // top row has no tap above, bottom none below
+              const bool vx = !((cx == 0 && kx == 0) || (cx == 2 && kx == 2));
+              if (vy && vx) b += T[(size_t)o * 9 + ky * 3 + kx];
+            }
+          tab[(size_t)(cy * 3 + cx) * DEC_FEAT + o] = (float)b;
+        }
+    c.btab = upload(tab);
+    c.b = nullptr;
+    c.Cout = DEC_FEAT; c.Cin = C; c.CinReal = C; c.KH = c.KW = 3; c.stride = 1; c.pad = 1;
+    return c;
+  }
   LNW make_ln(const std::string& pfx, int C, float eps) {
     LNW l;
     l.g = upload(get(pfx + ".weight", {C}).data);
@@ -224,8 +274,12 @@ struct pf_engine {
     const std::string p = "persformer_heads." + name + "_head.";
     for (int k = 0; k < 4; ++k) {
       const std::string ks = std::to_string(k + 1);
-      hd.lin[k] = make_linear(p + "linear_c" + ks + ".proj", DEC_EMBED, MIT_DIMS[k]);
-      hd.proc[k] = make_conv(p + "linear_c" + ks + "_proc.weight", p + "linear_c" + ks + "_proc.bias", DEC_FEAT, DEC_EMBED, 3, 1, 1);
+      if (fold_mlp) {
+        hd.fold[k] = make_folded(p + "linear_c" + ks + ".proj", p + "linear_c" + ks + "_proc", MIT_DIMS[k]);
+      } else {
+        hd.lin[k] = make_linear(p + "linear_c" + ks + ".proj", DEC_EMBED, MIT_DIMS[k]);
+        hd.proc[k] = make_conv(p + "linear_c" + ks + "_proc.weight", p + "linear_c" + ks + "_proc.bias", DEC_FEAT, DEC_EMBED, 3, 1, 1);
+      }
       const std::string f = p + "fusion" + ks + ".";
       if (k < 3) {
         hd.r1c1[k] = make_conv(f + "resConfUnit1.conv1.weight", f + "resConfUnit1.conv1.bias", DEC_FEAT, DEC_FEAT, 3, 1, 1);
@@ -330,21 +384,34 @@ struct pf_engine {
   }
 
   // ------------------------------------------------------------------ layer helpers
+  struct ConvCall {  // one problem of a (possibly grouped) conv launch
+    const ConvW* w; const float* x; float* y;
+    const float* res1 = nullptr; const float* res2 = nullptr; const float* x2 = nullptr;
+  };
+  void conv_g(Ctx& c, int ngroups, const ConvCall* calls, int B, int H, int W, int act = ACT_NONE, int post_relu = 0, int C1 = -1, int nchw = 0) {
+    if (c.dry) return;
+    const ConvW& w = *calls[0].w;
+    ConvParams p;
+    p.groups = ngroups;
+    for (int g = 0; g < ngroups; ++g) {
+      const ConvW& wg = *calls[g].w;
+      ConvPtrs& q = p.g[g];
+      q.x = calls[g].x; q.x2 = calls[g].x2; q.w = wg.w; q.bias = wg.b; q.bias_tab = wg.btab;
+      q.res1 = calls[g].res1; q.res2 = calls[g].res2; q.y = calls[g].y;
+    }
+    p.B = B; p.H = H; p.W = W;
+    p.C1 = C1 < 0 ? w.Cin : C1; p.C2 = w.Cin - p.C1;
+    p.KH = w.KH; p.KW = w.KW; p.stride = w.stride; p.pad = w.pad;
+    p.Cout = w.Cout; p.KWC = w.KWC; p.KWCp = w.KWCp;
+    p.act = act; p.post_relu = post_relu; p.nchw_out = nchw;
+    p.finish();
+    ProfScope ps(c.prof, c.s, PC_IGEMM, 2.0 * ngroups * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal, p.M * ngroups, w.Cout, w.KH * w.KW * w.CinReal, w.KH);
+    launch_conv(p, c.s);
+  }
   void conv(Ctx& c, const ConvW& w, const float* x, int B, int H, int W, float* y, int act = ACT_NONE, const float* res1 = nullptr,
             const float* res2 = nullptr, int post_relu = 0, const float* x2 = nullptr, int C1 = -1, int nchw = 0) {
-    if (c.dry) return;
-    ConvParams p;
-    p.x = x; p.x2 = x2; p.w = w.w; p.bias = w.b; p.res1 = res1; p.res2 = res2; p.y = y;
-    p.B = B; p.H = H; p.W = W;
-    p.C1 = C1 < 0 ? w.Cin : C1; p.C2 = w.Cin - p.C1; p.Cin = w.Cin;
-    p.KH = w.KH; p.KW = w.KW; p.stride = w.stride; p.pad = w.pad;
-    p.Ho = (H + 2 * w.pad - w.KH) / w.stride + 1;
-    p.Wo = (W + 2 * w.pad - w.KW) / w.stride + 1;
-    p.Cout = w.Cout; p.KWC = w.KWC; p.KWCp = w.KWCp;
-    p.M = B * p.Ho * p.Wo;
-    p.act = act; p.post_relu = post_relu; p.ldy = w.Cout; p.nchw_out = nchw;
-    ProfScope ps(c.prof, c.s, PC_IGEMM, 2.0 * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal, p.M, w.Cout, w.KH * w.KW * w.CinReal, w.KH);
-    launch_conv(p, c.s);
+    ConvCall one{&w, x, y, res1, res2, x2};
+    conv_g(c, 1, &one, B, H, W, act, post_relu, C1, nchw);
   }
   void gemm(Ctx& c, const ConvW& w, const float* x, long rows, float* y, int act = ACT_NONE, const float* res1 = nullptr) {
     conv(c, w, x, 1, (int)rows, 1, y, act, res1);
@@ -410,49 +477,73 @@ struct pf_engine {
     }
   }
 
-  // decoder head up to the 32-channel 320x320 map (gravity_head.py:139-173 / latitude_head.py:138-172).
+  // Both decoder heads up to their 32-channel 320x320 maps (gravity_head.py:139-173 / latitude_head.py:138-172).
+  // The two heads have identical shapes and independent weights, so every conv runs as ONE grouped launch
+  // (2x the grid: fewer partially filled last waves, half the launches); their tensors are allocated as
+  // [2][B][h][w][C] pairs so the bilinear kernels simply see a batch of 2B.
   // Stored tensors are post-ReLU wherever every consumer applies ReLU first (ResidualConvUnit's in-place
   // ReLU, decode_head.py:242-256): RCU(x) = conv2(relu(conv1(relu x))) + relu x.
-  void head(Ctx& c, Head& hd, int B, float* feats[4], const float* llf, float* t32) {
-    float* up[4];
+  void heads_fwd(Ctx& c, int B, float* feats[4], const float* llf, float* t32 /*[2][B][320][320][32]*/) {
+    Head& hg = heads[0];
+    Head& hl = heads[1];
+    auto pair = [&](size_t per_head, float*& a, float*& b) { a = c.alloc(2 * per_head); b = a + per_head; };
+    float* up[4][2];
     for (int k = 3; k >= 0; --k) {
       const int h = NET >> (k + 2);
-      up[k] = c.alloc((size_t)B * 4 * h * h * DEC_FEAT);
+      pair((size_t)B * 4 * h * h * DEC_FEAT, up[k][0], up[k][1]);
     }
     for (int k = 3; k >= 0; --k) {
       const int h = NET >> (k + 2);
-      const long M = (long)B * h * h;
+      const size_t M = (size_t)B * h * h;
       const size_t mk = c.mark();
-      float* e = c.alloc(M * DEC_EMBED);
-      gemm(c, hd.lin[k], feats[k], M, e);                                   // MLP (decode_head.py:49-53)
-      float* p = c.alloc(M * DEC_FEAT);
-      conv(c, hd.proc[k], e, B, h, h, p, ACT_NONE, nullptr, nullptr, 1);     // relu(_ck)
-      float* o = p;
-      if (k < 3) {                                                           // o = relu(up(prev) + RCU1(_ck))
-        float* t = c.alloc(M * DEC_FEAT);
-        conv(c, hd.r1c1[k], p, B, h, h, t, ACT_RELU);
-        o = c.alloc(M * DEC_FEAT);
-        conv(c, hd.r1c2[k], t, B, h, h, o, ACT_NONE, p, up[k + 1], 1);
+      float *p0, *p1;
+      pair(M * DEC_FEAT, p0, p1);
+      if (fold_mlp) {
+        ConvCall cc[2] = {{&hg.fold[k], feats[k], p0}, {&hl.fold[k], feats[k], p1}};
+        conv_g(c, 2, cc, B, h, h, ACT_NONE, 1);                               // relu(_ck), Linear folded into the conv
+      } else {
+        float *e0, *e1;
+        pair(M * DEC_EMBED, e0, e1);
+        ConvCall l[2] = {{&hg.lin[k], feats[k], e0}, {&hl.lin[k], feats[k], e1}};
+        conv_g(c, 2, l, 1, (int)M, 1);                                        // MLP (decode_head.py:49-53)
+        ConvCall cc[2] = {{&hg.proc[k], e0, p0}, {&hl.proc[k], e1, p1}};
+        conv_g(c, 2, cc, B, h, h, ACT_NONE, 1);                               // relu(_ck)
       }
-      float* t2 = c.alloc(M * DEC_FEAT);
-      conv(c, hd.r2c1[k], o, B, h, h, t2, ACT_RELU);
-      float* o2 = c.alloc(M * DEC_FEAT);
-      conv(c, hd.r2c2[k], t2, B, h, h, o2, ACT_NONE, o);                     // RCU2 output, raw
-      if (!c.dry) {                                                          // decode_head.py:284-286
-        ProfScope ps(c.prof, c.s, PC_UPSAMPLE, 20.0 * M * DEC_FEAT);
-        launch_upsample2x(o2, up[k], B, h, h, DEC_FEAT, c.s);
+      float *o0 = p0, *o1 = p1;
+      if (k < 3) {                                                            // o = relu(up(prev) + RCU1(_ck))
+        float *t0, *t1;
+        pair(M * DEC_FEAT, t0, t1);
+        ConvCall a[2] = {{&hg.r1c1[k], p0, t0}, {&hl.r1c1[k], p1, t1}};
+        conv_g(c, 2, a, B, h, h, ACT_RELU);
+        pair(M * DEC_FEAT, o0, o1);
+        ConvCall b2[2] = {{&hg.r1c2[k], t0, o0, p0, up[k + 1][0]}, {&hl.r1c2[k], t1, o1, p1, up[k + 1][1]}};
+        conv_g(c, 2, b2, B, h, h, ACT_NONE, 1);
+      }
+      float *t0, *t1, *q0, *q1;
+      pair(M * DEC_FEAT, t0, t1);
+      ConvCall a[2] = {{&hg.r2c1[k], o0, t0}, {&hl.r2c1[k], o1, t1}};
+      conv_g(c, 2, a, B, h, h, ACT_RELU);
+      pair(M * DEC_FEAT, q0, q1);
+      ConvCall b2[2] = {{&hg.r2c2[k], t0, q0, o0}, {&hl.r2c2[k], t1, q1, o1}};
+      conv_g(c, 2, b2, B, h, h);                                              // RCU2 output, raw
+      if (!c.dry) {                                                           // decode_head.py:284-286
+        ProfScope ps(c.prof, c.s, PC_UPSAMPLE, 40.0 * M * DEC_FEAT);
+        launch_upsample2x(q0, up[k][0], 2 * B, h, h, DEC_FEAT, c.s);
       }
       c.release(mk);
     }
     const int h = NET / 2;
-    float* z = c.alloc((size_t)B * h * h * 64);
-    conv(c, hd.conv0, up[0], B, h, h, z, ACT_RELU, nullptr, nullptr, 0, llf, DEC_FEAT);  // cat fused into the A gather (:170-171)
-    float* zu = c.alloc((size_t)B * NET * NET * 64);
+    float *z0, *z1, *zu0, *zu1;
+    pair((size_t)B * h * h * 64, z0, z1);
+    ConvCall a[2] = {{&hg.conv0, up[0][0], z0, nullptr, nullptr, llf}, {&hl.conv0, up[0][1], z1, nullptr, nullptr, llf}};
+    conv_g(c, 2, a, B, h, h, ACT_RELU, 0, DEC_FEAT);                          // cat fused into the A gather (:170-171)
+    pair((size_t)B * NET * NET * 64, zu0, zu1);
     if (!c.dry) {
-      ProfScope ps(c.prof, c.s, PC_UPSAMPLE, 20.0 * B * h * h * 64);
-      launch_upsample2x(z, zu, B, h, h, 64, c.s);
+      ProfScope ps(c.prof, c.s, PC_UPSAMPLE, 40.0 * B * h * h * 64);
+      launch_upsample2x(z0, zu0, 2 * B, h, h, 64, c.s);
     }
-    conv(c, hd.conv1, zu, B, NET, NET, t32, ACT_RELU);
+    ConvCall b2[2] = {{&hg.conv1, zu0, t32}, {&hl.conv1, zu1, t32 + (size_t)B * NET * NET * 32}};
+    conv_g(c, 2, b2, B, NET, NET, ACT_RELU);
   }
 
   // ConvNeXt-T + heads of the ParamNets (convnext.py:140-152)
@@ -511,13 +602,11 @@ struct pf_engine {
     mit(c, B, x0, feats);
     float* llf = c.alloc((size_t)B * (NET / 2) * (NET / 2) * LL_CH);
     conv(c, ll, x0, B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
-    float* tg = c.alloc((size_t)B * NET * NET * 32);
-    float* tl = c.alloc((size_t)B * NET * NET * 32);
+    float* tg = c.alloc((size_t)2 * B * NET * NET * 32);
+    float* tl = tg + (size_t)B * NET * NET * 32;
     float* pn = has_param ? c.alloc((size_t)B * NET * NET * 4) : nullptr;
     const size_t mk = c.mark();
-    head(c, heads[0], B, feats, llf, tg);
-    c.release(mk);
-    head(c, heads[1], B, feats, llf, tl);
+    heads_fwd(c, B, feats, llf, tg);
     c.release(mk);
     if (arch == PF_ARCH_PERSNET_CLS) {
       // 1x1 convs to 73 / 180 logits, stored NCHW because the logits are API-visible (gravity_head.py:259)
@@ -602,6 +691,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   pf_engine* e = new pf_engine();
   e->device = device;
   e->arch = arch;
+  if (const char* v = getenv("PF_FOLD_MLP")) e->fold_mlp = atoi(v) != 0;
   *out = e;
   return PF_OK;
 }
@@ -609,7 +699,7 @@ int pf_create(pf_handle* out, int device, int arch) {
 int pf_destroy(pf_handle h) {
   if (!h) return PF_ERR_ARG;
   hipSetDevice(h->device);
-  for (void* d : h->dev_allocs) hipFree(d);
+  for (void* d : h->dev_allocs) (void)hipFree(d);
   delete h;
   return PF_OK;
 }
@@ -749,16 +839,59 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   TmpDev tmp;
   ConvParams p;
   std::vector<float> packed = pack_conv(hw, Cout, Cin, KH, KW, Cin, nullptr, &p.KWC, &p.KWCp);
-  p.w = tmp.up(packed);
-  p.bias = tmp.up(hb, Cout);
-  p.x = x; p.x2 = x2; p.res1 = res1; p.res2 = res2; p.y = y;
-  p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.Cin = Cin;
+  p.g[0].w = tmp.up(packed);
+  p.g[0].bias = tmp.up(hb, Cout);
+  p.g[0].x = x; p.g[0].x2 = x2; p.g[0].res1 = res1; p.g[0].res2 = res2; p.g[0].y = y;
+  p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
-  p.Ho = (H + 2 * pad - KH) / stride + 1; p.Wo = (W + 2 * pad - KW) / stride + 1;
-  p.Cout = Cout; p.M = B * p.Ho * p.Wo; p.act = act; p.post_relu = post_relu; p.ldy = Cout; p.nchw_out = nchw_out;
+  p.Cout = Cout; p.act = act; p.post_relu = post_relu; p.nchw_out = nchw_out;
+  p.finish();
   launch_conv_tile(p, tile_id, s);
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, float* ms_out) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (Cin % 4 != 0 || iters <= 0 || !ms_out) { g_create_error = "pf_op_conv2d_bench: bad argument"; return PF_ERR_ARG; }
+  ConvParams p;
+  p.KWC = K * Cin; p.KWCp = roundup(p.KWC, 32);
+  p.B = B; p.H = H; p.W = W; p.C1 = Cin; p.C2 = 0; p.KH = K; p.KW = K; p.stride = stride; p.pad = pad;
+  p.Cout = Cout; p.act = ACT_RELU; p.post_relu = 0; p.nchw_out = 0;
+  p.finish();
+  const size_t nx = (size_t)B * H * W * Cin, nw = (size_t)Cout * K * p.KWCp, ny = (size_t)p.M * Cout;
+  float *dx = nullptr, *dw = nullptr, *dy = nullptr, *db = nullptr;
+  if (hipMalloc(&dx, nx * 4) != hipSuccess || hipMalloc(&dw, nw * 4) != hipSuccess || hipMalloc(&dy, ny * 4) != hipSuccess ||
+      hipMalloc(&db, (size_t)Cout * 4) != hipSuccess) { g_create_error = "pf_op_conv2d_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
+  {  // uniform [-1,1) data (never zero-fill a bench: DVFS gives zeros a higher clock)
+    std::vector<float> hx(nx), hw(nw), hb(Cout);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : hx) v = rnd();
+    for (auto& v : hw) v = rnd() * 0.05f;
+    for (auto& v : hb) v = rnd();
+    (void)hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, hb.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
+  }
+  p.g[0].x = dx; p.g[0].w = dw; p.g[0].bias = db; p.g[0].y = dy;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  launch_conv_tile(p, tile_id, nullptr);
+  launch_conv_tile(p, tile_id, nullptr);
+  (void)hipEventRecord(a, nullptr);
+  for (int i = 0; i < iters; ++i) launch_conv_tile(p, tile_id, nullptr);
+  (void)hipEventRecord(b, nullptr);
+  (void)hipEventSynchronize(b);
+  float t = 0.f;
+  (void)hipEventElapsedTime(&t, a, b);
+  *ms_out = t / iters;
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db);
   return rc;
 }
 

@@ -17,6 +17,8 @@
 // (the K order is permuted identically for A and B, which a dot product permits).
 // Global->LDS is register-staged and double-buffered: loads of tile t+1 are issued
 // before the MFMAs of tile t, one barrier per K step.
+#include <stdlib.h>
+
 #include "pf_kernels.h"
 
 namespace pf {
@@ -28,13 +30,23 @@ static constexpr int LDS_ROW = BK + 4;  // floats; 36*i mod 64 = 4*(9i mod 16): 
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static constexpr unsigned OOB = 0x80000000u;  // beyond any buffer (< 2 GiB): hardware range check returns 0
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 template <int BM, int BN, int WM, int WN, bool SMALLC, bool NCHW>
-__global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
-  static_assert(WM * WN == 4, "4 waves per block");
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p) {
+  constexpr int NT = WM * WN * 64;      // threads per block
+  constexpr int RPP = NT / 8;           // tile rows staged per pass (8 threads x float4 = one 32-float row)
   constexpr int SM = BM / (WM * 32);
   constexpr int SN = BN / (WN * 32);
-  constexpr int A_ROWS = BM / 32;
-  constexpr int B_ROWS = BN / 32;
+  constexpr int A_ROWS = BM / RPP;
+  constexpr int B_ROWS = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_ROW];
   float* As = smem;
   float* Bs = smem + 2 * BM * LDS_ROW;
@@ -50,36 +62,59 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
   // n-tiles of one m-tile (same A rows) meet in one L2.
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
-  const int nblk = tilesM * tilesN;
+  const int nblk1 = tilesM * tilesN;
+  const int nblk = nblk1 * p.groups;
   int t;
   {
     const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // grouped launch: group 1 = a second problem of identical shape (the other decoder head)
+  const bool g1 = t >= nblk1;
+  if (g1) t -= nblk1;
+  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
   const int m0 = (t / tilesN) * BM;
   const int n0 = (t % tilesN) * BN;
 
-  // ---- staging geometry: thread -> (row r + 32 i, float4 column c4)
+  // ---- staging geometry: thread -> (row r0 + RPP i, float4 column c4).  Everything that depends on
+  // the row is computed once: byte offset of the tap-(0,0) pixel and a bit mask of the taps that fall
+  // inside the image (bit ky*KW+kx; KH*KW <= 64).  The K loop then needs one add, one shift and one
+  // select per row; out-of-image taps and padded rows read offset OOB, for which the buffer range
+  // check returns zeros (no branches, no per-tap compares).
   const int c4 = tid & 7;
   const int r0 = tid >> 3;
-  long a_base[A_ROWS];
-  int a_iy0[A_ROWS], a_ix0[A_ROWS];
-  bool a_ok[A_ROWS];
   const int HoWo = p.Ho * p.Wo;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x2 ? P.x2 : P.x), 0, P.x2 ? p.x2_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.w), 0, p.w_bytes, 0x00020000);
+  int a_off1[A_ROWS], a_off2[A_ROWS];
+  unsigned long long a_mask[A_ROWS];
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
-    const int m = m0 + r0 + 32 * i;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
+    const int m = m0 + r0 + RPP * i;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
     const int b = mm / HoWo;
     const int rem = mm - b * HoWo;
     const int oy = rem / p.Wo;
     const int ox = rem - oy * p.Wo;
-    a_iy0[i] = oy * p.stride - p.pad;
-    a_ix0[i] = ox * p.stride - p.pad;
-    a_base[i] = ((long)b * p.H + a_iy0[i]) * p.W + a_ix0[i];
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+    const int pix = (b * p.H + iy0) * p.W + ix0;
+    a_off1[i] = pix * p.C1 * 4 + (SMALLC ? 0 : c4 * 16);
+    a_off2[i] = pix * p.C2 * 4 + (SMALLC ? 0 : c4 * 16);
+    unsigned long long mk = 0;
+    if (ok)
+      for (int ky = 0; ky < p.KH; ++ky)
+        for (int kx = 0; kx < p.KW; ++kx)
+          if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W) mk |= 1ull << (ky * p.KW + kx);
+    a_mask[i] = mk;
   }
-  const long wrow = (long)p.KH * p.KWCp;
+  unsigned b_off[B_ROWS];
+#pragma unroll
+  for (int i = 0; i < B_ROWS; ++i) {
+    const int n = n0 + r0 + RPP * i;
+    b_off[i] = n < p.Cout ? (unsigned)(n * p.KH * p.KWCp + c4 * 4) * 4u : OOB;
+  }
 
   float4 a_reg[A_ROWS], b_reg[B_ROWS];
   const int nJ = p.KWCp / BK;
@@ -88,33 +123,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
   auto load_tiles = [&](int it) {
     const int ky = it / nJ;
     const int j0 = (it - ky * nJ) * BK;
-    const int j = j0 + c4 * 4;
-    int kx;
-    if (SMALLC) kx = j / p.Cin; else kx = j0 / p.Cin;
-    const int ci = j - kx * p.Cin;
-    const bool jok = j < p.KWC;
+    if (SMALLC) {
+      // Cin == 4: a float4 is one pixel; this thread's tap kx differs per thread
+      const int j = j0 + c4 * 4;
+      const int kx = j >> 2;
+      const bool jok = j < p.KWC;
+      const int toff = (ky * p.W + kx) * 16;
+      const int bit = ky * p.KW + kx;
 #pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) {
-      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-      const bool ok = a_ok[i] && jok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const long pix = a_base[i] + (long)ky * p.W + kx;
-      const float* src = (ci < p.C1) ? p.x + pix * p.C1 + ci : p.x2 + pix * p.C2 + (ci - p.C1);
-      a_reg[i] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+      for (int i = 0; i < A_ROWS; ++i) {
+        const bool ok = jok && ((a_mask[i] >> bit) & 1ull);
+        a_reg[i] = buf_load16(rx, ok ? (unsigned)(a_off1[i] + toff) : OOB);
+      }
+    } else {
+      // Cin % 32 == 0: the whole 32-float chunk lies in one tap and one source tensor (all uniform)
+      const int kx = j0 / p.Cin;
+      const int ci0 = j0 - kx * p.Cin;
+      const int bit = ky * p.KW + kx;
+      if (ci0 < p.C1) {
+        const int toff = ((ky * p.W + kx) * p.C1 + ci0) * 4;
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) {
-      const int n = n0 + r0 + 32 * i;
-      b_reg[i] = (n < p.Cout) ? *reinterpret_cast<const float4*>(p.w + (long)n * wrow + (long)ky * p.KWCp + j)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < A_ROWS; ++i) a_reg[i] = buf_load16(rx, ((a_mask[i] >> bit) & 1ull) ? (unsigned)(a_off1[i] + toff) : OOB);
+      } else {
+        const int toff = ((ky * p.W + kx) * p.C2 + (ci0 - p.C1)) * 4;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) a_reg[i] = buf_load16(rx2, ((a_mask[i] >> bit) & 1ull) ? (unsigned)(a_off2[i] + toff) : OOB);
+      }
     }
+    const unsigned woff = (unsigned)(ky * p.KWCp + j0) * 4u;
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) b_reg[i] = buf_load16(rw, b_off[i] == OOB ? OOB : b_off[i] + woff);
   };
   auto store_tiles = [&](int buf) {
     float* Ad = As + buf * BM * LDS_ROW;
     float* Bd = Bs + buf * BN * LDS_ROW;
 #pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<float4*>(Ad + (r0 + 32 * i) * LDS_ROW + c4 * 4) = a_reg[i];
+    for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<float4*>(Ad + (r0 + RPP * i) * LDS_ROW + c4 * 4) = a_reg[i];
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<float4*>(Bd + (r0 + 32 * i) * LDS_ROW + c4 * 4) = b_reg[i];
+    for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<float4*>(Bd + (r0 + RPP * i) * LDS_ROW + c4 * 4) = b_reg[i];
   };
 
   f32x16 acc[SM][SN];
@@ -168,21 +214,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
     for (int j = 0; j < SN; ++j) {
       const int n = n0 + wn0 + j * 32 + l31;
       const bool nok = n < p.Cout;
-      const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+      const float bias = (P.bias && nok) ? P.bias[n] : 0.f;
 #pragma unroll
       for (int i = 0; i < SM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           if (nok && m < p.M) {
-            float v = acc[i][j][r] + bias;
+            float bsel = bias;
+            if (P.bias_tab) {  // position-dependent bias of a folded (Linear -> zero-padded 3x3) pair: 3x3 border cases
+              const int rem = m % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+              const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
+              bsel = P.bias_tab[(cy * 3 + cx) * p.Cout + n];
+            }
+            float v = acc[i][j][r] + bsel;
             if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
             else if (p.act == ACT_GELU) v = gelu_erf(v);
             const long o = (long)m * p.ldy + n;
-            if (p.res1) v += p.res1[o];
-            if (p.res2) v += p.res2[o];
+            if (P.res1) v += P.res1[o];
+            if (P.res2) v += P.res2[o];
             if (p.post_relu) v = fmaxf(v, 0.f);
-            p.y[o] = v;
+            P.y[o] = v;
           }
         }
       }
@@ -202,10 +254,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
         for (int r = 0; r < 16; ++r) {
           const int n = n0 + wn0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           if (mok && n < p.Cout) {
-            float v = acc[i][j][r] + (p.bias ? p.bias[n] : 0.f);
+            float v = acc[i][j][r] + (P.bias ? P.bias[n] : 0.f);
             if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
             else if (p.act == ACT_GELU) v = gelu_erf(v);
-            p.y[((long)b * p.Cout + n) * HoWo + pix] = v;
+            P.y[((long)b * p.Cout + n) * HoWo + pix] = v;
           }
         }
       }
@@ -215,12 +267,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvParams p) {
 
 // ---------------------------------------------------------------------------------------
 struct TileCfg { int bm, bn; const char* name; float eff; int blocks_per_cu; };
+// eff = intrinsic throughput (TFLOP/s, all CUs busy, quantisation divided out) measured with scripts/tune_conv.py
 static const TileCfg kTiles[] = {
-    {128, 128, "128x128", 1.00f, 2},
-    {128, 64, "128x64", 0.95f, 2},
-    {64, 64, "64x64", 0.88f, 4},
-    {128, 32, "128x32", 0.85f, 3},
-    {64, 128, "64x128", 0.93f, 2},
+    {128, 128, "128x128", 107.f, 2},
+    {128, 64, "128x64", 94.f, 2},
+    {64, 64, "64x64", 93.f, 4},
+    {128, 32, "128x32", 83.f, 3},
+    {64, 128, "64x128", 97.f, 2},
+    {128, 256, "128x256", 105.f, 1},
+    {256, 128, "256x128", 102.f, 1},
+    {256, 128, "256x128w8", 111.f, 1},
+    {256, 256, "256x256w8", 120.f, 1},
 };
 int conv_num_tiles() { return (int)(sizeof(kTiles) / sizeof(kTiles[0])); }
 const char* conv_tile_name(int id) { return (id >= 0 && id < conv_num_tiles()) ? kTiles[id].name : "auto"; }
@@ -228,7 +285,7 @@ const char* conv_tile_name(int id) { return (id >= 0 && id < conv_num_tiles()) ?
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
-  const dim3 grid(tilesM * tilesN), block(256);
+  const dim3 grid(tilesM * tilesN * p.groups), block(WM * WN * 64);
   const bool smallc = (p.Cin % BK) != 0;
   if (p.nchw_out) {
     if (smallc) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
@@ -239,19 +296,28 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
   }
 }
 
-static int pick_tile(const ConvParams& p) {
-  // cost = rounds of resident blocks x padded tile work / per-tile efficiency
+static int g_forced_tile = -2;  // -2: not read yet; PF_CONV_TILE=<id> forces one tile config (tuning aid)
+static int g_max_auto_tile = 9; // tiles with id >= this are opt-in until measured (PF_CONV_AUTO_MAX)
+
+int pick_tile(const ConvParams& p) {
+  if (g_forced_tile == -2) {
+    const char* e = getenv("PF_CONV_TILE");
+    g_forced_tile = e ? atoi(e) : -1;
+    const char* m = getenv("PF_CONV_AUTO_MAX");
+    if (m) g_max_auto_tile = atoi(m);
+  }
+  if (g_forced_tile >= 0 && g_forced_tile < conv_num_tiles()) return g_forced_tile;
+  // MFMA-bound model: a CU works through its share of the blocks at the tile's intrinsic rate, so
+  // time ~ ceil(blocks / 256 CUs) x tile area / eff  (captures the partially filled last wave of blocks)
   int best = 0;
   double best_cost = 1e300;
-  for (int id = 0; id < conv_num_tiles(); ++id) {
+  for (int id = 0; id < conv_num_tiles() && id < g_max_auto_tile; ++id) {
     const TileCfg& c = kTiles[id];
+    if (c.bn > 32 && p.Cout <= 32) continue;
     const long tm = (p.M + c.bm - 1) / c.bm, tn = (p.Cout + c.bn - 1) / c.bn;
-    const long blocks = tm * tn;
-    const long slots = 256L * c.blocks_per_cu;
-    const long rounds = (blocks + slots - 1) / slots;
-    // partial last round still costs a full tile time; blend with the ideal to avoid cliffs
-    const double tile_t = (double)c.bm * c.bn / c.eff;
-    const double cost = 0.5 * rounds * tile_t * c.blocks_per_cu + 0.5 * (double)blocks * tile_t / 256.0;
+    const long blocks = tm * tn * p.groups;
+    const long per_cu = (blocks + 255) / 256;
+    const double cost = (double)per_cu * c.bm * c.bn / c.eff;
     if (cost < best_cost) { best_cost = cost; best = id; }
   }
   return best;
@@ -264,7 +330,11 @@ void launch_conv_tile(const ConvParams& p, int tile_id, hipStream_t s) {
     case 1: launch_cfg<128, 64, 2, 2>(p, s); break;
     case 2: launch_cfg<64, 64, 2, 2>(p, s); break;
     case 3: launch_cfg<128, 32, 4, 1>(p, s); break;
-    default: launch_cfg<64, 128, 2, 2>(p, s); break;
+    case 4: launch_cfg<64, 128, 2, 2>(p, s); break;
+    case 5: launch_cfg<128, 256, 2, 2>(p, s); break;
+    case 6: launch_cfg<256, 128, 2, 2>(p, s); break;
+    case 7: launch_cfg<256, 128, 4, 2>(p, s); break;
+    default: launch_cfg<256, 256, 2, 4>(p, s); break;
   }
 }
 void launch_conv(const ConvParams& p, hipStream_t s) { launch_conv_tile(p, -1, s); }

@@ -15,14 +15,19 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 //   y[m][n] = post( act( sum_k A[m][k] * Wp[n][k] + bias[n] ) + res1[m][n] + res2[m][n] )
 // m = (b, oy, ox) output pixel, k = (ky, kx, ci) with ci fastest, A gathered on the fly
 // from one NHWC tensor or from the channel-concat of two (x: C1 channels, x2: C2).
+struct ConvPtrs {
+  const float* x = nullptr;
+  const float* x2 = nullptr;        // nullptr unless channel-concat input
+  const float* w = nullptr;         // packed [Cout][KH][KWCp], KWCp = roundup(KW*Cin, 32), zero padded
+  const float* bias = nullptr;      // [Cout] or nullptr
+  const float* bias_tab = nullptr;  // [9][Cout]: bias per 3x3 border case (folded Linear->conv), overrides bias
+  const float* res1 = nullptr;      // [M][Cout] or nullptr (may alias y)
+  const float* res2 = nullptr;      // [M][Cout] or nullptr
+  float* y = nullptr;               // [M][ldy]
+};
 struct ConvParams {
-  const float* x;
-  const float* x2;    // nullptr unless channel-concat input
-  const float* w;     // packed [Cout][KH][KWCp], KWCp = roundup(KW*Cin, 32), zero padded
-  const float* bias;  // [Cout] or nullptr
-  const float* res1;  // [M][Cout] or nullptr (may alias y)
-  const float* res2;  // [M][Cout] or nullptr
-  float* y;           // [M][ldy] rows, written at column offset 0..Cout-1
+  ConvPtrs g[2];   // grouped launch: `groups` problems of identical shape (the two decoder heads) in one grid
+  int groups = 1;
   int B, H, W, C1, C2, Cin;
   int KH, KW, stride, pad;
   int Ho, Wo, Cout;
@@ -32,6 +37,18 @@ struct ConvParams {
   int post_relu;  // relu after the residual adds
   int ldy;        // row stride of y / res1 / res2 in floats (normally Cout)
   int nchw_out;   // 1: store y as [B][Cout][Ho*Wo] (API-visible logits), residuals unsupported
+  unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)
+  // fills the derived fields (Ho, Wo, M, Cin, *_bytes) from the primary ones
+  void finish() {
+    Cin = C1 + C2;
+    Ho = (H + 2 * pad - KH) / stride + 1;
+    Wo = (W + 2 * pad - KW) / stride + 1;
+    M = B * Ho * Wo;
+    x_bytes = (unsigned)((size_t)B * H * W * C1 * 4);
+    x2_bytes = (unsigned)((size_t)B * H * W * C2 * 4);
+    w_bytes = (unsigned)((size_t)Cout * KH * KWCp * 4);
+    ldy = Cout;
+  }
 };
 
 void launch_conv(const ConvParams& p, hipStream_t s);

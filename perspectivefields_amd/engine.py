@@ -41,6 +41,7 @@ _SIGNATURES = {
     "pf_op_conv2d": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P,
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_int,
                                 _c.c_int, _c.c_int, _P, _P]),
+    "pf_op_conv2d_bench": (_c.c_int, [_c.c_int] * 11 + [_c.POINTER(_c.c_float)]),
     "pf_op_layernorm": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_long, _c.c_int, _c.c_float, _P]),
     "pf_op_dwconv3x3_gelu": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
     "pf_op_dwconv7x7": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),

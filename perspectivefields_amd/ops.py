@@ -123,3 +123,11 @@ def upsample2x(x):
 def conv_tiles():
     lib = load_library()
     return [lib.pf_op_conv_tile_name(i).decode() for i in range(lib.pf_op_num_conv_tiles())]
+
+
+def conv2d_bench(B, H, W, Cin, Cout, K, stride=1, pad=0, tile=-1, iters=10, device=0):
+    """Average ms per launch of one conv shape on random data (tuning aid)."""
+    lib = load_library()
+    ms = ctypes.c_float()
+    _check(lib.pf_op_conv2d_bench(device, B, H, W, Cin, Cout, K, stride, pad, tile, iters, ctypes.byref(ms)), None, "pf_op_conv2d_bench")
+    return ms.value

@@ -150,3 +150,21 @@ def test_errors_are_loud():
     cpu_model = PerspectiveFields(CASES["centered"], weights="synthetic")
     with pytest.raises(PfError):
         cpu_model.inference(synthetic_image(32, 32, 1))
+
+
+def test_folded_and_unfolded_mlp_agree(monkeypatch):
+    """PF_FOLD_MLP=0 keeps Linear(C->768) + conv3x3(768->256) as two kernels.  It must agree with the default
+    (folded) path far inside the parity tolerances."""
+    from perspectivefields_amd import PerspectiveFields
+
+    imgs = [synthetic_image(72, 96, seed=80 + i) for i in range(3)]
+    base = model("centered").inference_batch(imgs)
+    monkeypatch.setenv("PF_FOLD_MLP", "0")
+    alt_model = PerspectiveFields(CASES["centered"], weights="synthetic:0").eval().cuda()
+    alt = alt_model.inference_batch(imgs)
+    for i, (a, b) in enumerate(zip(base, alt)):
+        c = one_minus_cos(a["pred_gravity"].cpu().numpy(), b["pred_gravity"].cpu().numpy()).max()
+        e = l1(a["pred_latitude"].cpu().numpy(), b["pred_latitude"].cpu().numpy())
+        d = max(abs(float(a[k]) - float(b[k])) for k in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
+        print(f"[fold vs unfold img{i}] 1-cos {c:.2e} latL1 {e:.2e} param {d:.2e}")
+        assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5

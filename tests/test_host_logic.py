@@ -1,0 +1,167 @@
+"""CPU-only tests of the host side: config / zoo, checkpoint schema and strict validation, synthetic
+checkpoint determinism, C-ABI library loading + symbol export, weight-fold algebra, shard logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from perspectivefields_amd import config as cfgmod
+from perspectivefields_amd.config import arch_of, get_cfg, model_zoo
+from perspectivefields_amd.schema import checkpoint_schema, validate_state_dict
+from perspectivefields_amd.synth import synthetic_image, synthetic_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_zoo_and_cfg():
+    assert list(model_zoo) == [
+        "Paramnet-360Cities-edina-centered", "Paramnet-360Cities-edina-uncentered", "PersNet-360Cities",
+        "PersNet_Paramnet-GSV-uncentered", "PersNet_Paramnet-GSV-centered",
+    ]
+    c = get_cfg("Paramnet-360Cities-edina-centered")
+    assert c.MODEL.GRAVITY_DECODER.LOSS_TYPE == "regression" and c.MODEL.RECOVER_RPF and not c.MODEL.RECOVER_PP
+    assert c.DATALOADER.RESIZE == [320, 320] and c.INPUT.FORMAT == "BGR" and c.MODEL.PIXEL_MEAN == [103.53, 116.28, 123.675]
+    with pytest.raises(AttributeError):
+        c.MODEL.RECOVER_PP = True  # frozen like the reference's cfg
+    with pytest.raises(KeyError):
+        get_cfg("nope")
+    a = arch_of(get_cfg("PersNet-360Cities"))
+    assert (a["gravity_out"], a["latitude_out"], a["param_net"]) == (73, 180, None)
+    a = arch_of(get_cfg("PersNet_Paramnet-GSV-uncentered"))
+    assert a["param_net"] == "ParamNetConvNextRegress" and a["param_input_size"] == 64 and a["param_out"] == 5
+    a = arch_of(get_cfg("PersNet_Paramnet-GSV-centered"))
+    assert a["param_net"] == "ParamNet" and (a["gravity_out"], a["latitude_out"]) == (2, 1)
+
+
+def test_schema_sizes():
+    # 860 keys / 104,570,633 elements; 678 / 76,754,910
+    s = checkpoint_schema("Paramnet-360Cities-edina-centered")
+    assert len(s) == 860 and sum(int(np.prod(v)) if len(v) else 1 for v in s.values()) == 104570633
+    s = checkpoint_schema("PersNet-360Cities")
+    assert len(s) == 678 and sum(int(np.prod(v)) if len(v) else 1 for v in s.values()) == 76754910
+
+
+def test_strict_validation():
+    v = "Paramnet-360Cities-edina-centered"
+    sd = synthetic_state_dict(v, 0)
+    validate_state_dict(v, sd)
+    bad = dict(sd); bad.pop("backbone.norm3.weight")
+    with pytest.raises(ValueError, match="missing"):
+        validate_state_dict(v, bad)
+    bad = dict(sd); bad["extra.key"] = np.zeros(3, np.float32)
+    with pytest.raises(ValueError, match="unexpected"):
+        validate_state_dict(v, bad)
+    bad = dict(sd); bad["ll_enc.conv1.weight"] = np.zeros((64, 3, 3, 3), np.float32)
+    with pytest.raises(ValueError, match="shape"):
+        validate_state_dict(v, bad)
+    with pytest.raises(ValueError):
+        validate_state_dict("PersNet-360Cities", sd)  # wrong architecture
+
+
+def test_synth_deterministic():
+    a = synthetic_state_dict("PersNet-360Cities", 0)
+    b = synthetic_state_dict("PersNet-360Cities", 0)
+    c = synthetic_state_dict("PersNet-360Cities", 1)
+    k = "backbone.block3.7.mlp.fc1.weight"
+    assert np.array_equal(a[k], b[k]) and not np.array_equal(a[k], c[k])
+    assert a[k].dtype == np.float32
+    # pinned values (platform-independent PCG64 streams): golden fixtures depend on them
+    assert abs(float(a["backbone.norm1.weight"][0]) - float(b["backbone.norm1.weight"][0])) == 0
+    im = synthetic_image(40, 30, 5)
+    assert im.shape == (40, 30, 3) and im.dtype == np.uint8 and np.array_equal(im, synthetic_image(40, 30, 5))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads without a GPU and exports every symbol include/pf_hip.h declares."""
+    from perspectivefields_amd.engine import LIB_PATH, declared_symbols, load_library
+
+    hdr = open(os.path.join(ROOT, "include", "pf_hip.h")).read()
+    declared = set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"pf_engine"}
+    assert declared, "no declarations parsed"
+    assert os.path.exists(LIB_PATH), "libpf_hip.so not built (python -m perspectivefields_amd.build)"
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"library lacks {missing}"
+    assert declared == set(declared_symbols()), (declared ^ set(declared_symbols()))
+    assert load_library().pf_version().startswith(b"pf_hip")
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from perspectivefields_amd.engine import Engine, PfError, load_library
+
+    with pytest.raises(PfError):
+        Engine(0, "cuda:0")
+    lib = load_library()
+    h = ctypes.c_void_p()
+    assert lib.pf_create(ctypes.byref(h), 0, 0) == -2  # PF_ERR_DEVICE, no CPU fallback
+    assert b"no HIP device" in lib.pf_last_error(None)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "perspectivefields_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|import_module\(.oracle", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_fold_linear_into_conv_algebra():
+    """The engine folds Linear(C->768) + zero-padded conv3x3(768->256) into one conv3x3(C->256) with a 9-case
+    bias table (csrc/engine.hip make_folded).  Same algebra in numpy, checked against the two-step form."""
+    g = torch.Generator().manual_seed(0)
+    C, E, O, H, W = 8, 24, 6, 5, 7
+    x = torch.randn(2, C, H, W, generator=g, dtype=torch.float64)
+    wl, bl = torch.randn(E, C, generator=g, dtype=torch.float64), torch.randn(E, generator=g, dtype=torch.float64)
+    wp, bp = torch.randn(O, E, 3, 3, generator=g, dtype=torch.float64), torch.randn(O, generator=g, dtype=torch.float64)
+    e = F.linear(x.permute(0, 2, 3, 1), wl, bl).permute(0, 3, 1, 2)
+    ref = F.conv2d(e, wp, bp, padding=1)
+    wf = torch.einsum("oekl,ec->ockl", wp, wl)
+    T = torch.einsum("oekl,e->okl", wp, bl)
+    out = F.conv2d(x, wf, None, padding=1)
+    for y in range(H):
+        for xx in range(W):
+            cy = 0 if y == 0 else (2 if y == H - 1 else 1)
+            cx = 0 if xx == 0 else (2 if xx == W - 1 else 1)
+            b = bp.clone()
+            for ky in range(3):
+                for kx in range(3):
+                    vy = not ((cy == 0 and ky == 0) or (cy == 2 and ky == 2))
+                    vx = not ((cx == 0 and kx == 0) or (cx == 2 and kx == 2))
+                    if vy and vx:
+                        b = b + T[:, ky, kx]
+            out[:, :, y, xx] += b
+    assert torch.allclose(out, ref, atol=1e-10)
+
+
+def test_general_vfov_closed_form_matches_fsolve():
+    from oracle import pf_oracle
+    from perspectivefields_amd.perspectivefields import general_vfov_to_focal
+
+    rng = np.random.default_rng(0)
+    cx, cy = rng.uniform(-0.3, 0.3, 50), rng.uniform(-0.3, 0.3, 50)
+    fov = rng.uniform(15, 110, 50)
+    np.testing.assert_allclose(general_vfov_to_focal(cx, cy, fov), pf_oracle.general_vfov_to_focal(cx, cy, fov), rtol=1e-7, atol=1e-9)
+
+
+def test_shard_helpers():
+    from perspectivefields_amd.dist import shard_range, shard_round_robin_by_bucket
+
+    for n, w in [(256, 8), (10, 4), (3, 8), (33, 2)]:
+        got = [shard_range(n, r, w) for r in range(w)]
+        assert got[0][0] == 0 and got[-1][1] == n
+        assert all(got[i][1] == got[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in got]
+        assert max(sizes) - min(sizes) <= 1
+    sizes = [(384, 512), (640, 640), (640, 640), (1024, 1365)] * 16
+    parts = [shard_round_robin_by_bucket(sizes, r, 8) for r in range(8)]
+    assert sorted(sum(parts, [])) == list(range(64))
+    for p in parts:
+        assert len(p) == 8 and sum(1 for i in p if sizes[i] == (640, 640)) == 4
