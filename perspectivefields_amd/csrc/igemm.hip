@@ -210,31 +210,57 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p)
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   if (!NCHW) {
+    // The accumulator layout gives each lane ONE float per store (row stride between registers), which makes
+    // the epilogue store-issue bound.  Stage the tile through LDS (free after the K loop) in chunks of WM*32
+    // rows and write it back row-major: every thread then moves 16 bytes per instruction, fully coalesced, and
+    // the residual / bias operands are read as float4 as well.
+    constexpr int CROW = BN + 4;            // floats per staged row (keeps 16-B alignment, shifts banks)
+    constexpr int CH_ROWS = WM * 32;        // rows per chunk: subtile row i of every wave row
+    constexpr int F4_PER_ROW = BN / 4;
+    static_assert(CH_ROWS * CROW <= 2 * (BM + BN) * LDS_ROW, "epilogue chunk must fit the operand buffers");
+    float* Cs = smem;
+    const int wave_m = wave / WN;
+    const bool vec_ok = (p.Cout & 3) == 0 && (p.ldy & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < SN; ++j) {
-      const int n = n0 + wn0 + j * 32 + l31;
-      const bool nok = n < p.Cout;
-      const float bias = (P.bias && nok) ? P.bias[n] : 0.f;
+    for (int i = 0; i < SM; ++i) {
+      __syncthreads();  // previous chunk fully written back / K loop finished reading the operand tiles
 #pragma unroll
-      for (int i = 0; i < SM; ++i) {
+      for (int j = 0; j < SN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (nok && m < p.M) {
-            float bsel = bias;
-            if (P.bias_tab) {  // position-dependent bias of a folded (Linear -> zero-padded 3x3) pair: 3x3 border cases
-              const int rem = m % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-              const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
-              bsel = P.bias_tab[(cy * 3 + cx) * p.Cout + n];
-            }
-            float v = acc[i][j][r] + bsel;
-            if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-            else if (p.act == ACT_GELU) v = gelu_erf(v);
-            const long o = (long)m * p.ldy + n;
-            if (P.res1) v += P.res1[o];
-            if (P.res2) v += P.res2[o];
-            if (p.post_relu) v = fmaxf(v, 0.f);
-            P.y[o] = v;
+        for (int r = 0; r < 16; ++r)
+          Cs[(wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CROW + wn0 + j * 32 + l31] = acc[i][j][r];
+      __syncthreads();
+      for (int idx = tid; idx < CH_ROWS * F4_PER_ROW; idx += NT) {
+        const int row_l = idx / F4_PER_ROW, cq = idx - row_l * F4_PER_ROW;
+        const int m = m0 + (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
+        const int n = n0 + cq * 4;
+        if (m >= p.M || n >= p.Cout) continue;
+        float4 v = *reinterpret_cast<const float4*>(Cs + row_l * CROW + cq * 4);
+        const float* bsrc = P.bias;
+        if (P.bias_tab) {  // position-dependent bias of a folded (Linear -> zero-padded 3x3) pair: 3x3 border cases
+          const int rem = m % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
+          bsrc = P.bias_tab + (cy * 3 + cx) * p.Cout;
+        }
+        const long o = (long)m * p.ldy + n;
+        if (vec_ok) {
+          if (bsrc) { const float4 bb = *reinterpret_cast<const float4*>(bsrc + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+          if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          else if (p.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+          if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+          if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+          if (p.post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          *reinterpret_cast<float4*>(P.y + o) = v;
+        } else {  // ragged channel count: scalar tail
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+            float x = vv[e] + (bsrc ? bsrc[n + e] : 0.f);
+            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+            else if (p.act == ACT_GELU) x = gelu_erf(x);
+            if (P.res1) x += P.res1[o + e];
+            if (P.res2) x += P.res2[o + e];
+            if (p.post_relu) x = fmaxf(x, 0.f);
+            P.y[o + e] = x;
           }
         }
       }
@@ -269,15 +295,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p)
 struct TileCfg { int bm, bn; const char* name; float eff; int blocks_per_cu; };
 // eff = intrinsic throughput (TFLOP/s, all CUs busy, quantisation divided out) measured with scripts/tune_conv.py
 static const TileCfg kTiles[] = {
-    {128, 128, "128x128", 107.f, 2},
-    {128, 64, "128x64", 94.f, 2},
-    {64, 64, "64x64", 93.f, 4},
-    {128, 32, "128x32", 83.f, 3},
-    {64, 128, "64x128", 97.f, 2},
-    {128, 256, "128x256", 105.f, 1},
-    {256, 128, "256x128", 102.f, 1},
-    {256, 128, "256x128w8", 111.f, 1},
-    {256, 256, "256x256w8", 120.f, 1},
+    {128, 128, "128x128", 114.f, 2},
+    {128, 64, "128x64", 105.f, 2},
+    {64, 64, "64x64", 108.f, 4},
+    {128, 32, "128x32", 101.f, 3},
+    {64, 128, "64x128", 107.f, 2},
+    {128, 256, "128x256", 109.f, 1},
+    {256, 128, "256x128", 109.f, 1},
+    {256, 128, "256x128w8", 115.f, 1},
+    {256, 256, "256x256w8", 122.f, 1},
 };
 int conv_num_tiles() { return (int)(sizeof(kTiles) / sizeof(kTiles[0])); }
 const char* conv_tile_name(int id) { return (id >= 0 && id < conv_num_tiles()) ? kTiles[id].name : "auto"; }
@@ -317,7 +343,10 @@ int pick_tile(const ConvParams& p) {
     const long tm = (p.M + c.bm - 1) / c.bm, tn = (p.Cout + c.bn - 1) / c.bn;
     const long blocks = tm * tn * p.groups;
     const long per_cu = (blocks + 255) / 256;
-    const double cost = (double)per_cu * c.bm * c.bn / c.eff;
+    // per block: MFMA time (us) + a fixed fill/drain latency that `blocks_per_cu` resident blocks overlap
+    const double K = (double)p.KH * p.KWCp;
+    const double t_mfma = 2.0 * c.bm * c.bn * K / (c.eff * 1e6 / 256.0);
+    const double cost = (double)per_cu * (t_mfma + 4.0 / c.blocks_per_cu);
     if (cost < best_cost) { best_cost = cost; best = id; }
   }
   return best;
