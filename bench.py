@@ -45,6 +45,18 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_pmc_traffic.json, produced by scripts/gpu_rocprof.sh + scripts/summarize_rocprof.py)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(version, size, budget_s=12.0, max_images=12):
     """The oracle (CPU port of the reference algorithm) timed on this host's cores on a bounded sample
     of the same workload.  The unmodified reference cannot travel to the GPU box (kind = "port")."""
@@ -173,12 +185,13 @@ def main():
         },
     }
     if prof is not None:
+        traffic, traffic_src = pmc_traffic()
         ig = prof["igemm"]
         if ig["ms"] > 0:
             ach = ig["work"] / (ig["ms"] * 1e-3) / 1e12
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                 "kernel": "pf::igemm_kernel (implicit-GEMM conv/GEMM, v_mfma_f32_32x32x2_f32)",
                 "launches_per_step": ig["launches"] // args.steps,
                 "avg_launch_us": round(1000.0 * ig["ms"] / max(ig["launches"], 1), 2),

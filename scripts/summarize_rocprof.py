@@ -1,0 +1,54 @@
+"""Aggregates rocprofv3 CSVs (kernel trace + PMC passes) per kernel name -> gpurun_out/rocprof_summary.{json,md}."""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    m = re.search(r"pf::(\w+)", name)
+    if m:
+        t = re.search(r"igemm_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+        return f"pf::{m.group(1)}" + (f"<{t.group(1)}x{t.group(2)},w{int(t.group(3))*int(t.group(4))}>" if t else "")
+    return name[:60]
+
+out = {"kernels": {}}
+# ---- kernel trace: durations
+for f in glob.glob(os.path.join(root, "rocprof_trace", "**", "*kernel_trace.csv"), recursive=True):
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"]); d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        agg[k][0] += 1; agg[k][1] += d
+    tot = sum(v[1] for v in agg.values())
+    for k, (n, us) in agg.items():
+        out["kernels"].setdefault(k, {})["trace"] = {"calls": n, "total_us": round(us, 1), "avg_us": round(us / n, 2), "pct": round(100 * us / tot, 2)}
+    out["trace_total_us"] = round(tot, 1)
+# ---- PMC passes
+for d in glob.glob(os.path.join(root, "rocprof_pmc_*")):
+    if not os.path.isdir(d): continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"]); c = r["Counter_Name"]; agg[k][c] += float(r["Counter_Value"]); cnt[k][c] += 1
+        for k in agg:
+            for c in agg[k]:
+                out["kernels"].setdefault(k, {}).setdefault("pmc", {})[c] = {"sum": agg[k][c], "dispatches": cnt[k][c], "avg": agg[k][c] / max(cnt[k][c], 1)}
+# derived: HBM traffic per launch (guide: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 on gfx950; FETCH_SIZE under-reports wide reads by 2x)
+for k, v in out["kernels"].items():
+    p = v.get("pmc", {})
+    if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+        v["hbm_bytes_per_launch"] = (2 * p["FETCH_SIZE"]["avg"] + p["WRITE_SIZE"]["avg"]) * 1024
+    if "TCC_HIT_sum" in p and "TCC_MISS_sum" in p:
+        h, m = p["TCC_HIT_sum"]["sum"], p["TCC_MISS_sum"]["sum"]
+        v["l2_hit_rate"] = h / max(h + m, 1)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in p and "GRBM_GUI_ACTIVE" in p and p["GRBM_GUI_ACTIVE"]["sum"] > 0:
+        # SQ_VALU_MFMA_BUSY_CYCLES: 64 per v_mfma_f32_32x32x2_f32, summed over all SIMDs
+        v["mfma_busy_frac"] = p["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / (p["GRBM_GUI_ACTIVE"]["sum"] / 8.0 * 1024)  # GRBM counter is summed over the 8 XCDs; 1024 SIMDs
+json.dump(out, open(os.path.join(root, "rocprof_summary.json"), "w"), indent=1)
+rows = sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("trace", {}).get("total_us", 0))
+md = ["| kernel | calls | total us | avg us | % | HBM MB/launch | L2 hit | MFMA busy |", "|---|---|---|---|---|---|---|---|"]
+for k, v in rows[:40]:
+    t = v.get("trace", {})
+    md.append(f"| {k} | {t.get('calls','')} | {t.get('total_us','')} | {t.get('avg_us','')} | {t.get('pct','')} | "
+              f"{v.get('hbm_bytes_per_launch', 0)/1e6:.1f} | {v.get('l2_hit_rate', float('nan')):.3f} | {v.get('mfma_busy_frac', float('nan')):.3f} |")
+open(os.path.join(root, "rocprof_summary.md"), "w").write("\n".join(md) + "\n")
+print("\n".join(md))
