@@ -92,6 +92,14 @@ int pf_forward_u8(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_p
 int pf_forward_f32(pf_handle h, int batch, const float* d_images_f32, float* d_pred_gravity, float* d_pred_latitude,
                    float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* One-time tile autotuning for a batch size: a normal forward (same arguments and results as pf_forward_u8) in which
+ * every conv/GEMM launch is additionally timed with each tile configuration on this device (HIP events; this call DOES
+ * wait on the stream) and the fastest is cached in the handle.  Optional: untuned batch sizes use a static cost model.
+ * pf_is_tuned returns 1 once a batch size has been tuned (or when autotuning is disabled with PF_AUTOTUNE=0). */
+int pf_autotune(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_pred_gravity, float* d_pred_latitude,
+                float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
+int pf_is_tuned(pf_handle h, int batch);
+
 /* Post-process ONE image's 320x320 predictions to its original size (H, W):
  *   d_up_out  : [2][H][W] unit up-vectors (x right, y down), d_lat_out : [H][W] degrees.
  * For the classification arch d_workspace must hold 3*320*320 floats (decoded fields). */
@@ -119,6 +127,8 @@ int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, 
                  float* d_y, void* stream);
 /* times `iters` launches of one conv shape on random data with tile config `tile_id` (-1 auto); avg ms per launch */
 int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, float* ms_out);
+/* times one depthwise-3x3+GELU launch variant on random data (0 = LDS halo tile, 1-4 = register-window direct, 99 = plain copy) */
+int pf_op_dwconv3x3_bench(int device, int variant, int B, int H, int W, int C, int iters, float* ms_out);
 int pf_op_layernorm(int device, const float* d_x, const float* h_gamma, const float* h_beta, float* d_y, long rows, int C, float eps, void* stream);
 int pf_op_dwconv3x3_gelu(int device, const float* d_x, const float* h_weight /*[C][1][3][3]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);
 int pf_op_dwconv7x7(int device, const float* d_x, const float* h_weight /*[C][1][7][7]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);

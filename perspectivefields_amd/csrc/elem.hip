@@ -1,6 +1,8 @@
 // HBM-bound kernels of the PerspectiveFields path for gfx950: LayerNorm, depthwise
 // 3x3(+GELU) / 7x7 with LDS-staged halo tiles, bilinear x2, prediction heads,
 // post-process, input normalisation, ConvNeXt tail.  All NHWC fp32, 16-byte accesses.
+#include <stdlib.h>
+
 #include "pf_kernels.h"
 
 namespace pf {
@@ -144,10 +146,103 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __rest
   }
 }
 
+// Variant without LDS: thread (channel quad q, column x) marches down a strip of rows keeping a 3x3 window of
+// float4 in registers and fetching 3 new values per output straight from global memory; the x-1/x/x+1 overlap
+// between neighbouring lanes/waves is served by L1/L2, HBM sees each input once (plus strip halos).
+template <int CQB /*quads per block*/, int XB /*columns per block*/, int TH /*rows per strip*/>
+__global__ __launch_bounds__(CQB * XB) void dwconv3x3_gelu_direct_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
+                                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                                         int B, int H, int W, int C) {
+  const int CQ = C >> 2;
+  const int slabs = CQ / CQB, tilesX = (W + XB - 1) / XB, strips = (H + TH - 1) / TH;
+  const int nblk = B * strips * tilesX * slabs;
+  int t;
+  {  // XCD-aware order: consecutive work items (slabs of a tile, then x-neighbours) share one L2
+    const int b = blockIdx.x, qd = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    t = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+  }
+  const int slab = t % slabs; t /= slabs;
+  const int tx = t % tilesX; t /= tilesX;
+  const int st = t % strips; t /= strips;
+  const int b = t;
+  const int q = slab * CQB + threadIdx.x % CQB;
+  const int ox = tx * XB + threadIdx.x / CQB;
+  if (ox >= W) return;
+  const int y0 = st * TH, y1 = min(y0 + TH, H);
+  const float4* xin = reinterpret_cast<const float4*>(x) + (long)b * H * W * CQ + q;
+  float4* yout = reinterpret_cast<float4*>(y) + (long)b * H * W * CQ + q;
+  float4 wk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const float4*>(w9c)[(long)k * CQ + q];
+  const float4 bv = reinterpret_cast<const float4*>(bias)[q];
+  const bool lx = ox > 0, rx = ox < W - 1;
+  auto load_row = [&](int iy, float4 (&row)[3]) {
+    if ((unsigned)iy < (unsigned)H) {
+      const float4* p = xin + ((long)iy * W + ox) * CQ;
+      row[0] = lx ? p[-CQ] : f4(0.f);
+      row[1] = p[0];
+      row[2] = rx ? p[CQ] : f4(0.f);
+    } else {
+      row[0] = row[1] = row[2] = f4(0.f);
+    }
+  };
+  float4 r0[3], r1[3], r2[3];
+  load_row(y0 - 1, r0);
+  load_row(y0, r1);
+  for (int oy = y0; oy < y1; ++oy) {
+    load_row(oy + 1, r2);
+    float4 a = bv;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a = fma4(r0[c], wk[c], a);
+      a = fma4(r1[c], wk[3 + c], a);
+      a = fma4(r2[c], wk[6 + c], a);
+    }
+    a.x = gelu_erf_e(a.x); a.y = gelu_erf_e(a.y); a.z = gelu_erf_e(a.z); a.w = gelu_erf_e(a.w);
+    yout[((long)oy * W + ox) * CQ] = a;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r0[c] = r1[c]; r1[c] = r2[c]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_f4_kernel(const float4* __restrict__ x, float4* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = x[i];
+}
+
+static int g_dw3_variant = -1;
+void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+  const int CQ = C / 4;
+  if (variant == 0) {
+    const int tilesX = (W + DW3_T - 1) / DW3_T, tilesY = (H + DW3_T - 1) / DW3_T;
+    const long blocks = (long)B * tilesY * tilesX * (C / (DW3_CQ * 4));
+    hipLaunchKernelGGL(dwconv3x3_gelu_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+  } else if (variant == 1) {  // 32 quads x 8 columns, strips of 16 rows
+    const long blocks = (long)B * ((H + 15) / 16) * ((W + 7) / 8) * (CQ / 32);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+  } else if (variant == 2) {  // 64 quads x 4 columns, strips of 16 rows
+    if (CQ % 64 != 0) return launch_dwconv3x3_gelu_variant(1, x, w9c, bias, y, B, H, W, C, s);
+    const long blocks = (long)B * ((H + 15) / 16) * ((W + 3) / 4) * (CQ / 64);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<64, 4, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+  } else if (variant == 3) {  // 32 quads x 8 columns, strips of 40 rows
+    const long blocks = (long)B * ((H + 39) / 40) * ((W + 7) / 8) * (CQ / 32);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 40>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+  } else if (variant == 4) {  // 32 quads x 8 columns, strips of 8 rows
+    const long blocks = (long)B * ((H + 7) / 8) * ((W + 7) / 8) * (CQ / 32);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 8>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+  } else {  // 99: plain copy of the same bytes (achievable streaming ceiling, diagnostic only)
+    const long n = (long)B * H * W * CQ;
+    hipLaunchKernelGGL(copy_f4_kernel, dim3(256 * 16), dim3(256), 0, s, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), n);
+  }
+}
+
 void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
-  const int tilesX = (W + DW3_T - 1) / DW3_T, tilesY = (H + DW3_T - 1) / DW3_T;
-  const long blocks = (long)B * tilesY * tilesX * (C / (DW3_CQ * 4));
-  hipLaunchKernelGGL(dwconv3x3_gelu_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+  if (g_dw3_variant == -1) {
+    const char* e = getenv("PF_DW3_VARIANT");
+    g_dw3_variant = e ? atoi(e) : -2;
+  }
+  // default: register-window kernel; strip height / block shape by map size (scripts/tune_dw.py, profiles/r01_tune_dw.txt)
+  const int v = g_dw3_variant >= 0 ? g_dw3_variant : (H >= 64 ? 3 : (H >= 16 ? 4 : 2));
+  launch_dwconv3x3_gelu_variant(v, x, w9c, bias, y, B, H, W, C, s);
 }
 
 // ------------------------------------------------------------------------- depthwise 7x7
@@ -216,10 +311,90 @@ __global__ __launch_bounds__(192) void dwconv7x7_kernel(const float* __restrict_
     if (x0 + o < W) yout[(long)(x0 + o) * CQ] = acc[o];
 }
 
+// Register/ring variant: thread (channel quad q, column x) streams INPUT rows of a strip.  Its 49 per-channel
+// weights stay in registers (196 VGPRs: one wave per SIMD, the whole unified register file), the next input row
+// (7 float4 from global/L1: x-3..x+3) is prefetched while the current one is scattered into a ring of 7 output-row
+// accumulators (tap ky feeds the row 6-ky ahead); the oldest accumulator is complete after each row and is stored.
+// No LDS, no block-wide sync.  Measured 1.27 ms per B=32 forward vs 1.44 ms for the halo-tile kernel; variants with
+// LDS-resident weights / two columns per thread spill under hipcc and are slower (2.3 ms) -- see DESIGN.md.
+template <int CQB, int XB, int TH>
+__global__ __launch_bounds__(CQB * XB) void dwconv7x7_ring_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
+                                                                  const float* __restrict__ bias, float* __restrict__ y,
+                                                                  int B, int H, int W, int C) {
+  const int CQ = C >> 2;
+  const int slabs = CQ / CQB, tilesX = (W + XB - 1) / XB, strips = (H + TH - 1) / TH;
+  const int nblk = B * strips * tilesX * slabs;
+  int t;
+  {
+    const int b = blockIdx.x, qd = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    t = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+  }
+  const int slab = t % slabs; t /= slabs;
+  const int tx = t % tilesX; t /= tilesX;
+  const int st = t % strips; t /= strips;
+  const int b = t;
+  const int q = slab * CQB + threadIdx.x % CQB;
+  const int ox = tx * XB + threadIdx.x / CQB;
+  if (ox >= W) return;
+  const int y0 = st * TH, y1 = min(y0 + TH, H);
+  const float4* xin = reinterpret_cast<const float4*>(x) + (long)b * H * W * CQ + q;
+  float4* yout = reinterpret_cast<float4*>(y) + (long)b * H * W * CQ + q;
+  const float4 bv = reinterpret_cast<const float4*>(bias)[q];
+  float4 wk[49];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) wk[k] = reinterpret_cast<const float4*>(w49c)[(long)k * CQ + q];
+  auto load_row = [&](int iy, float4 (&row)[7]) {
+    const bool rowok = (unsigned)iy < (unsigned)H;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const int ix = ox + kx - 3;
+      row[kx] = (rowok && (unsigned)ix < (unsigned)W) ? xin[((long)iy * W + ix) * CQ] : f4(0.f);
+    }
+  };
+  // acc[r] belongs to output row (iy - 3 + r) while input row iy is processed: tap ky feeds acc[6 - ky];
+  // afterwards acc[0] is complete, the ring rotates by one slot and acc[6] restarts from the bias.
+  float4 acc[7], cur[7], nxt[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = bv;
+  load_row(y0 - 3, cur);
+#pragma unroll 1
+  for (int iy = y0 - 3; iy < y1 + 3; ++iy) {
+    load_row(iy + 1 < y1 + 3 ? iy + 1 : -1, nxt);  // prefetch (row -1 = zeros, unused)
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      float4 a = acc[6 - ky];
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) a = fma4(cur[kx], wk[ky * 7 + kx], a);
+      acc[6 - ky] = a;
+    }
+    const int oy = iy - 3;
+    if (oy >= y0 && oy < y1) yout[((long)oy * W + ox) * CQ] = acc[0];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] = acc[j + 1];
+    acc[6] = bv;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) cur[j] = nxt[j];
+  }
+}
+
+static int g_dw7_variant = -1;
 void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
-  const int tilesX = (W + DW7_T - 1) / DW7_T, tilesY = (H + DW7_T - 1) / DW7_T;
-  const long blocks = (long)B * tilesY * tilesX * (C / (DW7_CQ * 4));
-  hipLaunchKernelGGL(dwconv7x7_kernel, dim3((unsigned)blocks), dim3(192), 0, s, x, w49c, bias, y, B, H, W, C);
+  if (g_dw7_variant == -1) {
+    const char* e = getenv("PF_DW7_VARIANT");
+    g_dw7_variant = e ? atoi(e) : 1;
+  }
+  const int CQ = C / 4;
+  if (g_dw7_variant == 0) {  // LDS halo-tile kernel (kept for A/B)
+    const int tilesX = (W + DW7_T - 1) / DW7_T, tilesY = (H + DW7_T - 1) / DW7_T;
+    const long blocks = (long)B * tilesY * tilesX * (C / (DW7_CQ * 4));
+    hipLaunchKernelGGL(dwconv7x7_kernel, dim3((unsigned)blocks), dim3(192), 0, s, x, w49c, bias, y, B, H, W, C);
+  } else if (H >= 40) {
+    const long blocks = (long)B * ((H + 39) / 40) * ((W + 31) / 32) * (CQ / 8);
+    hipLaunchKernelGGL((dwconv7x7_ring_kernel<8, 32, 40>), dim3((unsigned)blocks), dim3(256), 0, s, x, w49c, bias, y, B, H, W, C);
+  } else {
+    const long blocks = (long)B * ((H + 19) / 20) * ((W + 7) / 8) * (CQ / 24);
+    hipLaunchKernelGGL((dwconv7x7_ring_kernel<24, 8, 20>), dim3((unsigned)blocks), dim3(192), 0, s, x, w49c, bias, y, B, H, W, C);
+  }
 }
 
 // --------------------------------------------------------------------------- bilinear x2

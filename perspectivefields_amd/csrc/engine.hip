@@ -74,6 +74,9 @@ struct Ctx {
   size_t off = 0, peak = 0;
   bool dry;
   Profiler* prof = nullptr;
+  bool tuning = false;      // autotune pass: time every tile config per conv shape
+  float* tune_scratch = nullptr;
+  size_t max_conv_out = 0;  // floats of the largest (grouped) conv output seen by the dry run = tuning scratch size
   float* alloc(size_t nfloats) {
     const size_t bytes = (nfloats * 4 + 255) & ~(size_t)255;
     const size_t o = off;
@@ -149,6 +152,10 @@ struct pf_engine {
   std::vector<void*> dev_allocs;
   std::map<int, size_t> ws_cache;
   Profiler prof;
+  bool autotune = true;      // PF_AUTOTUNE=0: tile choice from the static cost model only
+  std::map<std::vector<int>, int> tile_cache;  // conv shape (+batch) -> fastest tile config, measured on this device
+  std::map<int, bool> tuned_batches;
+  std::map<int, size_t> scratch_off;
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
 
   MitStage stages[4];
@@ -389,8 +396,12 @@ struct pf_engine {
     const float* res1 = nullptr; const float* res2 = nullptr; const float* x2 = nullptr;
   };
   void conv_g(Ctx& c, int ngroups, const ConvCall* calls, int B, int H, int W, int act = ACT_NONE, int post_relu = 0, int C1 = -1, int nchw = 0) {
-    if (c.dry) return;
     const ConvW& w = *calls[0].w;
+    if (c.dry) {
+      const size_t Ho = (H + 2 * w.pad - w.KH) / w.stride + 1, Wo = (W + 2 * w.pad - w.KW) / w.stride + 1;
+      c.max_conv_out = std::max(c.max_conv_out, (size_t)ngroups * B * Ho * Wo * w.Cout);
+      return;
+    }
     ConvParams p;
     p.groups = ngroups;
     for (int g = 0; g < ngroups; ++g) {
@@ -405,8 +416,42 @@ struct pf_engine {
     p.Cout = w.Cout; p.KWC = w.KWC; p.KWCp = w.KWCp;
     p.act = act; p.post_relu = post_relu; p.nchw_out = nchw;
     p.finish();
+    int tile = -1;
+    if (autotune) {
+      const std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out,
+                                    (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0), p.act};
+      auto it = tile_cache.find(key);
+      if (it != tile_cache.end()) tile = it->second;
+      else if (c.tuning && c.tune_scratch) { tile = tune_conv(p, c); tile_cache[key] = tile; }
+    }
     ProfScope ps(c.prof, c.s, PC_IGEMM, 2.0 * ngroups * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal, p.M * ngroups, w.Cout, w.KH * w.KW * w.CinReal, w.KH);
-    launch_conv(p, c.s);
+    launch_conv_tile(p, tile, c.s);
+  }
+  // Measure, don't guess: run the launch with every tile configuration (outputs redirected to scratch so in-place
+  // residual layers are not disturbed) and keep the fastest.  Results are identical across tiles (same K order).
+  int tune_conv(const ConvParams& p0, Ctx& c) {
+    ConvParams p = p0;
+    const size_t out_floats = (size_t)p.M * p.Cout;
+    for (int g = 0; g < p.groups; ++g) p.g[g].y = c.tune_scratch + g * out_floats;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+    int best = -1;
+    float best_ms = 1e30f;
+    for (int t = 0; t < conv_num_tiles(); ++t) {
+      if (conv_tile_bn(t) > 32 && p.Cout <= 32) continue;
+      if ((long)conv_tile_bm(t) * conv_tile_bn(t) > 16L * p.M * p.Cout) continue;  // tile far larger than the problem
+      launch_conv_tile(p, t, c.s);
+      (void)hipEventRecord(a, c.s);
+      launch_conv_tile(p, t, c.s);
+      launch_conv_tile(p, t, c.s);
+      (void)hipEventRecord(b, c.s);
+      if (hipEventSynchronize(b) != hipSuccess) break;
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, a, b);
+      if (ms < best_ms) { best_ms = ms; best = t; }
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return best;
   }
   void conv(Ctx& c, const ConvW& w, const float* x, int B, int H, int W, float* y, int act = ACT_NONE, const float* res1 = nullptr,
             const float* res2 = nullptr, int post_relu = 0, const float* x2 = nullptr, int C1 = -1, int nchw = 0) {
@@ -624,12 +669,14 @@ struct pf_engine {
     if (it != ws_cache.end()) return it->second;
     Ctx c{nullptr, 4096, 0, 0, true, nullptr};
     run(c, B, nullptr, true, nullptr, nullptr, nullptr);
-    const size_t need = c.peak + 4096;
+    const size_t scratch = autotune ? c.max_conv_out * 4 + 4096 : 0;  // largest conv output, target of the tuning launches
+    const size_t need = c.peak + 4096 + scratch;
     ws_cache[B] = need;
+    scratch_off[B] = c.peak;
     return need;
   }
 
-  int forward(int B, const void* in, bool is_u8, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, hipStream_t s) {
+  int forward(int B, const void* in, bool is_u8, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, hipStream_t s, bool tune = false) {
     if (!finalized) return fail(PF_ERR_WEIGHTS, "pf_forward called before pf_finalize_weights");
     if (B <= 0 || !in || !pg || !pl || !ws) return fail(PF_ERR_ARG, "pf_forward: null pointer or batch <= 0");
     if (has_param && !params) return fail(PF_ERR_ARG, "pf_forward: d_params is required for a ParamNet architecture");
@@ -640,6 +687,10 @@ struct pf_engine {
     uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255;
     Ctx c{s, base, 0, 0, false, nullptr};
     c.prof = prof.on ? &prof : nullptr;
+    if (tune && autotune) {
+      c.tuning = true;
+      c.tune_scratch = reinterpret_cast<float*>(base + scratch_off[B]);
+    }
     run(c, B, in, is_u8, pg, pl, params);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(PF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
@@ -692,6 +743,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   e->device = device;
   e->arch = arch;
   if (const char* v = getenv("PF_FOLD_MLP")) e->fold_mlp = atoi(v) != 0;
+  if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   *out = e;
   return PF_OK;
 }
@@ -766,6 +818,15 @@ int pf_forward_f32(pf_handle h, int batch, const float* in, float* pg, float* pl
   if (!h) return PF_ERR_ARG;
   return h->forward(batch, in, false, pg, pl, params, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
+
+int pf_autotune(pf_handle h, int batch, const uint8_t* in, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return PF_ERR_ARG;
+  const int rc = h->forward(batch, in, true, pg, pl, params, ws, ws_bytes, static_cast<hipStream_t>(stream), true);
+  if (rc == PF_OK) h->tuned_batches[batch] = true;
+  return rc;
+}
+
+int pf_is_tuned(pf_handle h, int batch) { return (h && (!h->autotune || h->tuned_batches.count(batch))) ? 1 : 0; }
 
 int pf_postprocess(pf_handle h, const float* pg, const float* pl, int H, int W, float* up, float* lat, void* ws, size_t ws_bytes, void* stream) {
   if (!h) return PF_ERR_ARG;
@@ -892,6 +953,42 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db);
+  return rc;
+}
+
+int pf_op_dwconv3x3_bench(int device, int variant, int B, int H, int W, int C, int iters, float* ms_out) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (C % 128 != 0 || iters <= 0 || !ms_out) { g_create_error = "pf_op_dwconv3x3_bench: bad argument"; return PF_ERR_ARG; }
+  const size_t n = (size_t)B * H * W * C;
+  float *dx = nullptr, *dy = nullptr, *dw = nullptr, *db = nullptr;
+  if (hipMalloc(&dx, n * 4) != hipSuccess || hipMalloc(&dy, n * 4) != hipSuccess || hipMalloc(&dw, (size_t)9 * C * 4) != hipSuccess ||
+      hipMalloc(&db, (size_t)C * 4) != hipSuccess) { g_create_error = "pf_op_dwconv3x3_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
+  {
+    std::vector<float> hx(n), hw((size_t)9 * C), hb(C);
+    uint32_t st = 777u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : hx) v = rnd();
+    for (auto& v : hw) v = rnd() * 0.3f;
+    for (auto& v : hb) v = rnd() * 0.1f;
+    (void)hipMemcpy(dx, hx.data(), n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+  }
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  launch_dwconv3x3_gelu_variant(variant, dx, dw, db, dy, B, H, W, C, nullptr);
+  (void)hipEventRecord(a, nullptr);
+  for (int i = 0; i < iters; ++i) launch_dwconv3x3_gelu_variant(variant, dx, dw, db, dy, B, H, W, C, nullptr);
+  (void)hipEventRecord(b, nullptr);
+  (void)hipEventSynchronize(b);
+  float t = 0.f;
+  (void)hipEventElapsedTime(&t, a, b);
+  *ms_out = t / iters;
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(db);
   return rc;
 }
 

@@ -305,6 +305,8 @@ static const TileCfg kTiles[] = {
     {256, 128, "256x128w8", 115.f, 1},
     {256, 256, "256x256w8", 122.f, 1},
 };
+int conv_tile_bm(int id) { return kTiles[id].bm; }
+int conv_tile_bn(int id) { return kTiles[id].bn; }
 int conv_num_tiles() { return (int)(sizeof(kTiles) / sizeof(kTiles[0])); }
 const char* conv_tile_name(int id) { return (id >= 0 && id < conv_num_tiles()) ? kTiles[id].name : "auto"; }
 

@@ -55,6 +55,8 @@ void launch_conv(const ConvParams& p, hipStream_t s);
 // tile choice is exposed for tests / tuning: -1 = auto
 void launch_conv_tile(const ConvParams& p, int tile_id, hipStream_t s);
 int conv_num_tiles();
+int conv_tile_bm(int tile_id);
+int conv_tile_bn(int tile_id);
 const char* conv_tile_name(int tile_id);
 
 // rows x C LayerNorm (biased variance), y may alias x
@@ -62,6 +64,7 @@ void launch_layernorm(const float* x, const float* g, const float* b, float* y, 
 
 // depthwise 3x3 (pad 1) + bias + exact-erf GELU, NHWC, w packed [9][C]
 void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
+void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
 // depthwise 7x7 (pad 3) + bias, NHWC, w packed [49][C]
 void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
 

@@ -34,6 +34,8 @@ _SIGNATURES = {
     "pf_workspace_bytes": (_c.c_size_t, [_P, _c.c_int]),
     "pf_forward_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_forward_f32": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_autotune": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_is_tuned": (_c.c_int, [_P, _c.c_int]),
     "pf_postprocess": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
     "pf_profile_begin": (_c.c_int, [_P, _c.c_uint]),
     "pf_profile_end": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.c_int]),
@@ -42,6 +44,7 @@ _SIGNATURES = {
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_int,
                                 _c.c_int, _c.c_int, _P, _P]),
     "pf_op_conv2d_bench": (_c.c_int, [_c.c_int] * 11 + [_c.POINTER(_c.c_float)]),
+    "pf_op_dwconv3x3_bench": (_c.c_int, [_c.c_int] * 7 + [_c.POINTER(_c.c_float)]),
     "pf_op_layernorm": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_long, _c.c_int, _c.c_float, _P]),
     "pf_op_dwconv3x3_gelu": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
     "pf_op_dwconv7x7": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
@@ -186,6 +189,8 @@ class Engine:
             params = torch.empty((B, PARAMS_STRIDE), dtype=torch.float32, device=self.device) if self.param_outputs else None
             need = self.workspace_bytes(B)
             ws = self._workspace(need)
+            if images.dtype == torch.uint8 and not self.lib.pf_is_tuned(self._h, B):
+                fn = self.lib.pf_autotune  # first call with this batch size: same forward, plus per-shape tile timing
             rc = fn(
                 self._h, B, images.data_ptr(), pg.data_ptr(), pl.data_ptr(),
                 params.data_ptr() if params is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr(),

@@ -131,3 +131,10 @@ def conv2d_bench(B, H, W, Cin, Cout, K, stride=1, pad=0, tile=-1, iters=10, devi
     ms = ctypes.c_float()
     _check(lib.pf_op_conv2d_bench(device, B, H, W, Cin, Cout, K, stride, pad, tile, iters, ctypes.byref(ms)), None, "pf_op_conv2d_bench")
     return ms.value
+
+
+def dwconv3x3_bench(variant, B, H, W, C, iters=10, device=0):
+    lib = load_library()
+    ms = ctypes.c_float()
+    _check(lib.pf_op_dwconv3x3_bench(device, variant, B, H, W, C, iters, ctypes.byref(ms)), None, "pf_op_dwconv3x3_bench")
+    return ms.value
