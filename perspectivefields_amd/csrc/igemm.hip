@@ -38,8 +38,10 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned 
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BM, int BN, int WM, int WN, bool SMALLC, bool NCHW>
+// MODE: 0 = Cin % 32 == 0, single source tensor; 1 = Cin == 4 (padded 3-channel inputs); 2 = channel-concat of two tensors
+template <int BM, int BN, int WM, int WN, int MODE, bool NCHW, bool PIPE>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p) {
+  constexpr bool SMALLC = MODE == 1;
   constexpr int NT = WM * WN * 64;      // threads per block
   constexpr int RPP = NT / 8;           // tile rows staged per pass (8 threads x float4 = one 32-float row)
   constexpr int SM = BM / (WM * 32);
@@ -120,6 +122,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p)
   const int nJ = p.KWCp / BK;
   const int nK = p.KH * nJ;
 
+  // Branch-free (one basic block per K step, so the scheduler may interleave it with the MFMAs): all
+  // decisions are selects on wave-uniform values.
   auto load_tiles = [&](int it) {
     const int ky = it / nJ;
     const int j0 = (it - ky * nJ) * BK;
@@ -140,14 +144,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p)
       const int kx = j0 / p.Cin;
       const int ci0 = j0 - kx * p.Cin;
       const int bit = ky * p.KW + kx;
-      if (ci0 < p.C1) {
+      if (MODE == 2) {
+        const bool first = ci0 < p.C1;
+        const int toff = ((ky * p.W + kx) * (first ? p.C1 : p.C2) + (first ? ci0 : ci0 - p.C1)) * 4;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+          const unsigned off = ((a_mask[i] >> bit) & 1ull) ? (unsigned)((first ? a_off1[i] : a_off2[i]) + toff) : OOB;
+          const float4 v1 = buf_load16(rx, first ? off : OOB);
+          const float4 v2 = buf_load16(rx2, first ? OOB : off);
+          a_reg[i] = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);  // the other one is an OOB zero
+        }
+      } else {
         const int toff = ((ky * p.W + kx) * p.C1 + ci0) * 4;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) a_reg[i] = buf_load16(rx, ((a_mask[i] >> bit) & 1ull) ? (unsigned)(a_off1[i] + toff) : OOB);
-      } else {
-        const int toff = ((ky * p.W + kx) * p.C2 + (ci0 - p.C1)) * 4;
-#pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) a_reg[i] = buf_load16(rx2, ((a_mask[i] >> bit) & 1ull) ? (unsigned)(a_off2[i] + toff) : OOB);
       }
     }
     const unsigned woff = (unsigned)(ky * p.KWCp + j0) * 4u;
@@ -178,33 +188,69 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p)
   store_tiles(0);
   __syncthreads();
 
-  for (int it = 0; it < nK; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nK) load_tiles(it + 1);
-    const float* Ab = As + buf * BM * LDS_ROW + (wm0 + l31) * LDS_ROW + 4 * hi;
-    const float* Bb = Bs + buf * BN * LDS_ROW + (wn0 + l31) * LDS_ROW + 4 * hi;
+  auto mfma_step = [&](const float* Ab, const float* Bb, int kk) {
+    float4 af[SM], bf[SN];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float4 af[SM], bf[SN];
+    for (int i = 0; i < SM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + kk * 8);
 #pragma unroll
-      for (int i = 0; i < SM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + kk * 8);
+    for (int j = 0; j < SN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + kk * 8);
 #pragma unroll
-      for (int j = 0; j < SN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + kk * 8);
+    for (int e = 0; e < 4; ++e) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int i = 0; i < SM; ++i) {
+        const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
 #pragma unroll
-        for (int i = 0; i < SM; ++i) {
-          const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
-#pragma unroll
-          for (int j = 0; j < SN; ++j) {
-            const float bv = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
-            if (NCHW) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[i][j], 0, 0, 0);
-            else      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-          }
+        for (int j = 0; j < SN; ++j) {
+          const float bv = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
+          if (NCHW) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[i][j], 0, 0, 0);
+          else      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
         }
       }
     }
-    if (it + 1 < nK) store_tiles(buf ^ 1);
+  };
+
+  for (int it = 0; it < nK; ++it) {
+    const int buf = it & 1;
+    const float* Ab = As + buf * BM * LDS_ROW + (wm0 + l31) * LDS_ROW + 4 * hi;
+    const float* Bb = Bs + buf * BN * LDS_ROW + (wn0 + l31) * LDS_ROW + 4 * hi;
+    if (PIPE) {
+      // Software-pipelined order, pinned with scheduling fences: the MFMAs of the first quarter start right
+      // after the barrier; the address arithmetic + global loads of the next tile are issued behind them (they
+      // execute while the matrix pipe is busy); the LDS stores of the next tile go in front of the last quarter
+      // so that only the barrier itself separates the last MFMA of this tile from the first of the next.
+      constexpr int NM = SM * SN * 4;  // MFMAs per quarter
+      const int nxt = it + 1 < nK ? it + 1 : it;  // last step: harmless reload into the buffer nobody reads again
+      mfma_step(Ab, Bb, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_tiles(nxt);
+      mfma_step(Ab, Bb, 1);
+      // interleave: fragment reads first, then one MFMA followed by a slice of the address math / loads
+      __builtin_amdgcn_sched_group_barrier(0x100, SM + SN, 0);
+#pragma unroll
+      for (int g = 0; g < NM; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(Ab, Bb, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      store_tiles(buf ^ 1);
+      mfma_step(Ab, Bb, 3);
+      __builtin_amdgcn_sched_group_barrier(0x100, SM + SN, 0);
+#pragma unroll
+      for (int g = 0; g < NM; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+    } else {
+      if (it + 1 < nK) load_tiles(it + 1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) mfma_step(Ab, Bb, kk);
+      if (it + 1 < nK) store_tiles(buf ^ 1);
+    }
     __syncthreads();
   }
 
@@ -304,23 +350,30 @@ static const TileCfg kTiles[] = {
     {256, 128, "256x128", 109.f, 1},
     {256, 128, "256x128w8", 115.f, 1},
     {256, 256, "256x256w8", 122.f, 1},
+    // software-pipelined issue order (PIPE): picked by the autotuner where they win
+    {128, 128, "128x128p", 114.f, 2},
+    {64, 64, "64x64p", 108.f, 4},
+    {128, 64, "128x64p", 105.f, 2},
+    {256, 256, "256x256w8p", 122.f, 1},
 };
 int conv_tile_bm(int id) { return kTiles[id].bm; }
 int conv_tile_bn(int id) { return kTiles[id].bn; }
 int conv_num_tiles() { return (int)(sizeof(kTiles) / sizeof(kTiles[0])); }
 const char* conv_tile_name(int id) { return (id >= 0 && id < conv_num_tiles()) ? kTiles[id].name : "auto"; }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PIPE = false>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const dim3 grid(tilesM * tilesN * p.groups), block(WM * WN * 64);
-  const bool smallc = (p.Cin % BK) != 0;
+  const int mode = (p.Cin % BK) != 0 ? 1 : (p.C2 > 0 ? 2 : 0);
   if (p.nchw_out) {
-    if (smallc) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
-    else        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
+    if (mode == 1)      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, true, PIPE>), grid, block, 0, s, p);
+    else if (mode == 2) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 2, true, PIPE>), grid, block, 0, s, p);
+    else                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 0, true, PIPE>), grid, block, 0, s, p);
   } else {
-    if (smallc) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
-    else        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
+    if (mode == 1)      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, false, PIPE>), grid, block, 0, s, p);
+    else if (mode == 2) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 2, false, PIPE>), grid, block, 0, s, p);
+    else                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 0, false, PIPE>), grid, block, 0, s, p);
   }
 }
 
@@ -365,7 +418,11 @@ void launch_conv_tile(const ConvParams& p, int tile_id, hipStream_t s) {
     case 5: launch_cfg<128, 256, 2, 2>(p, s); break;
     case 6: launch_cfg<256, 128, 2, 2>(p, s); break;
     case 7: launch_cfg<256, 128, 4, 2>(p, s); break;
-    default: launch_cfg<256, 256, 2, 4>(p, s); break;
+    case 8: launch_cfg<256, 256, 2, 4>(p, s); break;
+    case 9: launch_cfg<128, 128, 2, 2, true>(p, s); break;
+    case 10: launch_cfg<64, 64, 2, 2, true>(p, s); break;
+    case 11: launch_cfg<128, 64, 2, 2, true>(p, s); break;
+    default: launch_cfg<256, 256, 2, 4, true>(p, s); break;
   }
 }
 void launch_conv(const ConvParams& p, hipStream_t s) { launch_conv_tile(p, -1, s); }
