@@ -108,10 +108,11 @@ int pf_postprocess(pf_handle h, const float* d_pred_gravity, const float* d_pred
 
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py `roofline`) ----
  * classes: 0 implicit-GEMM conv/GEMM (work = algorithmic FLOPs, 2*M*Cout*KH*KW*Cin), 1 attention (FLOPs),
- * 2 LayerNorm, 3 depthwise3x3+GELU, 4 depthwise7x7, 5 bilinear x2 (work = algorithmic bytes in+out), 6 other.
+ * 2 LayerNorm, 3 depthwise3x3+GELU, 4 depthwise7x7, 5 bilinear x2 (work = algorithmic bytes in+out), 6 other,
+ * 7 implicit-GEMM launches served by the split-bf16 kernel (class 0 then counts only the exact-fp32 MFMA launches).
  * Between begin and end every launch of a class whose bit is set in class_mask is bracketed by an
  * event pair; pf_profile_end synchronises those events and sums elapsed ms / work / launches per class. */
-#define PF_PROFILE_CLASSES 7
+#define PF_PROFILE_CLASSES 8
 int pf_profile_begin(pf_handle h, unsigned class_mask);
 int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n);
 /* per-launch records of the last begin/end window (valid until the next pf_profile_begin); returns the

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpf_hip.so")
-SOURCES = ["igemm.hip", "attn.hip", "elem.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "igemm_sb.hip", "attn.hip", "elem.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 
 

@@ -53,6 +53,7 @@ struct ConvW {
   float* w = nullptr;
   float* b = nullptr;
   float* btab = nullptr;  // [9][Cout] border-case biases of a folded Linear->3x3 pair
+  unsigned short* wsb = nullptr;  // weights split exactly into 3 bf16 planes (split-bf16 kernel), when Cin % 32 == 0
   int Cout = 0, Cin = 0 /*padded*/, CinReal = 0, KH = 1, KW = 1, stride = 1, pad = 0, KWC = 0, KWCp = 0;
 };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-6f; };
@@ -92,7 +93,7 @@ int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
 // Per-kernel-class timing with HIP events on the launch stream (bench.py's `roofline` object):
 // every launch of a class is bracketed by an event pair; work = algorithmic FLOPs or bytes.
-enum ProfCat { PC_IGEMM = 0, PC_ATTN, PC_LAYERNORM, PC_DW3, PC_DW7, PC_UPSAMPLE, PC_OTHER, PC_COUNT };
+enum ProfCat { PC_IGEMM = 0, PC_ATTN, PC_LAYERNORM, PC_DW3, PC_DW7, PC_UPSAMPLE, PC_OTHER, PC_IGEMM_SB, PC_COUNT };
 struct Profiler {
   struct Rec { int cat; double work; hipEvent_t a, b; int m, n, k, kh; float ms; };
   std::vector<Rec> recs;
@@ -141,6 +142,26 @@ std::vector<float> pack_dw(const float* w, int C, int K) {  // [C][1][K][K] -> [
   return o;
 }
 
+// exact 3-way truncation split of packed fp32 weights into bf16 planes [3][n] (see igemm_sb.hip)
+std::vector<unsigned short> split_bf16x3(const std::vector<float>& w) {
+  const size_t n = w.size();
+  std::vector<unsigned short> o(3 * n);
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t u; float a = w[i];
+    std::memcpy(&u, &a, 4);
+    const uint32_t hb = u & 0xffff0000u;
+    float hf; std::memcpy(&hf, &hb, 4);
+    const float r = a - hf;
+    uint32_t ru; std::memcpy(&ru, &r, 4);
+    const uint32_t mb = ru & 0xffff0000u;
+    float mf; std::memcpy(&mf, &mb, 4);
+    const float r2 = r - mf;
+    uint32_t lu; std::memcpy(&lu, &r2, 4);
+    o[i] = (unsigned short)(hb >> 16); o[n + i] = (unsigned short)(mb >> 16); o[2 * n + i] = (unsigned short)(lu >> 16);
+  }
+  return o;
+}
+
 }  // namespace
 
 struct pf_engine {
@@ -156,6 +177,7 @@ struct pf_engine {
   std::map<std::vector<int>, int> tile_cache;  // conv shape (+batch) -> fastest tile config, measured on this device
   std::map<int, bool> tuned_batches;
   std::map<int, size_t> scratch_off;
+  bool split_bf16 = true;    // PF_SPLIT_BF16=0: exact-fp32 MFMA kernels only (no split-bf16 tiles)
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
 
   MitStage stages[4];
@@ -177,6 +199,18 @@ struct pf_engine {
     dev_allocs.push_back(d);
     return static_cast<float*>(d);
   }
+  unsigned short* upload_u16(const std::vector<unsigned short>& v) {
+    void* d = nullptr;
+    if (hipMalloc(&d, v.size() * 2) != hipSuccess) throw std::string("hipMalloc failed for weights");
+    if (hipMemcpy(d, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess) throw std::string("hipMemcpy H2D failed for weights");
+    dev_allocs.push_back(d);
+    return static_cast<unsigned short*>(d);
+  }
+  // packed fp32 weights -> device, plus the split-bf16 planes when the layer is eligible for igemm_sb
+  void upload_conv_weights(ConvW& c, const std::vector<float>& packed, int CinP) {
+    c.w = upload(packed);
+    if (split_bf16 && CinP % 32 == 0) c.wsb = upload_u16(split_bf16x3(packed));
+  }
   const HostTensor& get(const std::string& key, std::initializer_list<int64_t> shape) {
     auto it = host.find(key);
     if (it == host.end()) throw fmt("missing checkpoint tensor '%s'", key.c_str());
@@ -195,7 +229,7 @@ struct pf_engine {
     ConvW c;
     const int CinP = roundup(Cin, 4);
     const HostTensor& w = get(wkey, {Cout, Cin, K, K});
-    c.w = upload(pack_conv(w.data.data(), Cout, Cin, K, K, CinP, out_scale, &c.KWC, &c.KWCp));
+    upload_conv_weights(c, pack_conv(w.data.data(), Cout, Cin, K, K, CinP, out_scale, &c.KWC, &c.KWCp), CinP);
     if (bias_override) c.b = upload(*bias_override);
     else if (!bkey.empty()) {
       std::vector<float> b = get(bkey, {Cout}).data;
@@ -208,7 +242,7 @@ struct pf_engine {
   ConvW make_linear(const std::string& pfx, int N, int K, const double* out_scale = nullptr) {
     ConvW c;
     const HostTensor& w = get(pfx + ".weight", {N, K});
-    c.w = upload(pack_conv(w.data.data(), N, K, 1, 1, K, out_scale, &c.KWC, &c.KWCp));
+    upload_conv_weights(c, pack_conv(w.data.data(), N, K, 1, 1, K, out_scale, &c.KWC, &c.KWCp), K);
     std::vector<float> b = get(pfx + ".bias", {N}).data;
     if (out_scale) for (int n = 0; n < N; ++n) b[n] = (float)(b[n] * out_scale[n]);
     c.b = upload(b);
@@ -243,7 +277,7 @@ struct pf_engine {
         T[(size_t)o * 9 + t] = tb;
       }
     ConvW c;
-    c.w = upload(pack_conv(wf.data(), DEC_FEAT, C, 3, 3, C, nullptr, &c.KWC, &c.KWCp));
+    upload_conv_weights(c, pack_conv(wf.data(), DEC_FEAT, C, 3, 3, C, nullptr, &c.KWC, &c.KWCp), C);
     std::vector<float> tab((size_t)9 * DEC_FEAT);
     for (int cy = 0; cy < 3; ++cy)
       for (int cx = 0; cx < 3; ++cx)
@@ -407,7 +441,7 @@ struct pf_engine {
     for (int g = 0; g < ngroups; ++g) {
       const ConvW& wg = *calls[g].w;
       ConvPtrs& q = p.g[g];
-      q.x = calls[g].x; q.x2 = calls[g].x2; q.w = wg.w; q.bias = wg.b; q.bias_tab = wg.btab;
+      q.x = calls[g].x; q.x2 = calls[g].x2; q.w = wg.w; q.w_sb = wg.wsb; q.bias = wg.b; q.bias_tab = wg.btab;
       q.res1 = calls[g].res1; q.res2 = calls[g].res2; q.y = calls[g].y;
     }
     p.B = B; p.H = H; p.W = W;
@@ -424,7 +458,7 @@ struct pf_engine {
       if (it != tile_cache.end()) tile = it->second;
       else if (c.tuning && c.tune_scratch) { tile = tune_conv(p, c); tile_cache[key] = tile; }
     }
-    ProfScope ps(c.prof, c.s, PC_IGEMM, 2.0 * ngroups * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal, p.M * ngroups, w.Cout, w.KH * w.KW * w.CinReal, w.KH);
+    ProfScope ps(c.prof, c.s, conv_tile_is_sb(tile) ? PC_IGEMM_SB : PC_IGEMM, 2.0 * ngroups * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal, p.M * ngroups, w.Cout, w.KH * w.KW * w.CinReal, w.KH);
     launch_conv_tile(p, tile, c.s);
   }
   // Measure, don't guess: run the launch with every tile configuration (outputs redirected to scratch so in-place
@@ -438,6 +472,7 @@ struct pf_engine {
     int best = -1;
     float best_ms = 1e30f;
     for (int t = 0; t < conv_num_tiles(); ++t) {
+      if (!conv_tile_usable(p, t)) continue;
       if (conv_tile_bn(t) > 32 && p.Cout <= 32) continue;
       if ((long)conv_tile_bm(t) * conv_tile_bn(t) > 16L * p.M * p.Cout) continue;  // tile far larger than the problem
       launch_conv_tile(p, t, c.s);
@@ -723,6 +758,13 @@ struct TmpDev {  // test-entry-point helper: upload host weights, free on scope 
     return static_cast<float*>(d);
   }
   float* up(const std::vector<float>& v) { return up(v.data(), v.size()); }
+  unsigned short* up_u16(const std::vector<unsigned short>& v) {
+    void* d = nullptr;
+    if (hipMalloc(&d, v.size() * 2) != hipSuccess) return nullptr;
+    (void)hipMemcpy(d, v.data(), v.size() * 2, hipMemcpyHostToDevice);
+    p.push_back(d);
+    return static_cast<unsigned short*>(d);
+  }
   void sync_free(hipStream_t s) { hipStreamSynchronize(s); for (void* d : p) hipFree(d); p.clear(); }
 };
 }  // namespace
@@ -744,6 +786,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   e->arch = arch;
   if (const char* v = getenv("PF_FOLD_MLP")) e->fold_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
+  if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   *out = e;
   return PF_OK;
 }
@@ -901,6 +944,8 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   ConvParams p;
   std::vector<float> packed = pack_conv(hw, Cout, Cin, KH, KW, Cin, nullptr, &p.KWC, &p.KWCp);
   p.g[0].w = tmp.up(packed);
+  std::vector<unsigned short> sb;
+  if (Cin % 32 == 0) { sb = split_bf16x3(packed); p.g[0].w_sb = tmp.up_u16(sb); }
   p.g[0].bias = tmp.up(hb, Cout);
   p.g[0].x = x; p.g[0].x2 = x2; p.g[0].res1 = res1; p.g[0].res2 = res2; p.g[0].y = y;
   p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
@@ -925,8 +970,9 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   p.finish();
   const size_t nx = (size_t)B * H * W * Cin, nw = (size_t)Cout * K * p.KWCp, ny = (size_t)p.M * Cout;
   float *dx = nullptr, *dw = nullptr, *dy = nullptr, *db = nullptr;
+  unsigned short* dsb = nullptr;
   if (hipMalloc(&dx, nx * 4) != hipSuccess || hipMalloc(&dw, nw * 4) != hipSuccess || hipMalloc(&dy, ny * 4) != hipSuccess ||
-      hipMalloc(&db, (size_t)Cout * 4) != hipSuccess) { g_create_error = "pf_op_conv2d_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
+      hipMalloc(&db, (size_t)Cout * 4) != hipSuccess || hipMalloc(&dsb, nw * 6) != hipSuccess) { g_create_error = "pf_op_conv2d_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
   {  // uniform [-1,1) data (never zero-fill a bench: DVFS gives zeros a higher clock)
     std::vector<float> hx(nx), hw(nw), hb(Cout);
     uint32_t st = 12345u;
@@ -937,8 +983,12 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
     (void)hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(db, hb.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
+    const std::vector<unsigned short> sb = split_bf16x3(hw);
+    (void)hipMemcpy(dsb, sb.data(), nw * 6, hipMemcpyHostToDevice);
   }
   p.g[0].x = dx; p.g[0].w = dw; p.g[0].bias = db; p.g[0].y = dy;
+  if (Cin % 32 == 0) p.g[0].w_sb = dsb;
+  if (!conv_tile_usable(p, tile_id) && tile_id >= 0) { *ms_out = -1.f; (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); return PF_OK; }
   hipEvent_t a, b;
   (void)hipEventCreate(&a); (void)hipEventCreate(&b);
   launch_conv_tile(p, tile_id, nullptr);
@@ -952,7 +1002,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   *ms_out = t / iters;
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db);
+  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb);
   return rc;
 }
 

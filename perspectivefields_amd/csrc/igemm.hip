@@ -19,24 +19,11 @@
 // before the MFMAs of tile t, one barrier per K step.
 #include <stdlib.h>
 
-#include "pf_kernels.h"
+#include "igemm_common.h"
 
 namespace pf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-static constexpr int BK = 32;
 static constexpr int LDS_ROW = BK + 4;  // floats; 36*i mod 64 = 4*(9i mod 16): 16 rows hit 16 distinct 16-B slots
-
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-static constexpr unsigned OOB = 0x80000000u;  // beyond any buffer (< 2 GiB): hardware range check returns 0
-
-__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
 
 // MODE: 0 = Cin % 32 == 0, single source tensor; 1 = Cin == 4 (padded 3-channel inputs); 2 = channel-concat of two tensors
 template <int BM, int BN, int WM, int WN, int MODE, bool NCHW, bool PIPE>
@@ -59,18 +46,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p)
   const int l31 = lane & 31;
   const int hi = lane >> 5;
 
-  // XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a
-  // contiguous run of tiles so that neighbouring m-tiles (shared halo rows) and the
-  // n-tiles of one m-tile (same A rows) meet in one L2.
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
   const int nblk1 = tilesM * tilesN;
-  const int nblk = nblk1 * p.groups;
-  int t;
-  {
-    const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  int t = xcd_tile_index(nblk1 * p.groups);
   // grouped launch: group 1 = a second problem of identical shape (the other decoder head)
   const bool g1 = t >= nblk1;
   if (g1) t -= nblk1;
@@ -256,61 +235,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p)
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   if (!NCHW) {
-    // The accumulator layout gives each lane ONE float per store (row stride between registers), which makes
-    // the epilogue store-issue bound.  Stage the tile through LDS (free after the K loop) in chunks of WM*32
-    // rows and write it back row-major: every thread then moves 16 bytes per instruction, fully coalesced, and
-    // the residual / bias operands are read as float4 as well.
-    constexpr int CROW = BN + 4;            // floats per staged row (keeps 16-B alignment, shifts banks)
-    constexpr int CH_ROWS = WM * 32;        // rows per chunk: subtile row i of every wave row
-    constexpr int F4_PER_ROW = BN / 4;
-    static_assert(CH_ROWS * CROW <= 2 * (BM + BN) * LDS_ROW, "epilogue chunk must fit the operand buffers");
-    float* Cs = smem;
-    const int wave_m = wave / WN;
-    const bool vec_ok = (p.Cout & 3) == 0 && (p.ldy & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < SM; ++i) {
-      __syncthreads();  // previous chunk fully written back / K loop finished reading the operand tiles
-#pragma unroll
-      for (int j = 0; j < SN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          Cs[(wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CROW + wn0 + j * 32 + l31] = acc[i][j][r];
-      __syncthreads();
-      for (int idx = tid; idx < CH_ROWS * F4_PER_ROW; idx += NT) {
-        const int row_l = idx / F4_PER_ROW, cq = idx - row_l * F4_PER_ROW;
-        const int m = m0 + (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
-        const int n = n0 + cq * 4;
-        if (m >= p.M || n >= p.Cout) continue;
-        float4 v = *reinterpret_cast<const float4*>(Cs + row_l * CROW + cq * 4);
-        const float* bsrc = P.bias;
-        if (P.bias_tab) {  // position-dependent bias of a folded (Linear -> zero-padded 3x3) pair: 3x3 border cases
-          const int rem = m % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-          const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
-          bsrc = P.bias_tab + (cy * 3 + cx) * p.Cout;
-        }
-        const long o = (long)m * p.ldy + n;
-        if (vec_ok) {
-          if (bsrc) { const float4 bb = *reinterpret_cast<const float4*>(bsrc + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-          if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          else if (p.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-          if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-          if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-          if (p.post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          *reinterpret_cast<float4*>(P.y + o) = v;
-        } else {  // ragged channel count: scalar tail
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-            float x = vv[e] + (bsrc ? bsrc[n + e] : 0.f);
-            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
-            else if (p.act == ACT_GELU) x = gelu_erf(x);
-            if (P.res1) x += P.res1[o + e];
-            if (P.res2) x += P.res2[o + e];
-            if (p.post_relu) x = fmaxf(x, 0.f);
-            P.y[o + e] = x;
-          }
-        }
-      }
-    }
+    epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, 2 * (BM + BN) * LDS_ROW>(p, P, acc, smem, m0, n0);
   } else {
     // transposed accumulators: col (lane) = pixel, row (register) = output channel
 #pragma unroll
@@ -339,27 +264,34 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const ConvParams p)
 
 // ---------------------------------------------------------------------------------------
 struct TileCfg { int bm, bn; const char* name; float eff; int blocks_per_cu; };
-// eff = intrinsic throughput (TFLOP/s, all CUs busy, quantisation divided out) measured with scripts/tune_conv.py
+// eff = intrinsic throughput (TFLOP/s, all CUs busy, quantisation divided out) measured with scripts/tune_conv.py;
+// "p" = software-pipelined issue order.  Ids >= kNumF32 are the split-bf16 tiles of igemm_sb.hip.
 static const TileCfg kTiles[] = {
-    {128, 128, "128x128", 114.f, 2},
-    {128, 64, "128x64", 105.f, 2},
-    {64, 64, "64x64", 108.f, 4},
-    {128, 32, "128x32", 101.f, 3},
-    {64, 128, "64x128", 107.f, 2},
-    {128, 256, "128x256", 109.f, 1},
-    {256, 128, "256x128", 109.f, 1},
-    {256, 128, "256x128w8", 115.f, 1},
-    {256, 256, "256x256w8", 122.f, 1},
-    // software-pipelined issue order (PIPE): picked by the autotuner where they win
-    {128, 128, "128x128p", 114.f, 2},
-    {64, 64, "64x64p", 108.f, 4},
-    {128, 64, "128x64p", 105.f, 2},
+    {128, 128, "128x128", 114.f, 2},    // plain order, kept for A/B
+    {64, 64, "64x64", 108.f, 4},        // plain order, kept for A/B
+    {128, 128, "128x128p", 120.f, 2},
+    {128, 64, "128x64p", 112.f, 2},
+    {64, 64, "64x64p", 115.f, 4},
+    {128, 32, "128x32p", 101.f, 3},
+    {64, 128, "64x128p", 110.f, 2},
+    {128, 256, "128x256p", 109.f, 1},
+    {256, 128, "256x128w8p", 115.f, 1},
     {256, 256, "256x256w8p", 122.f, 1},
 };
-int conv_tile_bm(int id) { return kTiles[id].bm; }
-int conv_tile_bn(int id) { return kTiles[id].bn; }
-int conv_num_tiles() { return (int)(sizeof(kTiles) / sizeof(kTiles[0])); }
-const char* conv_tile_name(int id) { return (id >= 0 && id < conv_num_tiles()) ? kTiles[id].name : "auto"; }
+static constexpr int kNumF32 = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
+int conv_num_tiles() { return kNumF32 + conv_sb_num_tiles(); }
+int conv_tile_bm(int id) { return id < kNumF32 ? kTiles[id].bm : conv_sb_tile_bm(id - kNumF32); }
+int conv_tile_bn(int id) { return id < kNumF32 ? kTiles[id].bn : conv_sb_tile_bn(id - kNumF32); }
+const char* conv_tile_name(int id) {
+  if (id < 0 || id >= conv_num_tiles()) return "auto";
+  return id < kNumF32 ? kTiles[id].name : conv_sb_tile_name(id - kNumF32);
+}
+bool conv_tile_is_sb(int id) { return id >= kNumF32 && id < conv_num_tiles(); }
+bool conv_tile_usable(const ConvParams& p, int id) {
+  if (id < 0 || id >= conv_num_tiles()) return false;
+  if (id >= kNumF32) return conv_sb_eligible(p);
+  return true;
+}
 
 template <int BM, int BN, int WM, int WN, bool PIPE = false>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
@@ -378,27 +310,24 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
 }
 
 static int g_forced_tile = -2;  // -2: not read yet; PF_CONV_TILE=<id> forces one tile config (tuning aid)
-static int g_max_auto_tile = 9; // tiles with id >= this are opt-in until measured (PF_CONV_AUTO_MAX)
 
+// static cost model over the fp32 tiles (used for shapes the autotuner has not seen)
 int pick_tile(const ConvParams& p) {
   if (g_forced_tile == -2) {
     const char* e = getenv("PF_CONV_TILE");
     g_forced_tile = e ? atoi(e) : -1;
-    const char* m = getenv("PF_CONV_AUTO_MAX");
-    if (m) g_max_auto_tile = atoi(m);
   }
-  if (g_forced_tile >= 0 && g_forced_tile < conv_num_tiles()) return g_forced_tile;
+  if (g_forced_tile >= 0 && conv_tile_usable(p, g_forced_tile)) return g_forced_tile;
   // MFMA-bound model: a CU works through its share of the blocks at the tile's intrinsic rate, so
-  // time ~ ceil(blocks / 256 CUs) x tile area / eff  (captures the partially filled last wave of blocks)
-  int best = 0;
+  // time ~ ceil(blocks / 256 CUs) x (tile MFMA time + fill latency hidden by the resident blocks)
+  int best = 2;
   double best_cost = 1e300;
-  for (int id = 0; id < conv_num_tiles() && id < g_max_auto_tile; ++id) {
+  for (int id = 2; id < kNumF32; ++id) {
     const TileCfg& c = kTiles[id];
     if (c.bn > 32 && p.Cout <= 32) continue;
     const long tm = (p.M + c.bm - 1) / c.bm, tn = (p.Cout + c.bn - 1) / c.bn;
     const long blocks = tm * tn * p.groups;
     const long per_cu = (blocks + 255) / 256;
-    // per block: MFMA time (us) + a fixed fill/drain latency that `blocks_per_cu` resident blocks overlap
     const double K = (double)p.KH * p.KWCp;
     const double t_mfma = 2.0 * c.bm * c.bn * K / (c.eff * 1e6 / 256.0);
     const double cost = (double)per_cu * (t_mfma + 4.0 / c.blocks_per_cu);
@@ -408,20 +337,18 @@ int pick_tile(const ConvParams& p) {
 }
 
 void launch_conv_tile(const ConvParams& p, int tile_id, hipStream_t s) {
-  if (tile_id < 0 || tile_id >= conv_num_tiles()) tile_id = pick_tile(p);
+  if (!conv_tile_usable(p, tile_id)) tile_id = pick_tile(p);
+  if (tile_id >= kNumF32) { launch_conv_sb(p, tile_id - kNumF32, s); return; }
   switch (tile_id) {
     case 0: launch_cfg<128, 128, 2, 2>(p, s); break;
-    case 1: launch_cfg<128, 64, 2, 2>(p, s); break;
-    case 2: launch_cfg<64, 64, 2, 2>(p, s); break;
-    case 3: launch_cfg<128, 32, 4, 1>(p, s); break;
-    case 4: launch_cfg<64, 128, 2, 2>(p, s); break;
-    case 5: launch_cfg<128, 256, 2, 2>(p, s); break;
-    case 6: launch_cfg<256, 128, 2, 2>(p, s); break;
-    case 7: launch_cfg<256, 128, 4, 2>(p, s); break;
-    case 8: launch_cfg<256, 256, 2, 4>(p, s); break;
-    case 9: launch_cfg<128, 128, 2, 2, true>(p, s); break;
-    case 10: launch_cfg<64, 64, 2, 2, true>(p, s); break;
-    case 11: launch_cfg<128, 64, 2, 2, true>(p, s); break;
+    case 1: launch_cfg<64, 64, 2, 2>(p, s); break;
+    case 2: launch_cfg<128, 128, 2, 2, true>(p, s); break;
+    case 3: launch_cfg<128, 64, 2, 2, true>(p, s); break;
+    case 4: launch_cfg<64, 64, 2, 2, true>(p, s); break;
+    case 5: launch_cfg<128, 32, 4, 1, true>(p, s); break;
+    case 6: launch_cfg<64, 128, 2, 2, true>(p, s); break;
+    case 7: launch_cfg<128, 256, 2, 2, true>(p, s); break;
+    case 8: launch_cfg<256, 128, 4, 2, true>(p, s); break;
     default: launch_cfg<256, 256, 2, 4, true>(p, s); break;
   }
 }

@@ -1,0 +1,89 @@
+// Shared device helpers of the implicit-GEMM kernels (igemm.hip: exact fp32 MFMA; igemm_sb.hip: split-bf16 MFMA).
+#pragma once
+#include "pf_kernels.h"
+
+namespace pf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BK = 32;            // K step in elements
+static constexpr unsigned OOB = 0x80000000u;  // beyond any buffer (< 2 GiB): hardware range check returns 0
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a contiguous run of tiles so that
+// neighbouring m-tiles (shared halo rows) and the n-tiles of one m-tile (same A rows) meet in one L2.
+__device__ __forceinline__ int xcd_tile_index(int nblk) {
+  const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Epilogue for accumulators in the 32x32 MFMA C/D layout (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)),
+// identical for the fp32 and the bf16 instructions.  The layout gives each lane ONE float per store (row stride
+// between registers), which makes a direct epilogue store-issue bound: stage the tile through LDS (free after the
+// K loop) in chunks of WM*32 rows and write it back row-major -- every thread then moves 16 bytes per instruction,
+// fully coalesced, and the bias / residual operands are read as float4 as well.
+template <int BM, int BN, int WM, int WN, int SM, int SN, int NT, int SMEM_FLOATS>
+__device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[SM][SN], float* Cs, int m0, int n0) {
+  constexpr int CROW = BN + 4;            // floats per staged row (keeps 16-B alignment, shifts banks)
+  constexpr int CH_ROWS = WM * 32;        // rows per chunk: subtile row i of every wave row
+  constexpr int F4_PER_ROW = BN / 4;
+  static_assert(CH_ROWS * CROW <= SMEM_FLOATS, "epilogue chunk must fit the operand buffers");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wave_m = wave / WN;
+  const int wn0 = (wave % WN) * (SN * 32);
+  const int HoWo = p.Ho * p.Wo;
+  const bool vec_ok = (p.Cout & 3) == 0 && (p.ldy & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < SM; ++i) {
+    __syncthreads();  // previous chunk fully written back / K loop finished reading the operand tiles
+#pragma unroll
+    for (int j = 0; j < SN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Cs[(wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CROW + wn0 + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    for (int idx = tid; idx < CH_ROWS * F4_PER_ROW; idx += NT) {
+      const int row_l = idx / F4_PER_ROW, cq = idx - row_l * F4_PER_ROW;
+      const int m = m0 + (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
+      const int n = n0 + cq * 4;
+      if (m >= p.M || n >= p.Cout) continue;
+      float4 v = *reinterpret_cast<const float4*>(Cs + row_l * CROW + cq * 4);
+      const float* bsrc = P.bias;
+      if (P.bias_tab) {  // position-dependent bias of a folded (Linear -> zero-padded 3x3) pair: 3x3 border cases
+        const int rem = m % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
+        bsrc = P.bias_tab + (cy * 3 + cx) * p.Cout;
+      }
+      const long o = (long)m * p.ldy + n;
+      if (vec_ok) {
+        if (bsrc) { const float4 bb = *reinterpret_cast<const float4*>(bsrc + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+        if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (p.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        if (p.post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(P.y + o) = v;
+      } else {  // ragged channel count: scalar tail
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+          float x = vv[e] + (bsrc ? bsrc[n + e] : 0.f);
+          if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+          else if (p.act == ACT_GELU) x = gelu_erf(x);
+          if (P.res1) x += P.res1[o + e];
+          if (P.res2) x += P.res2[o + e];
+          if (p.post_relu) x = fmaxf(x, 0.f);
+          P.y[o + e] = x;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace pf

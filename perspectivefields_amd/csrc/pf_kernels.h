@@ -19,6 +19,7 @@ struct ConvPtrs {
   const float* x = nullptr;
   const float* x2 = nullptr;        // nullptr unless channel-concat input
   const float* w = nullptr;         // packed [Cout][KH][KWCp], KWCp = roundup(KW*Cin, 32), zero padded
+  const unsigned short* w_sb = nullptr;  // same weights split exactly into 3 bf16 planes [3][Cout][KH][KWCp] (split-bf16 kernel)
   const float* bias = nullptr;      // [Cout] or nullptr
   const float* bias_tab = nullptr;  // [9][Cout]: bias per 3x3 border case (folded Linear->conv), overrides bias
   const float* res1 = nullptr;      // [M][Cout] or nullptr (may alias y)
@@ -38,6 +39,7 @@ struct ConvParams {
   int ldy;        // row stride of y / res1 / res2 in floats (normally Cout)
   int nchw_out;   // 1: store y as [B][Cout][Ho*Wo] (API-visible logits), residuals unsupported
   unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)
+  unsigned w_sb_plane_bytes;            // bytes of one bf16 weight plane
   // fills the derived fields (Ho, Wo, M, Cin, *_bytes) from the primary ones
   void finish() {
     Cin = C1 + C2;
@@ -47,6 +49,7 @@ struct ConvParams {
     x_bytes = (unsigned)((size_t)B * H * W * C1 * 4);
     x2_bytes = (unsigned)((size_t)B * H * W * C2 * 4);
     w_bytes = (unsigned)((size_t)Cout * KH * KWCp * 4);
+    w_sb_plane_bytes = (unsigned)((size_t)Cout * KH * KWCp * 2);
     ldy = Cout;
   }
 };
@@ -57,6 +60,15 @@ void launch_conv_tile(const ConvParams& p, int tile_id, hipStream_t s);
 int conv_num_tiles();
 int conv_tile_bm(int tile_id);
 int conv_tile_bn(int tile_id);
+bool conv_tile_is_sb(int tile_id);
+bool conv_tile_usable(const ConvParams& p, int tile_id);  // split-bf16 tiles need pre-split weights and Cin % 32 == 0
+// split-bf16 kernel family (igemm_sb.hip)
+int conv_sb_num_tiles();
+const char* conv_sb_tile_name(int id);
+int conv_sb_tile_bm(int id);
+int conv_sb_tile_bn(int id);
+bool conv_sb_eligible(const ConvParams& p);
+void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s);
 const char* conv_tile_name(int tile_id);
 
 // rows x C LayerNorm (biased variance), y may alias x

@@ -198,7 +198,7 @@ class Engine:
         _check(rc, self._h, "pf_forward")
         return pg, pl, params
 
-    PROFILE_CLASSES = ("igemm", "attention", "layernorm", "dwconv3x3_gelu", "dwconv7x7", "upsample2x", "other")
+    PROFILE_CLASSES = ("igemm", "attention", "layernorm", "dwconv3x3_gelu", "dwconv7x7", "upsample2x", "other", "igemm_sb")
 
     def profile_begin(self, classes=None):
         mask = 0

@@ -19,14 +19,14 @@ allms = sum(v["ms"] for v in tot.values())
 lines.append(f"batch {a.batch}: profiled classes total {allms:.2f} ms")
 for k, v in tot.items():
     if v["launches"]:
-        unit = "TFLOP/s" if k in ("igemm", "attention") else "GB/s"
+        unit = "TFLOP/s" if k in ("igemm", "igemm_sb", "attention") else "GB/s"
         rate = v["work"] / (v["ms"] * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
         lines.append(f"  {k:16s} {v['launches']:4d} launches {v['ms']:8.3f} ms  {100*v['ms']/allms:5.1f}%  {rate:8.1f} {unit}")
 g = collections.OrderedDict()
 for cls, work, ms, mnk in recs:
-    if cls != "igemm": continue
-    e = g.setdefault(mnk, [0, 0.0, 0.0]); e[0] += 1; e[1] += ms; e[2] += work
+    if cls not in ("igemm", "igemm_sb"): continue
+    e = g.setdefault(mnk + (cls,), [0, 0.0, 0.0]); e[0] += 1; e[1] += ms; e[2] += work
 lines.append("igemm by shape (M, N, K, KH): launches, total ms, TFLOP/s")
 for mnk, (n, ms, work) in sorted(g.items(), key=lambda kv: -kv[1][1]):
-    lines.append(f"  M={mnk[0]:8d} N={mnk[1]:5d} K={mnk[2]:6d} KH={mnk[3]}  x{n:3d}  {ms:8.3f} ms  {work/(ms*1e-3)/1e12:7.1f} TF")
+    lines.append(f"  M={mnk[0]:8d} N={mnk[1]:5d} K={mnk[2]:6d} KH={mnk[3]} {mnk[4]:8s} x{n:3d}  {ms:8.3f} ms  {work/(ms*1e-3)/1e12:7.1f} TF")
 open(a.out, "w").write("\n".join(lines) + "\n"); print("\n".join(lines))

@@ -28,6 +28,8 @@ for name, b, h, w, cin, cout, k, st, pd in SHAPES:
     for t in range(len(tiles)):
         iters = max(3, min(30, int(3e9 / max(flops, 1)) * 0 + (20 if flops < 2e10 else 5)))
         ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=t, iters=iters)
+        if ms <= 0:  # tile not usable for this shape
+            continue
         res.append((flops / (ms * 1e-3) / 1e12, t, ms))
     auto_ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=-1, iters=5)
     best = max(res)

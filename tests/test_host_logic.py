@@ -165,3 +165,31 @@ def test_shard_helpers():
     assert sorted(sum(parts, [])) == list(range(64))
     for p in parts:
         assert len(p) == 8 and sum(1 for i in p if sizes[i] == (640, 640)) == 4
+
+
+def test_split_bf16_scheme_is_fp32_accurate():
+    """The split-bf16 MFMA kernel (csrc/igemm_sb.hip) splits every fp32 value exactly into three bf16 parts by
+    truncation and keeps six of the nine partial products.  Emulated here in numpy: the split is exact and the
+    six-term dot product is as close to the fp64 result as a plain fp32 dot product."""
+    rng = np.random.default_rng(0)
+
+    def split(a):
+        a = a.astype(np.float32)
+        h = (a.view(np.uint32) & 0xFFFF0000).view(np.float32)
+        r = a - h
+        m = (r.view(np.uint32) & 0xFFFF0000).view(np.float32)
+        l = r - m
+        assert np.array_equal((l.view(np.uint32) & 0xFFFF0000).view(np.float32), l), "third part must fit 8 significant bits"
+        return h, m, l
+
+    a = (rng.standard_normal((64, 2304)) * np.exp(rng.uniform(-6, 6, (64, 2304)))).astype(np.float32)
+    b = rng.standard_normal((2304, 32)).astype(np.float32) / 48
+    ah, am, al = split(a)
+    bh, bm, bl = split(b)
+    assert np.array_equal(ah.astype(np.float64) + am + al, a.astype(np.float64))  # exact
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    six = sum((x.astype(np.float64) @ y.astype(np.float64)) for x, y in [(al, bh), (ah, bl), (am, bm), (am, bh), (ah, bm), (ah, bh)])
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert np.max(np.abs(six - ref) / scale) < 4 * 2.0 ** -24  # dropped terms: m*l, l*m, l*l
+    f32 = (a @ b).astype(np.float64)
+    assert np.max(np.abs(six - ref)) <= 2 * np.max(np.abs(f32 - ref)) + 1e-12
