@@ -733,6 +733,9 @@ struct pf_engine {
   }
 };
 
+static void tune_cache_load(pf_engine* h);
+static void tune_cache_save(pf_engine* h);
+
 // =========================================================================== C ABI
 namespace {
 int check_device(int device, std::string* err) {
@@ -787,6 +790,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FOLD_MLP")) e->fold_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
+  tune_cache_load(e);
   *out = e;
   return PF_OK;
 }
@@ -862,10 +866,38 @@ int pf_forward_f32(pf_handle h, int batch, const float* in, float* pg, float* pl
   return h->forward(batch, in, false, pg, pl, params, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
+// Optional on-disk tile cache (PF_TUNE_CACHE=<file>): lines "<12 key ints> <tile name>"; lets a profiled run skip the
+// tuning launches.  Entries are keyed by shape, so a stale file can only cost speed, never correctness.
+static void tune_cache_load(pf_engine* h) {
+  const char* path = getenv("PF_TUNE_CACHE");
+  if (!path) return;
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char name[64];
+  int k[12];
+  while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %63s", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7], &k[8], &k[9], &k[10], &k[11], name) == 13) {
+    for (int t = 0; t < conv_num_tiles(); ++t)
+      if (std::strcmp(conv_tile_name(t), name) == 0) { h->tile_cache[std::vector<int>(k, k + 12)] = t; break; }
+  }
+  fclose(f);
+}
+static void tune_cache_save(pf_engine* h) {
+  const char* path = getenv("PF_TUNE_CACHE");
+  if (!path) return;
+  FILE* f = fopen(path, "w");
+  if (!f) return;
+  for (auto& kv : h->tile_cache) {
+    if (kv.second < 0) continue;
+    for (int v : kv.first) fprintf(f, "%d ", v);
+    fprintf(f, "%s\n", conv_tile_name(kv.second));
+  }
+  fclose(f);
+}
+
 int pf_autotune(pf_handle h, int batch, const uint8_t* in, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, void* stream) {
   if (!h) return PF_ERR_ARG;
   const int rc = h->forward(batch, in, true, pg, pl, params, ws, ws_bytes, static_cast<hipStream_t>(stream), true);
-  if (rc == PF_OK) h->tuned_batches[batch] = true;
+  if (rc == PF_OK) { h->tuned_batches[batch] = true; tune_cache_save(h); }
   return rc;
 }
 

@@ -13,7 +13,7 @@
 // Structure = igemm.hip (same A gather with tap masks and buffer-load range checks, same grouped launch, same
 // LDS-staged epilogue): weights are pre-split on the host into three bf16 planes; activations are split by the
 // staging threads (5 VALU ops + packing per element, once per block) and written to three bf16 LDS planes with
-// an 80-byte row stride (20 i mod 64 hits 16 distinct 16-byte slots over 16 rows: conflict-free ds_read_b128).
+// 64-byte rows and an XOR piece swizzle (conflict-free ds_read_b128 and staging writes).
 // One LDS buffer + register prefetch: global loads of step t+1 fly during the MFMAs of step t.
 // [r01] 3x3 256->256 @80^2 (both heads): 177 TFLOP/s fp32-equivalent vs 132 for the exact-fp32 MFMA kernel.
 #include <stdlib.h>
@@ -23,7 +23,12 @@
 namespace pf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-static constexpr int SB_ROW = BK + 8;  // ushorts per LDS row (80 bytes)
+static constexpr int SB_ROW = BK;  // ushorts per LDS row: 64 bytes = four 16-byte pieces, no padding
+// Bank-conflict freedom comes from an XOR swizzle of the piece index with bits 2-3 of the row: a ds_read_b128
+// lane group covers 16 rows at one logical piece -> rows r, r+4, r+8, r+12 (same 16-byte slot mod 256 B) land on
+// four different pieces; the b64 / b128 staging writes always cover whole 64-byte rows (PMC: the earlier 80-byte
+// padded layout cost 8.8e7 SQ_LDS_BANK_CONFLICT cycles per launch on the write side and 25 % more LDS).
+__device__ __forceinline__ int sb_piece(int row, int piece) { return piece ^ ((row >> 2) & 3); }
 
 __device__ __forceinline__ unsigned pack_hi16(unsigned lo_src, unsigned hi_src) { return (lo_src >> 16) | (hi_src & 0xffff0000u); }
 
@@ -47,7 +52,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2
 
 // PF2: global loads run two K steps ahead (two raw register sets) instead of one
 template <int BM, int BN, int WM, int WN, int MODE, bool PF2>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_sb_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN >= 128 * 128) ? 3 : 1) void igemm_sb_kernel(const ConvParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int RPP = NT / 8;    // A rows staged per pass (8 threads x float4 = 32 floats)
   constexpr int RPB = NT / 4;    // B rows staged per pass (4 threads x 16 B = 32 bf16)
@@ -157,7 +162,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_sb_kernel(const ConvParams
     for (int i = 0; i < A_ROWS; ++i) {
       uint2 h, m, l;
       split4(a_reg[i], h, m, l);
-      unsigned short* d = As + (r0 + RPP * i) * SB_ROW + c4 * 4;
+      const int row = r0 + RPP * i;
+      unsigned short* d = As + row * SB_ROW + sb_piece(row, c4 >> 1) * 8 + (c4 & 1) * 4;
       *reinterpret_cast<uint2*>(d) = h;
       *reinterpret_cast<uint2*>(d + PLANE_A) = m;
       *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_sb_kernel(const ConvParams
     for (int i = 0; i < B_ROWS; ++i)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * SB_ROW + pc * 8) = b_reg[i][pl];
+        *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = b_reg[i][pl];
   };
 
   f32x16 acc[SM][SN];
@@ -179,33 +185,34 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_sb_kernel(const ConvParams
 
   const int wm0 = (wave / WN) * (SM * 32);
   const int wn0 = (wave % WN) * (SN * 32);
-  const unsigned short* Ab = As + (wm0 + l31) * SB_ROW + hi * 8;
-  const unsigned short* Bb = Bs + (wn0 + l31) * SB_ROW + hi * 8;
+  const unsigned short* Ab = As + (wm0 + l31) * SB_ROW;
+  const unsigned short* Bb = Bs + (wn0 + l31) * SB_ROW;
+  const int swz = (l31 >> 2) & 3;  // wm0, wn0 and i*32 are multiples of 32: the swizzle depends on the lane only
 
   auto compute = [&]() {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per K step
+    for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per K step; this lane's 8 k-values = piece 2c + hi
+      const int po = ((2 * c + hi) ^ swz) * 8;
       bf16x8 af[SM][3], bf[SN][3];
 #pragma unroll
       for (int i = 0; i < SM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * PLANE_A + i * 32 * SB_ROW + c * 16);
+        for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * PLANE_A + i * 32 * SB_ROW + po);
 #pragma unroll
       for (int j = 0; j < SN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * PLANE_B + j * 32 * SB_ROW + c * 16);
+        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * PLANE_B + j * 32 * SB_ROW + po);
+      // six partial products, smallest first; the (i, j) loop is innermost so that consecutive MFMAs never
+      // depend on each other's accumulator
+      constexpr int TA[6] = {2, 0, 1, 1, 0, 0};  // plane of A: l h m m h h
+      constexpr int TB[6] = {0, 2, 1, 0, 1, 0};  // plane of B: h l m h m h
 #pragma unroll
-      for (int i = 0; i < SM; ++i)
+      for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-        for (int j = 0; j < SN; ++j) {
-          // smallest terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);  // l h
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);  // h l
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);  // m m
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);  // m h
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);  // h m
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);  // h h
-        }
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+          for (int j = 0; j < SN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j], 0, 0, 0);
     }
   };
 

@@ -1,0 +1,56 @@
+"""The other BASELINE.json configurations on one GPU (parity-test cases, not the headline bench line):
+  configs[1]: batch 8, 640x640, PersNet-360Cities (classification heads, no ParamNet)
+  configs[4]: mixed-resolution stream, batch 64, short edge 384/640/1024 (1:2:1); the network batch is resolution
+              independent (everything is resized to 320x320), only the post-process output size differs per bucket.
+Writes gpurun_out/bench_configs.json."""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from perspectivefields_amd import PerspectiveFields
+from perspectivefields_amd.synth import synthetic_image
+
+def timed(fn, warm=2, iters=8):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters
+
+out = []
+# ---- configs[1]
+m = PerspectiveFields("PersNet-360Cities", weights="synthetic:0").eval().cuda()
+eng = m._get_engine()
+B = 8
+x = torch.from_numpy(np.stack([m.aug.apply_image(synthetic_image(640, 640, 100 + i)) for i in range(B)])).cuda()
+def step1():
+    pg, pl, _ = eng.forward(x)
+    return [eng.postprocess(pg[i], pl[i], 640, 640) for i in range(B)]
+dt = timed(step1)
+out.append({"config": "configs[1]: batch 8, 640x640, PersNet-360Cities (73/180-way logits + argmax decode), fp32-accurate arithmetic",
+            "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 2),
+            "note": "the engine has one precision mode (fp32 accumulate; split-bf16 MFMA is fp32-accurate); a reduced-precision bf16 mode is not implemented"})
+del m, eng
+# ---- configs[4]
+m = PerspectiveFields("Paramnet-360Cities-edina-centered", weights="synthetic:0").eval().cuda()
+eng = m._get_engine()
+sizes = [(384, 512), (640, 640), (640, 640), (1024, 1365)] * 16
+B = len(sizes)
+uniq = {s: m.aug.apply_image(synthetic_image(s[0], s[1], 7)) for s in set(sizes)}
+x = torch.from_numpy(np.stack([uniq[s] for s in sizes])).cuda()
+pg, pl, par = eng.forward(x)
+def step4():
+    pg, pl, par = eng.forward(x)
+    return [eng.postprocess(pg[i], pl[i], h, w) for i, (h, w) in enumerate(sizes)]
+dt = timed(step4, iters=5)
+buckets = {}
+for s in sorted(set(sizes)):
+    idx = [i for i, t in enumerate(sizes) if t == s]
+    d = timed(lambda: [eng.postprocess(pg[i], pl[i], s[0], s[1]) for i in idx], iters=5)
+    buckets[f"{s[0]}x{s[1]}"] = {"images": len(idx), "postprocess_us_per_image": round(d / len(idx) * 1e6, 1)}
+fwd = timed(lambda: eng.forward(x), iters=5)
+for k, v in buckets.items():
+    v["images_per_sec_in_stream"] = round(1.0 / (fwd / B + v["postprocess_us_per_image"] * 1e-6), 1)
+out.append({"config": "configs[4]: mixed-resolution stream, batch 64 (384x512 : 640x640 : 1024x1365 = 1:2:1), Paramnet-360Cities-edina-centered",
+            "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 2), "forward_ms": round(fwd * 1e3, 2), "per_bucket": buckets})
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/bench_configs.json", "w"), indent=1)
+print(json.dumps(out, indent=1))

@@ -7,7 +7,7 @@ def short(name):
     name = re.sub(r"\(.*$", "", name)
     m = re.search(r"pf::(\w+)", name)
     if m:
-        t = re.search(r"igemm_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+        t = re.search(r"igemm(?:_sb)?_kernel<(\d+), (\d+), (\d+), (\d+)", name)
         return f"pf::{m.group(1)}" + (f"<{t.group(1)}x{t.group(2)},w{int(t.group(3))*int(t.group(4))}>" if t else "")
     return name[:60]
 
