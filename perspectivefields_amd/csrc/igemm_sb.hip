@@ -258,7 +258,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN >= 128 * 128
 struct SbCfg { int bm, bn; const char* name; };
 // Two-step-ahead prefetch variants (PF2 = true) were measured and rejected: the second raw register set drops
 // occupancy (128x128: 350 registers -> 1 wave/SIMD) and loses 8-25 % on every shape (profiles/r01_tune_conv_v6_sb_pf2.txt).
-static const SbCfg kSb[] = {{128, 128, "sb128x128"}, {64, 64, "sb64x64"}, {128, 64, "sb128x64"}, {256, 128, "sb256x128w8"}};
+static const SbCfg kSb[] = {{128, 128, "sb128x128"}, {64, 64, "sb64x64"}, {128, 64, "sb128x64"}, {256, 128, "sb256x128w8"},
+                             {128, 256, "sb128x256w8"}};
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }
 const char* conv_sb_tile_name(int id) { return kSb[id].name; }
 int conv_sb_tile_bm(int id) { return kSb[id].bm; }
@@ -284,7 +285,8 @@ void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
     case 0: launch_sb_cfg<128, 128, 2, 2, false>(p, s); break;
     case 1: launch_sb_cfg<64, 64, 2, 2, false>(p, s); break;
     case 2: launch_sb_cfg<128, 64, 2, 2, false>(p, s); break;
-    default: launch_sb_cfg<256, 128, 4, 2, false>(p, s); break;
+    case 3: launch_sb_cfg<256, 128, 4, 2, false>(p, s); break;
+    default: launch_sb_cfg<128, 256, 2, 4, false>(p, s); break;  // whole N = 256 per block: A staged / split once per m-tile
   }
 }
 

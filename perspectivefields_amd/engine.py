@@ -68,11 +68,25 @@ def load_library(path: Optional[str] = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    if not os.path.exists(p) and path is None:
+        # in-tree build on first use when hipcc is present (one process builds, the others wait on the lock)
+        try:
+            import fcntl
+
+            from . import build as _build
+
+            os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+            with open(os.path.join(os.path.dirname(LIB_PATH), ".build.lock"), "w") as lk:
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                if not os.path.exists(LIB_PATH):
+                    _build.build(verbose=False)
+        except Exception as e:  # no hipcc / build failure: fail loudly below
+            raise PfError(
+                f"{p} not found and could not be built ({e}); the HIP extension is required, there is no CPU fallback. "
+                "Build it with `python -m perspectivefields_amd.build` (needs hipcc)."
+            ) from e
     if not os.path.exists(p):
-        raise PfError(
-            f"{p} not found: the HIP extension is not built and there is no CPU fallback. "
-            "Build it with `python -m perspectivefields_amd.build` (needs hipcc)."
-        )
+        raise PfError(f"{p} not found: the HIP extension is not built and there is no CPU fallback.")
     lib = ctypes.CDLL(p)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = ABI drift between header and library
