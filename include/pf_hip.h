@@ -92,6 +92,14 @@ int pf_forward_u8(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_p
 int pf_forward_f32(pf_handle h, int batch, const float* d_images_f32, float* d_pred_gravity, float* d_pred_latitude,
                    float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Device-side replacement of ResizeTransform.apply_image (perspectivefields.py:34-46,201): PIL's antialiased BILINEAR
+ * resize of one uint8 [H][W][3] image to [320][320][3], bit-identical to PIL (integer two-pass filter; coefficient
+ * tables built on the host exactly as Pillow does and cached per extent in the handle -- the first call for a new
+ * extent performs a small blocking upload).  d_out may point into the batch tensor given to pf_forward_u8. */
+size_t pf_resize_workspace_bytes(int H, int W);
+int pf_resize_bilinear_u8(pf_handle h, const uint8_t* d_img, int H, int W, uint8_t* d_out_320, void* d_workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* One-time tile autotuning for a batch size: a normal forward (same arguments and results as pf_forward_u8) in which
  * every conv/GEMM launch is additionally timed with each tile configuration on this device (HIP events; this call DOES
  * wait on the stream) and the fastest is cached in the handle.  Optional: untuned batch sizes use a static cost model.

@@ -642,6 +642,57 @@ void launch_gap_ln_head(const float* x, const float* g, const float* b, const fl
   hipLaunchKernelGGL(gap_ln_head_kernel, dim3(B), dim3(256), 0, s, x, g, b, w, hb, out, HW, C, nout, eps);
 }
 
+// ------------------------------------------------------------------------- bit-exact PIL resize
+// Reference: ResizeTransform.apply_image -> PIL Image.resize(BILINEAR) on uint8 (perspectivefields.py:34-46,201).
+// Pillow's resample is a two-pass (horizontal, then vertical) antialiased triangle filter in 22-bit fixed point;
+// the coefficient tables are computed on the host in double exactly as Pillow does (engine.hip resize_coeffs),
+// the passes below are pure integer arithmetic, so the result is bit-identical to PIL (tests/test_gpu_resize.py).
+static constexpr int RS_PREC = 32 - 8 - 2;
+__device__ __forceinline__ uint8_t rs_clip8(int v) { v >>= RS_PREC; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H, int W, int OW,
+                                                       const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
+  const long total = (long)H * OW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xx = (int)(i % OW);
+    const long y = i / OW;
+    const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+    const int* k = kk + (long)xx * ksize;
+    const uint8_t* p = in + (y * W + xmin) * 3;
+    int s0 = 1 << (RS_PREC - 1), s1 = s0, s2 = s0;
+    for (int x = 0; x < n; ++x) {
+      const int w = k[x];
+      s0 += p[3 * x] * w; s1 += p[3 * x + 1] * w; s2 += p[3 * x + 2] * w;
+    }
+    uint8_t* o = out + i * 3;
+    o[0] = rs_clip8(s0); o[1] = rs_clip8(s1); o[2] = rs_clip8(s2);
+  }
+}
+__global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H, int OW, int OH,
+                                                       const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
+  const long total = (long)OH * OW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xx = (int)(i % OW);
+    const int yy = (int)(i / OW);
+    const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
+    const int* k = kk + (long)yy * ksize;
+    const uint8_t* p = in + ((long)ymin * OW + xx) * 3;
+    int s0 = 1 << (RS_PREC - 1), s1 = s0, s2 = s0;
+    for (int y = 0; y < n; ++y) {
+      const int w = k[y];
+      s0 += p[0] * w; s1 += p[1] * w; s2 += p[2] * w;
+      p += (long)OW * 3;
+    }
+    uint8_t* o = out + i * 3;
+    o[0] = rs_clip8(s0); o[1] = rs_clip8(s1); o[2] = rs_clip8(s2);
+  }
+}
+void launch_resize_u8(const uint8_t* in, int H, int W, uint8_t* tmp, uint8_t* out, int OH, int OW, const int* bh, const int* kh, int ksh,
+                      const int* bv, const int* kv, int ksv, hipStream_t s) {
+  hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for((long)H * OW)), dim3(256), 0, s, in, tmp, H, W, OW, bh, kh, ksh);
+  hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((long)OH * OW)), dim3(256), 0, s, tmp, out, H, OW, OH, bv, kv, ksv);
+}
+
 // Reference: ParamNet.forward eval branch (param_network.py:62-67).  out is [B][8]:
 // mode 0 (centered): roll, pitch, vfov (deg), rel_focal = 1/(2 tan x2), raw x0..x3
 // mode 1 (uncentered): raw x0..x(n-1), zero padded (host applies the factors / fsolve, param_network.py:204-220)

@@ -162,6 +162,44 @@ std::vector<unsigned short> split_bf16x3(const std::vector<float>& w) {
   return o;
 }
 
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR (triangle, support 1) filter, in double, so that
+// the integer tables are bit-identical to the ones PIL builds (reference path: perspectivefields.py:45 -> Image.resize).
+struct ResizeTable { int ksize = 0; std::vector<int> bounds, kk; int *d_bounds = nullptr, *d_kk = nullptr; };
+void resize_coeffs(int in_size, int out_size, ResizeTable* t) {
+  const double scale = (double)in_size / out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  const int ksize = (int)std::ceil(support) * 2 + 1;
+  t->ksize = ksize;
+  t->bounds.assign((size_t)out_size * 2, 0);
+  t->kk.assign((size_t)out_size * ksize, 0);
+  std::vector<double> k(ksize);
+  const double ss = 1.0 / filterscale;
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    double ww = 0.0;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    for (int x = 0; x < ksize; ++x) k[x] = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      double v = (x + xmin - center + 0.5) * ss;
+      if (v < 0.0) v = -v;
+      const double w = v < 1.0 ? 1.0 - v : 0.0;
+      k[x] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; ++x)
+      if (ww != 0.0) k[x] /= ww;
+    for (int x = 0; x < ksize; ++x)
+      t->kk[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << 22)) : (int)(0.5 + k[x] * (1 << 22));
+    t->bounds[2 * xx] = xmin;
+    t->bounds[2 * xx + 1] = xmax;
+  }
+}
+
 }  // namespace
 
 struct pf_engine {
@@ -176,6 +214,7 @@ struct pf_engine {
   bool autotune = true;      // PF_AUTOTUNE=0: tile choice from the static cost model only
   std::map<std::vector<int>, int> tile_cache;  // conv shape (+batch) -> fastest tile config, measured on this device
   std::map<int, bool> tuned_batches;
+  std::map<int, ResizeTable> resize_tables;  // input extent -> tables for resizing that extent to NET
   std::map<int, size_t> scratch_off;
   bool split_bf16 = true;    // PF_SPLIT_BF16=0: exact-fp32 MFMA kernels only (no split-bf16 tiles)
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
@@ -192,6 +231,19 @@ struct pf_engine {
   int fail(int code, const std::string& m) { err = m; return code; }
 
   // ------------------------------------------------------------------ weights
+  ResizeTable* resize_table(int in_size) {
+    auto it = resize_tables.find(in_size);
+    if (it != resize_tables.end()) return &it->second;
+    ResizeTable& t = resize_tables[in_size];
+    resize_coeffs(in_size, NET, &t);
+    void *db = nullptr, *dk = nullptr;
+    if (hipMalloc(&db, t.bounds.size() * 4) != hipSuccess || hipMalloc(&dk, t.kk.size() * 4) != hipSuccess) return nullptr;
+    if (hipMemcpy(db, t.bounds.data(), t.bounds.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dk, t.kk.data(), t.kk.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    dev_allocs.push_back(db); dev_allocs.push_back(dk);
+    t.d_bounds = static_cast<int*>(db); t.d_kk = static_cast<int*>(dk);
+    return &t;
+  }
   float* upload(const std::vector<float>& v) {
     void* d = nullptr;
     if (hipMalloc(&d, v.size() * sizeof(float)) != hipSuccess) throw std::string("hipMalloc failed for weights");
@@ -902,6 +954,23 @@ int pf_autotune(pf_handle h, int batch, const uint8_t* in, float* pg, float* pl,
 }
 
 int pf_is_tuned(pf_handle h, int batch) { return (h && (!h->autotune || h->tuned_batches.count(batch))) ? 1 : 0; }
+
+size_t pf_resize_workspace_bytes(int H, int W) { (void)W; return H > 0 ? (size_t)H * NET * 3 + 256 : 0; }
+
+int pf_resize_bilinear_u8(pf_handle h, const uint8_t* d_img, int H, int W, uint8_t* d_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return PF_ERR_ARG;
+  if (!d_img || !d_out || H <= 0 || W <= 0) return h->fail(PF_ERR_ARG, "pf_resize_bilinear_u8: bad argument");
+  if (!ws || ws_bytes < pf_resize_workspace_bytes(H, W)) return h->fail(PF_ERR_WORKSPACE, "pf_resize_bilinear_u8: workspace too small");
+  if (hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
+  ResizeTable* th = h->resize_table(W);  // first use of an extent builds + uploads its table (blocking copy, once)
+  ResizeTable* tv = h->resize_table(H);
+  if (!th || !tv) return h->fail(PF_ERR_DEVICE, "pf_resize_bilinear_u8: could not upload coefficient tables");
+  uint8_t* tmp = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+  launch_resize_u8(d_img, H, W, tmp, d_out, NET, NET, th->d_bounds, th->d_kk, th->ksize, tv->d_bounds, tv->d_kk, tv->ksize, static_cast<hipStream_t>(stream));
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return h->fail(PF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+  return PF_OK;
+}
 
 int pf_postprocess(pf_handle h, const float* pg, const float* pl, int H, int W, float* up, float* lat, void* ws, size_t ws_bytes, void* stream) {
   if (!h) return PF_ERR_ARG;

@@ -90,6 +90,10 @@ void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hip
 void launch_prep_u8(const uint8_t* in, float* out, long npix, const float* mean3, const float* std3, hipStream_t s);
 void launch_prep_f32_nchw(const float* in, float* out, int B, int HW, const float* mean3, const float* std3, hipStream_t s);
 
+// bit-exact PIL antialiased bilinear resize of one uint8 HxWx3 image to OHxOWx3 (two integer passes; tables from the host)
+void launch_resize_u8(const uint8_t* in, int H, int W, uint8_t* tmp, uint8_t* out, int OH, int OW, const int* bh, const int* kh, int ksh,
+                      const int* bv, const int* kv, int ksv, hipStream_t s);
+
 // regression prediction heads: 1x1 (32->2) + L2-normalise, 1x1 (32->1) + clamp; writes NCHW API outputs and the NHWC4 ParamNet input
 void launch_pred_regression(const float* tg, const float* tl, const float* wg, const float* bg, const float* wl, const float* bl,
                             float* pred_g_nchw, float* pred_l_nchw, float* pn_in_nhwc4, int B, int HW, hipStream_t s);

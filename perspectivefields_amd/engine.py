@@ -34,6 +34,8 @@ _SIGNATURES = {
     "pf_workspace_bytes": (_c.c_size_t, [_P, _c.c_int]),
     "pf_forward_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_forward_f32": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_resize_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "pf_resize_bilinear_u8": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
     "pf_autotune": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_is_tuned": (_c.c_int, [_P, _c.c_int]),
     "pf_postprocess": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
@@ -211,6 +213,19 @@ class Engine:
             )
         _check(rc, self._h, "pf_forward")
         return pg, pl, params
+
+    def resize_into(self, img_u8, out_u8_320):
+        """Bit-exact PIL BILINEAR resize on the device: img_u8 (H,W,3) uint8 cuda -> out_u8_320 (320,320,3) uint8 cuda view."""
+        import torch
+
+        H, W = int(img_u8.shape[0]), int(img_u8.shape[1])
+        need = int(self.lib.pf_resize_workspace_bytes(H, W))
+        if getattr(self, "_rs_ws", None) is None or self._rs_ws.numel() < need:
+            self._rs_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.pf_resize_bilinear_u8(self._h, img_u8.data_ptr(), H, W, out_u8_320.data_ptr(),
+                                                self._rs_ws.data_ptr(), self._rs_ws.numel(), _stream_ptr())
+        _check(rc, self._h, "pf_resize_bilinear_u8")
 
     PROFILE_CLASSES = ("igemm", "attention", "layernorm", "dwconv3x3_gelu", "dwconv7x7", "upsample2x", "other", "igemm_sb")
 

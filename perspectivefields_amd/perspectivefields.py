@@ -84,6 +84,9 @@ class PerspectiveFields(nn.Module):
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
         self.input_format = cfg.INPUT.FORMAT
         self.aug = ResizeTransform(cfg.DATALOADER.RESIZE[0], cfg.DATALOADER.RESIZE[1])
+        # True: inference()/inference_batch() upload the original uint8 image and run the (bit-identical) PIL resize
+        # on the GPU instead of on a host core (1.7 ms/image/core); same bytes reach the network either way.
+        self.device_resize = os.environ.get("PF_DEVICE_RESIZE", "0") == "1"
         self._engine: Optional[Engine] = None
         self._state: Dict[str, np.ndarray] = OrderedDict()
         self._init_weights(weights)
@@ -139,9 +142,17 @@ class PerspectiveFields(nn.Module):
             original = img_bgr  # never mutated: apply_image returns a new array (reference copies, :196,211)
             if self.input_format == "RGB":
                 original = original[:, :, ::-1]
+            if original.dtype != np.uint8:
+                raise TypeError("PerspectiveFields expects uint8 BGR images (as cv2.imread returns)")
             sizes.append(tuple(int(v) for v in original.shape[:2]))
-            resized.append(self.aug.apply_image(np.ascontiguousarray(original)))
-        batch = torch.from_numpy(np.stack(resized)).to(self.device, non_blocking=False)  # uint8 (B,320,320,3)
+            resized.append(np.ascontiguousarray(original) if self.device_resize else self.aug.apply_image(np.ascontiguousarray(original)))
+        if self.device_resize:
+            eng = self._get_engine()
+            batch = torch.empty((len(resized), NET_H, NET_W, 3), dtype=torch.uint8, device=self.device)
+            for i, im in enumerate(resized):
+                eng.resize_into(torch.from_numpy(im).to(self.device), batch[i])
+        else:
+            batch = torch.from_numpy(np.stack(resized)).to(self.device, non_blocking=False)  # uint8 (B,320,320,3)
         return self._run(batch, sizes)
 
     def forward(self, batched_inputs) -> List[dict]:

@@ -193,3 +193,43 @@ def test_split_bf16_scheme_is_fp32_accurate():
     assert np.max(np.abs(six - ref) / scale) < 4 * 2.0 ** -24  # dropped terms: m*l, l*m, l*l
     f32 = (a @ b).astype(np.float64)
     assert np.max(np.abs(six - ref)) <= 2 * np.max(np.abs(f32 - ref)) + 1e-12
+
+
+def test_pil_resize_algorithm_restatement():
+    """The integer two-pass filter that csrc (resize_coeffs + resize_h/v_kernel) implements, restated in numpy and
+    checked bit-for-bit against PIL (the reference's host resize, perspectivefields.py:34-46)."""
+    import math
+
+    from PIL import Image
+
+    PREC = 22
+
+    def coeffs(n_in, n_out):
+        scale = n_in / n_out
+        fs = max(scale, 1.0)
+        support = fs
+        ks = int(math.ceil(support)) * 2 + 1
+        b, kk = [], np.zeros((n_out, ks), np.int64)
+        for xx in range(n_out):
+            c = (xx + 0.5) * scale
+            x0 = max(int(c - support + 0.5), 0)
+            x1 = min(int(c + support + 0.5), n_in) - x0
+            k = np.array([max(0.0, 1.0 - abs((x + x0 - c + 0.5) / fs)) for x in range(x1)])
+            k = k / k.sum() if k.sum() != 0 else k
+            kk[xx, :x1] = [int(0.5 + v * (1 << PREC)) for v in k]
+            b.append((x0, x1))
+        return b, kk
+
+    def one_pass(a, n_out):  # resample axis 1
+        b, kk = coeffs(a.shape[1], n_out)
+        out = np.zeros((a.shape[0], n_out, a.shape[2]), np.uint8)
+        for xx, (x0, n) in enumerate(b):
+            acc = (a[:, x0:x0 + n, :].astype(np.int64) * kk[xx, :n][None, :, None]).sum(1) + (1 << (PREC - 1))
+            out[:, xx, :] = np.clip(acc >> PREC, 0, 255)
+        return out
+
+    rng = np.random.default_rng(1)
+    for h, w in [(97, 211), (640, 640), (50, 30)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = one_pass(one_pass(img, 320).transpose(1, 0, 2), 320).transpose(1, 0, 2)
+        assert np.array_equal(got, np.asarray(Image.fromarray(img).resize((320, 320), Image.BILINEAR)))
