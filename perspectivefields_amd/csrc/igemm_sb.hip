@@ -52,15 +52,15 @@ __device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2
 
 // PF2: global loads run two K steps ahead (two raw register sets) instead of one
 template <int BM, int BN, int WM, int WN, int MODE, bool PF2>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN >= 128 * 128) ? 3 : 1) void igemm_sb_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? 3 : 1) void igemm_sb_kernel(const ConvParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int RPP = NT / 8;    // A rows staged per pass (8 threads x float4 = 32 floats)
   constexpr int RPB = NT / 4;    // B rows staged per pass (4 threads x 16 B = 32 bf16)
   constexpr int SM = BM / (WM * 32);
   constexpr int SN = BN / (WN * 32);
   constexpr int A_ROWS = BM / RPP;
-  constexpr int B_ROWS = BN / RPB;
-  static_assert(BM % RPP == 0 && BN % RPB == 0, "tile rows must be a multiple of the staging pass");
+  constexpr int B_ROWS = (BN + RPB - 1) / RPB;  // BN < RPB (N = 32 tiles): the upper threads stage no B rows
+  static_assert(BM % RPP == 0 && (BN % RPB == 0 || BN < RPB), "tile rows must be a multiple of the staging pass");
   constexpr int PLANE_A = BM * SB_ROW, PLANE_B = BN * SB_ROW;  // ushorts
   constexpr int SMEM_USHORTS = 3 * (PLANE_A + PLANE_B);
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN >= 128 * 128
 #pragma unroll
   for (int i = 0; i < B_ROWS; ++i) {
     const int n = n0 + rb0 + RPB * i;
-    b_off[i] = n < p.Cout ? (unsigned)(n * p.KH * p.KWCp + pc * 8) * 2u : OOB;
+    b_off[i] = (n < p.Cout && rb0 + RPB * i < BN) ? (unsigned)(n * p.KH * p.KWCp + pc * 8) * 2u : OOB;
   }
 
   // two raw register sets: loads run TWO K steps ahead of their split/store (one 48-MFMA step is too short to
@@ -170,9 +170,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN >= 128 * 128
     }
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i)
+      if (BN % RPB == 0 || rb0 + RPB * i < BN) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = b_reg[i][pl];
+        for (int pl = 0; pl < 3; ++pl)
+          *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = b_reg[i][pl];
+      }
   };
 
   f32x16 acc[SM][SN];
@@ -259,7 +261,7 @@ struct SbCfg { int bm, bn; const char* name; };
 // Two-step-ahead prefetch variants (PF2 = true) were measured and rejected: the second raw register set drops
 // occupancy (128x128: 350 registers -> 1 wave/SIMD) and loses 8-25 % on every shape (profiles/r01_tune_conv_v6_sb_pf2.txt).
 static const SbCfg kSb[] = {{128, 128, "sb128x128"}, {64, 64, "sb64x64"}, {128, 64, "sb128x64"}, {256, 128, "sb256x128w8"},
-                             {128, 256, "sb128x256w8"}};
+                             {128, 256, "sb128x256w8"}, {128, 32, "sb128x32"}, {256, 256, "sb256x256w8"}};
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }
 const char* conv_sb_tile_name(int id) { return kSb[id].name; }
 int conv_sb_tile_bm(int id) { return kSb[id].bm; }
@@ -286,7 +288,9 @@ void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
     case 1: launch_sb_cfg<64, 64, 2, 2, false>(p, s); break;
     case 2: launch_sb_cfg<128, 64, 2, 2, false>(p, s); break;
     case 3: launch_sb_cfg<256, 128, 4, 2, false>(p, s); break;
-    default: launch_sb_cfg<128, 256, 2, 4, false>(p, s); break;  // whole N = 256 per block: A staged / split once per m-tile
+    case 4: launch_sb_cfg<128, 256, 2, 4, false>(p, s); break;  // whole N = 256 per block: A staged / split once per m-tile
+    case 5: launch_sb_cfg<128, 32, 4, 1, false>(p, s); break;  // N = 32 layers (conv_fuse_conv1)
+    default: launch_sb_cfg<256, 256, 2, 4, false>(p, s); break;  // half the global / LDS / split work per MFMA, one block per CU
   }
 }
 
