@@ -128,21 +128,32 @@ int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n)
 int pf_profile_records(pf_handle h, int max_records, int* cat, double* work, float* ms, int* mnk);
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels pf_forward runs) ----
- * NHWC fp32 device activations; weights are HOST pointers in the reference's layouts. */
+ * NHWC fp32 device activations; weights are HOST pointers in the reference's layouts.
+ * "planes": the engine's internal split-bf16 activation format -- an fp32 tensor stored losslessly as three bf16
+ * planes (x == h + m + l exactly), plane k at `planes + k * plane_elems`, each laid out like the fp32 tensor.
+ * Producers write it for tensors that only feed the split-bf16 GEMMs; every *_planes argument is optional (NULL). */
 int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, int W, int C1, int C2,
                  const float* h_weight /*[Cout][C1+C2][KH][KW]*/, const float* h_bias /*[Cout] or NULL*/,
                  int Cout, int KH, int KW, int stride, int pad, int act /*0 none 1 relu 2 gelu*/,
                  const float* d_res1, const float* d_res2, int post_relu, int nchw_out, int tile_id /*-1 auto*/,
-                 float* d_y, void* stream);
-/* times `iters` launches of one conv shape on random data with tile config `tile_id` (-1 auto); avg ms per launch */
-int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, float* ms_out);
+                 float* d_y /*may be NULL when d_y_planes is given*/,
+                 const uint16_t* d_x_planes /*replaces d_x*/, long x_plane_elems, const uint16_t* d_x2_planes, long x2_plane_elems,
+                 uint16_t* d_y_planes, long y_plane_elems, void* stream);
+/* times `iters` launches of one conv shape on random data with tile config `tile_id` (-1 auto); avg ms per launch.
+ * fmt 0: fp32 in / out; 1: input as planes; 2: input and output as planes */
+int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt, float* ms_out);
+int pf_op_split_bf16(int device, const float* d_x, long n, uint16_t* d_planes, long plane_elems, void* stream);
+int pf_op_merge_bf16(int device, const uint16_t* d_planes, long plane_elems, long n, float* d_y, void* stream);
 /* times one depthwise-3x3+GELU launch variant on random data (0 = LDS halo tile, 1-4 = register-window direct, 99 = plain copy) */
 int pf_op_dwconv3x3_bench(int device, int variant, int B, int H, int W, int C, int iters, float* ms_out);
-int pf_op_layernorm(int device, const float* d_x, const float* h_gamma, const float* h_beta, float* d_y, long rows, int C, float eps, void* stream);
-int pf_op_dwconv3x3_gelu(int device, const float* d_x, const float* h_weight /*[C][1][3][3]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);
+int pf_op_layernorm(int device, const float* d_x, const float* h_gamma, const float* h_beta, float* d_y, long rows, int C, float eps,
+                    uint16_t* d_y_planes, long plane_elems, void* stream);
+int pf_op_dwconv3x3_gelu(int device, const float* d_x, const float* h_weight /*[C][1][3][3]*/, const float* h_bias, float* d_y, int B, int H, int W, int C,
+                         uint16_t* d_y_planes, long plane_elems, void* stream);
 int pf_op_dwconv7x7(int device, const float* d_x, const float* h_weight /*[C][1][7][7]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);
-int pf_op_sr_attention(int device, const float* d_q, const float* d_kv, float* d_out, int B, int N, int M, int heads, void* stream);
-int pf_op_upsample2x(int device, const float* d_x, float* d_y, int B, int H, int W, int C, void* stream);
+int pf_op_sr_attention(int device, const float* d_q, const float* d_kv, float* d_out, int B, int N, int M, int heads,
+                       uint16_t* d_out_planes, long plane_elems, void* stream);
+int pf_op_upsample2x(int device, const float* d_x, float* d_y, int B, int H, int W, int C, uint16_t* d_y_planes, long plane_elems, void* stream);
 int pf_op_num_conv_tiles(void);
 const char* pf_op_conv_tile_name(int tile_id);
 

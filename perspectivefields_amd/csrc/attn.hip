@@ -10,6 +10,7 @@
 // single cross-half shuffle, and P^T in the accumulator layout is *already* the B operand
 // of the second product O^T = V^T P^T (k-pair = the two kv rows held by the half-waves).
 #include "pf_kernels.h"
+#include "sb_split.h"
 
 namespace pf {
 
@@ -20,7 +21,7 @@ static constexpr int KV_PAD = 128;   // kv rows padded to 4 MFMA row blocks
 static constexpr int K_ROW = HD + 4; // 68 floats: 68*i mod 64 = 4i -> conflict-free ds_read_b128 over 16 rows
 
 __global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restrict__ q, const float* __restrict__ kv,
-                                                           float* __restrict__ out, int N, int M, int heads) {
+                                                           float* __restrict__ out, unsigned short* __restrict__ out_sb, size_t sb_plane, int N, int M, int heads) {
   __shared__ __attribute__((aligned(16))) float Ks[KV_PAD * K_ROW];
   __shared__ __attribute__((aligned(16))) float Vs[KV_PAD * HD];
   const int C = heads * HD;
@@ -119,20 +120,22 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restri
 
   // ---- store: lane holds O[q = lane&31][d = 32 j + (r & 3) + 8 (r >> 2) + 4 hi]; 4 consecutive d per float4
   if (qrow < N) {
-    float* op = out + ((long)b * N + qrow) * C + h * HD;
+    const size_t o0 = ((size_t)b * N + qrow) * C + h * HD;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 v = make_float4(oacc[j][4 * g] * inv, oacc[j][4 * g + 1] * inv, oacc[j][4 * g + 2] * inv, oacc[j][4 * g + 3] * inv);
-        *reinterpret_cast<float4*>(op + 32 * j + 8 * g + 4 * hi) = v;
+        const size_t o = o0 + 32 * j + 8 * g + 4 * hi;
+        if (out) *reinterpret_cast<float4*>(out + o) = v;
+        if (out_sb) store_sb4(out_sb, sb_plane, o, v);
       }
   }
 }
 
-void launch_sr_attention(const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s) {
+void launch_sr_attention(const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s, unsigned short* out_sb, size_t sb_plane) {
   const dim3 grid((N + 127) / 128, heads, B);
-  hipLaunchKernelGGL(sr_attention_kernel, grid, dim3(256), 0, s, q, kv, out, N, M, heads);
+  hipLaunchKernelGGL(sr_attention_kernel, grid, dim3(256), 0, s, q, kv, out, out_sb, sb_plane, N, M, heads);
 }
 
 }  // namespace pf

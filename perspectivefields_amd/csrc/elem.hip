@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "pf_kernels.h"
+#include "sb_split.h"
 
 namespace pf {
 
@@ -19,7 +20,8 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 // LPR lanes cooperate on one row (wave-shuffle reductions); two-pass mean / centred variance.
 template <int LPR, int VPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                        const float* __restrict__ b, float* __restrict__ y, long rows, int C, float eps) {
+                                                        const float* __restrict__ b, float* __restrict__ y, unsigned short* __restrict__ y_sb,
+                                                        size_t sb_plane, long rows, int C, float eps) {
   constexpr int RPB = 256 / LPR;
   const int sub = threadIdx.x % LPR;
   const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
@@ -63,23 +65,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
       o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
       o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
-      reinterpret_cast<float4*>(y + row * C)[c] = o;
+      if (y) reinterpret_cast<float4*>(y + row * C)[c] = o;
+      if (y_sb) store_sb4(y_sb, sb_plane, (size_t)row * C + 4 * c, o);
     }
   }
 }
 
-void launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps, hipStream_t s) {
+void launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps, hipStream_t s,
+                      unsigned short* y_sb, size_t sb_plane) {
   const int nv = C / 4;
   if (nv <= 16) {
-    hipLaunchKernelGGL((layernorm_kernel<16, 1>), dim3((rows + 15) / 16), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+    hipLaunchKernelGGL((layernorm_kernel<16, 1>), dim3((rows + 15) / 16), dim3(256), 0, s, x, g, b, y, y_sb, sb_plane, rows, C, eps);
   } else if (nv <= 32) {
-    hipLaunchKernelGGL((layernorm_kernel<32, 1>), dim3((rows + 7) / 8), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+    hipLaunchKernelGGL((layernorm_kernel<32, 1>), dim3((rows + 7) / 8), dim3(256), 0, s, x, g, b, y, y_sb, sb_plane, rows, C, eps);
   } else if (nv <= 64) {
-    hipLaunchKernelGGL((layernorm_kernel<64, 1>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+    hipLaunchKernelGGL((layernorm_kernel<64, 1>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, y_sb, sb_plane, rows, C, eps);
   } else if (nv <= 128) {
-    hipLaunchKernelGGL((layernorm_kernel<64, 2>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+    hipLaunchKernelGGL((layernorm_kernel<64, 2>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, y_sb, sb_plane, rows, C, eps);
   } else {
-    hipLaunchKernelGGL((layernorm_kernel<64, 4>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, C, eps);
+    hipLaunchKernelGGL((layernorm_kernel<64, 4>), dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, y_sb, sb_plane, rows, C, eps);
   }
 }
 
@@ -93,6 +97,7 @@ static constexpr int DW3_CQ = 32;  // channel quads per block (128 channels)
 
 __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                             unsigned short* __restrict__ y_sb, size_t sb_plane,
                                                              int B, int H, int W, int C) {
   __shared__ __attribute__((aligned(16))) float4 tile[(DW3_T + 2) * (DW3_T + 2) * DW3_CQ];
   const int tilesX = (W + DW3_T - 1) / DW3_T, tilesY = (H + DW3_T - 1) / DW3_T;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __rest
     win[r][1] = tile[((ry + r) * (DW3_T + 2) + 0) * DW3_CQ + q];
     win[r][2] = tile[((ry + r) * (DW3_T + 2) + 1) * DW3_CQ + q];
   }
-  float4* yout = reinterpret_cast<float4*>(y) + ((long)b * H + oy) * W * CQ + cq0 + q;
+  const long yrow = ((long)b * H + oy) * W * CQ + cq0 + q;  // float4 index of (b, oy, 0, q)
 #pragma unroll
   for (int ox = 0; ox < DW3_T; ++ox) {
 #pragma unroll
@@ -142,7 +147,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __rest
 #pragma unroll
       for (int c = 0; c < 3; ++c) a = fma4(win[r][c], wk[r * 3 + c], a);
     a.x = gelu_erf_e(a.x); a.y = gelu_erf_e(a.y); a.z = gelu_erf_e(a.z); a.w = gelu_erf_e(a.w);
-    if (x0 + ox < W) yout[(long)(x0 + ox) * CQ] = a;
+    if (x0 + ox < W) {
+      const long o4 = yrow + (long)(x0 + ox) * CQ;
+      if (y) reinterpret_cast<float4*>(y)[o4] = a;
+      if (y_sb) store_sb4(y_sb, sb_plane, (size_t)o4 * 4, a);
+    }
   }
 }
 
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __rest
 template <int CQB /*quads per block*/, int XB /*columns per block*/, int TH /*rows per strip*/>
 __global__ __launch_bounds__(CQB * XB) void dwconv3x3_gelu_direct_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                                         unsigned short* __restrict__ y_sb, size_t sb_plane,
                                                                          int B, int H, int W, int C) {
   const int CQ = C >> 2;
   const int slabs = CQ / CQB, tilesX = (W + XB - 1) / XB, strips = (H + TH - 1) / TH;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(CQB * XB) void dwconv3x3_gelu_direct_kernel(const f
   if (ox >= W) return;
   const int y0 = st * TH, y1 = min(y0 + TH, H);
   const float4* xin = reinterpret_cast<const float4*>(x) + (long)b * H * W * CQ + q;
-  float4* yout = reinterpret_cast<float4*>(y) + (long)b * H * W * CQ + q;
+  const long ybase = (long)b * H * W * CQ + q;  // float4 index of (b, 0, 0, q)
   float4 wk[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const float4*>(w9c)[(long)k * CQ + q];
@@ -199,7 +209,9 @@ __global__ __launch_bounds__(CQB * XB) void dwconv3x3_gelu_direct_kernel(const f
       a = fma4(r2[c], wk[6 + c], a);
     }
     a.x = gelu_erf_e(a.x); a.y = gelu_erf_e(a.y); a.z = gelu_erf_e(a.z); a.w = gelu_erf_e(a.w);
-    yout[((long)oy * W + ox) * CQ] = a;
+    const long o4 = ybase + ((long)oy * W + ox) * CQ;
+    if (y) reinterpret_cast<float4*>(y)[o4] = a;
+    if (y_sb) store_sb4(y_sb, sb_plane, (size_t)o4 * 4, a);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { r0[c] = r1[c]; r1[c] = r2[c]; }
   }
@@ -210,39 +222,41 @@ __global__ __launch_bounds__(256) void copy_f4_kernel(const float4* __restrict__
 }
 
 static int g_dw3_variant = -1;
-void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s,
+                                   unsigned short* y_sb, size_t sb_plane) {
   const int CQ = C / 4;
   if (variant == 0) {
     const int tilesX = (W + DW3_T - 1) / DW3_T, tilesY = (H + DW3_T - 1) / DW3_T;
     const long blocks = (long)B * tilesY * tilesX * (C / (DW3_CQ * 4));
-    hipLaunchKernelGGL(dwconv3x3_gelu_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+    hipLaunchKernelGGL(dwconv3x3_gelu_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
   } else if (variant == 1) {  // 32 quads x 8 columns, strips of 16 rows
     const long blocks = (long)B * ((H + 15) / 16) * ((W + 7) / 8) * (CQ / 32);
-    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
   } else if (variant == 2) {  // 64 quads x 4 columns, strips of 16 rows
-    if (CQ % 64 != 0) return launch_dwconv3x3_gelu_variant(1, x, w9c, bias, y, B, H, W, C, s);
+    if (CQ % 64 != 0) return launch_dwconv3x3_gelu_variant(1, x, w9c, bias, y, B, H, W, C, s, y_sb, sb_plane);
     const long blocks = (long)B * ((H + 15) / 16) * ((W + 3) / 4) * (CQ / 64);
-    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<64, 4, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<64, 4, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
   } else if (variant == 3) {  // 32 quads x 8 columns, strips of 40 rows
     const long blocks = (long)B * ((H + 39) / 40) * ((W + 7) / 8) * (CQ / 32);
-    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 40>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 40>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
   } else if (variant == 4) {  // 32 quads x 8 columns, strips of 8 rows
     const long blocks = (long)B * ((H + 7) / 8) * ((W + 7) / 8) * (CQ / 32);
-    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 8>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, B, H, W, C);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 8>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
   } else {  // 99: plain copy of the same bytes (achievable streaming ceiling, diagnostic only)
     const long n = (long)B * H * W * CQ;
     hipLaunchKernelGGL(copy_f4_kernel, dim3(256 * 16), dim3(256), 0, s, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), n);
   }
 }
 
-void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s,
+                           unsigned short* y_sb, size_t sb_plane) {
   if (g_dw3_variant == -1) {
     const char* e = getenv("PF_DW3_VARIANT");
     g_dw3_variant = e ? atoi(e) : -2;
   }
   // default: register-window kernel; strip height / block shape by map size (scripts/tune_dw.py, profiles/r01_tune_dw.txt)
   const int v = g_dw3_variant >= 0 ? g_dw3_variant : (H >= 64 ? 3 : (H >= 16 ? 4 : 2));
-  launch_dwconv3x3_gelu_variant(v, x, w9c, bias, y, B, H, W, C, s);
+  launch_dwconv3x3_gelu_variant(v, x, w9c, bias, y, B, H, W, C, s, y_sb, sb_plane);
 }
 
 // ------------------------------------------------------------------------- depthwise 7x7
@@ -400,7 +414,8 @@ void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, floa
 // --------------------------------------------------------------------------- bilinear x2
 // Reference: F.interpolate(scale_factor=2, mode="bilinear", align_corners=False)
 // (decode_head.py:284-286; gravity_head.py:172).  src = (dst + 0.5) * 0.5 - 0.5 clamped at 0.
-__global__ __launch_bounds__(256) void upsample2x_kernel(const float4* __restrict__ x, float4* __restrict__ y, int B, int H, int W, int CQ) {
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float4* __restrict__ x, float4* __restrict__ y, unsigned short* __restrict__ y_sb,
+                                                         size_t sb_plane, int B, int H, int W, int CQ) {
   const int Ho = 2 * H, Wo = 2 * W;
   const long total = (long)B * Ho * Wo * CQ;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -423,16 +438,49 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float4* __restric
     o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
     o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
     o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-    y[i] = o;
+    if (y) y[i] = o;
+    if (y_sb) store_sb4(y_sb, sb_plane, (size_t)i * 4, o);
   }
 }
 
-void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s) {
+// ---------------------------------------------------------- fp32 <-> split-bf16 planes (sb_split.h), 4 elements per thread
+__global__ __launch_bounds__(256) void split_planes_kernel(const float4* __restrict__ x, unsigned short* __restrict__ y_sb, size_t sb_plane, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) store_sb4(y_sb, sb_plane, (size_t)i * 4, x[i]);
+}
+__global__ __launch_bounds__(256) void merge_planes_kernel(const unsigned short* __restrict__ x_sb, size_t sb_plane, float4* __restrict__ y, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) y[i] = load_sb4(x_sb, sb_plane, (size_t)i * 4);
+}
+// uniform [-scale, scale) pseudo-random fill (benchmark inputs: never time kernels on zeros, DVFS clocks them higher)
+__global__ __launch_bounds__(256) void fill_random_kernel(float* __restrict__ p, long n, unsigned seed, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    p[i] = ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
+  }
+}
+void launch_fill_random(float* p, long n, unsigned seed, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(fill_random_kernel, dim3(256 * 16), dim3(256), 0, s, p, n, seed, scale);
+}
+
+void launch_split_planes(const float* x, unsigned short* y_sb, size_t sb_plane, long n, hipStream_t s) {
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), y_sb, sb_plane, n / 4);
+}
+void launch_merge_planes(const unsigned short* x_sb, size_t sb_plane, float* y, long n, hipStream_t s) {
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x_sb, sb_plane, reinterpret_cast<float4*>(y), n / 4);
+}
+
+void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb, size_t sb_plane) {
   const long total = (long)B * 4 * H * W * (C / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
-                     reinterpret_cast<float4*>(y), B, H, W, C / 4);
+                     reinterpret_cast<float4*>(y), y_sb, sb_plane, B, H, W, C / 4);
 }
 
 // ---------------------------------------------------------------------- input normalise

@@ -68,6 +68,20 @@ struct Head {
 struct CnxBlock { DwW dw; LNW n; ConvW pw1, pw2; };
 struct Cnx { ConvW stem, ds[3]; LNW stemn, dsn[3], norm; std::vector<CnxBlock> blocks[4]; float* headw = nullptr; float* headb = nullptr; int nout = 0; };
 
+// Split-bf16 activation tensor (sb_split.h): three exact bf16 planes `plane` elements apart.
+struct SbT {
+  unsigned short* p = nullptr;
+  size_t plane = 0;
+};
+// An activation as the kernels see it: fp32 NHWC and / or split planes (producers write what their consumers read).
+struct Ten {
+  float* f = nullptr;
+  SbT s;
+  Ten() {}
+  Ten(float* f_) : f(f_) {}
+  Ten(float* f_, SbT s_) : f(f_), s(s_) {}
+};
+
 struct Profiler;
 struct Ctx {
   hipStream_t s;
@@ -76,14 +90,28 @@ struct Ctx {
   bool dry;
   Profiler* prof = nullptr;
   bool tuning = false;      // autotune pass: time every tile config per conv shape
-  float* tune_scratch = nullptr;
-  size_t max_conv_out = 0;  // floats of the largest (grouped) conv output seen by the dry run = tuning scratch size
+  float* tune_scratch = nullptr;  // [max_conv_out] floats, followed by 3 bf16 planes of max_conv_out elements
+  size_t tune_scratch_elems = 0;
+  size_t max_conv_out = 0;  // elements of the largest (grouped) conv output seen by the dry run = tuning scratch size
   float* alloc(size_t nfloats) {
     const size_t bytes = (nfloats * 4 + 255) & ~(size_t)255;
     const size_t o = off;
     off += bytes;
     if (off > peak) peak = off;
     return reinterpret_cast<float*>(base + o);
+  }
+  SbT alloc_sb(size_t elems) {
+    SbT t;
+    t.plane = (elems + 127) & ~(size_t)127;
+    t.p = reinterpret_cast<unsigned short*>(alloc((3 * t.plane * 2 + 3) / 4));
+    return t;
+  }
+  // fp32 and / or split planes, as requested
+  Ten ten(size_t elems, bool want_f32, bool want_sb) {
+    Ten t;
+    if (want_f32) t.f = alloc(elems);
+    if (want_sb) t.s = alloc_sb(elems);
+    return t;
   }
   size_t mark() const { return off; }
   void release(size_t m) { off = m; }
@@ -215,9 +243,10 @@ struct pf_engine {
   std::map<std::vector<int>, int> tile_cache;  // conv shape (+batch) -> fastest tile config, measured on this device
   std::map<int, bool> tuned_batches;
   std::map<int, ResizeTable> resize_tables;  // input extent -> tables for resizing that extent to NET
-  std::map<int, size_t> scratch_off;
+  std::map<int, size_t> scratch_off, scratch_elems;
   bool split_bf16 = true;    // PF_SPLIT_BF16=0: exact-fp32 MFMA kernels only (no split-bf16 tiles)
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
+  bool sba = true;           // PF_SBA=0: GEMM inputs stay fp32 and are split inside the GEMM (sb_split.h)
 
   MitStage stages[4];
   ConvW ll;
@@ -478,8 +507,8 @@ struct pf_engine {
 
   // ------------------------------------------------------------------ layer helpers
   struct ConvCall {  // one problem of a (possibly grouped) conv launch
-    const ConvW* w; const float* x; float* y;
-    const float* res1 = nullptr; const float* res2 = nullptr; const float* x2 = nullptr;
+    const ConvW* w; Ten x; Ten y;
+    const float* res1 = nullptr; const float* res2 = nullptr; Ten x2 = Ten();
   };
   void conv_g(Ctx& c, int ngroups, const ConvCall* calls, int B, int H, int W, int act = ACT_NONE, int post_relu = 0, int C1 = -1, int nchw = 0) {
     const ConvW& w = *calls[0].w;
@@ -493,9 +522,11 @@ struct pf_engine {
     for (int g = 0; g < ngroups; ++g) {
       const ConvW& wg = *calls[g].w;
       ConvPtrs& q = p.g[g];
-      q.x = calls[g].x; q.x2 = calls[g].x2; q.w = wg.w; q.w_sb = wg.wsb; q.bias = wg.b; q.bias_tab = wg.btab;
-      q.res1 = calls[g].res1; q.res2 = calls[g].res2; q.y = calls[g].y;
+      q.x = calls[g].x.f; q.x2 = calls[g].x2.f; q.w = wg.w; q.w_sb = wg.wsb; q.bias = wg.b; q.bias_tab = wg.btab;
+      q.res1 = calls[g].res1; q.res2 = calls[g].res2; q.y = calls[g].y.f;
+      q.x_sb = calls[g].x.s.p; q.x2_sb = calls[g].x2.s.p; q.y_sb = calls[g].y.s.p;
     }
+    p.x_sb_plane = calls[0].x.s.plane; p.x2_sb_plane = calls[0].x2.s.plane; p.y_sb_plane = calls[0].y.s.plane;
     p.B = B; p.H = H; p.W = W;
     p.C1 = C1 < 0 ? w.Cin : C1; p.C2 = w.Cin - p.C1;
     p.KH = w.KH; p.KW = w.KW; p.stride = w.stride; p.pad = w.pad;
@@ -504,12 +535,14 @@ struct pf_engine {
     p.finish();
     int tile = -1;
     if (autotune) {
-      const std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out,
-                                    (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0), p.act};
+      // operand formats are part of the key: a split-plane input changes which tile is fastest
+      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16);
+      const std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out, fmt_bits, p.act};
       auto it = tile_cache.find(key);
       if (it != tile_cache.end()) tile = it->second;
       else if (c.tuning && c.tune_scratch) { tile = tune_conv(p, c); tile_cache[key] = tile; }
     }
+    if (!conv_tile_usable(p, tile)) tile = conv_default_tile(p);
     ProfScope ps(c.prof, c.s, conv_tile_is_sb(tile) ? PC_IGEMM_SB : PC_IGEMM, 2.0 * ngroups * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal, p.M * ngroups, w.Cout, w.KH * w.KW * w.CinReal, w.KH);
     launch_conv_tile(p, tile, c.s);
   }
@@ -517,8 +550,13 @@ struct pf_engine {
   // residual layers are not disturbed) and keep the fastest.  Results are identical across tiles (same K order).
   int tune_conv(const ConvParams& p0, Ctx& c) {
     ConvParams p = p0;
-    const size_t out_floats = (size_t)p.M * p.Cout;
-    for (int g = 0; g < p.groups; ++g) p.g[g].y = c.tune_scratch + g * out_floats;
+    const size_t out_elems = (size_t)p.M * p.Cout;
+    unsigned short* sb_scratch = reinterpret_cast<unsigned short*>(c.tune_scratch + c.tune_scratch_elems);
+    for (int g = 0; g < p.groups; ++g) {
+      if (p.g[g].y) p.g[g].y = c.tune_scratch + g * out_elems;
+      if (p.g[g].y_sb) p.g[g].y_sb = sb_scratch + g * out_elems;
+    }
+    p.y_sb_plane = c.tune_scratch_elems;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
     int best = -1;
@@ -540,23 +578,27 @@ struct pf_engine {
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     return best;
   }
-  void conv(Ctx& c, const ConvW& w, const float* x, int B, int H, int W, float* y, int act = ACT_NONE, const float* res1 = nullptr,
-            const float* res2 = nullptr, int post_relu = 0, const float* x2 = nullptr, int C1 = -1, int nchw = 0) {
+  void conv(Ctx& c, const ConvW& w, Ten x, int B, int H, int W, Ten y, int act = ACT_NONE, const float* res1 = nullptr,
+            const float* res2 = nullptr, int post_relu = 0, Ten x2 = Ten(), int C1 = -1, int nchw = 0) {
     ConvCall one{&w, x, y, res1, res2, x2};
     conv_g(c, 1, &one, B, H, W, act, post_relu, C1, nchw);
   }
-  void gemm(Ctx& c, const ConvW& w, const float* x, long rows, float* y, int act = ACT_NONE, const float* res1 = nullptr) {
+  void gemm(Ctx& c, const ConvW& w, Ten x, long rows, Ten y, int act = ACT_NONE, const float* res1 = nullptr) {
     conv(c, w, x, 1, (int)rows, 1, y, act, res1);
   }
-  void ln(Ctx& c, const LNW& l, const float* x, float* y, long rows) {
+  // y.f may alias x; y may carry fp32, split planes, or both
+  void ln(Ctx& c, const LNW& l, const float* x, Ten y, long rows) {
     if (c.dry) return;
-    ProfScope ps(c.prof, c.s, PC_LAYERNORM, 8.0 * rows * l.C);
-    launch_layernorm(x, l.g, l.b, y, rows, l.C, l.eps, c.s);
+    ProfScope ps(c.prof, c.s, PC_LAYERNORM, (4.0 + (y.f ? 4.0 : 0.0) + (y.s.p ? 6.0 : 0.0)) * rows * l.C);
+    launch_layernorm(x, l.g, l.b, y.f, rows, l.C, l.eps, c.s, y.s.p, y.s.plane);
   }
 
-  // MiT-B3 forward_features (mix_transformers.py:449-485); feats[s] = NHWC stage outputs
-  void mit(Ctx& c, int B, const float* x0, float* feats[4]) {
-    const float* cur = x0;
+  // MiT-B3 forward_features (mix_transformers.py:449-485); feats[s] = NHWC stage outputs.
+  // With `sba` every tensor that only feeds GEMMs (LayerNorm outputs, attention output, the GELU'd hidden map) is
+  // written as split planes by its producer and never exists in fp32.
+  void mit(Ctx& c, int B, const float* x0, Ten feats[4]) {
+    const bool S = sba;
+    Ten cur(const_cast<float*>(x0));
     int H = NET, W = NET;
     for (int s = 0; s < 4; ++s) {
       MitStage& st = stages[s];
@@ -564,47 +606,49 @@ struct pf_engine {
       const int Ho = (H + 2 * MIT_PP[s] - MIT_PK[s]) / MIT_PS[s] + 1, Wo = (W + 2 * MIT_PP[s] - MIT_PK[s]) / MIT_PS[s] + 1;
       const long N = (long)Ho * Wo, M = (long)B * N;
       float* x = c.alloc(M * C);  // token stream, updated in place by the residual epilogues
-      conv(c, st.pe, cur, B, H, W, x);
-      ln(c, st.pen, x, x, M);
+      const SbT xs = S ? c.alloc_sb(M * C) : SbT();  // split copy of the stage output (next patch embed + decoder)
+      conv(c, st.pe, cur, B, H, W, Ten(x));
+      ln(c, st.pen, x, Ten(x), M);
       const size_t mk = c.mark();
       const int kvh = Ho / sr, kvw = Wo / sr;
       const long Mkv = (long)B * kvh * kvw;
-      float* xn = c.alloc(M * C);
+      const Ten xn = c.ten(M * C, !S, S);
       float* qb = c.alloc(M * C);
-      float* ab = c.alloc(M * C);
+      const Ten ab = c.ten(M * C, !S, S);
       float* srb = c.alloc(Mkv * C);
+      const Ten srn = S ? Ten(nullptr, c.alloc_sb(Mkv * C)) : Ten(srb);  // LN(sr conv): in place, or planes only
       float* kvb = c.alloc(Mkv * 2 * C);
       float* hb = c.alloc(M * 4 * C);
-      float* h2 = c.alloc(M * 4 * C);
+      const Ten h2 = c.ten(M * 4 * C, !S, S);
       for (MitBlock& mb : st.blocks) {
         // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
         ln(c, mb.n1, x, xn, M);
-        gemm(c, mb.q, xn, M, qb);
+        gemm(c, mb.q, xn, M, Ten(qb));
         if (sr > 1) {
-          conv(c, mb.sr, xn, B, Ho, Wo, srb);
-          ln(c, mb.srn, srb, srb, Mkv);
-          gemm(c, mb.kv, srb, Mkv, kvb);
+          conv(c, mb.sr, xn, B, Ho, Wo, Ten(srb));
+          ln(c, mb.srn, srb, srn, Mkv);
+          gemm(c, mb.kv, srn, Mkv, Ten(kvb));
         } else {
-          gemm(c, mb.kv, xn, M, kvb);
+          gemm(c, mb.kv, xn, M, Ten(kvb));
         }
         if (!c.dry) {
           ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
-          launch_sr_attention(qb, kvb, ab, B, (int)N, kvh * kvw, heads_n, c.s);
+          launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
         }
-        gemm(c, mb.proj, ab, M, x, ACT_NONE, x);
+        gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
         // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
         ln(c, mb.n2, x, xn, M);
-        gemm(c, mb.fc1, xn, M, hb);
+        gemm(c, mb.fc1, xn, M, Ten(hb));
         if (!c.dry) {
-          ProfScope ps(c.prof, c.s, PC_DW3, 8.0 * M * 4 * C);  // read + write of the hidden map
-          launch_dwconv3x3_gelu(hb, mb.dw.w, mb.dw.b, h2, B, Ho, Wo, 4 * C, c.s);
+          ProfScope ps(c.prof, c.s, PC_DW3, (4.0 + (h2.f ? 4.0 : 0.0) + (h2.s.p ? 6.0 : 0.0)) * M * 4 * C);  // read + write of the hidden map
+          launch_dwconv3x3_gelu(hb, mb.dw.w, mb.dw.b, h2.f, B, Ho, Wo, 4 * C, c.s, h2.s.p, h2.s.plane);
         }
-        gemm(c, mb.fc2, h2, M, x, ACT_NONE, x);
+        gemm(c, mb.fc2, h2, M, Ten(x), ACT_NONE, x);
       }
       c.release(mk);
-      ln(c, st.norm, x, x, M);  // stage norm; the normalised map is both the output and the next stage's input (:457-462)
-      feats[s] = x;
-      cur = x;
+      ln(c, st.norm, x, Ten(x, xs), M);  // stage norm; the normalised map is both the output and the next stage's input (:457-462)
+      feats[s] = Ten(x, xs);
+      cur = feats[s];
       H = Ho; W = Wo;
     }
   }
@@ -615,71 +659,81 @@ struct pf_engine {
   // [2][B][h][w][C] pairs so the bilinear kernels simply see a batch of 2B.
   // Stored tensors are post-ReLU wherever every consumer applies ReLU first (ResidualConvUnit's in-place
   // ReLU, decode_head.py:242-256): RCU(x) = conv2(relu(conv1(relu x))) + relu x.
-  void heads_fwd(Ctx& c, int B, float* feats[4], const float* llf, float* t32 /*[2][B][320][320][32]*/) {
+  // With `sba` a conv's epilogue writes split planes for the next conv (and fp32 only where a residual add reads it).
+  void heads_fwd(Ctx& c, int B, Ten feats[4], Ten llf, float* t32 /*[2][B][320][320][32]*/) {
+    const bool S = sba;
     Head& hg = heads[0];
     Head& hl = heads[1];
-    auto pair = [&](size_t per_head, float*& a, float*& b) { a = c.alloc(2 * per_head); b = a + per_head; };
-    float* up[4][2];
+    // a pair of per-head tensors, contiguous as [2][...] in fp32 and in every split plane
+    auto pair = [&](size_t per_head, bool want_f32, bool want_sb, Ten& a, Ten& b) {
+      a = Ten(); b = Ten();
+      if (want_f32) { a.f = c.alloc(2 * per_head); b.f = a.f + per_head; }
+      if (want_sb) { a.s = c.alloc_sb(2 * per_head); b.s = a.s; b.s.p = a.s.p + per_head; }
+    };
+    Ten up[4][2];
     for (int k = 3; k >= 0; --k) {
       const int h = NET >> (k + 2);
-      pair((size_t)B * 4 * h * h * DEC_FEAT, up[k][0], up[k][1]);
+      // up[k] is a residual operand (fp32) for k >= 1 and conv0's input (split planes) for k == 0
+      pair((size_t)B * 4 * h * h * DEC_FEAT, !(S && k == 0), S && k == 0, up[k][0], up[k][1]);
     }
     for (int k = 3; k >= 0; --k) {
       const int h = NET >> (k + 2);
       const size_t M = (size_t)B * h * h;
       const size_t mk = c.mark();
-      float *p0, *p1;
-      pair(M * DEC_FEAT, p0, p1);
+      Ten p0, p1;
+      pair(M * DEC_FEAT, true, S, p0, p1);
       if (fold_mlp) {
         ConvCall cc[2] = {{&hg.fold[k], feats[k], p0}, {&hl.fold[k], feats[k], p1}};
         conv_g(c, 2, cc, B, h, h, ACT_NONE, 1);                               // relu(_ck), Linear folded into the conv
       } else {
-        float *e0, *e1;
-        pair(M * DEC_EMBED, e0, e1);
+        Ten e0, e1;
+        pair(M * DEC_EMBED, !S, S, e0, e1);
         ConvCall l[2] = {{&hg.lin[k], feats[k], e0}, {&hl.lin[k], feats[k], e1}};
         conv_g(c, 2, l, 1, (int)M, 1);                                        // MLP (decode_head.py:49-53)
         ConvCall cc[2] = {{&hg.proc[k], e0, p0}, {&hl.proc[k], e1, p1}};
         conv_g(c, 2, cc, B, h, h, ACT_NONE, 1);                               // relu(_ck)
       }
-      float *o0 = p0, *o1 = p1;
+      Ten o0 = p0, o1 = p1;
       if (k < 3) {                                                            // o = relu(up(prev) + RCU1(_ck))
-        float *t0, *t1;
-        pair(M * DEC_FEAT, t0, t1);
+        Ten t0, t1;
+        pair(M * DEC_FEAT, !S, S, t0, t1);
         ConvCall a[2] = {{&hg.r1c1[k], p0, t0}, {&hl.r1c1[k], p1, t1}};
         conv_g(c, 2, a, B, h, h, ACT_RELU);
-        pair(M * DEC_FEAT, o0, o1);
-        ConvCall b2[2] = {{&hg.r1c2[k], t0, o0, p0, up[k + 1][0]}, {&hl.r1c2[k], t1, o1, p1, up[k + 1][1]}};
+        pair(M * DEC_FEAT, true, S, o0, o1);
+        ConvCall b2[2] = {{&hg.r1c2[k], t0, o0, p0.f, up[k + 1][0].f}, {&hl.r1c2[k], t1, o1, p1.f, up[k + 1][1].f}};
         conv_g(c, 2, b2, B, h, h, ACT_NONE, 1);
       }
-      float *t0, *t1, *q0, *q1;
-      pair(M * DEC_FEAT, t0, t1);
+      Ten t0, t1, q0, q1;
+      pair(M * DEC_FEAT, !S, S, t0, t1);
       ConvCall a[2] = {{&hg.r2c1[k], o0, t0}, {&hl.r2c1[k], o1, t1}};
       conv_g(c, 2, a, B, h, h, ACT_RELU);
-      pair(M * DEC_FEAT, q0, q1);
-      ConvCall b2[2] = {{&hg.r2c2[k], t0, q0, o0}, {&hl.r2c2[k], t1, q1, o1}};
+      pair(M * DEC_FEAT, true, false, q0, q1);
+      ConvCall b2[2] = {{&hg.r2c2[k], t0, q0, o0.f}, {&hl.r2c2[k], t1, q1, o1.f}};
       conv_g(c, 2, b2, B, h, h);                                              // RCU2 output, raw
       if (!c.dry) {                                                           // decode_head.py:284-286
-        ProfScope ps(c.prof, c.s, PC_UPSAMPLE, 40.0 * M * DEC_FEAT);
-        launch_upsample2x(q0, up[k][0], 2 * B, h, h, DEC_FEAT, c.s);
+        const Ten& u = up[k][0];
+        ProfScope ps(c.prof, c.s, PC_UPSAMPLE, (8.0 + (u.f ? 32.0 : 0.0) + (u.s.p ? 48.0 : 0.0)) * M * DEC_FEAT);
+        launch_upsample2x(q0.f, u.f, 2 * B, h, h, DEC_FEAT, c.s, u.s.p, u.s.plane);
       }
       c.release(mk);
     }
     const int h = NET / 2;
-    float *z0, *z1, *zu0, *zu1;
-    pair((size_t)B * h * h * 64, z0, z1);
+    Ten z0, z1, zu0, zu1;
+    pair((size_t)B * h * h * 64, true, false, z0, z1);
     ConvCall a[2] = {{&hg.conv0, up[0][0], z0, nullptr, nullptr, llf}, {&hl.conv0, up[0][1], z1, nullptr, nullptr, llf}};
     conv_g(c, 2, a, B, h, h, ACT_RELU, 0, DEC_FEAT);                          // cat fused into the A gather (:170-171)
-    pair((size_t)B * NET * NET * 64, zu0, zu1);
+    pair((size_t)B * NET * NET * 64, !S, S, zu0, zu1);
     if (!c.dry) {
-      ProfScope ps(c.prof, c.s, PC_UPSAMPLE, 40.0 * B * h * h * 64);
-      launch_upsample2x(z0, zu0, 2 * B, h, h, 64, c.s);
+      ProfScope ps(c.prof, c.s, PC_UPSAMPLE, (8.0 + (zu0.f ? 32.0 : 0.0) + (zu0.s.p ? 48.0 : 0.0)) * B * h * h * 64);
+      launch_upsample2x(z0.f, zu0.f, 2 * B, h, h, 64, c.s, zu0.s.p, zu0.s.plane);
     }
-    ConvCall b2[2] = {{&hg.conv1, zu0, t32}, {&hl.conv1, zu1, t32 + (size_t)B * NET * NET * 32}};
+    ConvCall b2[2] = {{&hg.conv1, zu0, Ten(t32)}, {&hl.conv1, zu1, Ten(t32 + (size_t)B * NET * NET * 32)}};
     conv_g(c, 2, b2, B, NET, NET, ACT_RELU);
   }
 
   // ConvNeXt-T + heads of the ParamNets (convnext.py:140-152)
   void paramnet(Ctx& c, int B, const float* pn_in, float* d_params) {
+    const bool S = sba;
     const float* src = pn_in;
     int H = NET;
     if (param_in != NET) {
@@ -690,30 +744,32 @@ struct pf_engine {
     }
     int h = H / 4;
     float* y = c.alloc((size_t)B * h * h * CNX_DIMS[0]);
-    conv(c, cnx.stem, src, B, H, H, y);
-    ln(c, cnx.stemn, y, y, (long)B * h * h);
+    conv(c, cnx.stem, Ten(const_cast<float*>(src)), B, H, H, Ten(y));
+    ln(c, cnx.stemn, y, Ten(y), (long)B * h * h);
     for (int s = 0; s < 4; ++s) {
       const int C = CNX_DIMS[s];
       if (s > 0) {
         const long Mi = (long)B * h * h;
-        ln(c, cnx.dsn[s - 1], y, y, Mi);
+        const Ten yn_in = S ? Ten(nullptr, c.alloc_sb(Mi * CNX_DIMS[s - 1])) : Ten(y);  // LN output feeds the 2x2 conv only
+        ln(c, cnx.dsn[s - 1], y, yn_in, Mi);
         float* yn = c.alloc((size_t)B * (h / 2) * (h / 2) * C);
-        conv(c, cnx.ds[s - 1], y, B, h, h, yn);
+        conv(c, cnx.ds[s - 1], yn_in, B, h, h, Ten(yn));
         y = yn;
         h /= 2;
       }
       const long M = (long)B * h * h;
       const size_t mk = c.mark();
       float* d = c.alloc(M * C);
-      float* hb = c.alloc(M * 4 * C);
+      const Ten dn = S ? Ten(nullptr, c.alloc_sb(M * C)) : Ten(d);
+      const Ten hb = c.ten(M * 4 * C, !S, S);
       for (CnxBlock& cb : cnx.blocks[s]) {
         if (!c.dry) {
           ProfScope ps(c.prof, c.s, PC_DW7, 8.0 * M * C);
           launch_dwconv7x7(y, cb.dw.w, cb.dw.b, d, B, h, h, C, c.s);
         }
-        ln(c, cb.n, d, d, M);
-        gemm(c, cb.pw1, d, M, hb, ACT_GELU);
-        gemm(c, cb.pw2, hb, M, y, ACT_NONE, y);  // y += gamma * pwconv2(...)  (gamma folded)
+        ln(c, cb.n, d, dn, M);
+        gemm(c, cb.pw1, dn, M, hb, ACT_GELU);
+        gemm(c, cb.pw2, hb, M, Ten(y), ACT_NONE, y);  // y += gamma * pwconv2(...)  (gamma folded)
       }
       c.release(mk);
     }
@@ -730,10 +786,11 @@ struct pf_engine {
       if (is_u8) launch_prep_u8(static_cast<const uint8_t*>(in), x0, (long)B * NET * NET, mean3, std3, c.s);
       else launch_prep_f32_nchw(static_cast<const float*>(in), x0, B, NET * NET, mean3, std3, c.s);
     }
-    float* feats[4];
+    Ten feats[4];
     mit(c, B, x0, feats);
-    float* llf = c.alloc((size_t)B * (NET / 2) * (NET / 2) * LL_CH);
-    conv(c, ll, x0, B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
+    // low-level encoder output: conv0's second (concatenated) input only
+    const Ten llf = c.ten((size_t)B * (NET / 2) * (NET / 2) * LL_CH, !sba, sba);
+    conv(c, ll, Ten(x0), B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
     float* tg = c.alloc((size_t)2 * B * NET * NET * 32);
     float* tl = tg + (size_t)B * NET * NET * 32;
     float* pn = has_param ? c.alloc((size_t)B * NET * NET * 4) : nullptr;
@@ -742,8 +799,8 @@ struct pf_engine {
     c.release(mk);
     if (arch == PF_ARCH_PERSNET_CLS) {
       // 1x1 convs to 73 / 180 logits, stored NCHW because the logits are API-visible (gravity_head.py:259)
-      conv(c, heads[0].predcls, tg, B, NET, NET, pg, ACT_NONE, nullptr, nullptr, 0, nullptr, -1, 1);
-      conv(c, heads[1].predcls, tl, B, NET, NET, pl, ACT_NONE, nullptr, nullptr, 0, nullptr, -1, 1);
+      conv(c, heads[0].predcls, Ten(tg), B, NET, NET, Ten(pg), ACT_NONE, nullptr, nullptr, 0, Ten(), -1, 1);
+      conv(c, heads[1].predcls, Ten(tl), B, NET, NET, Ten(pl), ACT_NONE, nullptr, nullptr, 0, Ten(), -1, 1);
       return;
     }
     if (!c.dry)
@@ -756,10 +813,11 @@ struct pf_engine {
     if (it != ws_cache.end()) return it->second;
     Ctx c{nullptr, 4096, 0, 0, true, nullptr};
     run(c, B, nullptr, true, nullptr, nullptr, nullptr);
-    const size_t scratch = autotune ? c.max_conv_out * 4 + 4096 : 0;  // largest conv output, target of the tuning launches
+    const size_t scratch = autotune ? c.max_conv_out * 10 + 4096 : 0;  // largest conv output (fp32 + 3 bf16 planes), target of the tuning launches
     const size_t need = c.peak + 4096 + scratch;
     ws_cache[B] = need;
     scratch_off[B] = c.peak;
+    scratch_elems[B] = c.max_conv_out;
     return need;
   }
 
@@ -777,6 +835,7 @@ struct pf_engine {
     if (tune && autotune) {
       c.tuning = true;
       c.tune_scratch = reinterpret_cast<float*>(base + scratch_off[B]);
+      c.tune_scratch_elems = scratch_elems[B];
     }
     run(c, B, in, is_u8, pg, pl, params);
     const hipError_t e = hipGetLastError();
@@ -842,6 +901,8 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FOLD_MLP")) e->fold_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
+  if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;
+  if (!e->split_bf16) e->sba = false;  // split planes are only read by the split-bf16 kernels
   tune_cache_load(e);
   *out = e;
   return PF_OK;
@@ -1034,7 +1095,8 @@ const char* pf_op_conv_tile_name(int id) { return conv_tile_name(id); }
 
 int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int W, int C1, int C2, const float* hw, const float* hb,
                  int Cout, int KH, int KW, int stride, int pad, int act, const float* res1, const float* res2, int post_relu,
-                 int nchw_out, int tile_id, float* y, void* stream) {
+                 int nchw_out, int tile_id, float* y, const uint16_t* x_planes, long x_plane_elems, const uint16_t* x2_planes,
+                 long x2_plane_elems, uint16_t* y_planes, long y_plane_elems, void* stream) {
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
@@ -1049,17 +1111,21 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   if (Cin % 32 == 0) { sb = split_bf16x3(packed); p.g[0].w_sb = tmp.up_u16(sb); }
   p.g[0].bias = tmp.up(hb, Cout);
   p.g[0].x = x; p.g[0].x2 = x2; p.g[0].res1 = res1; p.g[0].res2 = res2; p.g[0].y = y;
+  p.g[0].x_sb = x_planes; p.g[0].x2_sb = x2_planes; p.g[0].y_sb = y_planes;
+  p.x_sb_plane = (size_t)x_plane_elems; p.x2_sb_plane = (size_t)x2_plane_elems; p.y_sb_plane = (size_t)y_plane_elems;
   p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.Cout = Cout; p.act = act; p.post_relu = post_relu; p.nchw_out = nchw_out;
   p.finish();
+  if ((!x && !x_planes) || (!y && !y_planes) || (C2 > 0 && !x2 && !x2_planes)) { g_create_error = "pf_op_conv2d: missing input or output"; return PF_ERR_ARG; }
+  if (tile_id >= 0 && !conv_tile_usable(p, tile_id)) { g_create_error = "pf_op_conv2d: tile config cannot run this operand format"; return PF_ERR_ARG; }
   launch_conv_tile(p, tile_id, s);
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);
   return rc;
 }
 
-int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, float* ms_out) {
+int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt, float* ms_out) {
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
@@ -1071,17 +1137,17 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   p.finish();
   const size_t nx = (size_t)B * H * W * Cin, nw = (size_t)Cout * K * p.KWCp, ny = (size_t)p.M * Cout;
   float *dx = nullptr, *dw = nullptr, *dy = nullptr, *db = nullptr;
-  unsigned short* dsb = nullptr;
+  unsigned short *dsb = nullptr, *dxs = nullptr, *dys = nullptr;
   if (hipMalloc(&dx, nx * 4) != hipSuccess || hipMalloc(&dw, nw * 4) != hipSuccess || hipMalloc(&dy, ny * 4) != hipSuccess ||
-      hipMalloc(&db, (size_t)Cout * 4) != hipSuccess || hipMalloc(&dsb, nw * 6) != hipSuccess) { g_create_error = "pf_op_conv2d_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
-  {  // uniform [-1,1) data (never zero-fill a bench: DVFS gives zeros a higher clock)
-    std::vector<float> hx(nx), hw(nw), hb(Cout);
+      hipMalloc(&db, (size_t)Cout * 4) != hipSuccess || hipMalloc(&dsb, nw * 6) != hipSuccess ||
+      (fmt >= 1 && hipMalloc(&dxs, nx * 6) != hipSuccess) || (fmt >= 2 && hipMalloc(&dys, ny * 6) != hipSuccess)) { g_create_error = "pf_op_conv2d_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
+  {  // uniform [-1,1) data (never zero-fill a bench: DVFS gives zeros a higher clock); activations filled on the device
+    std::vector<float> hw(nw), hb(Cout);
     uint32_t st = 12345u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
-    for (auto& v : hx) v = rnd();
     for (auto& v : hw) v = rnd() * 0.05f;
     for (auto& v : hb) v = rnd();
-    (void)hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice);
+    launch_fill_random(dx, (long)nx, 777u, 1.0f, nullptr);
     (void)hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(db, hb.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
     const std::vector<unsigned short> sb = split_bf16x3(hw);
@@ -1089,7 +1155,10 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   }
   p.g[0].x = dx; p.g[0].w = dw; p.g[0].bias = db; p.g[0].y = dy;
   if (Cin % 32 == 0) p.g[0].w_sb = dsb;
-  if (!conv_tile_usable(p, tile_id) && tile_id >= 0) { *ms_out = -1.f; (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); return PF_OK; }
+  // fmt 1: A operand as split planes (fp32 copy withheld); fmt 2: split planes in and out
+  if (fmt >= 1) { launch_split_planes(dx, dxs, nx, (long)nx, nullptr); p.g[0].x_sb = dxs; p.x_sb_plane = nx; p.g[0].x = nullptr; }
+  if (fmt >= 2) { p.g[0].y_sb = dys; p.y_sb_plane = ny; p.g[0].y = nullptr; }
+  if (!conv_tile_usable(p, tile_id) && tile_id >= 0) { *ms_out = -1.f; (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys); return PF_OK; }
   hipEvent_t a, b;
   (void)hipEventCreate(&a); (void)hipEventCreate(&b);
   launch_conv_tile(p, tile_id, nullptr);
@@ -1103,7 +1172,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   *ms_out = t / iters;
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb);
+  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys);
   return rc;
 }
 
@@ -1143,26 +1212,26 @@ int pf_op_dwconv3x3_bench(int device, int variant, int B, int H, int W, int C, i
   return rc;
 }
 
-int pf_op_layernorm(int device, const float* x, const float* hg, const float* hbeta, float* y, long rows, int C, float eps, void* stream) {
+int pf_op_layernorm(int device, const float* x, const float* hg, const float* hbeta, float* y, long rows, int C, float eps, uint16_t* y_planes, long plane_elems, void* stream) {
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   TmpDev tmp;
-  launch_layernorm(x, tmp.up(hg, C), tmp.up(hbeta, C), y, rows, C, eps, s);
+  launch_layernorm(x, tmp.up(hg, C), tmp.up(hbeta, C), y, rows, C, eps, s, y_planes, (size_t)plane_elems);
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);
   return rc;
 }
 
-int pf_op_dwconv3x3_gelu(int device, const float* x, const float* hw, const float* hb, float* y, int B, int H, int W, int C, void* stream) {
+int pf_op_dwconv3x3_gelu(int device, const float* x, const float* hw, const float* hb, float* y, int B, int H, int W, int C, uint16_t* y_planes, long plane_elems, void* stream) {
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
   if (C % 128 != 0) { g_create_error = "pf_op_dwconv3x3_gelu: C must be a multiple of 128"; return PF_ERR_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   TmpDev tmp;
-  launch_dwconv3x3_gelu(x, tmp.up(pack_dw(hw, C, 3)), tmp.up(hb, C), y, B, H, W, C, s);
+  launch_dwconv3x3_gelu(x, tmp.up(pack_dw(hw, C, 3)), tmp.up(hb, C), y, B, H, W, C, s, y_planes, (size_t)plane_elems);
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);
   return rc;
@@ -1181,20 +1250,38 @@ int pf_op_dwconv7x7(int device, const float* x, const float* hw, const float* hb
   return rc;
 }
 
-int pf_op_sr_attention(int device, const float* q, const float* kv, float* out, int B, int N, int M, int heads, void* stream) {
+int pf_op_sr_attention(int device, const float* q, const float* kv, float* out, int B, int N, int M, int heads, uint16_t* out_planes, long plane_elems, void* stream) {
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
   if (M <= 0 || M > 128) { g_create_error = "pf_op_sr_attention: kv length must be in 1..128"; return PF_ERR_ARG; }
-  launch_sr_attention(q, kv, out, B, N, M, heads, static_cast<hipStream_t>(stream));
+  launch_sr_attention(q, kv, out, B, N, M, heads, static_cast<hipStream_t>(stream), out_planes, (size_t)plane_elems);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
 }
 
-int pf_op_upsample2x(int device, const float* x, float* y, int B, int H, int W, int C, void* stream) {
+int pf_op_upsample2x(int device, const float* x, float* y, int B, int H, int W, int C, uint16_t* y_planes, long plane_elems, void* stream) {
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
-  launch_upsample2x(x, y, B, H, W, C, static_cast<hipStream_t>(stream));
+  launch_upsample2x(x, y, B, H, W, C, static_cast<hipStream_t>(stream), y_planes, (size_t)plane_elems);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+}
+
+int pf_op_split_bf16(int device, const float* x, long n, uint16_t* planes, long plane_elems, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (!x || !planes || n <= 0 || (n & 3) || plane_elems < n) { g_create_error = "pf_op_split_bf16: n must be a positive multiple of 4 and plane_elems >= n"; return PF_ERR_ARG; }
+  launch_split_planes(x, planes, (size_t)plane_elems, n, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+}
+
+int pf_op_merge_bf16(int device, const uint16_t* planes, long plane_elems, long n, float* y, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (!y || !planes || n <= 0 || (n & 3) || plane_elems < n) { g_create_error = "pf_op_merge_bf16: n must be a positive multiple of 4 and plane_elems >= n"; return PF_ERR_ARG; }
+  launch_merge_planes(planes, (size_t)plane_elems, y, n, static_cast<hipStream_t>(stream));
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
 }
 

@@ -290,6 +290,8 @@ bool conv_tile_is_sb(int id) { return id >= kNumF32 && id < conv_num_tiles(); }
 bool conv_tile_usable(const ConvParams& p, int id) {
   if (id < 0 || id >= conv_num_tiles()) return false;
   if (id >= kNumF32) return conv_sb_eligible(p);
+  for (int g = 0; g < p.groups; ++g)  // the exact-fp32 kernel reads fp32 inputs; split-plane output only through the NHWC epilogue
+    if (!p.g[g].x || (p.C2 > 0 && !p.g[g].x2) || (p.nchw_out && (!p.g[g].y || p.g[g].y_sb))) return false;
   return true;
 }
 
@@ -318,6 +320,7 @@ int pick_tile(const ConvParams& p) {
     g_forced_tile = e ? atoi(e) : -1;
   }
   if (g_forced_tile >= 0 && conv_tile_usable(p, g_forced_tile)) return g_forced_tile;
+  if (!conv_tile_usable(p, 2)) return kNumF32 + conv_sb_default_tile(p);  // split-plane input or output: split-bf16 family only
   // MFMA-bound model: a CU works through its share of the blocks at the tile's intrinsic rate, so
   // time ~ ceil(blocks / 256 CUs) x (tile MFMA time + fill latency hidden by the resident blocks)
   int best = 2;
@@ -335,6 +338,8 @@ int pick_tile(const ConvParams& p) {
   }
   return best;
 }
+
+int conv_default_tile(const ConvParams& p) { return pick_tile(p); }
 
 void launch_conv_tile(const ConvParams& p, int tile_id, hipStream_t s) {
   if (!conv_tile_usable(p, tile_id)) tile_id = pick_tile(p);

@@ -1,6 +1,7 @@
 // Shared device helpers of the implicit-GEMM kernels (igemm.hip: exact fp32 MFMA; igemm_sb.hip: split-bf16 MFMA).
 #pragma once
 #include "pf_kernels.h"
+#include "sb_split.h"
 
 namespace pf {
 
@@ -69,7 +70,8 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
         if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         if (p.post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(P.y + o) = v;
+        if (P.y) *reinterpret_cast<float4*>(P.y + o) = v;
+        if (P.y_sb) store_sb4(P.y_sb, p.y_sb_plane, (size_t)o, v);  // split once here instead of per (tap, n-tile) in the consumer
       } else {  // ragged channel count: scalar tail
         const float vv[4] = {v.x, v.y, v.z, v.w};
         for (int e = 0; e < 4 && n + e < p.Cout; ++e) {

@@ -11,14 +11,20 @@
 // there is no overflow / underflow hazard (unlike an fp16 split).
 //
 // Structure = igemm.hip (same A gather with tap masks and buffer-load range checks, same grouped launch, same
-// LDS-staged epilogue): weights are pre-split on the host into three bf16 planes; activations are split by the
-// staging threads (5 VALU ops + packing per element, once per block) and written to three bf16 LDS planes with
-// 64-byte rows and an XOR piece swizzle (conflict-free ds_read_b128 and staging writes).
-// One LDS buffer + register prefetch: global loads of step t+1 fly during the MFMAs of step t.
-// [r01] 3x3 256->256 @80^2 (both heads): 177 TFLOP/s fp32-equivalent vs 132 for the exact-fp32 MFMA kernel.
+// LDS-staged epilogue).  Weights are pre-split on the host into three bf16 planes.  Activations come in one of two
+// forms (template ASB):
+//   ASB = false: fp32 NHWC; the staging threads split every element (5 VALU ops + packing) once per block and K step;
+//   ASB = true : already split by the producing kernel's epilogue (sb_split.h) -- staging is a plain 16-byte copy per
+//                plane, the inner loop carries no VALU work besides address selects.  The split is lossless, so both
+//                forms give bit-identical results.
+// LDS: three bf16 planes per operand, 64-byte rows, XOR piece swizzle (conflict-free ds_read_b128 and staging writes).
+// One LDS buffer + a ring of PFD register sets: global loads run PFD K steps ahead of their LDS store (branch-free:
+// loads past the last K step go to the out-of-range offset), which is what the small-M GEMMs need -- their K loop is
+// a chain of L2 round trips, not of MFMAs.
 #include <stdlib.h>
 
 #include "igemm_common.h"
+#include "sb_split.h"
 
 namespace pf {
 
@@ -30,37 +36,18 @@ static constexpr int SB_ROW = BK;  // ushorts per LDS row: 64 bytes = four 16-by
 // padded layout cost 8.8e7 SQ_LDS_BANK_CONFLICT cycles per launch on the write side and 25 % more LDS).
 __device__ __forceinline__ int sb_piece(int row, int piece) { return piece ^ ((row >> 2) & 3); }
 
-__device__ __forceinline__ unsigned pack_hi16(unsigned lo_src, unsigned hi_src) { return (lo_src >> 16) | (hi_src & 0xffff0000u); }
-
-// exact 3-way truncation split of 4 floats -> three 8-byte groups of 4 bf16
-__device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2& l) {
-  const float a[4] = {v.x, v.y, v.z, v.w};
-  unsigned hb[4], mb[4], lb[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned u = __float_as_uint(a[e]);
-    hb[e] = u & 0xffff0000u;
-    const float r = a[e] - __uint_as_float(hb[e]);
-    mb[e] = __float_as_uint(r) & 0xffff0000u;
-    const float r2 = r - __uint_as_float(mb[e]);
-    lb[e] = __float_as_uint(r2);  // <= 8 significant bits left: exactly representable
-  }
-  h = make_uint2(pack_hi16(hb[0], hb[1]), pack_hi16(hb[2], hb[3]));
-  m = make_uint2(pack_hi16(mb[0], mb[1]), pack_hi16(mb[2], mb[3]));
-  l = make_uint2(pack_hi16(lb[0], lb[1]), pack_hi16(lb[2], lb[3]));
-}
-
-// PF2: global loads run two K steps ahead (two raw register sets) instead of one
-template <int BM, int BN, int WM, int WN, int MODE, bool PF2>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? 3 : 1) void igemm_sb_kernel(const ConvParams p) {
+template <int BM, int BN, int WM, int WN, int MODE, bool ASB, int PFD>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? (PFD == 1 ? 3 : 2) : 1) void igemm_sb_kernel(const ConvParams p) {
   constexpr int NT = WM * WN * 64;
-  constexpr int RPP = NT / 8;    // A rows staged per pass (8 threads x float4 = 32 floats)
-  constexpr int RPB = NT / 4;    // B rows staged per pass (4 threads x 16 B = 32 bf16)
+  constexpr int RPP = NT / 8;    // fp32 A rows staged per pass (8 threads x float4 = 32 floats)
+  constexpr int RPB = NT / 4;    // bf16 rows staged per pass (4 threads x 16 B = 32 bf16): B, and A when ASB
   constexpr int SM = BM / (WM * 32);
   constexpr int SN = BN / (WN * 32);
-  constexpr int A_ROWS = BM / RPP;
-  constexpr int B_ROWS = (BN + RPB - 1) / RPB;  // BN < RPB (N = 32 tiles): the upper threads stage no B rows
-  static_assert(BM % RPP == 0 && (BN % RPB == 0 || BN < RPB), "tile rows must be a multiple of the staging pass");
+  constexpr int A_ROWS = ASB ? (BM + RPB - 1) / RPB : BM / RPP;
+  constexpr int A_REGS = ASB ? A_ROWS * 3 : A_ROWS;  // float4 registers per staged A tile
+  constexpr int B_ROWS = (BN + RPB - 1) / RPB;        // BN < RPB (N = 32 tiles): the upper threads stage no B rows
+  static_assert(ASB ? (BM % RPB == 0 || BM < RPB) : BM % RPP == 0, "A tile rows must be a multiple of the staging pass");
+  static_assert(BN % RPB == 0 || BN < RPB, "B tile rows must be a multiple of the staging pass");
   constexpr int PLANE_A = BM * SB_ROW, PLANE_B = BN * SB_ROW;  // ushorts
   constexpr int SMEM_USHORTS = 3 * (PLANE_A + PLANE_B);
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
@@ -83,19 +70,36 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   const int m0 = (t / tilesN) * BM;
   const int n0 = (t % tilesN) * BN;
 
-  // ---- A staging geometry (identical to igemm.hip)
+  // ---- staging geometry.  fp32 A: thread -> (row r0 + RPP i, float4 c4 of the 32-float K chunk).
+  //      bf16 (B, and A when ASB): thread -> (row rb0 + RPB i, 16-byte piece pc of the 64-byte K chunk), three planes.
   const int c4 = tid & 7;
   const int r0 = tid >> 3;
+  const int pc = tid & 3;
+  const int rb0 = tid >> 2;
   const int HoWo = p.Ho * p.Wo;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x2 ? P.x2 : P.x), 0, P.x2 ? p.x2_bytes : 0, 0x00020000);
+  constexpr int ESZ = ASB ? 2 : 4;  // bytes per A element in global memory
+  // one buffer descriptor per A plane (a plane of the largest activation, 320^2 x 64 channels x 2 heads x batch, is
+  // 0.8 GB: three of them under one descriptor would run into the out-of-range marker)
+  __amdgpu_buffer_rsrc_t rx[ASB ? 3 : 1], rx2[ASB ? 3 : 1];
+  if (ASB) {
+#pragma unroll
+    for (int pl = 0; pl < (ASB ? 3 : 1); ++pl) {
+      rx[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.x_sb + pl * p.x_sb_plane), 0, p.x_bytes / 2, 0x00020000);
+      rx2[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.x2_sb ? P.x2_sb + pl * p.x2_sb_plane : P.x_sb), 0,
+                                                  P.x2_sb ? p.x2_bytes / 2 : 0, 0x00020000);
+    }
+  } else {
+    rx[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
+    rx2[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x2 ? P.x2 : P.x), 0, P.x2 ? p.x2_bytes : 0, 0x00020000);
+  }
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_sb), 0, 3u * p.w_sb_plane_bytes, 0x00020000);
   int a_off1[A_ROWS], a_off2[A_ROWS];
   unsigned long long a_mask[A_ROWS];
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
-    const int m = m0 + r0 + RPP * i;
-    const bool ok = m < p.M;
+    const int rl = ASB ? rb0 + RPB * i : r0 + RPP * i;
+    const int m = m0 + rl;
+    const bool ok = m < p.M && rl < BM;
     const int mm = ok ? m : 0;
     const int b = mm / HoWo;
     const int rem = mm - b * HoWo;
@@ -103,8 +107,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     const int ox = rem - oy * p.Wo;
     const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
     const int pix = (b * p.H + iy0) * p.W + ix0;
-    a_off1[i] = pix * p.C1 * 4 + c4 * 16;
-    a_off2[i] = pix * p.C2 * 4 + c4 * 16;
+    a_off1[i] = pix * p.C1 * ESZ + (ASB ? pc : c4) * 16;
+    a_off2[i] = pix * p.C2 * ESZ + (ASB ? pc : c4) * 16;
     unsigned long long mk = 0;
     if (ok)
       for (int ky = 0; ky < p.KH; ++ky)
@@ -112,9 +116,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
           if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W) mk |= 1ull << (ky * p.KW + kx);
     a_mask[i] = mk;
   }
-  // ---- B staging: thread -> (row rb0 + RPB i, 16-byte piece pc of the 64-byte K chunk), three planes
-  const int pc = tid & 3;
-  const int rb0 = tid >> 2;
   unsigned b_off[B_ROWS];
 #pragma unroll
   for (int i = 0; i < B_ROWS; ++i) {
@@ -122,58 +123,79 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     b_off[i] = (n < p.Cout && rb0 + RPB * i < BN) ? (unsigned)(n * p.KH * p.KWCp + pc * 8) * 2u : OOB;
   }
 
-  // two raw register sets: loads run TWO K steps ahead of their split/store (one 48-MFMA step is too short to
-  // cover an L2/HBM round trip)
-  float4 a_raw0[A_ROWS], a_raw1[A_ROWS];
-  float4 b_raw0[B_ROWS][3], b_raw1[B_ROWS][3];
+  struct Raw { float4 a[A_REGS]; float4 b[B_ROWS][3]; };
+  Raw raw[PFD];
   const int nJ = p.KWCp / BK;
   const int nK = p.KH * nJ;
 
-  auto load_tiles = [&](int it, float4 (&a_reg)[A_ROWS], float4 (&b_reg)[B_ROWS][3]) {
+  // branch-free: a step at or past nK loads from the out-of-range offset (zeros, never stored)
+  auto load_tiles = [&](int it, Raw& R) {
+    const bool live = it < nK;
     const int ky = it / nJ;
     const int j0 = (it - ky * nJ) * BK;
     const int kx = j0 / p.Cin;
     const int ci0 = j0 - kx * p.Cin;
-    const int bit = ky * p.KW + kx;
-    if (MODE == 2) {
-      const bool first = ci0 < p.C1;
-      const int toff = ((ky * p.W + kx) * (first ? p.C1 : p.C2) + (first ? ci0 : ci0 - p.C1)) * 4;
+    const int bit = (ky * p.KW + kx) & 63;
+    const bool first = MODE != 2 || ci0 < p.C1;
+    const int toff = ((ky * p.W + kx) * (first ? p.C1 : p.C2) + (first ? ci0 : ci0 - p.C1)) * ESZ;
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        const unsigned off = ((a_mask[i] >> bit) & 1ull) ? (unsigned)((first ? a_off1[i] : a_off2[i]) + toff) : OOB;
-        const float4 v1 = buf_load16(rx, first ? off : OOB);
-        const float4 v2 = buf_load16(rx2, first ? OOB : off);
-        a_reg[i] = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);
+    for (int i = 0; i < A_ROWS; ++i) {
+      const bool valid = live && ((a_mask[i] >> bit) & 1ull);
+      const unsigned off = valid ? (unsigned)((first ? a_off1[i] : a_off2[i]) + toff) : OOB;
+      if (ASB) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          if (MODE == 2) {
+            const float4 v1 = buf_load16(rx[pl], first ? off : OOB);
+            const float4 v2 = buf_load16(rx2[pl], first ? OOB : off);
+            // one of the two is all-zero bits: OR keeps the other's bf16 bit patterns
+            R.a[i * 3 + pl] = make_float4(__uint_as_float(__float_as_uint(v1.x) | __float_as_uint(v2.x)), __uint_as_float(__float_as_uint(v1.y) | __float_as_uint(v2.y)),
+                                          __uint_as_float(__float_as_uint(v1.z) | __float_as_uint(v2.z)), __uint_as_float(__float_as_uint(v1.w) | __float_as_uint(v2.w)));
+          } else {
+            R.a[i * 3 + pl] = buf_load16(rx[pl], off);
+          }
+        }
+      } else if (MODE == 2) {
+        const float4 v1 = buf_load16(rx[0], first ? off : OOB);
+        const float4 v2 = buf_load16(rx2[0], first ? OOB : off);
+        R.a[i] = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);
+      } else {
+        R.a[i] = buf_load16(rx[0], off);
       }
-    } else {
-      const int toff = ((ky * p.W + kx) * p.C1 + ci0) * 4;
-#pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) a_reg[i] = buf_load16(rx, ((a_mask[i] >> bit) & 1ull) ? (unsigned)(a_off1[i] + toff) : OOB);
     }
     const unsigned woff = (unsigned)(ky * p.KWCp + j0) * 2u;
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        b_reg[i][pl] = buf_load16(rw, b_off[i] == OOB ? OOB : b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes);
+        R.b[i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes : OOB);
   };
-  auto store_tiles = [&](const float4 (&a_reg)[A_ROWS], const float4 (&b_reg)[B_ROWS][3]) {
+  auto store_tiles = [&](const Raw& R) {
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-      uint2 h, m, l;
-      split4(a_reg[i], h, m, l);
-      const int row = r0 + RPP * i;
-      unsigned short* d = As + row * SB_ROW + sb_piece(row, c4 >> 1) * 8 + (c4 & 1) * 4;
-      *reinterpret_cast<uint2*>(d) = h;
-      *reinterpret_cast<uint2*>(d + PLANE_A) = m;
-      *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
+      if (ASB) {
+        const int row = rb0 + RPB * i;
+        if (BM % RPB == 0 || row < BM) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<float4*>(As + pl * PLANE_A + row * SB_ROW + sb_piece(row, pc) * 8) = R.a[i * 3 + pl];
+        }
+      } else {
+        uint2 h, m, l;
+        split4(R.a[i], h, m, l);
+        const int row = r0 + RPP * i;
+        unsigned short* d = As + row * SB_ROW + sb_piece(row, c4 >> 1) * 8 + (c4 & 1) * 4;
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + PLANE_A) = m;
+        *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i)
       if (BN % RPB == 0 || rb0 + RPB * i < BN) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = b_reg[i][pl];
+          *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = R.b[i][pl];
       }
   };
 
@@ -218,50 +240,45 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     }
   };
 
-  if (PF2) {
-    // prologue: tile 0 -> LDS, tile 1 -> raw set 1
-    load_tiles(0, a_raw0, b_raw0);
-    if (nK > 1) load_tiles(1, a_raw1, b_raw1);
-    store_tiles(a_raw0, b_raw0);
-    __syncthreads();
-    for (int it = 0; it < nK; it += 2) {
-      // LDS holds tile it; raw1 holds tile it+1 (if any)
-      if (it + 2 < nK) load_tiles(it + 2, a_raw0, b_raw0);
-      compute();
-      if (it + 1 >= nK) break;
-      __syncthreads();  // every wave has read tile it
-      store_tiles(a_raw1, b_raw1);
-      __syncthreads();
-      // LDS holds tile it+1; raw0 holds tile it+2 (if any)
-      if (it + 3 < nK) load_tiles(it + 3, a_raw1, b_raw1);
-      compute();
-      if (it + 2 >= nK) break;
-      __syncthreads();
-      store_tiles(a_raw0, b_raw0);
+  // prologue: tiles 0 .. PFD-1 in flight, tile 0 -> LDS (tile k lives in register set k % PFD)
+#pragma unroll
+  for (int d = 0; d < PFD; ++d) load_tiles(d, raw[d]);
+  store_tiles(raw[0]);
+  __syncthreads();
+  // Main loop: whole groups of PFD steps with no exit inside, so that the loop header sees ONE load order and the
+  // compiler's s_waitcnt analysis keeps the partial vmcnt(N) waits (an exit inside the group rejoins the back edge
+  // with a different order and every PFD-th store then drains all loads).  The last 1..PFD tiles are already in
+  // flight when the loop ends and are consumed by the straight-line tail.
+  int it = 0;
+  for (; it + PFD < nK; it += PFD) {
+#pragma unroll
+    for (int d = 0; d < PFD; ++d) {
+      load_tiles(it + d + PFD, raw[d]);  // refill the set whose tile (it + d) is in LDS now
+      compute();                         // tile it + d
+      __syncthreads();                   // every wave has read this step's planes
+      store_tiles(raw[(d + 1) % PFD]);   // tile it + d + 1 (the oldest loads in flight)
       __syncthreads();
     }
-  } else {
-    load_tiles(0, a_raw0, b_raw0);
-    store_tiles(a_raw0, b_raw0);
+  }
+#pragma unroll
+  for (int d = 0; d < PFD; ++d) {
+    compute();
+    if (it + d + 1 >= nK) break;
     __syncthreads();
-    for (int it = 0; it < nK; ++it) {
-      if (it + 1 < nK) load_tiles(it + 1, a_raw0, b_raw0);
-      compute();
-      __syncthreads();  // every wave has read this step's planes
-      if (it + 1 < nK) store_tiles(a_raw0, b_raw0);
-      __syncthreads();
-    }
+    store_tiles(raw[(d + 1) % PFD]);
+    __syncthreads();
   }
 
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------
-struct SbCfg { int bm, bn; const char* name; };
-// Two-step-ahead prefetch variants (PF2 = true) were measured and rejected: the second raw register set drops
-// occupancy (128x128: 350 registers -> 1 wave/SIMD) and loses 8-25 % on every shape (profiles/r01_tune_conv_v6_sb_pf2.txt).
-static const SbCfg kSb[] = {{128, 128, "sb128x128"}, {64, 64, "sb64x64"}, {128, 64, "sb128x64"}, {256, 128, "sb256x128w8"},
-                             {128, 256, "sb128x256w8"}, {128, 32, "sb128x32"}, {256, 256, "sb256x256w8"}};
+struct SbCfg { int bm, bn, pfd; const char* name; };
+// "f2"/"f3" = register prefetch ring 2 / 3 K steps deep (small tiles: latency-bound K loops)
+static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, {128, 64, 1, "sb128x64"}, {256, 128, 1, "sb256x128w8"},
+                             {128, 256, 1, "sb128x256w8"}, {128, 32, 1, "sb128x32"}, {256, 256, 1, "sb256x256w8"},
+                             {64, 64, 2, "sb64x64f2"}, {64, 64, 3, "sb64x64f3"}, {128, 64, 2, "sb128x64f2"}, {128, 32, 2, "sb128x32f2"},
+                             {128, 128, 2, "sb128x128f2"}};
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }
 const char* conv_sb_tile_name(int id) { return kSb[id].name; }
 int conv_sb_tile_bm(int id) { return kSb[id].bm; }
@@ -269,28 +286,52 @@ int conv_sb_tile_bn(int id) { return kSb[id].bn; }
 
 bool conv_sb_eligible(const ConvParams& p) {
   if (p.nchw_out || (p.Cin % BK) != 0) return false;
-  for (int g = 0; g < p.groups; ++g)
-    if (!p.g[g].w_sb) return false;
+  for (int g = 0; g < p.groups; ++g) {
+    const ConvPtrs& q = p.g[g];
+    if (!q.w_sb) return false;
+    if (!q.x_sb && !q.x) return false;
+    if (p.C2 > 0 && (q.x_sb ? !q.x2_sb : !q.x2)) return false;
+  }
   return true;
 }
 
-template <int BM, int BN, int WM, int WN, bool PF2>
+// static choice for shapes the autotuner has not seen (and the only family that can read a split-plane input)
+int conv_sb_default_tile(const ConvParams& p) {
+  if (p.Cout <= 32) return 5;
+  const long blocks128 = ((long)(p.M + 127) / 128) * ((p.Cout + 127) / 128) * p.groups;
+  if (p.Cout >= 128 && blocks128 >= 1024) return 0;
+  if (p.Cout <= 64 && (long)p.M * p.groups >= 262144) return 2;
+  return 1;
+}
+
+template <int BM, int BN, int WM, int WN, int PFD>
 static void launch_sb_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const dim3 grid(tilesM * tilesN * p.groups), block(WM * WN * 64);
-  if (p.C2 > 0) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, PF2>), grid, block, 0, s, p);
-  else          hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, PF2>), grid, block, 0, s, p);
+  const bool asb = p.g[0].x_sb != nullptr;
+  if (p.C2 > 0) {
+    if (asb) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, true, PFD>), grid, block, 0, s, p);
+    else     hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, false, PFD>), grid, block, 0, s, p);
+  } else {
+    if (asb) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, true, PFD>), grid, block, 0, s, p);
+    else     hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, false, PFD>), grid, block, 0, s, p);
+  }
 }
 
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
   switch (sb_tile) {
-    case 0: launch_sb_cfg<128, 128, 2, 2, false>(p, s); break;
-    case 1: launch_sb_cfg<64, 64, 2, 2, false>(p, s); break;
-    case 2: launch_sb_cfg<128, 64, 2, 2, false>(p, s); break;
-    case 3: launch_sb_cfg<256, 128, 4, 2, false>(p, s); break;
-    case 4: launch_sb_cfg<128, 256, 2, 4, false>(p, s); break;  // whole N = 256 per block: A staged / split once per m-tile
-    case 5: launch_sb_cfg<128, 32, 4, 1, false>(p, s); break;  // N = 32 layers (conv_fuse_conv1)
-    default: launch_sb_cfg<256, 256, 2, 4, false>(p, s); break;  // half the global / LDS / split work per MFMA, one block per CU
+    case 0: launch_sb_cfg<128, 128, 2, 2, 1>(p, s); break;
+    case 1: launch_sb_cfg<64, 64, 2, 2, 1>(p, s); break;
+    case 2: launch_sb_cfg<128, 64, 2, 2, 1>(p, s); break;
+    case 3: launch_sb_cfg<256, 128, 4, 2, 1>(p, s); break;
+    case 4: launch_sb_cfg<128, 256, 2, 4, 1>(p, s); break;  // whole N = 256 per block: A staged once per m-tile
+    case 5: launch_sb_cfg<128, 32, 4, 1, 1>(p, s); break;   // N = 32 layers (conv_fuse_conv1)
+    case 6: launch_sb_cfg<256, 256, 2, 4, 1>(p, s); break;  // half the global / LDS work per MFMA, one block per CU
+    case 7: launch_sb_cfg<64, 64, 2, 2, 2>(p, s); break;
+    case 8: launch_sb_cfg<64, 64, 2, 2, 3>(p, s); break;
+    case 9: launch_sb_cfg<128, 64, 2, 2, 2>(p, s); break;
+    case 10: launch_sb_cfg<128, 32, 4, 1, 2>(p, s); break;
+    default: launch_sb_cfg<128, 128, 2, 2, 2>(p, s); break;
   }
 }
 

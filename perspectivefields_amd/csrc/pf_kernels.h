@@ -1,5 +1,5 @@
 // Internal kernel-launcher interface of libpf_hip.so (gfx950 / CDNA4 only).
-// All activations are NHWC fp32 in HBM; "tokens (B,N,C)" of the reference's MiT
+// All activations are NHWC in HBM, fp32 or (inputs of the split-bf16 GEMMs) three exact bf16 planes (sb_split.h); "tokens (B,N,C)" of the reference's MiT
 // blocks are the same memory as NHWC maps, so none of the reference's ~200
 // NCHW<->NLC round trips (mix_transformers.py:117-118,246,458,504-506) exist here.
 #pragma once
@@ -24,7 +24,12 @@ struct ConvPtrs {
   const float* bias_tab = nullptr;  // [9][Cout]: bias per 3x3 border case (folded Linear->conv), overrides bias
   const float* res1 = nullptr;      // [M][Cout] or nullptr (may alias y)
   const float* res2 = nullptr;      // [M][Cout] or nullptr
-  float* y = nullptr;               // [M][ldy]
+  float* y = nullptr;               // [M][ldy], or nullptr when only the split planes are wanted
+  // split-bf16 activation format (sb_split.h): plane 0 of the same NHWC tensors as three exact bf16 planes.  When x_sb
+  // is set the split-bf16 kernel copies its A operand instead of splitting it (x / x2 may then be nullptr).
+  const unsigned short* x_sb = nullptr;
+  const unsigned short* x2_sb = nullptr;
+  unsigned short* y_sb = nullptr;   // additional (or only) output in split planes
 };
 struct ConvParams {
   ConvPtrs g[2];   // grouped launch: `groups` problems of identical shape (the two decoder heads) in one grid
@@ -40,6 +45,7 @@ struct ConvParams {
   int nchw_out;   // 1: store y as [B][Cout][Ho*Wo] (API-visible logits), residuals unsupported
   unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)
   unsigned w_sb_plane_bytes;            // bytes of one bf16 weight plane
+  size_t x_sb_plane = 0, x2_sb_plane = 0, y_sb_plane = 0;  // elements between consecutive planes of x_sb / x2_sb / y_sb
   // fills the derived fields (Ho, Wo, M, Cin, *_bytes) from the primary ones
   void finish() {
     Cin = C1 + C2;
@@ -61,30 +67,43 @@ int conv_num_tiles();
 int conv_tile_bm(int tile_id);
 int conv_tile_bn(int tile_id);
 bool conv_tile_is_sb(int tile_id);
-bool conv_tile_usable(const ConvParams& p, int tile_id);  // split-bf16 tiles need pre-split weights and Cin % 32 == 0
+bool conv_tile_usable(const ConvParams& p, int tile_id);
+int conv_default_tile(const ConvParams& p);  // static choice (cost model) among the usable tiles  // split-bf16 tiles need pre-split weights and Cin % 32 == 0
 // split-bf16 kernel family (igemm_sb.hip)
 int conv_sb_num_tiles();
 const char* conv_sb_tile_name(int id);
 int conv_sb_tile_bm(int id);
 int conv_sb_tile_bn(int id);
 bool conv_sb_eligible(const ConvParams& p);
+int conv_sb_default_tile(const ConvParams& p);
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s);
 const char* conv_tile_name(int tile_id);
 
 // rows x C LayerNorm (biased variance), y may alias x
-void launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps, hipStream_t s);
+// Optional split-plane output (sb_split.h) of the elementwise / attention kernels: y_sb != nullptr writes the result as
+// three bf16 planes `sb_plane` elements apart (in addition to y, or instead of it when y == nullptr).
+void launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int C, float eps, hipStream_t s,
+                      unsigned short* y_sb = nullptr, size_t sb_plane = 0);
 
 // depthwise 3x3 (pad 1) + bias + exact-erf GELU, NHWC, w packed [9][C]
-void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
-void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
+void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s,
+                           unsigned short* y_sb = nullptr, size_t sb_plane = 0);
+void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s,
+                                   unsigned short* y_sb = nullptr, size_t sb_plane = 0);
 // depthwise 7x7 (pad 3) + bias, NHWC, w packed [49][C]
 void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
 
 // spatial-reduction attention: q [B][N][C], kv [B][M][2C] (k | v), out [B][N][C]; head_dim 64, M <= 128
-void launch_sr_attention(const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s);
+void launch_sr_attention(const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s,
+                         unsigned short* out_sb = nullptr, size_t sb_plane = 0);
 
 // bilinear x2 (align_corners=False), NHWC
-void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
+void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb = nullptr, size_t sb_plane = 0);
+
+// fp32 [n] <-> three exact bf16 planes (n a multiple of 4)
+void launch_split_planes(const float* x, unsigned short* y_sb, size_t sb_plane, long n, hipStream_t s);
+void launch_merge_planes(const unsigned short* x_sb, size_t sb_plane, float* y, long n, hipStream_t s);
+void launch_fill_random(float* p, long n, unsigned seed, float scale, hipStream_t s);
 
 // input normalisation: uint8 NHWC BGR [B][320][320][3] or fp32 NCHW [B][3][320][320] -> fp32 NHWC4 (x-mean)/std, ch3=0
 void launch_prep_u8(const uint8_t* in, float* out, long npix, const float* mean3, const float* std3, hipStream_t s);

@@ -25,8 +25,47 @@ def _dp(t):
     return t.data_ptr() if t is not None else None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, post_relu=False, x2=None, nchw_out=False, tile=-1):
-    """x: (B,H,W,C1) [+ x2: (B,H,W,C2) channel-concat]; weight: (Cout, C1+C2, KH, KW).  Returns (B,Ho,Wo,Cout) or NCHW."""
+class Planes:
+    """An fp32 tensor in the engine's split-bf16 activation format: three exact bf16 planes (include/pf_hip.h)."""
+
+    def __init__(self, shape, device):
+        import torch
+
+        self.shape = tuple(shape)
+        self.numel = int(np.prod(self.shape))
+        self.plane_elems = (self.numel + 127) // 128 * 128
+        self.data = torch.zeros(3 * self.plane_elems, dtype=torch.int16, device=device)
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def merge(self):
+        """h + m + l in fp32 (exact)."""
+        import torch
+
+        lib = load_library()
+        y = torch.empty(self.shape, dtype=torch.float32, device=self.data.device)
+        _check(lib.pf_op_merge_bf16(self.data.device.index, self.data_ptr(), self.plane_elems, self.numel, y.data_ptr(), _stream_ptr()), None, "pf_op_merge_bf16")
+        return y
+
+
+def split_planes(x):
+    lib = load_library()
+    x = x.contiguous()
+    pl = Planes(x.shape, x.device)
+    _check(lib.pf_op_split_bf16(x.device.index, x.data_ptr(), x.numel(), pl.data_ptr(), pl.plane_elems, _stream_ptr()), None, "pf_op_split_bf16")
+    return pl
+
+
+def _pl(planes):
+    return (planes.data_ptr(), planes.plane_elems) if planes is not None else (None, 0)
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, post_relu=False, x2=None, nchw_out=False, tile=-1,
+           planes_in=False, planes_out=False):
+    """x: (B,H,W,C1) [+ x2: (B,H,W,C2) channel-concat]; weight: (Cout, C1+C2, KH, KW).  Returns (B,Ho,Wo,Cout) or NCHW.
+    planes_in: hand the input(s) to the kernel as split-bf16 planes only; planes_out: take the output as planes
+    (returned merged back to fp32, which is exact)."""
     import torch
 
     lib = load_library()
@@ -40,14 +79,19 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, p
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     shape = (B, Cout, Ho, Wo) if nchw_out else (B, Ho, Wo, Cout)
-    y = torch.empty(shape, dtype=torch.float32, device=x.device)
     b = _np(bias)
+    x2 = x2.contiguous() if x2 is not None else None
+    xp = split_planes(x) if planes_in else None
+    x2p = split_planes(x2) if (planes_in and x2 is not None) else None
+    yp = Planes(shape, x.device) if planes_out else None
+    y = None if planes_out else torch.empty(shape, dtype=torch.float32, device=x.device)
     rc = lib.pf_op_conv2d(
-        x.device.index, x.data_ptr(), _dp(x2.contiguous() if x2 is not None else None), B, H, W, C1, C2, _hp(w), _hp(b),
-        Cout, KH, KW, stride, pad, act, _dp(res1), _dp(res2), int(post_relu), int(nchw_out), tile, y.data_ptr(), _stream_ptr(),
+        x.device.index, None if planes_in else x.data_ptr(), None if planes_in else _dp(x2), B, H, W, C1, C2, _hp(w), _hp(b),
+        Cout, KH, KW, stride, pad, act, _dp(res1), _dp(res2), int(post_relu), int(nchw_out), tile, _dp(y),
+        *_pl(xp), *_pl(x2p), *_pl(yp), _stream_ptr(),
     )
     _check(rc, None, "pf_op_conv2d")
-    return y
+    return yp.merge() if planes_out else y
 
 
 def linear(x, weight, bias=None, act=0, res1=None, tile=-1):
@@ -60,28 +104,30 @@ def linear(x, weight, bias=None, act=0, res1=None, tile=-1):
     return y.reshape(*x.shape[:-1], w.shape[0])
 
 
-def layernorm(x, gamma, beta, eps):
+def layernorm(x, gamma, beta, eps, planes_out=False):
     import torch
 
     lib = load_library()
     x = x.contiguous()
     C = x.shape[-1]
-    y = torch.empty_like(x)
+    y = None if planes_out else torch.empty_like(x)
+    yp = Planes(x.shape, x.device) if planes_out else None
     g, b = _np(gamma), _np(beta)
-    _check(lib.pf_op_layernorm(x.device.index, x.data_ptr(), _hp(g), _hp(b), y.data_ptr(), x.numel() // C, C, eps, _stream_ptr()), None, "pf_op_layernorm")
-    return y
+    _check(lib.pf_op_layernorm(x.device.index, x.data_ptr(), _hp(g), _hp(b), _dp(y), x.numel() // C, C, eps, *_pl(yp), _stream_ptr()), None, "pf_op_layernorm")
+    return yp.merge() if planes_out else y
 
 
-def dwconv3x3_gelu(x, weight, bias):
+def dwconv3x3_gelu(x, weight, bias, planes_out=False):
     import torch
 
     lib = load_library()
     x = x.contiguous()
     B, H, W, C = x.shape
-    y = torch.empty_like(x)
+    y = None if planes_out else torch.empty_like(x)
+    yp = Planes(x.shape, x.device) if planes_out else None
     w, b = _np(weight), _np(bias)
-    _check(lib.pf_op_dwconv3x3_gelu(x.device.index, x.data_ptr(), _hp(w), _hp(b), y.data_ptr(), B, H, W, C, _stream_ptr()), None, "pf_op_dwconv3x3_gelu")
-    return y
+    _check(lib.pf_op_dwconv3x3_gelu(x.device.index, x.data_ptr(), _hp(w), _hp(b), _dp(y), B, H, W, C, *_pl(yp), _stream_ptr()), None, "pf_op_dwconv3x3_gelu")
+    return yp.merge() if planes_out else y
 
 
 def dwconv7x7(x, weight, bias):
@@ -96,7 +142,7 @@ def dwconv7x7(x, weight, bias):
     return y
 
 
-def sr_attention(q, kv, heads):
+def sr_attention(q, kv, heads, planes_out=False):
     """q: (B,N,C), kv: (B,M,2C) -> (B,N,C); head_dim 64."""
     import torch
 
@@ -104,20 +150,23 @@ def sr_attention(q, kv, heads):
     q, kv = q.contiguous(), kv.contiguous()
     B, N, C = q.shape
     M = kv.shape[1]
-    out = torch.empty_like(q)
-    _check(lib.pf_op_sr_attention(q.device.index, q.data_ptr(), kv.data_ptr(), out.data_ptr(), B, N, M, heads, _stream_ptr()), None, "pf_op_sr_attention")
-    return out
+    out = None if planes_out else torch.empty_like(q)
+    op = Planes(q.shape, q.device) if planes_out else None
+    _check(lib.pf_op_sr_attention(q.device.index, q.data_ptr(), kv.data_ptr(), _dp(out), B, N, M, heads, *_pl(op), _stream_ptr()), None, "pf_op_sr_attention")
+    return op.merge() if planes_out else out
 
 
-def upsample2x(x):
+def upsample2x(x, planes_out=False):
     import torch
 
     lib = load_library()
     x = x.contiguous()
     B, H, W, C = x.shape
-    y = torch.empty((B, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
-    _check(lib.pf_op_upsample2x(x.device.index, x.data_ptr(), y.data_ptr(), B, H, W, C, _stream_ptr()), None, "pf_op_upsample2x")
-    return y
+    shape = (B, 2 * H, 2 * W, C)
+    y = None if planes_out else torch.empty(shape, dtype=torch.float32, device=x.device)
+    yp = Planes(shape, x.device) if planes_out else None
+    _check(lib.pf_op_upsample2x(x.device.index, x.data_ptr(), _dp(y), B, H, W, C, *_pl(yp), _stream_ptr()), None, "pf_op_upsample2x")
+    return yp.merge() if planes_out else y
 
 
 def conv_tiles():
@@ -125,11 +174,12 @@ def conv_tiles():
     return [lib.pf_op_conv_tile_name(i).decode() for i in range(lib.pf_op_num_conv_tiles())]
 
 
-def conv2d_bench(B, H, W, Cin, Cout, K, stride=1, pad=0, tile=-1, iters=10, device=0):
-    """Average ms per launch of one conv shape on random data (tuning aid)."""
+def conv2d_bench(B, H, W, Cin, Cout, K, stride=1, pad=0, tile=-1, iters=10, device=0, fmt=0):
+    """Average ms per launch of one conv shape on random data (tuning aid).  fmt 0: fp32 in / out; 1: split-plane
+    input; 2: split-plane input and output.  Returns -1 when the tile cannot run the format."""
     lib = load_library()
     ms = ctypes.c_float()
-    _check(lib.pf_op_conv2d_bench(device, B, H, W, Cin, Cout, K, stride, pad, tile, iters, ctypes.byref(ms)), None, "pf_op_conv2d_bench")
+    _check(lib.pf_op_conv2d_bench(device, B, H, W, Cin, Cout, K, stride, pad, tile, iters, fmt, ctypes.byref(ms)), None, "pf_op_conv2d_bench")
     return ms.value
 
 

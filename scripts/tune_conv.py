@@ -20,13 +20,35 @@ SHAPES = [
     ("cnx3_pw1", 1, B * 100, 1, 768, 3072, 1, 1, 0), ("cnx3_pw2", 1, B * 100, 1, 3072, 768, 1, 1, 0),
 ]
 tiles = ops.conv_tiles()
+# TUNE_SB=1: only the split-bf16 tiles, each with fp32 operands ("f") and with split-plane input + output ("p")
+SB_ONLY = os.environ.get("TUNE_SB", "0") == "1"
 out = [f"B={B}; tiles: " + ", ".join(f"{i}:{t}" for i, t in enumerate(tiles))]
+ONLY = [t for t in os.environ.get("TUNE_ONLY", "").split(",") if t]
 for name, b, h, w, cin, cout, k, st, pd in SHAPES:
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        continue
     ho, wo = (h + 2 * pd - k) // st + 1, (w + 2 * pd - k) // st + 1
     flops = 2.0 * b * ho * wo * cout * k * k * cin
     res = []
+    iters = 20 if flops < 2e10 else 5
+    if SB_ONLY:
+        if cin % 32:
+            continue
+        line = []
+        bestf, bestp = (0, ""), (0, "")
+        for t in range(len(tiles)):
+            if not tiles[t].startswith("sb"):
+                continue
+            tf = []
+            for fmt in (0, 2 if cout % 4 == 0 else 1):
+                ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=t, iters=iters, fmt=fmt)
+                tf.append(flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+            bestf = max(bestf, (tf[0], tiles[t])); bestp = max(bestp, (tf[1], tiles[t]))
+            line.append(f"{tiles[t]}:{tf[0]:5.1f}/{tf[1]:5.1f}")
+        out.append(f"{name:10s} M={b*ho*wo:8d} N={cout:5d} K={k*k*cin:6d}  fp32-in best {bestf[1]:12s} {bestf[0]:6.1f} TF | planes best {bestp[1]:12s} {bestp[0]:6.1f} TF "
+                   f"({(bestp[0]/bestf[0]-1)*100:+5.1f} %) | " + " ".join(line))
+        continue
     for t in range(len(tiles)):
-        iters = max(3, min(30, int(3e9 / max(flops, 1)) * 0 + (20 if flops < 2e10 else 5)))
         ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=t, iters=iters)
         if ms <= 0:  # tile not usable for this shape
             continue

@@ -169,3 +169,22 @@ def test_folded_and_unfolded_mlp_agree(monkeypatch):
         d = max(abs(float(a[k]) - float(b[k])) for k in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
         print(f"[fold vs unfold img{i}] 1-cos {c:.2e} latL1 {e:.2e} param {d:.2e}")
         assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
+
+
+def test_split_plane_activations_agree_with_fp32_activations(monkeypatch):
+    """PF_SBA=0 keeps every GEMM input in fp32 (split inside the GEMM); the default stores GEMM-only tensors as split
+    planes.  The planes are lossless, so the two engines differ only through the tile choices of the autotuner
+    (fp32 summation order): far inside the parity tolerances."""
+    from perspectivefields_amd import PerspectiveFields
+
+    imgs = [synthetic_image(72, 96, seed=90 + i) for i in range(3)]
+    base = model("centered").inference_batch(imgs)
+    monkeypatch.setenv("PF_SBA", "0")
+    alt_model = PerspectiveFields(CASES["centered"], weights="synthetic:0").eval().cuda()
+    alt = alt_model.inference_batch(imgs)
+    for i, (a, b) in enumerate(zip(base, alt)):
+        c = one_minus_cos(a["pred_gravity"].cpu().numpy(), b["pred_gravity"].cpu().numpy()).max()
+        e = l1(a["pred_latitude"].cpu().numpy(), b["pred_latitude"].cpu().numpy())
+        d = max(abs(float(a[k]) - float(b[k])) for k in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
+        print(f"[planes vs fp32 activations img{i}] 1-cos {c:.2e} latL1 {e:.2e} param {d:.2e}")
+        assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5

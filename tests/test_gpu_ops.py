@@ -75,6 +75,63 @@ def test_conv2d_all_tiles(ops, case):
         _close(got, ref, 2e-5, f"{name} tile {tile}")
 
 
+def test_split_planes_are_lossless(ops):
+    """fp32 -> three bf16 planes -> fp32 is the identity (8 + 8 + 8 significant bits), including tiny / huge magnitudes."""
+    x = _rand((3, 17, 5, 64), 40)
+    x.view(-1)[:64] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.0e-30, 1.17549435e-38] * 8)
+    x.view(-1)[64:128] *= 1e-20
+    xd = x.cuda()
+    back = ops.split_planes(xd).merge()
+    assert torch.equal(back, xd)
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] % 32 == 0 and c[5] % 32 == 0], ids=[c[0] for c in CONV_CASES if c[4] % 32 == 0 and c[5] % 32 == 0])
+def test_conv2d_split_plane_operands(ops, case):
+    """The split-bf16 kernel fed with pre-split planes (and writing planes) must reproduce ITS OWN fp32-operand result
+    bit for bit on every split tile: the planes are a lossless re-encoding and the MFMA sequence is the same."""
+    name, B, H, W, C1, C2, Cout, K, stride, pad = case
+    x = _rand((B, H, W, C1), 1).cuda()
+    x2 = _rand((B, H, W, C2), 2).cuda() if C2 else None
+    w = _rand((Cout, C1 + C2, K, K), 3, 1.0 / math.sqrt((C1 + C2) * K * K))
+    b = _rand((Cout,), 4, 0.1)
+    ref = _ref_conv(x.cpu(), w, b, stride, pad, None if x2 is None else x2.cpu())
+    names = ops.conv_tiles()
+    sb = [i for i, n in enumerate(names) if n.startswith("sb")]
+    assert sb
+    for tile in sb:
+        base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1)
+        got_in = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True)
+        assert torch.equal(got_in, base), f"{name} {names[tile]}: split-plane input differs from fp32 input"
+        if Cout % 4 == 0:
+            got_io = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_out=True)
+            assert torch.equal(got_io, base), f"{name} {names[tile]}: split-plane output differs"
+    # automatic tile choice with plane operands only (no fp32 tile can run) + oracle check
+    got = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, planes_in=True, planes_out=Cout % 4 == 0)
+    _close(got, ref, 2e-5, f"{name} planes auto")
+    # an exact-fp32 tile must refuse plane-only input loudly
+    from perspectivefields_amd.engine import PfError
+    with pytest.raises(PfError):
+        ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=2, planes_in=True)
+
+
+def test_elementwise_plane_outputs(ops):
+    """LayerNorm / depthwise+GELU / attention / bilinear x2 writing split planes == their fp32 output, exactly."""
+    x = _rand((2, 20, 20, 320), 50).cuda()
+    g, be = _rand((320,), 51), _rand((320,), 52, 0.1)
+    assert torch.equal(ops.layernorm(x, g, be, 1e-6, planes_out=True), ops.layernorm(x, g, be, 1e-6))
+    xh = _rand((2, 20, 20, 1280), 53).cuda()
+    wd, bd = _rand((1280, 1, 3, 3), 54, 0.3), _rand((1280,), 55, 0.1)
+    assert torch.equal(ops.dwconv3x3_gelu(xh, wd, bd, planes_out=True), ops.dwconv3x3_gelu(xh, wd, bd))
+    for (B, H, W, C) in [(1, 80, 80, 256), (2, 9, 13, 128)]:
+        xs = _rand((B, H, W, C), 56).cuda()
+        wd, bd = _rand((C, 1, 3, 3), 57, 0.3), _rand((C,), 58, 0.1)
+        assert torch.equal(ops.dwconv3x3_gelu(xs, wd, bd, planes_out=True), ops.dwconv3x3_gelu(xs, wd, bd))
+    q, kv = _rand((2, 400, 320), 59).cuda(), _rand((2, 100, 640), 60).cuda()
+    assert torch.equal(ops.sr_attention(q, kv, 5, planes_out=True), ops.sr_attention(q, kv, 5))
+    xu = _rand((2, 10, 12, 64), 61).cuda()
+    assert torch.equal(ops.upsample2x(xu, planes_out=True), ops.upsample2x(xu))
+
+
 def test_conv2d_epilogues(ops):
     B, H, W, C = 2, 12, 12, 256
     x = _rand((B, H, W, C), 5)
