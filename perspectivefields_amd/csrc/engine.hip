@@ -1118,7 +1118,8 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   p.Cout = Cout; p.act = act; p.post_relu = post_relu; p.nchw_out = nchw_out;
   p.finish();
   if ((!x && !x_planes) || (!y && !y_planes) || (C2 > 0 && !x2 && !x2_planes)) { g_create_error = "pf_op_conv2d: missing input or output"; return PF_ERR_ARG; }
-  if (tile_id >= 0 && !conv_tile_usable(p, tile_id)) { g_create_error = "pf_op_conv2d: tile config cannot run this operand format"; return PF_ERR_ARG; }
+  // an explicit tile that cannot read / write split planes is an error; with fp32 operands an unusable tile id falls back to the cost model
+  if (tile_id >= 0 && !conv_tile_usable(p, tile_id) && (x_planes || y_planes)) { g_create_error = "pf_op_conv2d: tile config cannot run this operand format"; return PF_ERR_ARG; }
   launch_conv_tile(p, tile_id, s);
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);
