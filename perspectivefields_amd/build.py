@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpf_hip.so")
-SOURCES = ["igemm.hip", "igemm_sb.hip", "attn.hip", "elem.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "igemm_sb.hip", "attn.hip", "elem.hip", "dw7.hip", "engine.hip"]
+# dw7.hip: the scalar one-channel-per-lane kernel must not be SLP-vectorised (see the file header)
+EXTRA_FLAGS = {"dw7.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 
 
@@ -31,6 +33,7 @@ def _digest() -> str:
                     h.update(f.encode())
                     h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -45,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -1,0 +1,164 @@
+// Depthwise 7x7 (ConvNeXt Block.dwconv, convnext.py:30-32,48) for gfx950: channels-per-lane streaming kernel.
+// Compiled with -fno-slp-vectorize (build.py): the one-channel-per-lane form must stay scalar v_fma_f32 -- the SLP
+// vectoriser otherwise pairs accumulators into v_pk_fma_f32 with register shuffles and doubles the VGPR count.
+//
+// Lane = CPL neighbouring channels (1 or 2); 32 / CPL lanes = 32 channels of one column; a wave = 2 CPL neighbouring
+// columns.  Thread (channels, column x) streams the input rows of a strip:
+//   * 7 buffer loads per row (x-3..x+3; the overlap between neighbouring columns is served by L1): the per-lane
+//     column/channel byte offset is fixed (out-of-image columns use the out-of-range offset -> hardware zeros), the
+//     row offset is a scalar register, so a row costs NO address VALU work;
+//   * 49 FMAs (CPL = 2: v_pk_fma_f32, both channels per instruction) into 7 output-row accumulators whose ring
+//     position is a compile-time constant (loop unrolled 7 NB times: 7 ring slots x NB row buffers, no register moves);
+//   * one store per row.
+// The 49 per-channel weights live in VGPRs: 98 registers at CPL = 2 (2-3 waves per SIMD), 49 at CPL = 1 (5 waves).
+// The op is latency-bound, not VALU- or HBM-bound, until enough rows are in flight per SIMD (PMC, profiles/): at 2 waves
+// x 2 rows ahead a row costs ~1800 cycles of which ~210 are VALU.  FLOP-heavy for a "memory-bound" op all the same: 98
+// flops per 8 bytes -- 0.09 ms (packed) / 0.18 ms (scalar) of VALU time per forward against 0.14 ms of HBM time at 8 TB/s.
+#include <stdlib.h>
+
+#include "pf_kernels.h"
+
+namespace pf {
+
+template <int N> struct LaneVec;
+template <> struct LaneVec<1> {
+  typedef float T;
+  static __device__ __forceinline__ T zero() { return 0.f; }
+  static __device__ __forceinline__ T fma(T a, T b, T c) { return fmaf(a, b, c); }
+  static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+  static __device__ __forceinline__ void store(T v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0); }
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+template <> struct LaneVec<2> {
+  typedef f32x2 T;
+  static __device__ __forceinline__ T zero() { return f32x2{0.f, 0.f}; }
+  static __device__ __forceinline__ T fma(T a, T b, T c) { return __builtin_elementwise_fma(a, b, c); }
+  static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x2v q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return f32x2{__uint_as_float(q.x), __uint_as_float(q.y)};
+  }
+  static __device__ __forceinline__ void store(T v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2v{__float_as_uint(v.x), __float_as_uint(v.y)}, r, voff, soff, 0);
+  }
+};
+
+template <int CPL /*channels per lane*/, int NB /*row buffers: loads run NB - 1 rows ahead*/, int MAXT /*max threads per block*/>
+__global__ __launch_bounds__(MAXT) void dwconv7x7_lane_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                int B, int H, int W, int C, int TH, int XB /*columns per block*/, int CPB /*channels per block*/) {
+  typedef LaneVec<CPL> V;
+  typedef typename V::T T;
+  const int LPC = CPB / CPL;  // lanes per column
+  const int slabs = C / CPB, tilesX = (W + XB - 1) / XB, strips = (H + TH - 1) / TH;
+  const int nblk = B * strips * tilesX * slabs;
+  int t;
+  {  // XCD-aware order: the slabs / x-neighbours of one image region share an L2
+    const int b = blockIdx.x, qd = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    t = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+  }
+  const int slab = t % slabs; t /= slabs;
+  const int tx = t % tilesX; t /= tilesX;
+  const int st = t % strips; t /= strips;
+  const int b = t;
+  const int col = threadIdx.x / LPC;
+  const int c = slab * CPB + CPL * (threadIdx.x - col * LPC);
+  const int ox = tx * XB + col;
+  const bool col_ok = ox < W;
+  const int y0 = st * TH, y1 = min(y0 + TH, H);
+  T wk[49];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) wk[k] = *reinterpret_cast<const T*>(w49c + (long)k * C + c);
+  const T bv = *reinterpret_cast<const T*>(bias + c);
+  float* const xb = const_cast<float*>(x + (long)b * H * W * C);
+  float* const yb = y + (long)b * H * W * C;
+  const unsigned img_bytes = (unsigned)((long)H * W * C * 4);
+  unsigned voff[7];
+#pragma unroll
+  for (int kx = 0; kx < 7; ++kx) {
+    const int ix = ox + kx - 3;
+    voff[kx] = (col_ok && (unsigned)ix < (unsigned)W) ? (unsigned)(ix * C + c) * 4u : 0x80000000u;
+  }
+  const unsigned voff_out = col_ok ? (unsigned)(ox * C + c) * 4u : 0x80000000u;
+  const unsigned row_bytes = (unsigned)(W * C) * 4u;
+  T acc[7], in[NB][7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) acc[j] = bv;
+  // Everything touching memory in the row loop is branch-free (a descriptor with zero records turns the loads of a row
+  // outside the image into hardware zeros and drops the stores of rows above the strip): with branches around loads the
+  // compiler's s_waitcnt analysis merges different load orders and drains every load each row -- no prefetch overlap.
+  auto load_row = [&](int iy, T (&v)[7]) {
+    const bool ok = (unsigned)iy < (unsigned)H;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(xb, 0, ok ? img_bytes : 0u, 0x00020000);
+    const unsigned soff = ok ? (unsigned)iy * row_bytes : 0u;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) v[kx] = V::load(r, voff[kx], soff);
+  };
+  // relative row index tt: input row iy = y0 - 3 + tt, tt in [0, nrows); it feeds output rows oy = iy - ky + 3, whose
+  // accumulator slot is (tt - ky + 3) mod 7; after row tt the output row iy - 3 (slot (tt + 4) mod 7) is complete.
+  // r = tt mod (7 NB) is a compile-time constant in the unrolled bodies: ring slot and row buffer are fixed registers.
+  auto do_row = [&](int tt, int r) {
+    const int iy = y0 - 3 + tt;
+    load_row(iy + NB - 1, in[(r + NB - 1) % NB]);  // prefetch; rows past the strip are loaded but never used
+    if ((unsigned)iy < (unsigned)H) {              // block-uniform, no memory operation inside
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        T a = acc[(r - ky + 3 + 7 * NB) % 7];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) a = V::fma(in[r % NB][kx], wk[ky * 7 + kx], a);
+        acc[(r - ky + 3 + 7 * NB) % 7] = a;
+      }
+    }
+    const int oy = iy - 3;  // < y1 always (tt < nrows)
+    const bool st_ok = oy >= y0;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yb, 0, st_ok ? img_bytes : 0u, 0x00020000);
+    V::store(acc[(r + 4) % 7], ry, voff_out, st_ok ? (unsigned)oy * row_bytes : 0u);
+    acc[(r + 4) % 7] = bv;
+  };
+  const int nrows = (y1 - y0) + 6;
+#pragma unroll
+  for (int d = 0; d < NB - 1; ++d) load_row(y0 - 3 + d, in[d]);
+  int t0 = 0;
+  for (; t0 + 7 * NB <= nrows; t0 += 7 * NB) {  // whole groups: no exit inside
+#pragma unroll
+    for (int r = 0; r < 7 * NB; ++r) do_row(t0 + r, r);
+  }
+#pragma unroll
+  for (int r = 0; r < 7 * NB; ++r) {  // straight-line tail
+    if (t0 + r >= nrows) break;
+    do_row(t0 + r, r);
+  }
+}
+
+template <int CPL, int NB>
+static void launch_lane(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int th_env, int cpb_env, hipStream_t s) {
+  // block = XB columns x CPB channels.  CPB = 32: 128-byte pieces of a pixel per block; CPB = C: whole pixels (contiguous
+  // C * 4 bytes per column and row), columns per block limited by the 1024-thread block
+  const int CPB = cpb_env == 0 ? 32 : C;
+  const int LPC = CPB / CPL;
+  int XB = 1;
+  for (int cand : {16, 10, 8, 5, 4, 2}) if (W % cand == 0 && cand * LPC <= (CPB == 32 ? 256 : 1024)) { XB = cand; break; }
+  if (CPB == 32 && XB < 4) XB = 4;
+  const int threads = (XB * LPC + 63) / 64 * 64;
+  const long per_strip = (long)B * ((W + XB - 1) / XB) * (C / CPB) * threads / 256;  // 256-thread block equivalents
+  int TH = th_env > 0 ? th_env : H;
+  if (th_env <= 0) while (TH > 20 && per_strip * ((H + TH - 1) / TH) < 768) TH = (TH + 1) / 2;
+  const long blocks = (long)B * ((H + TH - 1) / TH) * ((W + XB - 1) / XB) * (C / CPB);
+  if (threads <= 256) hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
+  else                hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 1024>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
+}
+
+static int g_cpl = -1, g_nb = 3, g_th = 0, g_cpb = 0;
+void launch_dwconv7x7_lane(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+  if (g_cpl == -1) {  // tuning knobs: PF_DW7_CPL (channels per lane), PF_DW7_NB (row buffers), PF_DW7_TH (strip height), PF_DW7_CPB (0: 32 channels per block, 1: all)
+    const char* e = getenv("PF_DW7_CPL"); g_cpl = e ? atoi(e) : 1;
+    const char* n = getenv("PF_DW7_NB"); g_nb = n ? atoi(n) : 3;
+    const char* t = getenv("PF_DW7_TH"); g_th = t ? atoi(t) : 0;
+    const char* c = getenv("PF_DW7_CPB"); g_cpb = c ? atoi(c) : 0;
+  }
+  if (g_cpl == 2) launch_lane<2, 3>(x, w49c, bias, y, B, H, W, C, g_th, 0, s);
+  else if (g_nb == 2) launch_lane<1, 2>(x, w49c, bias, y, B, H, W, C, g_th, g_cpb, s);
+  else launch_lane<1, 3>(x, w49c, bias, y, B, H, W, C, g_th, g_cpb, s);
+}
+
+}  // namespace pf

@@ -392,118 +392,16 @@ __global__ __launch_bounds__(CQB * XB) void dwconv7x7_ring_kernel(const float* _
 }
 
 
-// Channel-pair-per-lane variant (default).  Lane = two neighbouring channels, 16 lanes = 32 channels of one column,
-// a wave = 4 neighbouring columns: the 49 weights cost 98 VGPRs instead of the ring kernel's 196, so three waves per
-// SIMD hide the load latency that bounded it (0.84 TB/s, 13 % VALU).  Thread (channel pair, column x) streams the
-// input rows of a strip:
-//   * 7 buffer_load_dwordx2 per row (x-3..x+3; the overlap between neighbouring columns is served by L1): the
-//     per-lane column/channel byte offset is fixed (out-of-image columns use the out-of-range offset -> hardware
-//     zeros), the row offset is a scalar register, so a row costs NO address VALU work;
-//   * 49 v_pk_fma_f32 (both channels per instruction) into 7 output-row accumulators whose ring position is a
-//     compile-time constant (loop unrolled 21x = 7 ring slots x 3 row buffers, loads two rows ahead: no register moves);
-//   * one 8-byte store per row.
-// FLOP-heavy for a "memory-bound" op: 98 flops per 8 bytes -- 0.09 ms of packed-fp32 VALU time per forward against
-// 0.14 ms of HBM time at 8 TB/s.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
-template <int XB>
-__global__ __launch_bounds__(16 * XB) void dwconv7x7_lane_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
-                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                                int B, int H, int W, int C, int TH) {
-  const int slabs = C >> 5, tilesX = (W + XB - 1) / XB, strips = (H + TH - 1) / TH;
-  const int nblk = B * strips * tilesX * slabs;
-  int t;
-  {  // XCD-aware order: the slabs / x-neighbours of one image region share an L2
-    const int b = blockIdx.x, qd = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-    t = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
-  }
-  const int slab = t % slabs; t /= slabs;
-  const int tx = t % tilesX; t /= tilesX;
-  const int st = t % strips; t /= strips;
-  const int b = t;
-  const int c = slab * 32 + 2 * (threadIdx.x & 15);
-  const int ox = tx * XB + (threadIdx.x >> 4);
-  const bool col_ok = ox < W;
-  const int y0 = st * TH, y1 = min(y0 + TH, H);
-  f32x2 wk[49];
-#pragma unroll
-  for (int k = 0; k < 49; ++k) wk[k] = *reinterpret_cast<const f32x2*>(w49c + (long)k * C + c);
-  const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + c);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long)b * H * W * C), 0, (unsigned)((long)H * W * C * 4), 0x00020000);
-  unsigned voff[7];
-#pragma unroll
-  for (int kx = 0; kx < 7; ++kx) {
-    const int ix = ox + kx - 3;
-    voff[kx] = (col_ok && (unsigned)ix < (unsigned)W) ? (unsigned)(ix * C + c) * 4u : 0x80000000u;
-  }
-  float* yb = y + ((long)b * H * W + (col_ok ? ox : 0)) * C + c;
-  const long rowC = (long)W * C;
-  const unsigned row_bytes = (unsigned)(W * C) * 4u;
-  constexpr int NB = 3;  // row buffers: loads run NB - 1 rows ahead of the FMAs
-  f32x2 acc[7], in[NB][7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) acc[j] = bv;
-  auto load_row = [&](int iy, f32x2 (&v)[7]) {
-    if ((unsigned)iy < (unsigned)H) {  // block-uniform
-      const unsigned soff = (unsigned)iy * row_bytes;
-#pragma unroll
-      for (int kx = 0; kx < 7; ++kx) {
-        const u32x2v q = __builtin_amdgcn_raw_buffer_load_b64(rx, voff[kx], soff, 0);
-        v[kx] = f32x2{__uint_as_float(q.x), __uint_as_float(q.y)};
-      }
-    } else {
-#pragma unroll
-      for (int kx = 0; kx < 7; ++kx) v[kx] = f32x2{0.f, 0.f};
-    }
-  };
-  // relative row index tt: input row iy = y0 - 3 + tt, tt in [0, nrows); it feeds output rows oy = iy - ky + 3, whose
-  // accumulator slot is (tt - ky + 3) mod 7; after row tt the output row iy - 3 (slot (tt + 4) mod 7) is complete.
-  const int nrows = (y1 - y0) + 6;
-#pragma unroll
-  for (int d = 0; d < NB - 1; ++d) load_row(y0 - 3 + d, in[d]);
-  for (int t0 = 0; t0 < nrows; t0 += 7 * NB) {
-#pragma unroll
-    for (int r = 0; r < 7 * NB; ++r) {
-      const int tt = t0 + r;
-      if (tt >= nrows) break;
-      const int iy = y0 - 3 + tt;
-      load_row(tt + NB - 1 < nrows ? iy + NB - 1 : -1, in[(r + NB - 1) % NB]);  // prefetch (rows past the strip are not needed)
-      if ((unsigned)iy < (unsigned)H) {
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-          f32x2 a = acc[(r - ky + 3 + 7 * NB) % 7];
-#pragma unroll
-          for (int kx = 0; kx < 7; ++kx) a = __builtin_elementwise_fma(in[r % NB][kx], wk[ky * 7 + kx], a);
-          acc[(r - ky + 3 + 7 * NB) % 7] = a;
-        }
-      }
-      const int oy = iy - 3;
-      if (oy >= y0 && col_ok) *reinterpret_cast<f32x2*>(yb + (long)oy * rowC) = acc[(r + 4) % 7];  // oy < y1 always (tt < nrows)
-      acc[(r + 4) % 7] = bv;
-    }
-  }
-}
+// The default kernel (channels-per-lane, buffer loads, prefetch ring) lives in dw7.hip.
+void launch_dwconv7x7_lane(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
 
 static int g_dw7_variant = -1;
-static int g_dw7_th = -1;
 void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
   if (g_dw7_variant == -1) {
     const char* e = getenv("PF_DW7_VARIANT");
     g_dw7_variant = e ? atoi(e) : 2;
-    const char* t = getenv("PF_DW7_TH");
-    g_dw7_th = t ? atoi(t) : 0;
   }
-  if (g_dw7_variant == 2) {  // default: channel-per-lane kernel; whole-column strips unless that leaves the chip underfilled
-    const int XB = (W % 16 == 0) ? 16 : (W % 8 == 0 ? 8 : 4);  // columns per block (16 lanes each): 256 / 128 / 64 threads
-    const long per_strip = (long)B * ((W + XB - 1) / XB) * (C / 32) * XB / 16;  // 256-thread block equivalents
-    int TH = g_dw7_th > 0 ? g_dw7_th : H;
-    if (g_dw7_th <= 0) while (TH > 20 && per_strip * ((H + TH - 1) / TH) < 768) TH = (TH + 1) / 2;
-    const long blocks = (long)B * ((H + TH - 1) / TH) * ((W + XB - 1) / XB) * (C / 32);
-    if (XB == 16)     hipLaunchKernelGGL((dwconv7x7_lane_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w49c, bias, y, B, H, W, C, TH);
-    else if (XB == 8) hipLaunchKernelGGL((dwconv7x7_lane_kernel<8>), dim3((unsigned)blocks), dim3(128), 0, s, x, w49c, bias, y, B, H, W, C, TH);
-    else              hipLaunchKernelGGL((dwconv7x7_lane_kernel<4>), dim3((unsigned)blocks), dim3(64), 0, s, x, w49c, bias, y, B, H, W, C, TH);
-    return;
-  }
+  if (g_dw7_variant == 2) { launch_dwconv7x7_lane(x, w49c, bias, y, B, H, W, C, s); return; }
   const int CQ = C / 4;
   if (g_dw7_variant == 0) {  // LDS halo-tile kernel (kept for A/B)
     const int tilesX = (W + DW7_T - 1) / DW7_T, tilesY = (H + DW7_T - 1) / DW7_T;

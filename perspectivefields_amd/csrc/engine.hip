@@ -246,7 +246,8 @@ struct pf_engine {
   std::map<int, size_t> scratch_off, scratch_elems;
   bool split_bf16 = true;    // PF_SPLIT_BF16=0: exact-fp32 MFMA kernels only (no split-bf16 tiles)
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
-  bool sba = true;           // PF_SBA=0: GEMM inputs stay fp32 and are split inside the GEMM (sb_split.h)
+  bool sba = false;          // PF_SBA=1: tensors that only feed GEMMs are stored as split-bf16 planes by their producers (sb_split.h);
+                             // measured slower end to end (1.5x the bytes on HBM-bound layers), kept as an option -- DESIGN.md 4.2
 
   MitStage stages[4];
   ConvW ll;

@@ -172,14 +172,14 @@ def test_folded_and_unfolded_mlp_agree(monkeypatch):
 
 
 def test_split_plane_activations_agree_with_fp32_activations(monkeypatch):
-    """PF_SBA=0 keeps every GEMM input in fp32 (split inside the GEMM); the default stores GEMM-only tensors as split
-    planes.  The planes are lossless, so the two engines differ only through the tile choices of the autotuner
-    (fp32 summation order): far inside the parity tolerances."""
+    """PF_SBA=1 stores GEMM-only tensors as split-bf16 planes written by their producers; the default keeps every GEMM
+    input in fp32 and splits inside the GEMM.  The planes are lossless, so the two engines differ only through the
+    tile choices of the autotuner (fp32 summation order): far inside the parity tolerances."""
     from perspectivefields_amd import PerspectiveFields
 
     imgs = [synthetic_image(72, 96, seed=90 + i) for i in range(3)]
     base = model("centered").inference_batch(imgs)
-    monkeypatch.setenv("PF_SBA", "0")
+    monkeypatch.setenv("PF_SBA", "1")
     alt_model = PerspectiveFields(CASES["centered"], weights="synthetic:0").eval().cuda()
     alt = alt_model.inference_batch(imgs)
     for i, (a, b) in enumerate(zip(base, alt)):
