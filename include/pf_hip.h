@@ -87,6 +87,16 @@ size_t pf_workspace_bytes(pf_handle h, int batch);
  *                    CENTERED  : roll, pitch, vfov (deg), rel_focal, raw x0..x3   (param_network.py:62-67)
  *                    UNCENTERED: raw x0..x4 (roll/90, pitch/90, general_vfov/90, rel_cx, rel_cy), 0, 0, 0
  */
+/* Arithmetic of the dense contractions (everything else is always fp32).  FP32 (default, the parity mode): every
+ * product is evaluated as six bf16 MFMA partial products of exactly split operands -- fp32-accurate.  BF16X3: three
+ * partial products (operands carried to ~16 significant bits).  BF16: one (plain bf16 operands, fp32 accumulation), the
+ * reference's autocast-style mode.  The reduced modes trade accuracy for speed and are NOT held to the parity tolerances.
+ * May be called at any time; it applies to the following forwards (tile choices are tuned per mode). */
+#define PF_PRECISION_FP32 0
+#define PF_PRECISION_BF16X3 1
+#define PF_PRECISION_BF16 2
+int pf_set_precision(pf_handle h, int mode);
+
 int pf_forward_u8(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_pred_gravity, float* d_pred_latitude,
                   float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
 int pf_forward_f32(pf_handle h, int batch, const float* d_images_f32, float* d_pred_gravity, float* d_pred_latitude,
@@ -138,7 +148,7 @@ int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, 
                  const float* d_res1, const float* d_res2, int post_relu, int nchw_out, int tile_id /*-1 auto*/,
                  float* d_y /*may be NULL when d_y_planes is given*/,
                  const uint16_t* d_x_planes /*replaces d_x*/, long x_plane_elems, const uint16_t* d_x2_planes, long x2_plane_elems,
-                 uint16_t* d_y_planes, long y_plane_elems, void* stream);
+                 uint16_t* d_y_planes, long y_plane_elems, int precision /*PF_PRECISION_*: split-bf16 tiles only*/, void* stream);
 /* times `iters` launches of one conv shape on random data with tile config `tile_id` (-1 auto); avg ms per launch.
  * fmt 0: fp32 in / out; 1: input as planes; 2: input and output as planes */
 int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt, float* ms_out);

@@ -170,22 +170,23 @@ std::vector<float> pack_dw(const float* w, int C, int K) {  // [C][1][K][K] -> [
   return o;
 }
 
-// exact 3-way truncation split of packed fp32 weights into bf16 planes [3][n] (see igemm_sb.hip)
+// packed fp32 weights -> 5 bf16 planes [5][n] (igemm_sb_impl.h): exact 3-way truncation split h, m, l (h + m + l == w),
+// then round-to-nearest-even bf16(w) and round-to-nearest m (operands of the reduced-precision modes)
 std::vector<unsigned short> split_bf16x3(const std::vector<float>& w) {
   const size_t n = w.size();
-  std::vector<unsigned short> o(3 * n);
+  std::vector<unsigned short> o(5 * n);
+  auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  auto flt = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+  auto rne = [](uint32_t u) { return (uint32_t)((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u); };
   for (size_t i = 0; i < n; ++i) {
-    uint32_t u; float a = w[i];
-    std::memcpy(&u, &a, 4);
-    const uint32_t hb = u & 0xffff0000u;
-    float hf; std::memcpy(&hf, &hb, 4);
-    const float r = a - hf;
-    uint32_t ru; std::memcpy(&ru, &r, 4);
-    const uint32_t mb = ru & 0xffff0000u;
-    float mf; std::memcpy(&mf, &mb, 4);
-    const float r2 = r - mf;
-    uint32_t lu; std::memcpy(&lu, &r2, 4);
-    o[i] = (unsigned short)(hb >> 16); o[n + i] = (unsigned short)(mb >> 16); o[2 * n + i] = (unsigned short)(lu >> 16);
+    const float a = w[i];
+    const uint32_t hb = bits(a) & 0xffff0000u;
+    const float r = a - flt(hb);
+    const uint32_t mb = bits(r) & 0xffff0000u;
+    const float r2 = r - flt(mb);
+    o[i] = (unsigned short)(hb >> 16); o[n + i] = (unsigned short)(mb >> 16); o[2 * n + i] = (unsigned short)(bits(r2) >> 16);
+    o[3 * n + i] = (unsigned short)(rne(bits(a)) >> 16);
+    o[4 * n + i] = (unsigned short)(rne(bits(r)) >> 16);
   }
   return o;
 }
@@ -246,6 +247,7 @@ struct pf_engine {
   std::map<int, size_t> scratch_off, scratch_elems;
   bool split_bf16 = true;    // PF_SPLIT_BF16=0: exact-fp32 MFMA kernels only (no split-bf16 tiles)
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
+  int nterms = 6;            // pf_set_precision / PF_PRECISION: 6 fp32-accurate (default), 3 = "bf16x3", 1 = "bf16" (reduced precision, not parity modes)
   bool sba = false;          // PF_SBA=1: tensors that only feed GEMMs are stored as split-bf16 planes by their producers (sb_split.h);
                              // measured slower end to end (1.5x the bytes on HBM-bound layers), kept as an option -- DESIGN.md 4.2
 
@@ -533,11 +535,12 @@ struct pf_engine {
     p.KH = w.KH; p.KW = w.KW; p.stride = w.stride; p.pad = w.pad;
     p.Cout = w.Cout; p.KWC = w.KWC; p.KWCp = w.KWCp;
     p.act = act; p.post_relu = post_relu; p.nchw_out = nchw;
+    p.nterms = nterms;
     p.finish();
     int tile = -1;
     if (autotune) {
       // operand formats are part of the key: a split-plane input changes which tile is fastest
-      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16);
+      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * (6 - nterms);
       const std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out, fmt_bits, p.act};
       auto it = tile_cache.find(key);
       if (it != tile_cache.end()) tile = it->second;
@@ -903,9 +906,18 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;
+  if (const char* v = getenv("PF_PRECISION")) e->nterms = std::strcmp(v, "bf16") == 0 ? 1 : (std::strcmp(v, "bf16x3") == 0 ? 3 : 6);
   if (!e->split_bf16) e->sba = false;  // split planes are only read by the split-bf16 kernels
   tune_cache_load(e);
   *out = e;
+  return PF_OK;
+}
+
+int pf_set_precision(pf_handle h, int mode) {
+  if (!h) return PF_ERR_ARG;
+  if (mode != PF_PRECISION_FP32 && mode != PF_PRECISION_BF16X3 && mode != PF_PRECISION_BF16) return h->fail(PF_ERR_ARG, "pf_set_precision: unknown mode");
+  if (mode != PF_PRECISION_FP32 && !h->split_bf16) return h->fail(PF_ERR_ARG, "pf_set_precision: reduced precision needs the split-bf16 kernels (PF_SPLIT_BF16=0 is set)");
+  h->nterms = mode == PF_PRECISION_BF16 ? 1 : (mode == PF_PRECISION_BF16X3 ? 3 : 6);
   return PF_OK;
 }
 
@@ -1011,11 +1023,11 @@ static void tune_cache_save(pf_engine* h) {
 int pf_autotune(pf_handle h, int batch, const uint8_t* in, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, void* stream) {
   if (!h) return PF_ERR_ARG;
   const int rc = h->forward(batch, in, true, pg, pl, params, ws, ws_bytes, static_cast<hipStream_t>(stream), true);
-  if (rc == PF_OK) { h->tuned_batches[batch] = true; tune_cache_save(h); }
+  if (rc == PF_OK) { h->tuned_batches[batch * 8 + h->nterms] = true; tune_cache_save(h); }
   return rc;
 }
 
-int pf_is_tuned(pf_handle h, int batch) { return (h && (!h->autotune || h->tuned_batches.count(batch))) ? 1 : 0; }
+int pf_is_tuned(pf_handle h, int batch) { return (h && (!h->autotune || h->tuned_batches.count(batch * 8 + h->nterms))) ? 1 : 0; }
 
 size_t pf_resize_workspace_bytes(int H, int W) { (void)W; return H > 0 ? (size_t)H * NET * 3 + 256 : 0; }
 
@@ -1097,7 +1109,7 @@ const char* pf_op_conv_tile_name(int id) { return conv_tile_name(id); }
 int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int W, int C1, int C2, const float* hw, const float* hb,
                  int Cout, int KH, int KW, int stride, int pad, int act, const float* res1, const float* res2, int post_relu,
                  int nchw_out, int tile_id, float* y, const uint16_t* x_planes, long x_plane_elems, const uint16_t* x2_planes,
-                 long x2_plane_elems, uint16_t* y_planes, long y_plane_elems, void* stream) {
+                 long x2_plane_elems, uint16_t* y_planes, long y_plane_elems, int precision, void* stream) {
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
@@ -1117,6 +1129,7 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.Cout = Cout; p.act = act; p.post_relu = post_relu; p.nchw_out = nchw_out;
+  p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : 6);
   p.finish();
   if ((!x && !x_planes) || (!y && !y_planes) || (C2 > 0 && !x2 && !x2_planes)) { g_create_error = "pf_op_conv2d: missing input or output"; return PF_ERR_ARG; }
   // an explicit tile that cannot read / write split planes is an error; with fp32 operands an unusable tile id falls back to the cost model
@@ -1141,7 +1154,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   float *dx = nullptr, *dw = nullptr, *dy = nullptr, *db = nullptr;
   unsigned short *dsb = nullptr, *dxs = nullptr, *dys = nullptr;
   if (hipMalloc(&dx, nx * 4) != hipSuccess || hipMalloc(&dw, nw * 4) != hipSuccess || hipMalloc(&dy, ny * 4) != hipSuccess ||
-      hipMalloc(&db, (size_t)Cout * 4) != hipSuccess || hipMalloc(&dsb, nw * 6) != hipSuccess ||
+      hipMalloc(&db, (size_t)Cout * 4) != hipSuccess || hipMalloc(&dsb, nw * 10) != hipSuccess ||
       (fmt >= 1 && hipMalloc(&dxs, nx * 6) != hipSuccess) || (fmt >= 2 && hipMalloc(&dys, ny * 6) != hipSuccess)) { g_create_error = "pf_op_conv2d_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
   {  // uniform [-1,1) data (never zero-fill a bench: DVFS gives zeros a higher clock); activations filled on the device
     std::vector<float> hw(nw), hb(Cout);
@@ -1153,7 +1166,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
     (void)hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(db, hb.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
     const std::vector<unsigned short> sb = split_bf16x3(hw);
-    (void)hipMemcpy(dsb, sb.data(), nw * 6, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dsb, sb.data(), nw * 10, hipMemcpyHostToDevice);
   }
   p.g[0].x = dx; p.g[0].w = dw; p.g[0].bias = db; p.g[0].y = dy;
   if (Cin % 32 == 0) p.g[0].w_sb = dsb;

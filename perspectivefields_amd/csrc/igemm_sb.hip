@@ -1,276 +1,8 @@
-// Split-bf16 implicit-GEMM convolution / GEMM for gfx950: fp32-accurate results at 6/16 of the
-// fp32-MFMA cost, on v_mfma_f32_32x32x16_bf16.
-//
-// Every fp32 value is split EXACTLY into three bf16 parts by truncation, a = a_h + a_m + a_l (8 + 8 + 8
-// significant bits; r = a - trunc(a) is exact in fp32).  A product is then
-//   a*b = a_h b_h + (a_h b_m + a_m b_h) + (a_h b_l + a_l b_h + a_m b_m) + O(2^-24 |a b|)
-// i.e. six bf16 MFMAs with fp32 accumulation reproduce the fp32 dot product to fp32 rounding level (the three
-// dropped terms are < 3 * 2^-24 relative; bf16 x bf16 products are exact in the fp32 accumulator).  A CPU
-// emulation of this scheme is in tests/test_host_logic.py; on the device it is held to the same oracle parity
-// as the exact-fp32 kernel (tests/test_gpu_ops.py runs every tile id).  bf16 keeps the fp32 exponent range, so
-// there is no overflow / underflow hazard (unlike an fp16 split).
-//
-// Structure = igemm.hip (same A gather with tap masks and buffer-load range checks, same grouped launch, same
-// LDS-staged epilogue).  Weights are pre-split on the host into three bf16 planes.  Activations come in one of two
-// forms (template ASB):
-//   ASB = false: fp32 NHWC; the staging threads split every element (5 VALU ops + packing) once per block and K step;
-//   ASB = true : already split by the producing kernel's epilogue (sb_split.h) -- staging is a plain 16-byte copy per
-//                plane, the inner loop carries no VALU work besides address selects.  The split is lossless, so both
-//                forms give bit-identical results.
-// LDS: three bf16 planes per operand, 64-byte rows, XOR piece swizzle (conflict-free ds_read_b128 and staging writes).
-// One LDS buffer + a ring of PFD register sets: global loads run PFD K steps ahead of their LDS store (branch-free:
-// loads past the last K step go to the out-of-range offset), which is what the small-M GEMMs need -- their K loop is
-// a chain of L2 round trips, not of MFMAs.
-#include <stdlib.h>
-
-#include "igemm_common.h"
-#include "sb_split.h"
+// Split-bf16 implicit GEMM, fp32-accurate form (6 partial products): tile table, eligibility and dispatch by precision.
+// Kernel: igemm_sb_impl.h.
+#include "igemm_sb_impl.h"
 
 namespace pf {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-static constexpr int SB_ROW = BK;  // ushorts per LDS row: 64 bytes = four 16-byte pieces, no padding
-// Bank-conflict freedom comes from an XOR swizzle of the piece index with bits 2-3 of the row: a ds_read_b128
-// lane group covers 16 rows at one logical piece -> rows r, r+4, r+8, r+12 (same 16-byte slot mod 256 B) land on
-// four different pieces; the b64 / b128 staging writes always cover whole 64-byte rows (PMC: the earlier 80-byte
-// padded layout cost 8.8e7 SQ_LDS_BANK_CONFLICT cycles per launch on the write side and 25 % more LDS).
-__device__ __forceinline__ int sb_piece(int row, int piece) { return piece ^ ((row >> 2) & 3); }
-
-template <int BM, int BN, int WM, int WN, int MODE, bool ASB, int PFD>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? (PFD == 1 ? 3 : 2) : 1) void igemm_sb_kernel(const ConvParams p) {
-  constexpr int NT = WM * WN * 64;
-  constexpr int RPP = NT / 8;    // fp32 A rows staged per pass (8 threads x float4 = 32 floats)
-  constexpr int RPB = NT / 4;    // bf16 rows staged per pass (4 threads x 16 B = 32 bf16): B, and A when ASB
-  constexpr int SM = BM / (WM * 32);
-  constexpr int SN = BN / (WN * 32);
-  constexpr int A_ROWS = ASB ? (BM + RPB - 1) / RPB : BM / RPP;
-  constexpr int A_REGS = ASB ? A_ROWS * 3 : A_ROWS;  // float4 registers per staged A tile
-  constexpr int B_ROWS = (BN + RPB - 1) / RPB;        // BN < RPB (N = 32 tiles): the upper threads stage no B rows
-  static_assert(ASB ? (BM % RPB == 0 || BM < RPB) : BM % RPP == 0, "A tile rows must be a multiple of the staging pass");
-  static_assert(BN % RPB == 0 || BN < RPB, "B tile rows must be a multiple of the staging pass");
-  constexpr int PLANE_A = BM * SB_ROW, PLANE_B = BN * SB_ROW;  // ushorts
-  constexpr int SMEM_USHORTS = 3 * (PLANE_A + PLANE_B);
-  __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
-  unsigned short* As = smem_u;                // [3][BM][SB_ROW]
-  unsigned short* Bs = smem_u + 3 * PLANE_A;  // [3][BN][SB_ROW]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int l31 = lane & 31;
-  const int hi = lane >> 5;
-
-  const int tilesN = (p.Cout + BN - 1) / BN;
-  const int tilesM = (p.M + BM - 1) / BM;
-  const int nblk1 = tilesM * tilesN;
-  int t = xcd_tile_index(nblk1 * p.groups);
-  const bool g1 = t >= nblk1;
-  if (g1) t -= nblk1;
-  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
-  const int m0 = (t / tilesN) * BM;
-  const int n0 = (t % tilesN) * BN;
-
-  // ---- staging geometry.  fp32 A: thread -> (row r0 + RPP i, float4 c4 of the 32-float K chunk).
-  //      bf16 (B, and A when ASB): thread -> (row rb0 + RPB i, 16-byte piece pc of the 64-byte K chunk), three planes.
-  const int c4 = tid & 7;
-  const int r0 = tid >> 3;
-  const int pc = tid & 3;
-  const int rb0 = tid >> 2;
-  const int HoWo = p.Ho * p.Wo;
-  constexpr int ESZ = ASB ? 2 : 4;  // bytes per A element in global memory
-  // one buffer descriptor per A plane (a plane of the largest activation, 320^2 x 64 channels x 2 heads x batch, is
-  // 0.8 GB: three of them under one descriptor would run into the out-of-range marker)
-  __amdgpu_buffer_rsrc_t rx[ASB ? 3 : 1], rx2[ASB ? 3 : 1];
-  if (ASB) {
-#pragma unroll
-    for (int pl = 0; pl < (ASB ? 3 : 1); ++pl) {
-      rx[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.x_sb + pl * p.x_sb_plane), 0, p.x_bytes / 2, 0x00020000);
-      rx2[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.x2_sb ? P.x2_sb + pl * p.x2_sb_plane : P.x_sb), 0,
-                                                  P.x2_sb ? p.x2_bytes / 2 : 0, 0x00020000);
-    }
-  } else {
-    rx[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
-    rx2[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x2 ? P.x2 : P.x), 0, P.x2 ? p.x2_bytes : 0, 0x00020000);
-  }
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_sb), 0, 3u * p.w_sb_plane_bytes, 0x00020000);
-  int a_off1[A_ROWS], a_off2[A_ROWS];
-  unsigned long long a_mask[A_ROWS];
-#pragma unroll
-  for (int i = 0; i < A_ROWS; ++i) {
-    const int rl = ASB ? rb0 + RPB * i : r0 + RPP * i;
-    const int m = m0 + rl;
-    const bool ok = m < p.M && rl < BM;
-    const int mm = ok ? m : 0;
-    const int b = mm / HoWo;
-    const int rem = mm - b * HoWo;
-    const int oy = rem / p.Wo;
-    const int ox = rem - oy * p.Wo;
-    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-    const int pix = (b * p.H + iy0) * p.W + ix0;
-    a_off1[i] = pix * p.C1 * ESZ + (ASB ? pc : c4) * 16;
-    a_off2[i] = pix * p.C2 * ESZ + (ASB ? pc : c4) * 16;
-    unsigned long long mk = 0;
-    if (ok)
-      for (int ky = 0; ky < p.KH; ++ky)
-        for (int kx = 0; kx < p.KW; ++kx)
-          if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W) mk |= 1ull << (ky * p.KW + kx);
-    a_mask[i] = mk;
-  }
-  unsigned b_off[B_ROWS];
-#pragma unroll
-  for (int i = 0; i < B_ROWS; ++i) {
-    const int n = n0 + rb0 + RPB * i;
-    b_off[i] = (n < p.Cout && rb0 + RPB * i < BN) ? (unsigned)(n * p.KH * p.KWCp + pc * 8) * 2u : OOB;
-  }
-
-  struct Raw { float4 a[A_REGS]; float4 b[B_ROWS][3]; };
-  Raw raw[PFD];
-  const int nJ = p.KWCp / BK;
-  const int nK = p.KH * nJ;
-
-  // branch-free: a step at or past nK loads from the out-of-range offset (zeros, never stored)
-  auto load_tiles = [&](int it, Raw& R) {
-    const bool live = it < nK;
-    const int ky = it / nJ;
-    const int j0 = (it - ky * nJ) * BK;
-    const int kx = j0 / p.Cin;
-    const int ci0 = j0 - kx * p.Cin;
-    const int bit = (ky * p.KW + kx) & 63;
-    const bool first = MODE != 2 || ci0 < p.C1;
-    const int toff = ((ky * p.W + kx) * (first ? p.C1 : p.C2) + (first ? ci0 : ci0 - p.C1)) * ESZ;
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) {
-      const bool valid = live && ((a_mask[i] >> bit) & 1ull);
-      const unsigned off = valid ? (unsigned)((first ? a_off1[i] : a_off2[i]) + toff) : OOB;
-      if (ASB) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          if (MODE == 2) {
-            const float4 v1 = buf_load16(rx[pl], first ? off : OOB);
-            const float4 v2 = buf_load16(rx2[pl], first ? OOB : off);
-            // one of the two is all-zero bits: OR keeps the other's bf16 bit patterns
-            R.a[i * 3 + pl] = make_float4(__uint_as_float(__float_as_uint(v1.x) | __float_as_uint(v2.x)), __uint_as_float(__float_as_uint(v1.y) | __float_as_uint(v2.y)),
-                                          __uint_as_float(__float_as_uint(v1.z) | __float_as_uint(v2.z)), __uint_as_float(__float_as_uint(v1.w) | __float_as_uint(v2.w)));
-          } else {
-            R.a[i * 3 + pl] = buf_load16(rx[pl], off);
-          }
-        }
-      } else if (MODE == 2) {
-        const float4 v1 = buf_load16(rx[0], first ? off : OOB);
-        const float4 v2 = buf_load16(rx2[0], first ? OOB : off);
-        R.a[i] = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);
-      } else {
-        R.a[i] = buf_load16(rx[0], off);
-      }
-    }
-    const unsigned woff = (unsigned)(ky * p.KWCp + j0) * 2u;
-#pragma unroll
-    for (int i = 0; i < B_ROWS; ++i)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        R.b[i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes : OOB);
-  };
-  auto store_tiles = [&](const Raw& R) {
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) {
-      if (ASB) {
-        const int row = rb0 + RPB * i;
-        if (BM % RPB == 0 || row < BM) {
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            *reinterpret_cast<float4*>(As + pl * PLANE_A + row * SB_ROW + sb_piece(row, pc) * 8) = R.a[i * 3 + pl];
-        }
-      } else {
-        uint2 h, m, l;
-        split4(R.a[i], h, m, l);
-        const int row = r0 + RPP * i;
-        unsigned short* d = As + row * SB_ROW + sb_piece(row, c4 >> 1) * 8 + (c4 & 1) * 4;
-        *reinterpret_cast<uint2*>(d) = h;
-        *reinterpret_cast<uint2*>(d + PLANE_A) = m;
-        *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_ROWS; ++i)
-      if (BN % RPB == 0 || rb0 + RPB * i < BN) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = R.b[i][pl];
-      }
-  };
-
-  f32x16 acc[SM][SN];
-#pragma unroll
-  for (int i = 0; i < SM; ++i)
-#pragma unroll
-    for (int j = 0; j < SN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int wm0 = (wave / WN) * (SM * 32);
-  const int wn0 = (wave % WN) * (SN * 32);
-  const unsigned short* Ab = As + (wm0 + l31) * SB_ROW;
-  const unsigned short* Bb = Bs + (wn0 + l31) * SB_ROW;
-  const int swz = (l31 >> 2) & 3;  // wm0, wn0 and i*32 are multiples of 32: the swizzle depends on the lane only
-
-  auto compute = [&]() {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per K step; this lane's 8 k-values = piece 2c + hi
-      const int po = ((2 * c + hi) ^ swz) * 8;
-      bf16x8 af[SM][3], bf[SN][3];
-#pragma unroll
-      for (int i = 0; i < SM; ++i)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * PLANE_A + i * 32 * SB_ROW + po);
-#pragma unroll
-      for (int j = 0; j < SN; ++j)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * PLANE_B + j * 32 * SB_ROW + po);
-      // six partial products, smallest first; the (i, j) loop is innermost so that consecutive MFMAs never
-      // depend on each other's accumulator
-      constexpr int TA[6] = {2, 0, 1, 1, 0, 0};  // plane of A: l h m m h h
-      constexpr int TB[6] = {0, 2, 1, 0, 1, 0};  // plane of B: h l m h m h
-#pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-        for (int i = 0; i < SM; ++i)
-#pragma unroll
-          for (int j = 0; j < SN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  // prologue: tiles 0 .. PFD-1 in flight, tile 0 -> LDS (tile k lives in register set k % PFD)
-#pragma unroll
-  for (int d = 0; d < PFD; ++d) load_tiles(d, raw[d]);
-  store_tiles(raw[0]);
-  __syncthreads();
-  // Main loop: whole groups of PFD steps with no exit inside, so that the loop header sees ONE load order and the
-  // compiler's s_waitcnt analysis keeps the partial vmcnt(N) waits (an exit inside the group rejoins the back edge
-  // with a different order and every PFD-th store then drains all loads).  The last 1..PFD tiles are already in
-  // flight when the loop ends and are consumed by the straight-line tail.
-  int it = 0;
-  for (; it + PFD < nK; it += PFD) {
-#pragma unroll
-    for (int d = 0; d < PFD; ++d) {
-      load_tiles(it + d + PFD, raw[d]);  // refill the set whose tile (it + d) is in LDS now
-      compute();                         // tile it + d
-      __syncthreads();                   // every wave has read this step's planes
-      store_tiles(raw[(d + 1) % PFD]);   // tile it + d + 1 (the oldest loads in flight)
-      __syncthreads();
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < PFD; ++d) {
-    compute();
-    if (it + d + 1 >= nK) break;
-    __syncthreads();
-    store_tiles(raw[(d + 1) % PFD]);
-    __syncthreads();
-  }
-
-  epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0);
-}
 
 // ---------------------------------------------------------------------------------------
 struct SbCfg { int bm, bn, pfd; const char* name; };
@@ -304,35 +36,14 @@ int conv_sb_default_tile(const ConvParams& p) {
   return 1;
 }
 
-template <int BM, int BN, int WM, int WN, int PFD>
-static void launch_sb_cfg(const ConvParams& p, hipStream_t s) {
-  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
-  const dim3 grid(tilesM * tilesN * p.groups), block(WM * WN * 64);
-  const bool asb = p.g[0].x_sb != nullptr;
-  if (p.C2 > 0) {
-    if (asb) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, true, PFD>), grid, block, 0, s, p);
-    else     hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, false, PFD>), grid, block, 0, s, p);
-  } else {
-    if (asb) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, true, PFD>), grid, block, 0, s, p);
-    else     hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, false, PFD>), grid, block, 0, s, p);
-  }
-}
+
+void launch_conv_sb3(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb3.hip
+void launch_conv_sb1(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb1.hip
 
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
-  switch (sb_tile) {
-    case 0: launch_sb_cfg<128, 128, 2, 2, 1>(p, s); break;
-    case 1: launch_sb_cfg<64, 64, 2, 2, 1>(p, s); break;
-    case 2: launch_sb_cfg<128, 64, 2, 2, 1>(p, s); break;
-    case 3: launch_sb_cfg<256, 128, 4, 2, 1>(p, s); break;
-    case 4: launch_sb_cfg<128, 256, 2, 4, 1>(p, s); break;  // whole N = 256 per block: A staged once per m-tile
-    case 5: launch_sb_cfg<128, 32, 4, 1, 1>(p, s); break;   // N = 32 layers (conv_fuse_conv1)
-    case 6: launch_sb_cfg<256, 256, 2, 4, 1>(p, s); break;  // half the global / LDS work per MFMA, one block per CU
-    case 7: launch_sb_cfg<64, 64, 2, 2, 2>(p, s); break;
-    case 8: launch_sb_cfg<64, 64, 2, 2, 3>(p, s); break;
-    case 9: launch_sb_cfg<128, 64, 2, 2, 2>(p, s); break;
-    case 10: launch_sb_cfg<128, 32, 4, 1, 2>(p, s); break;
-    default: launch_sb_cfg<128, 128, 2, 2, 2>(p, s); break;
-  }
+  if (p.nterms == 3) launch_conv_sb3(p, sb_tile, s);
+  else if (p.nterms == 1) launch_conv_sb1(p, sb_tile, s);
+  else launch_conv_sb_nt<6>(p, sb_tile, s);
 }
 
 }  // namespace pf

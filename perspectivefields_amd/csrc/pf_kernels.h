@@ -19,7 +19,8 @@ struct ConvPtrs {
   const float* x = nullptr;
   const float* x2 = nullptr;        // nullptr unless channel-concat input
   const float* w = nullptr;         // packed [Cout][KH][KWCp], KWCp = roundup(KW*Cin, 32), zero padded
-  const unsigned short* w_sb = nullptr;  // same weights split exactly into 3 bf16 planes [3][Cout][KH][KWCp] (split-bf16 kernel)
+  const unsigned short* w_sb = nullptr;  // same weights as 5 bf16 planes [5][Cout][KH][KWCp]: exact split h, m, l (h + m + l == w), then
+                                         // round-to-nearest bf16(w) and round-to-nearest m for the reduced-precision modes
   const float* bias = nullptr;      // [Cout] or nullptr
   const float* bias_tab = nullptr;  // [9][Cout]: bias per 3x3 border case (folded Linear->conv), overrides bias
   const float* res1 = nullptr;      // [M][Cout] or nullptr (may alias y)
@@ -43,6 +44,7 @@ struct ConvParams {
   int post_relu;  // relu after the residual adds
   int ldy;        // row stride of y / res1 / res2 in floats (normally Cout)
   int nchw_out;   // 1: store y as [B][Cout][Ho*Wo] (API-visible logits), residuals unsupported
+  int nterms = 6; // split-bf16 kernel: partial products per element product -- 6 fp32-accurate (default), 3 (~16-bit operands), 1 (bf16)
   unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)
   unsigned w_sb_plane_bytes;            // bytes of one bf16 weight plane
   size_t x_sb_plane = 0, x2_sb_plane = 0, y_sb_plane = 0;  // elements between consecutive planes of x_sb / x2_sb / y_sb

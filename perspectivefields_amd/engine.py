@@ -38,13 +38,14 @@ _SIGNATURES = {
     "pf_resize_bilinear_u8": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
     "pf_autotune": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_is_tuned": (_c.c_int, [_P, _c.c_int]),
+    "pf_set_precision": (_c.c_int, [_P, _c.c_int]),
     "pf_postprocess": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
     "pf_profile_begin": (_c.c_int, [_P, _c.c_uint]),
     "pf_profile_end": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.c_int]),
     "pf_profile_records": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double), _c.POINTER(_c.c_float), _c.POINTER(_c.c_int)]),
     "pf_op_conv2d": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P,
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_int,
-                                _c.c_int, _c.c_int, _P, _P, _c.c_long, _P, _c.c_long, _P, _c.c_long, _P]),
+                                _c.c_int, _c.c_int, _P, _P, _c.c_long, _P, _c.c_long, _P, _c.c_long, _c.c_int, _P]),
     "pf_op_conv2d_bench": (_c.c_int, [_c.c_int] * 12 + [_c.POINTER(_c.c_float)]),
     "pf_op_split_bf16": (_c.c_int, [_c.c_int, _P, _c.c_long, _P, _c.c_long, _P]),
     "pf_op_merge_bf16": (_c.c_int, [_c.c_int, _P, _c.c_long, _c.c_long, _P, _P]),
@@ -142,6 +143,7 @@ class Engine:
         _check(self.lib.pf_create(ctypes.byref(self._h), self.device.index, arch_id), None, "pf_create")
         self._ws = None
         self._finalized = False
+        self.precision = "fp32"
         g, l, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self.lib.pf_output_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(p))
         self.gravity_channels, self.latitude_channels, self.param_outputs = g.value, l.value, p.value
@@ -169,6 +171,16 @@ class Engine:
             )
         _check(self.lib.pf_finalize_weights(self._h), self._h, "pf_finalize_weights")
         self._finalized = True
+
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+
+    def set_precision(self, mode: str):
+        """Arithmetic of the dense contractions: 'fp32' (default; fp32-accurate, the parity mode), 'bf16x3' (three bf16
+        partial products, ~16-bit operands) or 'bf16' (plain bf16 operands).  See pf_set_precision in include/pf_hip.h."""
+        if mode not in self.PRECISIONS:
+            raise PfError(f"unknown precision '{mode}' (expected one of {sorted(self.PRECISIONS)})")
+        _check(self.lib.pf_set_precision(self._h, self.PRECISIONS[mode]), self._h, "pf_set_precision")
+        self.precision = mode
 
     # ---------------------------------------------------------------- forward
     def workspace_bytes(self, batch: int) -> int:

@@ -62,10 +62,10 @@ def _pl(planes):
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, post_relu=False, x2=None, nchw_out=False, tile=-1,
-           planes_in=False, planes_out=False):
+           planes_in=False, planes_out=False, precision=0):
     """x: (B,H,W,C1) [+ x2: (B,H,W,C2) channel-concat]; weight: (Cout, C1+C2, KH, KW).  Returns (B,Ho,Wo,Cout) or NCHW.
     planes_in: hand the input(s) to the kernel as split-bf16 planes only; planes_out: take the output as planes
-    (returned merged back to fp32, which is exact)."""
+    (returned merged back to fp32, which is exact).  precision: 0 fp32-accurate, 1 bf16x3, 2 bf16 (split-bf16 tiles)."""
     import torch
 
     lib = load_library()
@@ -88,7 +88,7 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, p
     rc = lib.pf_op_conv2d(
         x.device.index, None if planes_in else x.data_ptr(), None if planes_in else _dp(x2), B, H, W, C1, C2, _hp(w), _hp(b),
         Cout, KH, KW, stride, pad, act, _dp(res1), _dp(res2), int(post_relu), int(nchw_out), tile, _dp(y),
-        *_pl(xp), *_pl(x2p), *_pl(yp), _stream_ptr(),
+        *_pl(xp), *_pl(x2p), *_pl(yp), precision, _stream_ptr(),
     )
     _check(rc, None, "pf_op_conv2d")
     return yp.merge() if planes_out else y

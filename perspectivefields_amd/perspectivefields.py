@@ -73,8 +73,11 @@ def _resolve_weights(version: str, weights) -> Dict[str, np.ndarray]:
 
 
 class PerspectiveFields(nn.Module):
-    def __init__(self, version: str = "Paramnet-360Cities-edina-centered", weights=None):
+    def __init__(self, version: str = "Paramnet-360Cities-edina-centered", weights=None, precision: str = "fp32"):
         super().__init__()
+        # 'fp32' (default) is the parity mode: fp32-accurate contractions.  'bf16x3' / 'bf16' are faster reduced-precision
+        # modes of the dense contractions (Engine.set_precision); their outputs are not held to the parity tolerances.
+        self.precision = precision
         cfg = get_cfg(version)  # KeyError on an unknown version, as the reference (:127)
         self.version = version
         self.param_on = model_zoo[version]["param"]
@@ -128,6 +131,8 @@ class PerspectiveFields(nn.Module):
         if self._engine is None or self._engine.device != dev:
             eng = Engine(self.arch["arch_id"], dev)
             eng.load_state_dict(self._state)
+            if self.precision != "fp32":
+                eng.set_precision(self.precision)
             self._engine = eng
         return self._engine
 
