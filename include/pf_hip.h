@@ -137,6 +137,13 @@ int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n)
  * total number of records, fills at most max_records entries; mnk = GEMM view [M, N, K, KH] for class 0 */
 int pf_profile_records(pf_handle h, int max_records, int* cat, double* work, float* ms, int* mnk);
 
+/* Row N4: camera parameters -> perspective fields on the device, the step every demo of the reference runs
+ * right after inference (utils/utils.py:325-381 -> PanoCam.get_up_general / get_lat_general, utils/panocam.py:451-556).
+ * d_cam5 = {roll, pitch (= elevation), both in RADIANS, rel_focal, rel_cx, rel_cy} in device memory (so the ParamNet
+ * output can feed it without a host round trip); outputs in the layout of pred_gravity_original /
+ * pred_latitude_original: d_up [2][H][W] unit vectors, d_lat [H][W] degrees.  No handle: the op is stateless. */
+int pf_fields_from_params(int device, const float* d_cam5, int H, int W, float* d_up, float* d_lat, void* stream);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels pf_forward runs) ----
  * NHWC fp32 device activations; weights are HOST pointers in the reference's layouts.
  * "planes": the engine's internal split-bf16 activation format -- an fp32 tensor stored losslessly as three bf16

@@ -111,10 +111,41 @@ def run(tag, version, sizes, out_dir):
           {n: float(blob['params_0'][j]) for j, n in enumerate(names)} if names else "-")
 
 
+FIELD_CASES = [  # roll, pitch, vfov (deg), rel_cx, rel_cy, H, W
+    (12.5, -23.0, 62.0, 0.0, 0.0, 48, 64),
+    (-31.0, 41.5, 95.0, 0.07, -0.05, 40, 56),
+    (5.0, 0.0, 50.0, -0.1, 0.12, 36, 36),     # elevation == 0: constant up field branch
+    (0.0, 88.0, 30.0, 0.0, 0.0, 32, 48),      # vanishing point inside the image
+    (170.0, -5.0, 118.0, 0.2, 0.2, 33, 47),
+]
+
+
+def run_fields(out_dir):
+    """PanoCam.get_up_general / get_lat_general + general_vfov_to_focal of the unmodified reference
+    (the camera-parameters -> perspective-field step of utils/utils.py:325-381)."""
+    ref_shim.install()
+    from perspective2d.utils import general_vfov_to_focal
+    from perspective2d.utils.panocam import PanoCam
+
+    blob = {"cases": np.array(FIELD_CASES, dtype=np.float64)}
+    for i, (roll, pitch, vfov, cx, cy, h, w) in enumerate(FIELD_CASES):
+        h, w = int(h), int(w)
+        r, p_, v = np.radians(roll), np.radians(pitch), np.radians(vfov)
+        focal = general_vfov_to_focal(cx, cy, 1, v, False)
+        blob[f"focal_{i}"] = np.float64(focal)
+        blob[f"lat_{i}"] = PanoCam.get_lat_general(focal_rel=focal, im_w=w, im_h=h, elevation=p_, roll=r, cx_rel=cx, cy_rel=cy)
+        blob[f"up_{i}"] = PanoCam.get_up_general(focal_rel=focal, im_w=w, im_h=h, elevation=p_, roll=r, cx_rel=cx, cy_rel=cy)
+    path = os.path.join(out_dir, "fields_from_params.npz")
+    np.savez_compressed(path, **blob)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB")
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     only = sys.argv[1:]
+    if not only or "fields" in only:
+        run_fields(out_dir)
     for tag, (version, sizes) in CASES.items():
         if only and tag not in only:
             continue

@@ -275,6 +275,44 @@ def general_vfov_to_focal(rel_cx, rel_cy, gvfov_deg):
     return np.abs(scipy.optimize.fsolve(fun, np.ones(len(rel_cx)) * 1.5))
 
 
+def fields_from_params(roll, pitch, vfov, rel_cx, rel_cy, im_h, im_w, mode="deg"):
+    """Camera parameters -> (up field (im_h, im_w, 2), latitude map (im_h, im_w) in degrees): the step the reference's
+    demos run right after inference (utils/utils.py:325-381 draw_from_r_p_f_cx_cy -> general_vfov_to_focal(:47-91),
+    PanoCam.get_up_general (utils/panocam.py:451-512), PanoCam.get_lat_general (:514-556)), restated in float64 numpy.
+    Quirks kept: the up field is sampled at pixel centres (j + 0.5), the latitude map on np.linspace(-c, size - c, size)
+    (end points included, spacing size / (size - 1)); elevation == 0 gives a constant up field."""
+    if mode == "deg":
+        roll, pitch, vfov = np.radians(roll), np.radians(pitch), np.radians(vfov)
+    elif mode != "rad":
+        raise ValueError("Bad argument")
+    # general_vfov_to_focal(rel_cx, rel_cy, h=1, gvfov, degree=False): same equation as general_vfov_to_focal above
+    focal_rel = float(general_vfov_to_focal([rel_cx], [rel_cy], [np.degrees(vfov)])[0])
+    elevation = pitch
+    cx, cy = (rel_cx + 0.5) * im_w, (rel_cy + 0.5) * im_h
+    focal_length = focal_rel * im_h
+    # ---- get_up_general
+    X = (np.linspace((-0.5 * im_w) + 0.5, (0.5 * im_w) - 0.5, im_w).reshape(1, im_w).repeat(im_h, 0).astype(np.float32) + 0.5 * im_w)
+    Y = (np.linspace((-0.5 * im_h) + 0.5, (0.5 * im_h) - 0.5, im_h).reshape(im_h, 1).repeat(im_w, 1).astype(np.float32) + 0.5 * im_h)
+    xy_cam = np.stack([X, Y], axis=2)
+    if elevation == 0:
+        up = np.ones(xy_cam.shape) * np.array([[-np.sin(roll)], [-np.cos(roll)]]).reshape((1, 2))
+    else:
+        vvp = np.array([[(np.sin(roll) * np.cos(elevation) * focal_length) / -np.sin(elevation) + cx],
+                        [(np.cos(roll) * np.cos(elevation) * focal_length) / -np.sin(elevation) + cy]]).reshape((1, 2))
+        up = (vvp - xy_cam) * np.sign(elevation)
+    up = up / np.linalg.norm(up, axis=2)[:, :, None]
+    # ---- get_lat_general
+    dy = np.linspace((-im_h / 2) - (cy - (im_h / 2)), (im_h / 2) - (cy - (im_h / 2)), im_h)
+    dx = np.linspace((-im_w / 2) - (cx - (im_w / 2)), (im_w / 2) - (cx - (im_w / 2)), im_w)
+    x, y = np.meshgrid(dx, dy)
+    x, y = x.ravel() / focal_length, y.ravel() / focal_length
+    x_world = x * np.cos(roll) - y * np.sin(roll)
+    y_world = x * np.cos(elevation) * np.sin(roll) + y * np.cos(elevation) * np.cos(roll) - np.sin(elevation)
+    z_world = x * np.sin(elevation) * np.sin(roll) + y * np.sin(elevation) * np.cos(roll) + np.cos(elevation)
+    lat = -np.arctan2(y_world, np.sqrt(x_world ** 2 + z_world ** 2)) / np.pi * 180
+    return up, lat.reshape(im_h, im_w), focal_rel
+
+
 def param_net(w, pred_gravity, pred_latitude, arch):
     """ParamNet.forward (param_network.py:46-69) and ParamNetConvNextRegress.forward
     (param_network.py:193-221).  Input is the *normalised 320x320* up-vector and the

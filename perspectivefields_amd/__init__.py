@@ -8,7 +8,7 @@ Sub-modules: config (zoo / cfg), schema (checkpoint keys), synth (seeded checkpo
 engine (ctypes binding of libpf_hip.so), ops (kernel-level entry points), dist (image-level data
 parallelism), build (hipcc build of csrc/).
 """
-__all__ = ["PerspectiveFields", "model_zoo"]
+__all__ = ["PerspectiveFields", "model_zoo", "fields_from_params"]
 
 
 def __getattr__(name):  # lazy: keeps `import perspectivefields_amd.synth` free of torch
@@ -16,6 +16,10 @@ def __getattr__(name):  # lazy: keeps `import perspectivefields_amd.synth` free 
         from .perspectivefields import PerspectiveFields
 
         return PerspectiveFields
+    if name == "fields_from_params":
+        from .perspectivefields import fields_from_params
+
+        return fields_from_params
     if name == "model_zoo":
         from .config import model_zoo
 

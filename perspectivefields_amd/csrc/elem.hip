@@ -744,6 +744,43 @@ void launch_gap_ln_head(const float* x, const float* g, const float* b, const fl
   hipLaunchKernelGGL(gap_ln_head_kernel, dim3(B), dim3(256), 0, s, x, g, b, w, hb, out, HW, C, nout, eps);
 }
 
+// ------------------------------------------------------ camera parameters -> perspective fields
+// Reference: PanoCam.get_up_general / get_lat_general (utils/panocam.py:451-556), the step the demos run on the ParamNet
+// output (utils/utils.py:325-381).  cam = {roll, elevation (radians), focal_rel, cx_rel, cy_rel} on the device.
+// Quirks kept: up vectors at pixel centres (j + 0.5); latitude on linspace(-c, size - c, size) (end points included);
+// elevation == 0 -> constant up field.  Output layout matches pred_*_original: up [2][H][W], latitude [H][W] degrees.
+__global__ __launch_bounds__(256) void fields_from_params_kernel(const float* __restrict__ cam, int H, int W, float* __restrict__ up,
+                                                                 float* __restrict__ lat) {
+  const float roll = cam[0], el = cam[1], f = cam[2] * (float)H;
+  const float cx = (cam[3] + 0.5f) * (float)W, cy = (cam[4] + 0.5f) * (float)H;
+  float sr, cr, se, ce;
+  sincosf(roll, &sr, &cr);
+  sincosf(el, &se, &ce);
+  const float sx = W > 1 ? (float)W / (float)(W - 1) : 0.f, sy = H > 1 ? (float)H / (float)(H - 1) : 0.f;
+  const float vx = el != 0.f ? sr * ce * f / -se + cx : 0.f, vy = el != 0.f ? cr * ce * f / -se + cy : 0.f;
+  const float sgn = el > 0.f ? 1.f : -1.f;
+  const long n = (long)H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / W), col = (int)(i - (long)row * W);
+    float ux, uy;
+    if (el == 0.f) { ux = -sr; uy = -cr; }
+    else { ux = (vx - ((float)col + 0.5f)) * sgn; uy = (vy - ((float)row + 0.5f)) * sgn; }
+    const float inv = 1.0f / sqrtf(ux * ux + uy * uy);
+    up[i] = ux * inv;
+    up[n + i] = uy * inv;
+    const float x = (-cx + (float)col * sx) / f, y = (-cy + (float)row * sy) / f;
+    const float xw = x * cr - y * sr;
+    const float yw = x * ce * sr + y * ce * cr - se;
+    const float zw = x * se * sr + y * se * cr + ce;
+    lat[i] = -atan2f(yw, sqrtf(xw * xw + zw * zw)) * 57.29577951308232f;
+  }
+}
+void launch_fields_from_params(const float* cam5, int H, int W, float* up, float* lat, hipStream_t s) {
+  long blocks = ((long)H * W + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fields_from_params_kernel, dim3((unsigned)blocks), dim3(256), 0, s, cam5, H, W, up, lat);
+}
+
 // ------------------------------------------------------------------------- bit-exact PIL resize
 // Reference: ResizeTransform.apply_image -> PIL Image.resize(BILINEAR) on uint8 (perspectivefields.py:34-46,201).
 // Pillow's resample is a two-pass (horizontal, then vertical) antialiased triangle filter in 22-bit fixed point;

@@ -1066,6 +1066,16 @@ int pf_postprocess(pf_handle h, const float* pg, const float* pl, int H, int W, 
   return PF_OK;
 }
 
+int pf_fields_from_params(int device, const float* d_cam5, int H, int W, float* d_up, float* d_lat, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (!d_cam5 || !d_up || !d_lat || H <= 0 || W <= 0) { g_create_error = "pf_fields_from_params: bad argument"; return PF_ERR_ARG; }
+  launch_fields_from_params(d_cam5, H, W, d_up, d_lat, static_cast<hipStream_t>(stream));
+  if (hipGetLastError() != hipSuccess) { g_create_error = "pf_fields_from_params: kernel launch failed"; return PF_ERR_DEVICE; }
+  return PF_OK;
+}
+
 int pf_profile_begin(pf_handle h, unsigned class_mask) {
   if (!h) return PF_ERR_ARG;
   h->prof.reset();

@@ -131,6 +131,10 @@ void launch_nearest_nhwc4(const float* x, float* y, int B, int H, int W, int Ho,
 // ConvNeXt tail: global average pool -> LN(C) -> Linear(C->nout); out [B][nout]
 void launch_gap_ln_head(const float* x, const float* g, const float* b, const float* w, const float* hb, float* out, int B, int HW, int C, int nout, float eps, hipStream_t s);
 
+// camera parameters {roll, elevation (rad), focal_rel, cx_rel, cy_rel} (device) -> up [2][H][W], latitude [H][W] degrees
+// (PanoCam.get_up_general / get_lat_general, utils/panocam.py:451-556)
+void launch_fields_from_params(const float* cam5, int H, int W, float* up, float* lat, hipStream_t s);
+
 // ParamNet scalar formulas (param_network.py:62-67): raw [B][nraw] -> [B][8] (layout: include/pf_hip.h)
 void launch_paramnet_scalars(const float* raw, int nraw, float* out8, int B, int mode, hipStream_t s);
 

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "pf_is_tuned": (_c.c_int, [_P, _c.c_int]),
     "pf_set_precision": (_c.c_int, [_P, _c.c_int]),
     "pf_postprocess": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_fields_from_params": (_c.c_int, [_c.c_int, _P, _c.c_int, _c.c_int, _P, _P, _P]),
     "pf_profile_begin": (_c.c_int, [_P, _c.c_uint]),
     "pf_profile_end": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.c_int]),
     "pf_profile_records": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double), _c.POINTER(_c.c_float), _c.POINTER(_c.c_int)]),

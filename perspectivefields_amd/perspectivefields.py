@@ -160,6 +160,79 @@ class PerspectiveFields(nn.Module):
             batch = torch.from_numpy(np.stack(resized)).to(self.device, non_blocking=False)  # uint8 (B,320,320,3)
         return self._run(batch, sizes)
 
+    # ------------------------------------------------------------------ streaming
+    _HOST_KEYS = ("pred_gravity", "pred_gravity_original", "pred_latitude", "pred_latitude_original")
+
+    @torch.no_grad()
+    def inference_stream(self, batches, to_host: bool = True, depth: int = 2):
+        """Pipelined inference over an iterable of image lists: yields one `inference_batch`-style result list per input
+        batch, in order.  Three HIP streams overlap the stages of consecutive batches -- upload (pinned staging buffer,
+        async H2D), compute (forward + post-process), download -- because the reference's callers move the fields to the
+        host right after inference (demo/demo.py:55-58, 4.9 MB per 640x640 image).  With `to_host` the four field tensors
+        of every result are pinned CPU tensors (filled by async D2H; complete when the batch is yielded); the ParamNet
+        scalars stay 0-d device tensors as in `inference_batch`.  `depth` = batches in flight."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise PfError(f"PerspectiveFields is on '{dev}': the MI355X engine has no CPU path. Call .cuda() first.")
+        eng = self._get_engine()
+        s_up, s_comp, s_down = (torch.cuda.Stream(device=dev) for _ in range(3))
+        inflight = []
+
+        def finish(item):
+            item["done"].synchronize()
+            return item["results"]
+
+        for imgs in batches:
+            sizes, resized = [], []
+            for img_bgr in imgs:
+                original = img_bgr[:, :, ::-1] if self.input_format == "RGB" else img_bgr
+                if original.dtype != np.uint8:
+                    raise TypeError("PerspectiveFields expects uint8 BGR images (as cv2.imread returns)")
+                sizes.append(tuple(int(v) for v in original.shape[:2]))
+                resized.append(np.ascontiguousarray(original) if self.device_resize else self.aug.apply_image(np.ascontiguousarray(original)))
+            with torch.cuda.stream(s_up):
+                if self.device_resize:
+                    batch = torch.empty((len(resized), NET_H, NET_W, 3), dtype=torch.uint8, device=dev)
+                    staged = [torch.from_numpy(im).pin_memory().to(dev, non_blocking=True) for im in resized]
+                    for i, t in enumerate(staged):
+                        eng.resize_into(t, batch[i])
+                else:
+                    host = torch.from_numpy(np.stack(resized)).pin_memory()
+                    batch = host.to(dev, non_blocking=True)
+                up_done = torch.cuda.Event()
+                up_done.record(s_up)
+            batch.record_stream(s_comp)
+            s_comp.wait_event(up_done)
+            with torch.cuda.stream(s_comp):
+                results = self._run(batch, sizes)
+                comp_done = torch.cuda.Event()
+                comp_done.record(s_comp)
+            done = comp_done
+            if to_host:
+                s_down.wait_event(comp_done)
+                with torch.cuda.stream(s_down):
+                    for r in results:
+                        for k in self._HOST_KEYS:
+                            src = r[k]
+                            src.record_stream(s_down)
+                            dst = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+                            dst.copy_(src, non_blocking=True)
+                            r[k] = dst
+                    done = torch.cuda.Event()
+                    done.record(s_down)
+            inflight.append({"results": results, "done": done})
+            if len(inflight) >= max(1, depth):
+                yield finish(inflight.pop(0))
+        while inflight:
+            yield finish(inflight.pop(0))
+
+    def fields_from_prediction(self, pred: dict, height: int, width: int):
+        """Perspective fields implied by the ParamNet scalars of one inference() result (see fields_from_params)."""
+        if not self.param_on:
+            raise PfError(f"'{self.version}' has no ParamNet: there are no camera parameters to synthesise fields from")
+        return fields_from_params(pred["pred_roll"], pred["pred_pitch"], pred["pred_rel_focal"], pred["pred_rel_cx"], pred["pred_rel_cy"],
+                                  height, width, mode="deg")
+
     def forward(self, batched_inputs) -> List[dict]:
         """batched_inputs: list of {"image": (3,320,320) float BGR 0..255, "height", "width"} (reference :223-272)."""
         with torch.no_grad():
@@ -212,6 +285,43 @@ class PerspectiveFields(nn.Module):
                 ).astype(np.float32)
             )
         return [{k: v[i] for k, v in cols.items()} for i in range(B)]
+
+
+def fields_from_params(roll, pitch, rel_focal, rel_cx=0.0, rel_cy=0.0, height=None, width=None, mode="deg", device=None):
+    """Camera parameters -> (up field (2,H,W) unit vectors, latitude map (H,W) in degrees) on the GPU: the step the
+    reference's demos run right after inference (utils/utils.py:325-381 -> PanoCam.get_up_general / get_lat_general,
+    utils/panocam.py:451-556), e.g. to compare the ParamNet output with the predicted fields.  Same layout and units as
+    `pred_gravity_original` / `pred_latitude_original`.  Arguments may be Python floats or 0-d tensors (the `pred_*`
+    entries of an inference dict: they stay on the device, no host round trip); angles in degrees unless mode="rad"."""
+    import ctypes  # noqa: F401
+
+    from .engine import _check, _stream_ptr, load_library
+
+    if height is None or width is None:
+        raise ValueError("fields_from_params needs the output size (height, width)")
+    dev = None
+    for v in (roll, pitch, rel_focal, rel_cx, rel_cy):
+        if torch.is_tensor(v) and v.is_cuda:
+            dev = v.device
+    if dev is None:
+        dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda":
+        raise PfError("fields_from_params runs on the GPU only (no CPU path)")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    t = [torch.as_tensor(v, dtype=torch.float64).to(dev).reshape(()) for v in (roll, pitch, rel_focal, rel_cx, rel_cy)]
+    if mode == "deg":
+        t[0], t[1] = torch.deg2rad(t[0]), torch.deg2rad(t[1])
+    elif mode != "rad":
+        raise ValueError("mode must be 'deg' or 'rad'")
+    cam = torch.stack(t).to(torch.float32).contiguous()
+    up = torch.empty((2, int(height), int(width)), dtype=torch.float32, device=dev)
+    lat = torch.empty((int(height), int(width)), dtype=torch.float32, device=dev)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        _check(lib.pf_fields_from_params(dev.index, cam.data_ptr(), int(height), int(width), up.data_ptr(), lat.data_ptr(), _stream_ptr()),
+               None, "pf_fields_from_params")
+    return up, lat
 
 
 def general_vfov_to_focal(rel_cx, rel_cy, gvfov_deg):

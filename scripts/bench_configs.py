@@ -16,7 +16,7 @@ def timed(fn, warm=2, iters=8):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters
 
 out = []
-# ---- configs[1]
+# ---- configs[1]: fp32-accurate (parity mode) and the reduced-precision modes, with argmax agreement against the parity mode
 m = PerspectiveFields("PersNet-360Cities", weights="synthetic:0").eval().cuda()
 eng = m._get_engine()
 B = 8
@@ -24,10 +24,32 @@ x = torch.from_numpy(np.stack([m.aug.apply_image(synthetic_image(640, 640, 100 +
 def step1():
     pg, pl, _ = eng.forward(x)
     return [eng.postprocess(pg[i], pl[i], 640, 640) for i in range(B)]
-dt = timed(step1)
-out.append({"config": "configs[1]: batch 8, 640x640, PersNet-360Cities (73/180-way logits + argmax decode), fp32-accurate arithmetic",
-            "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 2),
-            "note": "the engine has one precision mode (fp32 accumulate; split-bf16 MFMA is fp32-accurate); a reduced-precision bf16 mode is not implemented"})
+ref = None
+modes = {}
+for prec in ("fp32", "bf16x3", "bf16"):
+    eng.set_precision(prec)
+    dt = timed(step1)
+    pg, pl, _ = eng.forward(x)
+    fields = [eng.postprocess(pg[i], pl[i], 640, 640) for i in range(B)]
+    am_g, am_l = pg.argmax(1), pl.argmax(1)
+    entry = {"images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 2)}
+    if ref is None:
+        ref = (am_g, am_l, fields)
+    else:
+        up_ref = torch.stack([f[0] for f in ref[2]]); up = torch.stack([f[0] for f in fields])
+        lat_ref = torch.stack([f[1] for f in ref[2]]); lat = torch.stack([f[1] for f in fields])
+        entry.update({
+            "argmax_agreement_gravity": round(float((am_g == ref[0]).float().mean()), 6),
+            "argmax_agreement_latitude": round(float((am_l == ref[1]).float().mean()), 6),
+            "decoded_up_mean_1_minus_cos": float((1 - (up * up_ref).sum(1)).mean()),
+            "decoded_latitude_mean_abs_deg": float((lat - lat_ref).abs().mean()),
+        })
+    modes[prec] = entry
+eng.set_precision("fp32")
+out.append({"config": "configs[1]: batch 8, 640x640, PersNet-360Cities (73/180-way logits + argmax decode)",
+            "images_per_sec": modes["fp32"]["images_per_sec"], "ms_per_step": modes["fp32"]["ms_per_step"], "precision_modes": modes,
+            "note": "headline = fp32-accurate contractions (the parity mode); bf16x3 / bf16 are the optional reduced-precision modes "
+                    "(pf_set_precision), compared here against the parity mode on the same inputs"})
 del m, eng
 # ---- configs[4]
 m = PerspectiveFields("Paramnet-360Cities-edina-centered", weights="synthetic:0").eval().cuda()

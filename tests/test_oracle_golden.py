@@ -94,3 +94,21 @@ def test_output_keys_centered(golden_dir):
     version = CASES["centered"]
     arch = arch_of(get_cfg(version))
     assert arch["param_net"] == "ParamNet" and arch["param_out"] == 5
+
+
+def test_fields_from_params_restatement_matches_reference(golden_dir):
+    """oracle.fields_from_params vs PanoCam.get_up_general / get_lat_general + general_vfov_to_focal of the unmodified
+    reference (fixture: oracle/gen_golden.py run_fields)."""
+    import os
+
+    import numpy as np
+
+    from oracle import pf_oracle
+
+    g = np.load(os.path.join(golden_dir, "fields_from_params.npz"))
+    for i, (roll, pitch, vfov, cx, cy, h, w) in enumerate(g["cases"]):
+        up, lat, focal = pf_oracle.fields_from_params(roll, pitch, vfov, cx, cy, int(h), int(w), "deg")
+        assert abs(focal - float(g[f"focal_{i}"])) <= 1e-9 * max(1.0, abs(focal)), (i, focal, float(g[f"focal_{i}"]))
+        assert up.shape == g[f"up_{i}"].shape == (int(h), int(w), 2)
+        np.testing.assert_allclose(up, g[f"up_{i}"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(lat, g[f"lat_{i}"], rtol=0, atol=1e-7)
