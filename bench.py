@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=640, help="original image height = width")
     ap.add_argument("--version", default="Paramnet-360Cities-edina-centered")
+    ap.add_argument("--precision", default=os.environ.get("PF_PRECISION", "fp32"), choices=["fp32", "bf16x3", "bf16"],
+                    help="arithmetic of the dense contractions; fp32 (fp32-accurate) is the parity mode and the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--events-in-timed", type=int, default=1, help="bracket the dominant kernel with HIP events inside the timed region")
@@ -112,7 +114,8 @@ def main():
     from perspectivefields_amd.dist import gather_params
     from perspectivefields_amd.synth import synthetic_image
 
-    model = PerspectiveFields(args.version, weights="synthetic:0").eval().to(dev)
+    precision = args.precision
+    model = PerspectiveFields(args.version, weights="synthetic:0", precision=precision).eval().to(dev)
     B, S = args.batch, args.size
     # per-rank shard of the global batch: synthetic images, host resize (outside the timed region)
     imgs = [synthetic_image(S, S, seed=1000 + rank * B + i) for i in range(min(B, 4))]
@@ -142,7 +145,7 @@ def main():
     barrier()
     use_events = bool(args.events_in_timed) and not args.no_roofline
     if use_events:
-        eng.profile_begin(classes=("igemm", "igemm_sb", "dwconv3x3_gelu"))
+        eng.profile_begin(classes=("igemm", "igemm_sb", "dwconv3x3_gelu", "dwconv7x7", "upsample2x"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -177,7 +180,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if precision == "fp32" else precision,
         "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[2]: batch {B}/GPU {S}x{S} {args.version}, fields + ParamNet, 320x320 network inputs resident in HBM, post-process to {S}x{S}",
@@ -203,10 +206,12 @@ def main():
 
         objs = []
         if sb["ms"] > 0:
+            nt = {"fp32": 6, "bf16x3": 3, "bf16": 1}[precision]
             objs.append((sb["ms"], mfma_obj(
-                sb, "pf::igemm_sb_kernel (implicit-GEMM conv/GEMM, fp32-accurate split-bf16: 6 x v_mfma_f32_32x32x16_bf16 per product)",
-                BF16_MFMA_PEAK_TFLOPS, "achieved = algorithmic fp32 FLOPs (2*M*N*K) / time, priced against the DENSE bf16 MFMA peak; the kernel "
-                "executes 6 bf16 MFMA FLOPs per algorithmic FLOP (executed_mfma_tflops), i.e. its ceiling is 2500/6 = 416.7 TFLOP/s", 6.0)))
+                sb, f"pf::igemm_sb_kernel (implicit-GEMM conv/GEMM, split-bf16: {nt} x v_mfma_f32_32x32x16_bf16 per product"
+                + (", fp32-accurate)" if nt == 6 else ", reduced precision)"),
+                BF16_MFMA_PEAK_TFLOPS, "achieved = algorithmic FLOPs (2*M*N*K) / time, priced against the DENSE bf16 MFMA peak; the kernel "
+                f"executes {nt} bf16 MFMA FLOPs per algorithmic FLOP (executed_mfma_tflops), i.e. its ceiling is 2500/{nt} = {2500.0 / nt:.1f} TFLOP/s", float(nt))))
         if ig["ms"] > 0:
             objs.append((ig["ms"], mfma_obj(
                 ig, "pf::igemm_kernel (implicit-GEMM conv/GEMM, exact fp32: v_mfma_f32_32x32x2_f32)",
@@ -223,14 +228,19 @@ def main():
             line["implicit_gemm_all"] = {"achieved_tflops_fp32_equiv": round(tot_work / (tot_ms * 1e-3) / 1e12, 2),
                                          "vs_fp32_mfma_peak": round(tot_work / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                          "share_of_step_time": round(tot_ms / (1000.0 * dt), 4)}
-        dw = prof["dwconv3x3_gelu"]
-        if dw["ms"] > 0:
-            gbps = dw["work"] / (dw["ms"] * 1e-3) / 1e9
-            line["roofline_dwconv3x3"] = {
-                "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
-                "traffic": None, "kernel": "pf::dwconv3x3_gelu_kernel", "launches_per_step": dw["launches"] // args.steps,
-                "algorithmic_mb_per_step": round(dw["work"] / args.steps / 1e6, 1),
-            }
+        # HBM-bound classes (north_star: ">= 60 % of the HBM roofline on the depthwise stages"): algorithmic bytes / event time
+        for cls, key, kernel in (("dwconv3x3_gelu", "roofline_dwconv3x3", "pf::dwconv3x3_gelu_direct_kernel"),
+                                 ("dwconv7x7", "roofline_dwconv7x7", "pf::dwconv7x7_lane_kernel"),
+                                 ("layernorm", "roofline_layernorm", "pf::layernorm_kernel"),
+                                 ("upsample2x", "roofline_upsample2x", "pf::upsample2x_cell_kernel")):
+            dw = prof[cls]
+            if dw["ms"] > 0:
+                gbps = dw["work"] / (dw["ms"] * 1e-3) / 1e9
+                line[key] = {
+                    "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                    "traffic": None, "kernel": kernel, "launches_per_step": dw["launches"] // args.steps,
+                    "algorithmic_mb_per_step": round(dw["work"] / args.steps / 1e6, 1), "ms_per_step": round(dw["ms"] / args.steps, 3),
+                }
         line["achieved_tflops_ref_graph"] = round(value / world * GFLOP_PER_IMAGE_REF / 1e3, 2)
     line["host_resize_ms_per_image"] = round(1000.0 * t_resize, 3)
     if world == 1 and not args.no_cpu_baseline:
