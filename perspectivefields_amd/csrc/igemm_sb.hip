@@ -6,7 +6,10 @@ namespace pf {
 
 // ---------------------------------------------------------------------------------------
 struct SbCfg { int bm, bn, pfd; const char* name; };
-// "f2"/"f3" = register prefetch ring 2 / 3 K steps deep (small tiles: latency-bound K loops)
+// "f2"/"f3" = register prefetch ring 2 / 3 K steps deep (small tiles: latency-bound K loops).
+// (A software-pipelined variant -- K step 16, two LDS buffers, the next tile's split + LDS stores interleaved with this
+// tile's MFMAs in the same wave -- was built and measured 10-30 % SLOWER on every shape, profiles/r01_tune_conv_sbd_negative.txt:
+// twice the barriers and fragment-read latencies per K, while the 2-3 co-resident blocks already overlap the phases.)
 static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, {128, 64, 1, "sb128x64"}, {256, 128, 1, "sb256x128w8"},
                              {128, 256, 1, "sb128x256w8"}, {128, 32, 1, "sb128x32"}, {256, 256, 1, "sb256x256w8"},
                              {64, 64, 2, "sb64x64f2"}, {64, 64, 3, "sb64x64f3"}, {128, 64, 2, "sb128x64f2"}, {128, 32, 2, "sb128x32f2"},
@@ -39,6 +42,8 @@ int conv_sb_default_tile(const ConvParams& p) {
 
 void launch_conv_sb3(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb3.hip
 void launch_conv_sb1(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb1.hip
+
+bool conv_sb_tile_ok(const ConvParams&, int) { return true; }  // hook for tiles with operand-format restrictions (none today)
 
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
   if (p.nterms == 3) launch_conv_sb3(p, sb_tile, s);

@@ -77,6 +77,7 @@ const char* conv_sb_tile_name(int id);
 int conv_sb_tile_bm(int id);
 int conv_sb_tile_bn(int id);
 bool conv_sb_eligible(const ConvParams& p);
+bool conv_sb_tile_ok(const ConvParams& p, int sb_tile);  // per-tile restrictions (the pipelined "sbd" tiles: fp32 operands, fp32-accurate mode)
 int conv_sb_default_tile(const ConvParams& p);
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s);
 const char* conv_tile_name(int tile_id);
