@@ -871,7 +871,7 @@ struct TmpDev {  // test-entry-point helper: upload host weights, free on scope 
     if (!h) return nullptr;
     void* d = nullptr;
     if (hipMalloc(&d, n * 4) != hipSuccess) return nullptr;
-    hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice);
     p.push_back(d);
     return static_cast<float*>(d);
   }
@@ -883,7 +883,7 @@ struct TmpDev {  // test-entry-point helper: upload host weights, free on scope 
     p.push_back(d);
     return static_cast<unsigned short*>(d);
   }
-  void sync_free(hipStream_t s) { hipStreamSynchronize(s); for (void* d : p) hipFree(d); p.clear(); }
+  void sync_free(hipStream_t s) { (void)hipStreamSynchronize(s); for (void* d : p) (void)hipFree(d); p.clear(); }
 };
 }  // namespace
 
@@ -923,7 +923,7 @@ int pf_set_precision(pf_handle h, int mode) {
 
 int pf_destroy(pf_handle h) {
   if (!h) return PF_ERR_ARG;
-  hipSetDevice(h->device);
+  (void)hipSetDevice(h->device);
   for (void* d : h->dev_allocs) (void)hipFree(d);
   delete h;
   return PF_OK;

@@ -11,7 +11,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int BK = 32;            // K step in elements
 static constexpr unsigned OOB = 0x80000000u;  // beyond any buffer (< 2 GiB): hardware range check returns 0
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// erf-GELU, branch-free: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32; in fp32 as close to
+// the exact GELU as the libm erff form (max |error| 4.6e-7 vs 4.5e-7 on [-12, 12]) at less than half the instructions
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(x * x * -1.4426950408889634f);
+  return 0.5f * v * (1.0f + copysignf(fmaf(-p, e, 1.0f), v));
+}
 
 __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);

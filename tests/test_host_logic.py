@@ -233,3 +233,28 @@ def test_pil_resize_algorithm_restatement():
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         got = one_pass(one_pass(img, 320).transpose(1, 0, 2), 320).transpose(1, 0, 2)
         assert np.array_equal(got, np.asarray(Image.fromarray(img).resize((320, 320), Image.BILINEAR)))
+
+
+def test_branch_free_gelu_is_fp32_accurate():
+    """The kernels' erf-GELU (csrc/igemm_common.h gelu_erf, csrc/elem.hip gelu_fast): erf by Abramowitz-Stegun 7.1.26 on
+    rcp / exp2, emulated here in float32.  It must be as close to the exact GELU as the float32 libm-erf form the reference
+    effectively runs (torch GELU in fp32)."""
+    import numpy as np
+    from scipy.special import erf
+
+    f = np.float32
+    v = np.linspace(-12, 12, 400001).astype(f)
+    x = np.abs(v) * f(0.70710678118654752440)
+    t = (f(1.0) / (f(0.3275911) * x + f(1.0))).astype(f)
+    p = (f(1.061405429) * t + f(-1.453152027)).astype(f)
+    for c in (1.421413741, -0.284496736, 0.254829592):
+        p = (p * t + f(c)).astype(f)
+    p = (p * t).astype(f)
+    e = np.exp2((x * x * f(-1.4426950408889634)).astype(f)).astype(f)
+    er = np.copysign((f(1.0) - p * e).astype(f), v)
+    fast = (f(0.5) * v * (f(1.0) + er)).astype(f)
+    exact = 0.5 * v.astype(np.float64) * (1.0 + erf(v.astype(np.float64) / np.sqrt(2.0)))
+    libm32 = (f(0.5) * v * (f(1.0) + erf(v * f(0.70710678118654752440)).astype(f))).astype(f)
+    err_fast, err_libm = np.abs(fast - exact).max(), np.abs(libm32 - exact).max()
+    assert err_fast <= 6e-7, err_fast
+    assert err_fast <= 1.5 * err_libm + 1e-7, (err_fast, err_libm)
