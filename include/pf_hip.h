@@ -132,6 +132,8 @@ int pf_postprocess(pf_handle h, const float* d_pred_gravity, const float* d_pred
  * event pair; pf_profile_end synchronises those events and sums elapsed ms / work / launches per class. */
 #define PF_PROFILE_CLASSES 8
 int pf_profile_begin(pf_handle h, unsigned class_mask);
+/* stop bracketing further launches without synchronising (the window can cover the first steps of a timed loop only) */
+int pf_profile_pause(pf_handle h);
 int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n);
 /* per-launch records of the last begin/end window (valid until the next pf_profile_begin); returns the
  * total number of records, fills at most max_records entries; mnk = GEMM view [M, N, K, KH] for class 0 */

@@ -569,14 +569,19 @@ struct pf_engine {
       if (!conv_tile_usable(p, t)) continue;
       if (conv_tile_bn(t) > 32 && p.Cout <= 32) continue;
       if ((long)conv_tile_bm(t) * conv_tile_bn(t) > 16L * p.M * p.Cout) continue;  // tile far larger than the problem
-      launch_conv_tile(p, t, c.s);
-      (void)hipEventRecord(a, c.s);
-      launch_conv_tile(p, t, c.s);
-      launch_conv_tile(p, t, c.s);
-      (void)hipEventRecord(b, c.s);
-      if (hipEventSynchronize(b) != hipSuccess) break;
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, a, b);
+      launch_conv_tile(p, t, c.s);  // warm-up (instruction cache, L2 state)
+      float ms = 1e30f;
+      bool ok = true;
+      for (int rep = 0; rep < 2 && ok; ++rep) {  // best of two windows of two launches: one noisy window must not pick the tile
+        (void)hipEventRecord(a, c.s);
+        launch_conv_tile(p, t, c.s);
+        launch_conv_tile(p, t, c.s);
+        (void)hipEventRecord(b, c.s);
+        ok = hipEventSynchronize(b) == hipSuccess;
+        float w = 0.f;
+        if (ok) { (void)hipEventElapsedTime(&w, a, b); ms = std::min(ms, w); }
+      }
+      if (!ok) break;
       if (ms < best_ms) { best_ms = ms; best = t; }
     }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
@@ -1081,6 +1086,12 @@ int pf_profile_begin(pf_handle h, unsigned class_mask) {
   h->prof.reset();
   h->prof.mask = class_mask;
   h->prof.on = true;
+  return PF_OK;
+}
+
+int pf_profile_pause(pf_handle h) {
+  if (!h) return PF_ERR_ARG;
+  h->prof.on = false;  // no host synchronisation: the recorded events stay pending until pf_profile_end
   return PF_OK;
 }
 

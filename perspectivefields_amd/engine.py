@@ -42,6 +42,7 @@ _SIGNATURES = {
     "pf_postprocess": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
     "pf_fields_from_params": (_c.c_int, [_c.c_int, _P, _c.c_int, _c.c_int, _P, _P, _P]),
     "pf_profile_begin": (_c.c_int, [_P, _c.c_uint]),
+    "pf_profile_pause": (_c.c_int, [_P]),
     "pf_profile_end": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.c_int]),
     "pf_profile_records": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double), _c.POINTER(_c.c_float), _c.POINTER(_c.c_int)]),
     "pf_op_conv2d": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P,
@@ -250,6 +251,10 @@ class Engine:
             if classes is None or n in classes:
                 mask |= 1 << i
         _check(self.lib.pf_profile_begin(self._h, mask), self._h, "pf_profile_begin")
+
+    def profile_pause(self):
+        """Stop bracketing launches; no synchronisation (records are read by profile_end)."""
+        _check(self.lib.pf_profile_pause(self._h), self._h, "pf_profile_pause")
 
     def profile_end(self) -> Dict[str, dict]:
         n = len(self.PROFILE_CLASSES)

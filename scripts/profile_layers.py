@@ -32,9 +32,9 @@ for mnk, (n, ms, work) in sorted(g.items(), key=lambda kv: -kv[1][1]):
 # HBM-bound classes grouped by launch size (algorithmic bytes per launch)
 h = collections.OrderedDict()
 for cls, work, ms, mnk in recs:
-    if cls in ("igemm", "igemm_sb", "attention"): continue
+    if cls in ("igemm", "igemm_sb"): continue
     e = h.setdefault((cls, int(work)), [0, 0.0]); e[0] += 1; e[1] += ms
-lines.append("elementwise by launch size: class, MB per launch, launches, avg us, GB/s")
+lines.append("other classes by launch size: class, MB (attention: MFLOP) per launch, launches, avg us, GB/s (attention: GFLOP/s)")
 for (cls, work), (n, ms) in sorted(h.items(), key=lambda kv: (kv[0][0], -kv[0][1])):
     lines.append(f"  {cls:16s} {work/1e6:9.1f} MB x{n:3d}  {1e3*ms/n:8.1f} us  {work*n/(ms*1e-3)/1e9:8.1f} GB/s")
 open(a.out, "w").write("\n".join(lines) + "\n"); print("\n".join(lines))
