@@ -177,6 +177,10 @@ class PerspectiveFields(nn.Module):
         eng = self._get_engine()
         s_up, s_comp, s_down = (torch.cuda.Stream(device=dev) for _ in range(3))
         inflight = []
+        # pinned upload staging: a ring of depth + 1 reusable buffers (a slot is rewritten only after its copy has completed)
+        nslots = max(1, depth) + 1
+        slots = [{"buf": None, "done": None} for _ in range(nslots)]
+        nbatch = 0
 
         def finish(item):
             item["done"].synchronize()
@@ -190,17 +194,31 @@ class PerspectiveFields(nn.Module):
                     raise TypeError("PerspectiveFields expects uint8 BGR images (as cv2.imread returns)")
                 sizes.append(tuple(int(v) for v in original.shape[:2]))
                 resized.append(np.ascontiguousarray(original) if self.device_resize else self.aug.apply_image(np.ascontiguousarray(original)))
+            slot = slots[nbatch % nslots]
+            nbatch += 1
+            if slot["done"] is not None:
+                slot["done"].synchronize()
+            nbytes = sum(int(im.size) for im in resized)
+            if slot["buf"] is None or slot["buf"].numel() < nbytes:
+                slot["buf"] = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+            host = slot["buf"]
+            host_np = host.numpy()  # shares the pinned memory
+            offs, o = [], 0
+            for im in resized:
+                np.copyto(host_np[o:o + im.size], im.reshape(-1))
+                offs.append(o)
+                o += int(im.size)
             with torch.cuda.stream(s_up):
+                dev_in = host[:nbytes].to(dev, non_blocking=True)  # one H2D per batch
                 if self.device_resize:
                     batch = torch.empty((len(resized), NET_H, NET_W, 3), dtype=torch.uint8, device=dev)
-                    staged = [torch.from_numpy(im).pin_memory().to(dev, non_blocking=True) for im in resized]
-                    for i, t in enumerate(staged):
-                        eng.resize_into(t, batch[i])
+                    for i, im in enumerate(resized):
+                        eng.resize_into(dev_in[offs[i]:offs[i] + im.size].view(im.shape), batch[i])
                 else:
-                    host = torch.from_numpy(np.stack(resized)).pin_memory()
-                    batch = host.to(dev, non_blocking=True)
+                    batch = dev_in.view(len(resized), NET_H, NET_W, 3)
                 up_done = torch.cuda.Event()
                 up_done.record(s_up)
+            slot["done"] = up_done
             batch.record_stream(s_comp)
             s_comp.wait_event(up_done)
             with torch.cuda.stream(s_comp):
@@ -210,14 +228,18 @@ class PerspectiveFields(nn.Module):
             done = comp_done
             if to_host:
                 s_down.wait_event(comp_done)
+                total = sum(r[k].numel() for r in results for k in self._HOST_KEYS)
+                pinned = torch.empty(total, dtype=torch.float32, pin_memory=True)  # one pinned block per batch, sliced into views
                 with torch.cuda.stream(s_down):
+                    o = 0
                     for r in results:
                         for k in self._HOST_KEYS:
                             src = r[k]
                             src.record_stream(s_down)
-                            dst = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+                            dst = pinned[o:o + src.numel()].view(src.shape)
                             dst.copy_(src, non_blocking=True)
                             r[k] = dst
+                            o += src.numel()
                     done = torch.cuda.Event()
                     done.record(s_down)
             inflight.append({"results": results, "done": done})
