@@ -43,7 +43,8 @@ template <> struct LaneVec<2> {
   }
 };
 
-template <int CPL /*channels per lane*/, int NB /*row buffers: loads run NB - 1 rows ahead*/, int MAXT /*max threads per block*/>
+template <int CPL /*channels per lane*/, int NB /*row buffers: loads run NB - 1 rows ahead*/, int MAXT /*max threads per block*/,
+          int DIAG = 0 /*diagnostics: 1 = no stores, 2 = no loads*/>
 __global__ __launch_bounds__(MAXT) void dwconv7x7_lane_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 int B, int H, int W, int C, int TH, int XB /*columns per block*/, int CPB /*channels per block*/) {
@@ -92,11 +93,12 @@ __global__ __launch_bounds__(MAXT) void dwconv7x7_lane_kernel(const float* __res
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(xb, 0, ok ? img_bytes : 0u, 0x00020000);
     const unsigned soff = ok ? (unsigned)iy * row_bytes : 0u;
 #pragma unroll
-    for (int kx = 0; kx < 7; ++kx) v[kx] = V::load(r, voff[kx], soff);
+    for (int kx = 0; kx < 7; ++kx) v[kx] = DIAG == 2 ? bv : V::load(r, voff[kx], soff);
   };
   // relative row index tt: input row iy = y0 - 3 + tt, tt in [0, nrows); it feeds output rows oy = iy - ky + 3, whose
   // accumulator slot is (tt - ky + 3) mod 7; after row tt the output row iy - 3 (slot (tt + 4) mod 7) is complete.
   // r = tt mod (7 NB) is a compile-time constant in the unrolled bodies: ring slot and row buffer are fixed registers.
+  const int nrows = (y1 - y0) + 6;
   auto do_row = [&](int tt, int r) {
     const int iy = y0 - 3 + tt;
     load_row(iy + NB - 1, in[(r + NB - 1) % NB]);  // prefetch; rows past the strip are loaded but never used
@@ -112,10 +114,10 @@ __global__ __launch_bounds__(MAXT) void dwconv7x7_lane_kernel(const float* __res
     const int oy = iy - 3;  // < y1 always (tt < nrows)
     const bool st_ok = oy >= y0;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yb, 0, st_ok ? img_bytes : 0u, 0x00020000);
-    V::store(acc[(r + 4) % 7], ry, voff_out, st_ok ? (unsigned)oy * row_bytes : 0u);
+    if (DIAG != 1) V::store(acc[(r + 4) % 7], ry, voff_out, st_ok ? (unsigned)oy * row_bytes : 0u);
+    else if (tt == nrows - 1) V::store(acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6], ry, voff_out, 0u);  // keep the arithmetic alive
     acc[(r + 4) % 7] = bv;
   };
-  const int nrows = (y1 - y0) + 6;
 #pragma unroll
   for (int d = 0; d < NB - 1; ++d) load_row(y0 - 3 + d, in[d]);
   int t0 = 0;
@@ -144,7 +146,11 @@ static void launch_lane(const float* x, const float* w49c, const float* bias, fl
   int TH = th_env > 0 ? th_env : H;
   if (th_env <= 0) while (TH > 20 && per_strip * ((H + TH - 1) / TH) < 768) TH = (TH + 1) / 2;
   const long blocks = (long)B * ((H + TH - 1) / TH) * ((W + XB - 1) / XB) * (C / CPB);
-  if (threads <= 256) hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
+  static int diag = -1;
+  if (diag < 0) { const char* d = getenv("PF_DW7_DIAG"); diag = d ? atoi(d) : 0; }
+  if (diag == 1 && threads <= 256)      hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256, 1>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
+  else if (diag == 2 && threads <= 256) hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256, 2>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
+  else if (threads <= 256) hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
   else                hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 1024>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
 }
 
