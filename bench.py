@@ -137,7 +137,7 @@ def main():
 
     def step():
         pg, pl, params = eng.forward(batch)
-        outs = [eng.postprocess(pg[i], pl[i], h, w) for i, (h, w) in enumerate(sizes)]
+        outs = eng.postprocess_batch(pg, pl, sizes)
         allp = gather_params(params) if (params is not None and world > 1) else params
         return pg, pl, outs, allp
 

@@ -139,6 +139,12 @@ int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n)
  * total number of records, fills at most max_records entries; mnk = GEMM view [M, N, K, KH] for class 0 */
 int pf_profile_records(pf_handle h, int max_records, int* cat, double* work, float* ms, int* mnk);
 
+/* The same for a whole batch in one launch per 32 images (the reference's per-image Python loop,
+ * gravity_head.py:244-260 / latitude_head.py:201-218): h_hw = HOST array [B][2] of (H, W); h_up_out / h_lat_out = HOST
+ * arrays of B DEVICE pointers ([2][H][W] and [H][W] each).  Classification arch: workspace of B*3*320*320 floats. */
+int pf_postprocess_batch(pf_handle h, int batch, const float* d_pred_gravity, const float* d_pred_latitude, const int32_t* h_hw,
+                         float* const* h_up_out, float* const* h_lat_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Row N4: camera parameters -> perspective fields on the device, the step every demo of the reference runs
  * right after inference (utils/utils.py:325-381 -> PanoCam.get_up_general / get_lat_general, utils/panocam.py:451-556).
  * d_cam5 = {roll, pitch (= elevation), both in RADIANS, rel_focal, rel_cx, rel_cy} in device memory (so the ParamNet

@@ -3,6 +3,8 @@
 // post-process, input normalisation, ConvNeXt tail.  All NHWC fp32, 16-byte accesses.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "pf_kernels.h"
 #include "sb_split.h"
 
@@ -681,9 +683,9 @@ void launch_decode_cls(const float* logit_g, int ng, const float* logit_l, int n
 // (latitude_head.py:195-219), pf_postprocess (utils/utils.py:483-507): bilinear (align_corners
 // False, scale = in/out in fp32) of the (2,h,w)*[W/w, H/h] field then L2-normalise; latitude:
 // bilinear then asin -> degrees (regression) or degrees directly (classification).
-__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ g2, const float* __restrict__ l1, int h, int w,
-                                                          float* __restrict__ up, float* __restrict__ lat, int H, int W,
-                                                          float sx_scale, float sy_scale, float rh, float rw, int lat_is_sin) {
+__device__ __forceinline__ void postprocess_pixels(const float* __restrict__ g2, const float* __restrict__ l1, int h, int w,
+                                                   float* __restrict__ up, float* __restrict__ lat, int H, int W,
+                                                   float sx_scale, float sy_scale, float rh, float rw, int lat_is_sin) {
   const long total = (long)H * W;
   const long hw = (long)h * w;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -708,10 +710,32 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
     lat[i] = lv;
   }
 }
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ g2, const float* __restrict__ l1, int h, int w,
+                                                          float* __restrict__ up, float* __restrict__ lat, int H, int W,
+                                                          float sx_scale, float sy_scale, float rh, float rw, int lat_is_sin) {
+  postprocess_pixels(g2, l1, h, w, up, lat, H, W, sx_scale, sy_scale, rh, rw, lat_is_sin);
+}
+// the reference's per-image Python loop (gravity_head.py:244-260) as ONE launch: blockIdx.y = image, per-image sizes and
+// output pointers travel in the kernel arguments
+__global__ __launch_bounds__(256) void postprocess_batch_kernel(const PostBatch pb, int h, int w, int lat_is_sin) {
+  const int k = blockIdx.y;
+  postprocess_pixels(pb.g2[k], pb.l1[k], h, w, pb.up[k], pb.lat[k], pb.H[k], pb.W[k], pb.sxs[k], pb.sys[k], pb.rh[k], pb.rw[k], lat_is_sin);
+}
 void launch_postprocess(const float* g2, const float* l1, int h, int w, float* up_out, float* lat_out, int H, int W, int lat_is_sin, hipStream_t s) {
   const float rh = (float)h / (float)H, rw = (float)w / (float)W;  // area_pixel_compute_scale, fp32
   const float sxs = (float)((double)W / (double)w), sys = (float)((double)H / (double)h);  // python float -> float32 tensor
   hipLaunchKernelGGL(postprocess_kernel, dim3(grid_for((long)H * W)), dim3(256), 0, s, g2, l1, h, w, up_out, lat_out, H, W, sxs, sys, rh, rw, lat_is_sin);
+}
+void launch_postprocess_batch(PostBatch& pb, int h, int w, int lat_is_sin, hipStream_t s) {
+  long mx = 1;
+  for (int k = 0; k < pb.n; ++k) {
+    const int H = pb.H[k], W = pb.W[k];
+    pb.rh[k] = (float)h / (float)H; pb.rw[k] = (float)w / (float)W;
+    pb.sxs[k] = (float)((double)W / (double)w); pb.sys[k] = (float)((double)H / (double)h);
+    mx = std::max(mx, (long)H * W);
+  }
+  unsigned gx = (unsigned)std::min<long>((mx + 255) / 256, 2048);
+  hipLaunchKernelGGL(postprocess_batch_kernel, dim3(gx, pb.n), dim3(256), 0, s, pb, h, w, lat_is_sin);
 }
 
 // --------------------------------------------------------------------------- nearest resize

@@ -1071,6 +1071,41 @@ int pf_postprocess(pf_handle h, const float* pg, const float* pl, int H, int W, 
   return PF_OK;
 }
 
+int pf_postprocess_batch(pf_handle h, int B, const float* pg, const float* pl, const int32_t* hw, float* const* up, float* const* lat,
+                         void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return PF_ERR_ARG;
+  if (B <= 0 || !pg || !pl || !hw || !up || !lat) return h->fail(PF_ERR_ARG, "pf_postprocess_batch: bad argument");
+  for (int i = 0; i < B; ++i)
+    if (hw[2 * i] <= 0 || hw[2 * i + 1] <= 0 || !up[i] || !lat[i]) return h->fail(PF_ERR_ARG, "pf_postprocess_batch: bad size or output pointer");
+  if (hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool cls = h->arch == PF_ARCH_PERSNET_CLS;
+  const size_t npx = (size_t)NET * NET;
+  float *dg = nullptr, *dl = nullptr;
+  if (cls) {  // decode the argmax of all images first (workspace: 3 x 320 x 320 floats per image)
+    const size_t need = (size_t)B * 3 * npx * 4 + 256;
+    if (!ws || ws_bytes < need) return h->fail(PF_ERR_WORKSPACE, fmt("pf_postprocess_batch: classification needs %zu workspace bytes", need));
+    dg = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    dl = dg + (size_t)B * 2 * npx;
+    launch_decode_cls(pg, 73, pl, 180, dg, dl, B, NET * NET, s);
+  }
+  for (int i0 = 0; i0 < B; i0 += PostBatch::MAX) {
+    PostBatch pb;
+    pb.n = std::min(B - i0, (int)PostBatch::MAX);
+    for (int k = 0; k < pb.n; ++k) {
+      const int i = i0 + k;
+      pb.H[k] = hw[2 * i]; pb.W[k] = hw[2 * i + 1];
+      pb.g2[k] = cls ? dg + (size_t)i * 2 * npx : pg + (size_t)i * 2 * npx;
+      pb.l1[k] = cls ? dl + (size_t)i * npx : pl + (size_t)i * npx;
+      pb.up[k] = up[i]; pb.lat[k] = lat[i];
+    }
+    launch_postprocess_batch(pb, NET, NET, cls ? 0 : 1, s);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return h->fail(PF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+  return PF_OK;
+}
+
 int pf_fields_from_params(int device, const float* d_cam5, int H, int W, float* d_up, float* d_lat, void* stream) {
   std::string err;
   int rc = check_device(device, &err);

@@ -126,6 +126,19 @@ void launch_decode_cls(const float* logit_g, int ng, const float* logit_l, int n
 // post-process one image: gravity (2,h,w)*scale -> bilinear (H,W) -> normalise; latitude bilinear -> (asin->deg)
 void launch_postprocess(const float* g2, const float* l1, int h, int w, float* up_out, float* lat_out, int H, int W, int lat_is_sin, hipStream_t s);
 
+// the same for up to PostBatch::MAX images in one launch (per-image sizes / pointers in the kernel arguments)
+struct PostBatch {
+  static constexpr int MAX = 32;
+  int n;
+  int H[MAX], W[MAX];
+  float rh[MAX], rw[MAX], sxs[MAX], sys[MAX];  // filled by launch_postprocess_batch
+  const float* g2[MAX];
+  const float* l1[MAX];
+  float* up[MAX];
+  float* lat[MAX];
+};
+void launch_postprocess_batch(PostBatch& pb, int h, int w, int lat_is_sin, hipStream_t s);
+
 // nearest resize NHWC4 (ParamNetConvNextRegress input, param_network.py:197)
 void launch_nearest_nhwc4(const float* x, float* y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
 

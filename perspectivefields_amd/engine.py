@@ -40,6 +40,7 @@ _SIGNATURES = {
     "pf_is_tuned": (_c.c_int, [_P, _c.c_int]),
     "pf_set_precision": (_c.c_int, [_P, _c.c_int]),
     "pf_postprocess": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_postprocess_batch": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_fields_from_params": (_c.c_int, [_c.c_int, _P, _c.c_int, _c.c_int, _P, _P, _P]),
     "pf_profile_begin": (_c.c_int, [_P, _c.c_uint]),
     "pf_profile_pause": (_c.c_int, [_P]),
@@ -268,6 +269,34 @@ class Engine:
         cat, work, ms, mnk = (ctypes.c_int * n)(), (ctypes.c_double * n)(), (ctypes.c_float * n)(), (ctypes.c_int * (4 * n))()
         self.lib.pf_profile_records(self._h, n, cat, work, ms, mnk)
         return [(self.PROFILE_CLASSES[cat[i]], work[i], ms[i], tuple(mnk[4 * i : 4 * i + 4])) for i in range(n)]
+
+    def postprocess_batch(self, pred_gravity, pred_latitude, sizes):
+        """Whole batch in one launch: (B,Cg,320,320), (B,Cl,320,320), [(H, W)] * B -> list of ((2,H,W) unit up-vectors,
+        (H,W) degrees).  The outputs of one call are views of one device allocation."""
+        import torch
+
+        B = len(sizes)
+        pg, pl = pred_gravity.contiguous(), pred_latitude.contiguous()
+        counts = [3 * int(h) * int(w) for h, w in sizes]
+        with torch.cuda.device(self.device):
+            flat = torch.empty(sum(counts), dtype=torch.float32, device=self.device)
+            outs, o = [], 0
+            for (h, w), n in zip(sizes, counts):
+                h, w = int(h), int(w)
+                outs.append((flat[o:o + 2 * h * w].view(2, h, w), flat[o + 2 * h * w:o + n].view(h, w)))
+                o += n
+            hw = (ctypes.c_int32 * (2 * B))(*[int(v) for s in sizes for v in s])
+            ups = (ctypes.c_void_p * B)(*[u.data_ptr() for u, _ in outs])
+            lats = (ctypes.c_void_p * B)(*[l.data_ptr() for _, l in outs])
+            ws_ptr, ws_n = None, 0
+            if self.gravity_channels > 2:
+                need = B * 3 * NET * NET * 4 + 256
+                if getattr(self, "_pp_ws", None) is None or self._pp_ws.numel() < need:
+                    self._pp_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                ws_ptr, ws_n = self._pp_ws.data_ptr(), self._pp_ws.numel()
+            rc = self.lib.pf_postprocess_batch(self._h, B, pg.data_ptr(), pl.data_ptr(), hw, ups, lats, ws_ptr, ws_n, _stream_ptr())
+        _check(rc, self._h, "pf_postprocess_batch")
+        return outs
 
     def postprocess(self, pred_gravity_i, pred_latitude_i, height: int, width: int):
         """One image: (Cg,320,320), (Cl,320,320) -> (2,H,W) unit up-vectors, (H,W) degrees."""

@@ -267,8 +267,9 @@ class PerspectiveFields(nn.Module):
         eng = self._get_engine()
         pg, pl, params = eng.forward(batch)
         results = []
+        fields = eng.postprocess_batch(pg, pl, sizes)  # the reference's per-image post-process loop as one launch
         for i, (h, w) in enumerate(sizes):
-            up, lat = eng.postprocess(pg[i], pl[i], h, w)
+            up, lat = fields[i]
             results.append(
                 {
                     "pred_gravity": pg[i],

@@ -258,3 +258,19 @@ def test_inference_stream_matches_inference_batch():
                     assert float(g[k]) == float(w[k])
     on_dev = list(m.inference_stream(batches[:2], to_host=False))
     assert on_dev[0][0]["pred_gravity_original"].is_cuda
+
+
+@pytest.mark.parametrize("tag", ["centered", "persnet"])
+def test_postprocess_batch_equals_per_image(tag):
+    """pf_postprocess_batch (one launch for the batch) == pf_postprocess per image, bit for bit, mixed output sizes,
+    regression and classification decode."""
+    m = model(tag)
+    eng = m._get_engine()
+    sizes = [(48, 64), (96, 72), (33, 47), (320, 320), (64, 48)] * 8  # 40 images: more than one 32-image launch
+    x = torch.from_numpy(np.stack([m.aug.apply_image(synthetic_image(40, 56, seed=300 + i)) for i in range(len(sizes))])).cuda()
+    pg, pl, _ = eng.forward(x)
+    batch = eng.postprocess_batch(pg, pl, sizes)
+    for i, (h, w) in enumerate(sizes):
+        up, lat = eng.postprocess(pg[i], pl[i], h, w)
+        assert batch[i][0].shape == (2, h, w) and batch[i][1].shape == (h, w)
+        assert torch.equal(batch[i][0], up) and torch.equal(batch[i][1], lat), (tag, i)
