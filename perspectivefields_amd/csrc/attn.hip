@@ -77,25 +77,44 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restri
 
   // ---- softmax over kv for query column (lane & 31); rows held by this lane:
   //      kv = 32 c + (r & 3) + 8 (r >> 2) + 4 hi
+  // A 32-row kv block is either entirely valid (block-uniform test, no per-element masking) or the ragged last one.
+  // exp(x) for x <= 0 as v_exp_f32(x * log2 e): relative error <= ~1e-6 only where the weight itself is < 1e-8.
   float mx = -3.0e38f;
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < 4; ++c) {
+    if (32 * c + 32 <= M) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (kvi < M) mx = fmaxf(mx, sacc[c][r]);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[c][r]);
+    } else if (32 * c < M) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (kvi < M) mx = fmaxf(mx, sacc[c][r]);
+      }
     }
+  }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mx2 = mx * 1.4426950408889634f;
   float sum = 0.f;
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < 4; ++c) {
+    if (32 * c + 32 <= M) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float pexp = kvi < M ? expf(sacc[c][r] - mx) : 0.f;
-      sacc[c][r] = pexp;
-      sum += pexp;
+      for (int r = 0; r < 16; ++r) {
+        const float pexp = __builtin_amdgcn_exp2f(fmaf(sacc[c][r], 1.4426950408889634f, -mx2));
+        sacc[c][r] = pexp;
+        sum += pexp;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float pexp = kvi < M ? __builtin_amdgcn_exp2f(fmaf(sacc[c][r], 1.4426950408889634f, -mx2)) : 0.f;
+        sacc[c][r] = pexp;
+        sum += pexp;
+      }
     }
+  }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
 
