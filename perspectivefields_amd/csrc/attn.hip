@@ -22,24 +22,22 @@ static constexpr int K_ROW = HD + 4; // 68 floats: 68*i mod 64 = 4i -> conflict-
 
 __global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                            float* __restrict__ out, unsigned short* __restrict__ out_sb, size_t sb_plane, int N, int M, int heads) {
-  __shared__ __attribute__((aligned(16))) float Ks[KV_PAD * K_ROW];
-  __shared__ __attribute__((aligned(16))) float Vs[KV_PAD * HD];
+  // K and V rows of this (batch, head): exactly M rows each (52.8 KB at M = 100: three blocks per CU); the MFMA row
+  // blocks that reach past M read a clamped row, whose scores are masked / whose probabilities are zero
+  extern __shared__ __attribute__((aligned(16))) float smem_attn[];
+  float* Ks = smem_attn;              // [M][K_ROW]
+  float* Vs = smem_attn + M * K_ROW;  // [M][HD]
   const int C = heads * HD;
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
 
-  // stage K, V (rows >= M zero-filled so masked columns contribute exact zeros)
+  // stage K, V
   const float* kvb = kv + (long)b * M * 2 * C + h * HD;
-  for (int i = tid; i < KV_PAD * (HD / 4); i += 256) {
+  for (int i = tid; i < M * (HD / 4); i += 256) {
     const int row = i / (HD / 4), c4 = i % (HD / 4);
-    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
-    if (row < M) {
-      kk = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * C + c4 * 4);
-      vv = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * C + C + c4 * 4);
-    }
-    *reinterpret_cast<float4*>(Ks + row * K_ROW + c4 * 4) = kk;
-    *reinterpret_cast<float4*>(Vs + row * HD + c4 * 4) = vv;
+    *reinterpret_cast<float4*>(Ks + row * K_ROW + c4 * 4) = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * C + c4 * 4);
+    *reinterpret_cast<float4*>(Vs + row * HD + c4 * 4) = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * C + C + c4 * 4);
   }
 
   // this lane's query row (clamped; out-of-range rows are computed but not stored)
@@ -57,15 +55,18 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restri
 
   // ---- S^T[kv][q] = sum_d K[kv][d] * Q[q][d]; 4 kv blocks of 32 rows
   f32x16 sacc[4];
+  int krow[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < 4; ++c) {
+    krow[c] = min(c * 32 + l31, M - 1);
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[c][e] = 0.f;
+  }
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     float4 kf[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const float4*>(Ks + (c * 32 + l31) * K_ROW + 8 * t + 4 * hi);
+    for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const float4*>(Ks + krow[c] * K_ROW + 8 * t + 4 * hi);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       sacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].x, qf[t].x, sacc[c], 0, 0, 0);
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (32 * c + (r & 3) + 8 * (r >> 2) < M) {  // block-uniform skip of fully masked k-pairs (kv >= M in both halves => p = 0)
-        const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int kvi = min(32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi, M - 1);  // rows >= M carry p = 0
         const float v0 = Vs[kvi * HD + l31];
         const float v1 = Vs[kvi * HD + 32 + l31];
         oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sacc[c][r], oacc[0], 0, 0, 0);
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restri
 
 void launch_sr_attention(const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s, unsigned short* out_sb, size_t sb_plane) {
   const dim3 grid((N + 127) / 128, heads, B);
-  hipLaunchKernelGGL(sr_attention_kernel, grid, dim3(256), 0, s, q, kv, out, out_sb, sb_plane, N, M, heads);
+  const size_t lds = (size_t)M * (K_ROW + HD) * sizeof(float);
+  hipLaunchKernelGGL(sr_attention_kernel, grid, dim3(256), lds, s, q, kv, out, out_sb, sb_plane, N, M, heads);
 }
 
 }  // namespace pf
