@@ -42,8 +42,12 @@ __device__ __forceinline__ int xcd_tile_index(int nblk) {
 // between registers), which makes a direct epilogue store-issue bound: stage the tile through LDS (free after the
 // K loop) in chunks of WM*32 rows and write it back row-major -- every thread then moves 16 bytes per instruction,
 // fully coalesced, and the bias / residual operands are read as float4 as well.
+// Rows of the block tile are normally consecutive output pixels (m0 + local row); a kernel that tiles the output
+// spatially passes the patch instead: local row -> (oy0 + row / tx, ox0 + row % tx) of image b, rows outside the map are skipped.
+struct Tile2D { int b, oy0, ox0, tx; };
 template <int BM, int BN, int WM, int WN, int SM, int SN, int NT, int SMEM_FLOATS>
-__device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[SM][SN], float* Cs, int m0, int n0) {
+__device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[SM][SN], float* Cs, int m0, int n0,
+                                              const Tile2D* t2 = nullptr) {
   constexpr int CROW = BN + 4;            // floats per staged row (keeps 16-B alignment, shifts banks)
   constexpr int CH_ROWS = WM * 32;        // rows per chunk: subtile row i of every wave row
   constexpr int F4_PER_ROW = BN / 4;
@@ -64,8 +68,13 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
     __syncthreads();
     for (int idx = tid; idx < CH_ROWS * F4_PER_ROW; idx += NT) {
       const int row_l = idx / F4_PER_ROW, cq = idx - row_l * F4_PER_ROW;
-      const int m = m0 + (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
+      int m = m0 + (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
       const int n = n0 + cq * 4;
+      if (t2) {
+        const int lm = m - m0, oy = t2->oy0 + lm / t2->tx, ox = t2->ox0 + lm % t2->tx;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        m = (t2->b * p.Ho + oy) * p.Wo + ox;
+      }
       if (m >= p.M || n >= p.Cout) continue;
       float4 v = *reinterpret_cast<const float4*>(Cs + row_l * CROW + cq * 4);
       const float* bsrc = P.bias;

@@ -13,7 +13,10 @@ struct SbCfg { int bm, bn, pfd; const char* name; };
 static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, {128, 64, 1, "sb128x64"}, {256, 128, 1, "sb256x128w8"},
                              {128, 256, 1, "sb128x256w8"}, {128, 32, 1, "sb128x32"}, {256, 256, 1, "sb256x256w8"},
                              {64, 64, 2, "sb64x64f2"}, {64, 64, 3, "sb64x64f3"}, {128, 64, 2, "sb128x64f2"}, {128, 32, 2, "sb128x32f2"},
-                             {128, 128, 2, "sb128x128f2"}};
+                             {128, 128, 2, "sb128x128f2"},
+                             // "sbh": 3x3 / stride 1 convs with an LDS-staged input halo tile, 8 x 16 output patch per block (igemm_sbh.hip)
+                             {128, 128, 0, "sbh128x128"}, {128, 64, 0, "sbh128x64"}, {128, 32, 0, "sbh128x32"}};
+static constexpr int kFirstH = 12;  // index of the first "sbh" tile
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }
 const char* conv_sb_tile_name(int id) { return kSb[id].name; }
 int conv_sb_tile_bm(int id) { return kSb[id].bm; }
@@ -43,9 +46,16 @@ int conv_sb_default_tile(const ConvParams& p) {
 void launch_conv_sb3(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb3.hip
 void launch_conv_sb1(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb1.hip
 
-bool conv_sb_tile_ok(const ConvParams&, int) { return true; }  // hook for tiles with operand-format restrictions (none today)
+bool conv_sbh_ok(const ConvParams& p);                                   // igemm_sbh.hip
+void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
+
+bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) { return sb_tile < kFirstH || conv_sbh_ok(p); }
 
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
+  if (sb_tile >= kFirstH) {
+    if (conv_sbh_ok(p)) { launch_conv_sbh(p, sb_tile - kFirstH, s); return; }
+    sb_tile = conv_sb_default_tile(p);
+  }
   if (p.nterms == 3) launch_conv_sb3(p, sb_tile, s);
   else if (p.nterms == 1) launch_conv_sb1(p, sb_tile, s);
   else launch_conv_sb_nt<6>(p, sb_tile, s);

@@ -1,0 +1,246 @@
+// Split-bf16 implicit GEMM for 3x3 / stride 1 / pad 1 convolutions with an LDS-staged INPUT HALO TILE.
+//
+// igemm_sb_kernel gathers the A operand per tap: every input pixel of a 3x3 conv is fetched from L2 and split into its
+// three bf16 parts nine times (once per tap), by every n-tile.  Here a block owns an 8 x 16 patch of output pixels of one
+// image (128 GEMM rows) and, per 32-channel chunk, stages the 10 x 18 input halo ONCE (fetch + exact split, 180 rows);
+// the nine taps then read shifted windows of that tile straight from LDS: per lane the halo row of its output pixel plus
+// a block-uniform tap offset.  Per 9 K steps the A side costs 23 KB of loads and 180 x 32 splits instead of 144 KB and
+// 1152 x 32; the weight tile (B) is staged per step as before.  The XOR piece swizzle is keyed on the halo row, and any
+// 16 consecutive rows hit 16 distinct 16-byte bank slots, so the shifted ds_read_b128 stay conflict-free.
+// K order is (channel chunk, tap) instead of (tap, channel chunk): same products, different fp32 summation order.
+// fp32 operands, fp32-accurate mode (6 partial products) only.
+#include <stdlib.h>
+
+#include "igemm_common.h"
+#include "sb_split.h"
+
+namespace pf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+static constexpr int H_TY = 8, H_TX = 16;                      // output patch
+static constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;         // halo
+static constexpr int H_ROWS = H_HX * H_HY;                     // 180 halo pixels
+static constexpr int H_ROW = BK;                               // ushorts per LDS row (64 bytes)
+__device__ __forceinline__ int sbh_piece(int row, int piece) { return piece ^ ((row >> 2) & 3); }
+
+template <int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256, 2) void igemm_sbh_kernel(const ConvParams p) {
+  constexpr int BM = H_TY * H_TX;  // 128
+  constexpr int NT = 256;
+  static_assert(WM * WN * 64 == NT, "four waves");
+  constexpr int SM = BM / (WM * 32);
+  constexpr int SN = BN / (WN * 32);
+  constexpr int RPB = NT / 4;                        // B rows staged per pass
+  constexpr int B_ROWS = (BN + RPB - 1) / RPB;
+  constexpr int A_F4 = (H_ROWS * 8 + NT - 1) / NT;   // float4 loads per thread per halo chunk (6)
+  constexpr int PLANE_A = H_ROWS * H_ROW, PLANE_B = BN * H_ROW;  // ushorts
+  constexpr int EPI_USHORTS = 2 * (WM * 32) * (BN + 4);
+  constexpr int OPER_USHORTS = 3 * (PLANE_A + PLANE_B);
+  constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
+  __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
+  unsigned short* As = smem_u;                // [3][H_ROWS][H_ROW]
+  unsigned short* Bs = smem_u + 3 * PLANE_A;  // [3][BN][H_ROW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+
+  const int tilesN = (p.Cout + BN - 1) / BN;
+  const int tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
+  const int nblk1 = p.B * tilesY * tilesX * tilesN;
+  int t = xcd_tile_index(nblk1 * p.groups);
+  const bool g1 = t >= nblk1;
+  if (g1) t -= nblk1;
+  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
+  const int n0 = (t % tilesN) * BN;
+  int mt = t / tilesN;
+  const int tx = mt % tilesX; mt /= tilesX;
+  const int ty = mt % tilesY;
+  const int bimg = mt / tilesY;
+  const int oy0 = ty * H_TY, ox0 = tx * H_TX;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x2 ? P.x2 : P.x), 0, P.x2 ? p.x2_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_sb), 0, 5u * p.w_sb_plane_bytes, 0x00020000);
+
+  // ---- A halo staging: element e = tid + NT i -> (halo row e / 8, float4 e % 8 of the 32-channel chunk)
+  unsigned a_off1[A_F4], a_off2[A_F4];
+  int a_lds[A_F4];  // ushort offset inside a plane, -1 = nothing to store
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    const int e = tid + NT * i;
+    const int hrow = e >> 3, c4 = e & 7;
+    const int hy = hrow / H_HX, hx = hrow - hy * H_HX;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool in_tile = hrow < H_ROWS;
+    const bool ok = in_tile && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const int pix = (bimg * p.H + iy) * p.W + ix;
+    a_off1[i] = ok ? (unsigned)(pix * p.C1 * 4 + c4 * 16) : OOB;
+    a_off2[i] = ok ? (unsigned)(pix * p.C2 * 4 + c4 * 16) : OOB;
+    a_lds[i] = in_tile ? hrow * H_ROW + sbh_piece(hrow, c4 >> 1) * 8 + (c4 & 1) * 4 : -1;
+  }
+  // ---- B staging: thread -> (row rb0 + RPB i, 16-byte piece pc of the 64-byte K chunk), three planes
+  const int pc = tid & 3;
+  const int rb0 = tid >> 2;
+  unsigned b_off[B_ROWS];
+#pragma unroll
+  for (int i = 0; i < B_ROWS; ++i) {
+    const int n = n0 + rb0 + RPB * i;
+    b_off[i] = (n < p.Cout && rb0 + RPB * i < BN) ? (unsigned)(n * 3 * p.KWCp + pc * 8) * 2u : OOB;
+  }
+
+  float4 ra[A_F4], rb[B_ROWS][3];
+  const int nC = p.Cin / BK;  // 32-channel chunks (x first, then x2 when concatenating)
+
+  auto load_a = [&](int c) {  // chunk c (>= nC: nothing, out-of-range offsets)
+    const bool live = c < nC;
+    const int ci0 = c * BK;
+    const bool first = MODE != 2 || ci0 < p.C1;
+    const unsigned coff = (unsigned)((first ? ci0 : ci0 - p.C1) * 4);
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const unsigned base = first ? a_off1[i] : a_off2[i];
+      const unsigned off = (live && base != OOB) ? base + coff : OOB;
+      if (MODE == 2) {
+        const float4 v1 = buf_load16(rx, first ? off : OOB);
+        const float4 v2 = buf_load16(rx2, first ? OOB : off);
+        ra[i] = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);
+      } else {
+        ra[i] = buf_load16(rx, off);
+      }
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i)
+      if (a_lds[i] >= 0) {
+        uint2 h, m, l;
+        split4(ra[i], h, m, l);
+        unsigned short* d = As + a_lds[i];
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + PLANE_A) = m;
+        *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
+      }
+  };
+  auto load_b = [&](int c, int tap) {  // weights of (chunk c, tap); c >= nC: nothing
+    const bool live = c < nC;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const unsigned woff = (unsigned)(ky * p.KWCp + kx * p.Cin + c * BK) * 2u;
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        rb[i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes : OOB);
+  };
+  auto store_b = [&]() {
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i)
+      if (BN % RPB == 0 || rb0 + RPB * i < BN) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * H_ROW + sbh_piece(rb0 + RPB * i, pc) * 8) = rb[i][pl];
+      }
+  };
+
+  f32x16 acc[SM][SN];
+#pragma unroll
+  for (int i = 0; i < SM; ++i)
+#pragma unroll
+    for (int j = 0; j < SN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm0 = (wave / WN) * (SM * 32);
+  const int wn0 = (wave % WN) * (SN * 32);
+  int hb[SM];  // halo row of this lane's output pixel (tap (0,0)) per 32-row subtile
+#pragma unroll
+  for (int i = 0; i < SM; ++i) {
+    const int ml = wm0 + i * 32 + l31;
+    hb[i] = (ml / H_TX) * H_HX + (ml % H_TX);
+  }
+  const unsigned short* Bb = Bs + (wn0 + l31) * H_ROW;
+  const int swz_b = (l31 >> 2) & 3;
+
+  auto compute = [&](int tap) {
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const int toff = ky * H_HX + kx;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per K step; this lane's 8 k-values = piece 2c + hi
+      bf16x8 af[SM][3], bf[SN][3];
+#pragma unroll
+      for (int i = 0; i < SM; ++i) {
+        const int row = hb[i] + toff;
+        const unsigned short* ap = As + row * H_ROW + sbh_piece(row, 2 * c + hi) * 8;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANE_A);
+      }
+      const int pob = ((2 * c + hi) ^ swz_b) * 8;
+#pragma unroll
+      for (int j = 0; j < SN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * PLANE_B + j * 32 * H_ROW + pob);
+      constexpr int TA[6] = {2, 0, 1, 1, 0, 0};  // plane of A: l h m m h h
+      constexpr int TB[6] = {0, 2, 1, 0, 1, 0};  // plane of B: h l m h m h
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+          for (int j = 0; j < SN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // prologue: halo chunk 0 and the weights of (0, tap 0) -> LDS
+  load_a(0);
+  load_b(0, 0);
+  store_a();
+  store_b();
+  __syncthreads();
+  for (int c = 0; c < nC; ++c) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {  // unrolled: no branch around any load, the s_waitcnt counts stay exact
+      if (tap == 4) load_a(c + 1);       // next halo chunk: in flight during taps 4..8
+      if (tap < 8) load_b(c, tap + 1); else load_b(c + 1, 0);
+      compute(tap);
+      __syncthreads();  // every wave has read this step's weights (and, at tap 8, this chunk's halo)
+      store_b();
+      if (tap == 8 && c + 1 < nC) store_a();
+      __syncthreads();
+    }
+  }
+
+  const Tile2D t2{bimg, oy0, ox0, H_TX};
+  epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2);
+}
+
+template <int BN, int WM, int WN>
+static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
+  const int tilesN = (p.Cout + BN - 1) / BN;
+  const int tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
+  const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(256);
+  if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<BN, WM, WN, 2>), grid, block, 0, s, p);
+  else          hipLaunchKernelGGL((igemm_sbh_kernel<BN, WM, WN, 0>), grid, block, 0, s, p);
+}
+
+// 3x3 / stride 1 / pad 1, fp32 operands, fp32-accurate mode, channel counts multiples of 32
+bool conv_sbh_ok(const ConvParams& p) {
+  if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nterms != 6 || p.nchw_out) return false;
+  if ((p.C1 % BK) != 0 || (p.C2 % BK) != 0 || p.KWCp != p.KWC) return false;
+  for (int g = 0; g < p.groups; ++g)
+    if (!p.g[g].x || (p.C2 > 0 && !p.g[g].x2) || !p.g[g].w_sb) return false;
+  return true;
+}
+
+// ids = position among the "sbh" tiles of kSb[] (igemm_sb.hip)
+void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
+  switch (h_tile) {
+    case 0: launch_sbh_cfg<128, 2, 2>(p, s); break;
+    case 1: launch_sbh_cfg<64, 2, 2>(p, s); break;
+    default: launch_sbh_cfg<32, 4, 1>(p, s); break;
+  }
+}
+
+}  // namespace pf

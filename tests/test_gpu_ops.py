@@ -96,7 +96,7 @@ def test_conv2d_split_plane_operands(ops, case):
     b = _rand((Cout,), 4, 0.1)
     ref = _ref_conv(x.cpu(), w, b, stride, pad, None if x2 is None else x2.cpu())
     names = ops.conv_tiles()
-    sb = [i for i, n in enumerate(names) if n.startswith("sb")]
+    sb = [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbh")]  # the halo tiles take fp32 operands only
     assert sb
     for tile in sb:
         base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1)
@@ -126,7 +126,7 @@ def test_conv2d_reduced_precision_modes(ops, precision, tol):
     ref = _ref_conv(x, w, b, 1, 1)
     xd = x.cuda()
     names = ops.conv_tiles()
-    for tile in [i for i, n in enumerate(names) if n.startswith("sb")]:
+    for tile in [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbh")]:  # halo tiles: fp32-accurate mode only
         got = ops.conv2d(xd, w, b, pad=1, tile=tile, precision=precision)
         _close(got, ref, tol, f"{names[tile]} precision {precision}")
         e_red = float((got.double().cpu() - ref).abs().max())
@@ -156,6 +156,24 @@ def test_elementwise_plane_outputs(ops):
     assert torch.equal(ops.sr_attention(q, kv, 5, planes_out=True), ops.sr_attention(q, kv, 5))
     xu = _rand((2, 10, 12, 64), 61).cuda()
     assert torch.equal(ops.upsample2x(xu, planes_out=True), ops.upsample2x(xu))
+
+
+def test_conv2d_halo_tiles_partial_patches(ops):
+    """The 3x3 halo-tile kernels own 8 x 16 output patches: maps that are not multiples of the patch, one-pixel maps,
+    batch > 1, ragged Cout, concat input, residual / bias-table-free epilogue -- against the fp64 reference."""
+    names = ops.conv_tiles()
+    halo = [i for i, n in enumerate(names) if n.startswith("sbh")]
+    assert halo
+    for (B, H, W, C1, C2, Cout) in [(2, 10, 10, 64, 0, 256), (1, 23, 37, 32, 0, 40), (3, 8, 16, 96, 32, 64), (1, 1, 1, 32, 0, 32), (2, 40, 24, 128, 0, 128)]:
+        x = _rand((B, H, W, C1), 81)
+        x2 = _rand((B, H, W, C2), 82) if C2 else None
+        w = _rand((Cout, C1 + C2, 3, 3), 83, 1.0 / math.sqrt((C1 + C2) * 9))
+        b = _rand((Cout,), 84, 0.1)
+        r1 = _rand((B, H, W, Cout), 85)
+        ref = F.relu(_ref_conv(x, w, b, 1, 1, x2) + r1.double())
+        for tile in halo:
+            got = ops.conv2d(x.cuda(), w, b, pad=1, x2=None if x2 is None else x2.cuda(), res1=r1.cuda(), post_relu=True, tile=tile)
+            _close(got, ref, 2e-5, f"{names[tile]} {B}x{H}x{W} {C1}+{C2}->{Cout}")
 
 
 def test_conv2d_epilogues(ops):
