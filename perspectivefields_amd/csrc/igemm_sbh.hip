@@ -9,6 +9,9 @@
 // 16 consecutive rows hit 16 distinct 16-byte bank slots, so the shifted ds_read_b128 stay conflict-free.
 // K order is (channel chunk, tap) instead of (tap, channel chunk): same products, different fp32 summation order.
 // fp32 operands, fp32-accurate mode (6 partial products) only.
+// Measured and not kept (profiles/r01_tune_conv_sbh.txt): 16 x 16 patches with 8 waves (ties the 8 x 16 / 4-wave form on
+// 256 -> 256 @80^2, loses elsewhere) and staging the weights of a whole kernel row per barrier pair (TPG = 3: the extra
+// LDS costs a resident block, 3-7 % slower).
 #include <stdlib.h>
 
 #include "igemm_common.h"
@@ -17,17 +20,16 @@
 namespace pf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-static constexpr int H_TY = 8, H_TX = 16;                      // output patch
-static constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;         // halo
-static constexpr int H_ROWS = H_HX * H_HY;                     // 180 halo pixels
-static constexpr int H_ROW = BK;                               // ushorts per LDS row (64 bytes)
+static constexpr int H_ROW = BK;  // ushorts per LDS row (64 bytes)
 __device__ __forceinline__ int sbh_piece(int row, int piece) { return piece ^ ((row >> 2) & 3); }
 
-template <int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(256, 2) void igemm_sbh_kernel(const ConvParams p) {
-  constexpr int BM = H_TY * H_TX;  // 128
-  constexpr int NT = 256;
-  static_assert(WM * WN * 64 == NT, "four waves");
+template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE, int TPG /*taps whose weights are staged together: 1 or 3 (one kernel row)*/>
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_sbh_kernel(const ConvParams p) {
+  constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
+  constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
+  constexpr int BM = H_TY * H_TX;
+  constexpr int NT = WM * WN * 64;
+  static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave grid must tile the block");
   constexpr int SM = BM / (WM * 32);
   constexpr int SN = BN / (WN * 32);
   constexpr int RPB = NT / 4;                        // B rows staged per pass
@@ -35,11 +37,11 @@ __global__ __launch_bounds__(256, 2) void igemm_sbh_kernel(const ConvParams p) {
   constexpr int A_F4 = (H_ROWS * 8 + NT - 1) / NT;   // float4 loads per thread per halo chunk (6)
   constexpr int PLANE_A = H_ROWS * H_ROW, PLANE_B = BN * H_ROW;  // ushorts
   constexpr int EPI_USHORTS = 2 * (WM * 32) * (BN + 4);
-  constexpr int OPER_USHORTS = 3 * (PLANE_A + PLANE_B);
+  constexpr int OPER_USHORTS = 3 * (PLANE_A + TPG * PLANE_B);
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
   unsigned short* As = smem_u;                // [3][H_ROWS][H_ROW]
-  unsigned short* Bs = smem_u + 3 * PLANE_A;  // [3][BN][H_ROW]
+  unsigned short* Bs = smem_u + 3 * PLANE_A;  // [TPG][3][BN][H_ROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void igemm_sbh_kernel(const ConvParams p) {
     b_off[i] = (n < p.Cout && rb0 + RPB * i < BN) ? (unsigned)(n * 3 * p.KWCp + pc * 8) * 2u : OOB;
   }
 
-  float4 ra[A_F4], rb[B_ROWS][3];
+  float4 ra[A_F4], rb[TPG][B_ROWS][3];
   const int nC = p.Cin / BK;  // 32-channel chunks (x first, then x2 when concatenating)
 
   auto load_a = [&](int c) {  // chunk c (>= nC: nothing, out-of-range offsets)
@@ -124,24 +126,30 @@ __global__ __launch_bounds__(256, 2) void igemm_sbh_kernel(const ConvParams p) {
         *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
       }
   };
-  auto load_b = [&](int c, int tap) {  // weights of (chunk c, tap); c >= nC: nothing
+  auto load_b = [&](int c, int tap0) {  // weights of (chunk c, taps tap0 .. tap0 + TPG - 1); c >= nC: nothing
     const bool live = c < nC;
-    const int ky = tap / 3, kx = tap - 3 * ky;
-    const unsigned woff = (unsigned)(ky * p.KWCp + kx * p.Cin + c * BK) * 2u;
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i)
+    for (int u = 0; u < TPG; ++u) {
+      const int tap = tap0 + u;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const unsigned woff = (unsigned)(ky * p.KWCp + kx * p.Cin + c * BK) * 2u;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        rb[i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes : OOB);
+      for (int i = 0; i < B_ROWS; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          rb[u][i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes : OOB);
+    }
   };
   auto store_b = [&]() {
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i)
-      if (BN % RPB == 0 || rb0 + RPB * i < BN) {
+    for (int u = 0; u < TPG; ++u)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * H_ROW + sbh_piece(rb0 + RPB * i, pc) * 8) = rb[i][pl];
-      }
+      for (int i = 0; i < B_ROWS; ++i)
+        if (BN % RPB == 0 || rb0 + RPB * i < BN) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<float4*>(Bs + (u * 3 + pl) * PLANE_B + (rb0 + RPB * i) * H_ROW + sbh_piece(rb0 + RPB * i, pc) * 8) = rb[u][i][pl];
+        }
   };
 
   f32x16 acc[SM][SN];
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void igemm_sbh_kernel(const ConvParams p) {
   const unsigned short* Bb = Bs + (wn0 + l31) * H_ROW;
   const int swz_b = (l31 >> 2) & 3;
 
-  auto compute = [&](int tap) {
+  auto compute = [&](int tap, int slot /*position of this tap's weights in the staged group*/) {
     const int ky = tap / 3, kx = tap - 3 * ky;
     const int toff = ky * H_HX + kx;
 #pragma unroll
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void igemm_sbh_kernel(const ConvParams p) {
 #pragma unroll
       for (int j = 0; j < SN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * PLANE_B + j * 32 * H_ROW + pob);
+        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + (slot * 3 + pl) * PLANE_B + j * 32 * H_ROW + pob);
       constexpr int TA[6] = {2, 0, 1, 1, 0, 0};  // plane of A: l h m m h h
       constexpr int TB[6] = {0, 2, 1, 0, 1, 0};  // plane of B: h l m h m h
 #pragma unroll
@@ -193,21 +201,23 @@ __global__ __launch_bounds__(256, 2) void igemm_sbh_kernel(const ConvParams p) {
     }
   };
 
-  // prologue: halo chunk 0 and the weights of (0, tap 0) -> LDS
+  // prologue: halo chunk 0 and the weights of the first tap group -> LDS
   load_a(0);
   load_b(0, 0);
   store_a();
   store_b();
   __syncthreads();
+  constexpr int NG = 9 / TPG;  // tap groups per chunk
   for (int c = 0; c < nC; ++c) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {  // unrolled: no branch around any load, the s_waitcnt counts stay exact
-      if (tap == 4) load_a(c + 1);       // next halo chunk: in flight during taps 4..8
-      if (tap < 8) load_b(c, tap + 1); else load_b(c + 1, 0);
-      compute(tap);
-      __syncthreads();  // every wave has read this step's weights (and, at tap 8, this chunk's halo)
+    for (int g = 0; g < NG; ++g) {  // unrolled: no branch around any load, the s_waitcnt counts stay exact
+      if (g == NG / 2) load_a(c + 1);  // next halo chunk: in flight during the second half of this one
+      if (g + 1 < NG) load_b(c, (g + 1) * TPG); else load_b(c + 1, 0);
+#pragma unroll
+      for (int u = 0; u < TPG; ++u) compute(g * TPG + u, u);
+      __syncthreads();  // every wave has read this group's weights (and, in the last group, this chunk's halo)
       store_b();
-      if (tap == 8 && c + 1 < nC) store_a();
+      if (g == NG - 1 && c + 1 < nC) store_a();
       __syncthreads();
     }
   }
@@ -216,13 +226,13 @@ __global__ __launch_bounds__(256, 2) void igemm_sbh_kernel(const ConvParams p) {
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2);
 }
 
-template <int BN, int WM, int WN>
+template <int H_TY, int H_TX, int BN, int WM, int WN, int TPG = 1>
 static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
-  const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(256);
-  if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<BN, WM, WN, 2>), grid, block, 0, s, p);
-  else          hipLaunchKernelGGL((igemm_sbh_kernel<BN, WM, WN, 0>), grid, block, 0, s, p);
+  const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(WM * WN * 64);
+  if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, TPG>), grid, block, 0, s, p);
+  else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, TPG>), grid, block, 0, s, p);
 }
 
 // 3x3 / stride 1 / pad 1, fp32 operands, fp32-accurate mode, channel counts multiples of 32
@@ -237,9 +247,9 @@ bool conv_sbh_ok(const ConvParams& p) {
 // ids = position among the "sbh" tiles of kSb[] (igemm_sb.hip)
 void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
   switch (h_tile) {
-    case 0: launch_sbh_cfg<128, 2, 2>(p, s); break;
-    case 1: launch_sbh_cfg<64, 2, 2>(p, s); break;
-    default: launch_sbh_cfg<32, 4, 1>(p, s); break;
+    case 0: launch_sbh_cfg<8, 16, 128, 2, 2>(p, s); break;
+    case 1: launch_sbh_cfg<8, 16, 64, 2, 2>(p, s); break;
+    default: launch_sbh_cfg<8, 16, 32, 4, 1>(p, s); break;
   }
 }
 
