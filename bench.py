@@ -213,7 +213,7 @@ def main():
         if sb["ms"] > 0:
             nt = {"fp32": 6, "bf16x3": 3, "bf16": 1}[precision]
             objs.append((sb["ms"], mfma_obj(
-                sb, f"pf::igemm_sb_kernel (implicit-GEMM conv/GEMM, split-bf16: {nt} x v_mfma_f32_32x32x16_bf16 per product"
+                sb, f"pf::igemm_sb_kernel + pf::igemm_sbh_kernel (implicit-GEMM conv/GEMM, linear and 3x3 halo tiles; split-bf16: {nt} x v_mfma_f32_32x32x16_bf16 per product"
                 + (", fp32-accurate)" if nt == 6 else ", reduced precision)"),
                 BF16_MFMA_PEAK_TFLOPS, "achieved = algorithmic FLOPs (2*M*N*K) / time, priced against the DENSE bf16 MFMA peak; the kernel "
                 f"executes {nt} bf16 MFMA FLOPs per algorithmic FLOP (executed_mfma_tflops), i.e. its ceiling is 2500/{nt} = {2500.0 / nt:.1f} TFLOP/s", float(nt))))

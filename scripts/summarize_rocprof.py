@@ -43,6 +43,12 @@ for k, v in out["kernels"].items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in p and "GRBM_GUI_ACTIVE" in p and p["GRBM_GUI_ACTIVE"]["sum"] > 0:
         # SQ_VALU_MFMA_BUSY_CYCLES: 64 per v_mfma_f32_32x32x2_f32, summed over all SIMDs
         v["mfma_busy_frac"] = p["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / (p["GRBM_GUI_ACTIVE"]["sum"] / 8.0 * 1024)  # GRBM counter is summed over the 8 XCDs; 1024 SIMDs
+# class aggregate matching bench.py's `roofline` object (all split-bf16 implicit-GEMM launches: linear + halo tiles)
+cls = [v["trace"] for k, v in out["kernels"].items() if k.startswith("pf::igemm_sb") and "trace" in v]
+if cls:
+    n, us = sum(t["calls"] for t in cls), sum(t["total_us"] for t in cls)
+    out["split_bf16_igemm_class"] = {"calls": n, "total_us": round(us, 1), "avg_us": round(us / n, 2),
+                                     "pct": round(100 * us / out.get("trace_total_us", us), 2)}
 json.dump(out, open(os.path.join(root, "rocprof_summary.json"), "w"), indent=1)
 rows = sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("trace", {}).get("total_us", 0))
 md = ["| kernel | calls | total us | avg us | % | HBM MB/launch | L2 hit | MFMA busy |", "|---|---|---|---|---|---|---|---|"]
@@ -50,5 +56,10 @@ for k, v in rows[:40]:
     t = v.get("trace", {})
     md.append(f"| {k} | {t.get('calls','')} | {t.get('total_us','')} | {t.get('avg_us','')} | {t.get('pct','')} | "
               f"{v.get('hbm_bytes_per_launch', 0)/1e6:.1f} | {v.get('l2_hit_rate', float('nan')):.3f} | {v.get('mfma_busy_frac', float('nan')):.3f} |")
+if "split_bf16_igemm_class" in out:
+    c = out["split_bf16_igemm_class"]
+    md.append("")
+    md.append(f"split-bf16 implicit GEMM as one class (pf::igemm_sb_kernel<*> + pf::igemm_sbh_kernel = bench.py's `roofline` kernel): "
+              f"{c['calls']} calls, {c['total_us']} us, avg {c['avg_us']} us per launch, {c['pct']} % of kernel time")
 open(os.path.join(root, "rocprof_summary.md"), "w").write("\n".join(md) + "\n")
 print("\n".join(md))
