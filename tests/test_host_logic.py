@@ -258,3 +258,22 @@ def test_branch_free_gelu_is_fp32_accurate():
     err_fast, err_libm = np.abs(fast - exact).max(), np.abs(libm32 - exact).max()
     assert err_fast <= 6e-7, err_fast
     assert err_fast <= 1.5 * err_libm + 1e-7, (err_fast, err_libm)
+
+
+def test_bench_cli_contract_and_loud_failure_without_gpu():
+    """bench.py keeps the driver's flags (--gpus/--steps/--warmup) and, on a box without a GPU, exits non-zero instead of
+    printing a number from some fallback."""
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert h.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--precision", "--event-steps"):
+        assert flag in h.stdout, flag
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0
+        assert '"metric"' not in r.stdout
