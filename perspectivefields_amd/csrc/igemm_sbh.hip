@@ -24,7 +24,7 @@ static constexpr int H_ROW = BK;  // ushorts per LDS row (64 bytes)
 __device__ __forceinline__ int sbh_piece(int row, int piece) { return piece ^ ((row >> 2) & 3); }
 
 template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE, int TPG /*taps whose weights are staged together: 1 or 3 (one kernel row)*/>
-__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_sbh_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
   constexpr int BM = H_TY * H_TX;
@@ -68,8 +68,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_sbh_kernel(const ConvPa
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_sb), 0, 5u * p.w_sb_plane_bytes, 0x00020000);
 
   // ---- A halo staging: element e = tid + NT i -> (halo row e / 8, float4 e % 8 of the 32-channel chunk)
-  unsigned a_off1[A_F4], a_off2[A_F4];
-  int a_lds[A_F4];  // ushort offset inside a plane, -1 = nothing to store
+  unsigned a_off1[A_F4], a_off2[MODE == 2 ? A_F4 : 1];
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
     const int e = tid + NT * i;
@@ -80,8 +79,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_sbh_kernel(const ConvPa
     const bool ok = in_tile && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     const int pix = (bimg * p.H + iy) * p.W + ix;
     a_off1[i] = ok ? (unsigned)(pix * p.C1 * 4 + c4 * 16) : OOB;
-    a_off2[i] = ok ? (unsigned)(pix * p.C2 * 4 + c4 * 16) : OOB;
-    a_lds[i] = in_tile ? hrow * H_ROW + sbh_piece(hrow, c4 >> 1) * 8 + (c4 & 1) * 4 : -1;
+    if (MODE == 2) a_off2[i] = ok ? (unsigned)(pix * p.C2 * 4 + c4 * 16) : OOB;
   }
   // ---- B staging: thread -> (row rb0 + RPB i, 16-byte piece pc of the 64-byte K chunk), three planes
   const int pc = tid & 3;
@@ -103,7 +101,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_sbh_kernel(const ConvPa
     const unsigned coff = (unsigned)((first ? ci0 : ci0 - p.C1) * 4);
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      const unsigned base = first ? a_off1[i] : a_off2[i];
+      const unsigned base = (MODE != 2 || first) ? a_off1[i] : a_off2[MODE == 2 ? i : 0];
       const unsigned off = (live && base != OOB) ? base + coff : OOB;
       if (MODE == 2) {
         const float4 v1 = buf_load16(rx, first ? off : OOB);
@@ -116,15 +114,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_sbh_kernel(const ConvPa
   };
   auto store_a = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i)
-      if (a_lds[i] >= 0) {
+    for (int i = 0; i < A_F4; ++i) {
+      const int e = tid + NT * i, hrow = e >> 3, c4 = e & 7;  // recomputed (cheaper than six more live registers)
+      if (hrow < H_ROWS) {
         uint2 h, m, l;
         split4(ra[i], h, m, l);
-        unsigned short* d = As + a_lds[i];
+        unsigned short* d = As + hrow * H_ROW + sbh_piece(hrow, c4 >> 1) * 8 + (c4 & 1) * 4;
         *reinterpret_cast<uint2*>(d) = h;
         *reinterpret_cast<uint2*>(d + PLANE_A) = m;
         *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
       }
+    }
   };
   auto load_b = [&](int c, int tap0) {  // weights of (chunk c, taps tap0 .. tap0 + TPG - 1); c >= nC: nothing
     const bool live = c < nC;
@@ -249,7 +249,8 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
   switch (h_tile) {
     case 0: launch_sbh_cfg<8, 16, 128, 2, 2>(p, s); break;
     case 1: launch_sbh_cfg<8, 16, 64, 2, 2>(p, s); break;
-    default: launch_sbh_cfg<8, 16, 32, 4, 1>(p, s); break;
+    case 2: launch_sbh_cfg<8, 16, 32, 4, 1>(p, s); break;
+    default: launch_sbh_cfg<16, 16, 64, 4, 2>(p, s); break;  // 16 x 16 patch, 8 waves, two blocks per CU: weights staged once per 256 rows
   }
 }
 
