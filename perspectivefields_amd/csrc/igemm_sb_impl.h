@@ -57,8 +57,11 @@ __device__ __forceinline__ void split4_hm(const float4 v, uint2& h, uint2& m) {
   m = make_uint2(sb_pack_hi16(mb[0], mb[1]), sb_pack_hi16(mb[2], mb[3]));
 }
 
+#ifndef SB_W8_WAVES
+#define SB_W8_WAVES 4  // min waves per SIMD of the 256x128 / 128x256 8-wave tiles: 4 = two blocks per CU (<= 128 VGPRs)
+#endif
 template <int BM, int BN, int WM, int WN, int MODE, bool ASB, int PFD, int NTERM>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? (PFD == 1 ? 3 : 2) : 1) void igemm_sb_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? (PFD == 1 ? 3 : 2) : ((WM * WN == 8 && BM * BN == 256 * 128 && NTERM == 6) ? SB_W8_WAVES : 1)) void igemm_sb_kernel(const ConvParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int RPP = NT / 8;    // fp32 A rows staged per pass (8 threads x float4 = 32 floats)
   constexpr int RPB = NT / 4;    // bf16 rows staged per pass (4 threads x 16 B = 32 bf16): B, and A when ASB
