@@ -44,7 +44,7 @@ __device__ __forceinline__ int xcd_tile_index(int nblk) {
 // fully coalesced, and the bias / residual operands are read as float4 as well.
 // Rows of the block tile are normally consecutive output pixels (m0 + local row); a kernel that tiles the output
 // spatially passes the patch instead: local row -> (oy0 + row / tx, ox0 + row % tx) of image b, rows outside the map are skipped.
-struct Tile2D { int b, oy0, ox0, tx; };
+struct Tile2D { int b, oy0, ox0, tx, odd_shift; };  // odd_shift: cyclic column shift of the odd patch rows (LDS bank layout of the halo kernel)
 template <int BM, int BN, int WM, int WN, int SM, int SN, int NT, int SMEM_FLOATS>
 __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[SM][SN], float* Cs, int m0, int n0,
                                               const Tile2D* t2 = nullptr) {
@@ -71,7 +71,8 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
       int m = m0 + (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
       const int n = n0 + cq * 4;
       if (t2) {
-        const int lm = m - m0, oy = t2->oy0 + lm / t2->tx, ox = t2->ox0 + lm % t2->tx;
+        const int lm = m - m0, ry = lm / t2->tx, rx = lm - ry * t2->tx;
+        const int oy = t2->oy0 + ry, ox = t2->ox0 + ((ry & 1) ? (rx + t2->odd_shift) % t2->tx : rx);
         if (oy >= p.Ho || ox >= p.Wo) continue;
         m = (t2->b * p.Ho + oy) * p.Wo + ox;
       }

@@ -4,9 +4,9 @@
 // three bf16 parts nine times (once per tap), by every n-tile.  Here a block owns an 8 x 16 patch of output pixels of one
 // image (128 GEMM rows) and, per 32-channel chunk, stages the 10 x 18 input halo ONCE (fetch + exact split, 180 rows);
 // the nine taps then read shifted windows of that tile straight from LDS: per lane the halo row of its output pixel plus
-// a block-uniform tap offset.  Per 9 K steps the A side costs 23 KB of loads and 180 x 32 splits instead of 144 KB and
-// 1152 x 32; the weight tile (B) is staged per step as before.  The XOR piece swizzle is keyed on the halo row, and any
-// 16 consecutive rows hit 16 distinct 16-byte bank slots, so the shifted ds_read_b128 stay conflict-free.
+// a block-uniform tap offset (odd patch rows are rotated by two columns so that the shifted ds_read_b128 stay
+// bank-conflict free under the instruction's non-contiguous lane groups).  Per 9 K steps the A side costs 23 KB of loads and 180 x 32 splits instead of 144 KB and
+// 1152 x 32; the weight tile (B) is staged per step as before.  The XOR piece swizzle is keyed on the halo row.
 // K order is (channel chunk, tap) instead of (tap, channel chunk): same products, different fp32 summation order.
 // fp32 operands, fp32-accurate mode (6 partial products) only.
 // Measured and not kept (profiles/r01_tune_conv_sbh.txt): 16 x 16 patches with 8 waves (ties the 8 x 16 / 4-wave form on
@@ -160,13 +160,20 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // GEMM row -> patch pixel: rows 16 k .. 16 k + 15 are patch row k; ODD patch rows are rotated by ODD_SHIFT columns.
+  // ds_read_b128 is serviced in the non-contiguous lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: with the plain
+  // mapping lanes 16-31 sit 18 halo rows (not 16) after lanes 0-15 and two lanes of every group share a bank slot (PMC:
+  // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.26-0.34); rotating the odd rows by -2 columns makes every group cover 16
+  // distinct residues mod 16 again, for every tap offset (brute-force check in tests/test_host_logic.py).
+  constexpr int ODD_SHIFT = H_TX - 2;
   const int wm0 = (wave / WN) * (SM * 32);
   const int wn0 = (wave % WN) * (SN * 32);
   int hb[SM];  // halo row of this lane's output pixel (tap (0,0)) per 32-row subtile
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
     const int ml = wm0 + i * 32 + l31;
-    hb[i] = (ml / H_TX) * H_HX + (ml % H_TX);
+    const int pr = ml / H_TX, pc0 = ml % H_TX;
+    hb[i] = pr * H_HX + ((pr & 1) ? (pc0 + ODD_SHIFT) % H_TX : pc0);
   }
   const unsigned short* Bb = Bs + (wn0 + l31) * H_ROW;
   const int swz_b = (l31 >> 2) & 3;
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
     }
   }
 
-  const Tile2D t2{bimg, oy0, ox0, H_TX};
+  const Tile2D t2{bimg, oy0, ox0, H_TX, ODD_SHIFT};
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2);
 }
 

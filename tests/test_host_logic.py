@@ -277,3 +277,33 @@ def test_bench_cli_contract_and_loud_failure_without_gpu():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
         assert r.returncode != 0
         assert '"metric"' not in r.stdout
+
+
+def test_halo_kernel_lane_mapping_is_bank_conflict_free():
+    """igemm_sbh.hip: ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (and the same
+    +32); a group conflicts when two of its lanes hit the same 16-byte slot of the 256-byte bank row.  With the odd patch
+    rows rotated by -2 columns every group of every tap offset is conflict free; without the rotation it is not."""
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    hx = 18
+
+    def slot(row, piece):  # row * 64 B + swizzled piece * 16 B, in 16-byte slots mod 16
+        return (row & 3) * 4 + (piece ^ ((row >> 2) & 3))
+
+    def extra_cycles(shift):
+        bad = 0
+        for r0 in range(0, 16, 2):
+            for ky in range(3):
+                for kx in range(3):
+                    for piece in range(4):
+                        for g in groups:
+                            slots = []
+                            for lane in g:
+                                col = lane & 15
+                                if lane >= 16:
+                                    col = (col + shift) % 16
+                                slots.append(slot((r0 + (lane >> 4) + ky) * hx + col + kx, piece))
+                            bad += len(slots) - len(set(slots))
+        return bad
+
+    assert extra_cycles(14) == 0
+    assert extra_cycles(0) > 0
