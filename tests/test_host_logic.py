@@ -307,3 +307,37 @@ def test_halo_kernel_lane_mapping_is_bank_conflict_free():
 
     assert extra_cycles(14) == 0
     assert extra_cycles(0) > 0
+
+
+def test_kernel_resources_static():
+    """Static check of the built library (no GPU): every kernel is there for gfx950, fits the 160 KB LDS, and the kernels
+    of the default path do not spill (scripts/kernel_resources.py reads the AMDGPU metadata of the embedded code objects)."""
+    import importlib.util
+    import shutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or not shutil.which("c++filt"):
+        pytest.skip("llvm-readelf / c++filt not available")
+    from perspectivefields_amd import build as _b
+
+    lib = _b.build(verbose=False)
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = kr.kernels(lib)
+    assert len(rows) >= 200
+    assert all(r["lds"] <= 160 * 1024 for r in rows), [r for r in rows if r["lds"] > 160 * 1024]
+    by = {r["kernel"]: r for r in rows}
+    hot = [
+        "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 6>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 6>",
+        "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 6>", "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 6>",
+        "pf::igemm_sb_kernel<256, 256, 2, 4, 0, false, 1, 6>",
+        "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1>",
+        "pf::sr_attention_kernel", "pf::dwconv7x7_lane_kernel<1, 3, 256, 0>", "pf::upsample2x_cell_kernel",
+        "pf::dwconv3x3_gelu_direct_kernel<32, 8, 8, 0>", "pf::layernorm_kernel<64, 2>",
+    ]
+    for k in hot:
+        assert k in by, (k, [n for n in by if n.startswith(k.split("<")[0])][:4])
+        assert by[k]["spill"] == 0 and by[k]["scratch"] == 0, by[k]
+    # the two-blocks-per-CU 8-wave tiles trade a handful of spilled registers for the second resident block
+    assert by["pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 6>"]["vgpr"] <= 128
