@@ -58,8 +58,13 @@ enum pf_arch {
 
 #define PF_NET_SIZE 320  /* the network always runs at 320x320 (every reference YAML: DATALOADER.RESIZE) */
 #define PF_PARAMS_STRIDE 8
+/* Largest batch one pf_forward_* call accepts: the kernels address each activation with 32-bit byte offsets, and the
+ * largest per-head activation is 26.2 MB per image (2 GiB / 26.2 MB = 81).  Larger batches return PF_ERR_ARG; the host
+ * layer (PerspectiveFields._run) splits longer image lists into chunks, as the reference's callers may pass any length. */
+#define PF_MAX_BATCH 81
 
 const char* pf_version(void);
+const char* pf_build_digest(void); /* digest of the sources this library was built from (stale-library check of the loader) */
 const char* pf_last_error(pf_handle h); /* h may be NULL: error of the last failed pf_create on this thread */
 
 int pf_create(pf_handle* out, int device, int arch);
@@ -75,7 +80,9 @@ int pf_finalize_weights(pf_handle h);
 /* channel counts of the API-visible 320x320 maps and number of raw ParamNet outputs (0 if none) */
 int pf_output_info(pf_handle h, int* gravity_channels, int* latitude_channels, int* param_raw_outputs);
 
-/* bytes of scratch pf_forward_* needs for a batch of `batch` images */
+int pf_max_batch(void); /* = PF_MAX_BATCH */
+
+/* bytes of scratch pf_forward_* needs for a batch of `batch` images (0 for batch <= 0 or > PF_MAX_BATCH) */
 size_t pf_workspace_bytes(pf_handle h, int batch);
 
 /* Forward pass for `batch` images already resized to 320x320.
@@ -87,14 +94,22 @@ size_t pf_workspace_bytes(pf_handle h, int batch);
  *                    CENTERED  : roll, pitch, vfov (deg), rel_focal, raw x0..x3   (param_network.py:62-67)
  *                    UNCENTERED: raw x0..x4 (roll/90, pitch/90, general_vfov/90, rel_cx, rel_cy), 0, 0, 0
  */
-/* Arithmetic of the dense contractions (everything else is always fp32).  FP32 (default, the parity mode): every
- * product is evaluated as six bf16 MFMA partial products of exactly split operands -- fp32-accurate.  BF16X3: three
- * partial products (operands carried to ~16 significant bits).  BF16: one (plain bf16 operands, fp32 accumulation), the
- * reference's autocast-style mode.  The reduced modes trade accuracy for speed and are NOT held to the parity tolerances.
+/* Arithmetic of the dense contractions (everything else is always fp32).
+ *   FP32 (default, the parity mode): "split-f16" -- every fp32 activation is split on the fly into two fp16 values
+ *     (a ~ ah + al 2^-11, 22-23 significant bits), the weights (scaled per output channel by a power of two) into wh + wl,
+ *     and a product is three fp16 MFMA partial products (ah wh + ah wl + al wh) accumulated in fp32: per-product error
+ *     <= 3 * 2^-22, below the fp32 accumulation noise of the contraction itself (scripts/emulate_split.py).
+ *     Activations beyond the fp16 range (|x| > 65504) saturate.
+ *   FP32_BF16X6: every operand split EXACTLY into three bf16 values, six bf16 MFMA partial products -- fp32-accurate
+ *     for any fp32 input (no range restriction), twice the matrix-core work.
+ *   BF16X3: three bf16 partial products (operands carried to ~16 significant bits).  BF16: one (plain bf16 operands,
+ *     fp32 accumulation), the reference's autocast-style mode.  These two trade accuracy for speed and are NOT held to
+ *     the parity tolerances.
  * May be called at any time; it applies to the following forwards (tile choices are tuned per mode). */
 #define PF_PRECISION_FP32 0
 #define PF_PRECISION_BF16X3 1
 #define PF_PRECISION_BF16 2
+#define PF_PRECISION_FP32_BF16X6 3
 int pf_set_precision(pf_handle h, int mode);
 
 int pf_forward_u8(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_pred_gravity, float* d_pred_latitude,
@@ -110,13 +125,27 @@ size_t pf_resize_workspace_bytes(int H, int W);
 int pf_resize_bilinear_u8(pf_handle h, const uint8_t* d_img, int H, int W, uint8_t* d_out_320, void* d_workspace,
                           size_t workspace_bytes, void* stream);
 
-/* One-time tile autotuning for a batch size: a normal forward (same arguments and results as pf_forward_u8) in which
- * every conv/GEMM launch is additionally timed with each tile configuration on this device (HIP events; this call DOES
- * wait on the stream) and the fastest is cached in the handle.  Optional: untuned batch sizes use a static cost model.
- * pf_is_tuned returns 1 once a batch size has been tuned (or when autotuning is disabled with PF_AUTOTUNE=0). */
+/* The same for a whole batch in two launches per 32 images (inference_batch's per-image resize loop, :210-216):
+ * h_imgs = HOST array of B DEVICE pointers to uint8 [H_i][W_i][3] images, h_hw = HOST array [B][2] of (H_i, W_i);
+ * d_out = [B][320][320][3] (the tensor pf_forward_u8 takes).  Workspace: sum over images of roundup(H_i * 320 * 3, 256) + 256 bytes. */
+int pf_resize_batch_u8(pf_handle h, int batch, const uint8_t* const* h_imgs, const int32_t* h_hw, uint8_t* d_out_320,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Tile configuration of the conv / GEMM launches.  Default: a table keyed by launch shape (loaded with pf_load_tile_table;
+ * the Python layer loads the one shipped for gfx950, perspectivefields_amd/tuned/gfx950_tiles.txt) and a static heuristic
+ * for shapes the table does not hold -- deterministic, no first-call stall.
+ * pf_autotune: explicit one-time tuning for a batch size: a normal forward (same arguments and results as pf_forward_u8;
+ * workspace of pf_autotune_workspace_bytes) in which every conv / GEMM launch is additionally timed with each tile
+ * configuration on this device (HIP events; this call DOES wait on the stream); the fastest per shape is cached in the
+ * handle (pf_save_tile_table writes the cache out).  With PF_AUTOTUNE=1 in the environment the Python layer runs it on the
+ * first forward of every new batch size; pf_is_tuned then tells whether a batch size has been tuned.
+ * pf_load_tile_table / pf_save_tile_table return the number of entries read / written, or a negative pf_status. */
+size_t pf_autotune_workspace_bytes(pf_handle h, int batch);
 int pf_autotune(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_pred_gravity, float* d_pred_latitude,
                 float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
 int pf_is_tuned(pf_handle h, int batch);
+int pf_load_tile_table(pf_handle h, const char* path);
+int pf_save_tile_table(pf_handle h, const char* path);
 
 /* Post-process ONE image's 320x320 predictions to its original size (H, W):
  *   d_up_out  : [2][H][W] unit up-vectors (x right, y down), d_lat_out : [H][W] degrees.
@@ -163,10 +192,11 @@ int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, 
                  const float* d_res1, const float* d_res2, int post_relu, int nchw_out, int tile_id /*-1 auto*/,
                  float* d_y /*may be NULL when d_y_planes is given*/,
                  const uint16_t* d_x_planes /*replaces d_x*/, long x_plane_elems, const uint16_t* d_x2_planes, long x2_plane_elems,
-                 uint16_t* d_y_planes, long y_plane_elems, int precision /*PF_PRECISION_*: split-bf16 tiles only*/, void* stream);
+                 uint16_t* d_y_planes, long y_plane_elems, int precision /*PF_PRECISION_*: split tiles only*/, void* stream);
 /* times `iters` launches of one conv shape on random data with tile config `tile_id` (-1 auto); avg ms per launch.
- * fmt 0: fp32 in / out; 1: input as planes; 2: input and output as planes */
-int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt, float* ms_out);
+ * fmt_prec = fmt + 16 * precision; fmt 0: fp32 in / out; 1: input as bf16 planes; 2: input and output as planes
+ * (1 / 2: the exact bf16 split); precision = PF_PRECISION_* used by the split tiles */
+int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt_prec, float* ms_out);
 int pf_op_split_bf16(int device, const float* d_x, long n, uint16_t* d_planes, long plane_elems, void* stream);
 int pf_op_merge_bf16(int device, const uint16_t* d_planes, long plane_elems, long n, float* d_y, void* stream);
 /* times one depthwise-3x3+GELU launch variant on random data (0 = LDS halo tile, 1-4 = register-window direct, 99 = plain copy) */

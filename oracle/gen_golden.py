@@ -21,6 +21,13 @@ What is stored per zoo version (tag):
   param_names      list of scalar keys;  params_i (n,) f32;  params64_i (n,) f64 (reference run in float64)
   sums_i           (4,) f64            sum|pred_gravity|, sum pred_gravity, sum|pred_latitude|, sum pred_latitude (full res)
   c1_s..c4_s, ll_s                     stage-boundary activations of image 0 (subsampled)
+
+fullsize.npz (BASELINE.json's own image sizes: 640x640 = configs[0..3], 384x512 / 1024x1365 = configs[4]; the
+post-process up-sampling regime with its clamp-at-0 / last-pixel edge branches, gravity_head.py:248-257, utils.py:503-506):
+per (tag, image k): fs_<tag>_in_u8_k, fs_<tag>_size_k, the 320^2 predictions on a stride-2 grid (regression) or their
+argmax (classification), and of the post-processed (H, W) fields a stride-8 grid (fs_<tag>_grav_s8_k / lat_s8_k) plus
+the two outermost rows and columns on every side (…_rows_k = rows [0, 1, H-2, H-1], …_cols_k = columns [0, 1, W-2, W-1]),
+params as above.
 """
 from __future__ import annotations
 
@@ -140,12 +147,63 @@ def run_fields(out_dir):
     print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB")
 
 
+FULLSIZE = {
+    "centered": ("Paramnet-360Cities-edina-centered", [(640, 640), (384, 512), (1024, 1365)]),
+    "persnet": ("PersNet-360Cities", [(640, 640)]),
+    "uncentered": ("Paramnet-360Cities-edina-uncentered", [(640, 640)]),
+}
+
+
+def run_fullsize(out_dir):
+    """The sizes every BASELINE config names, through the unmodified reference (inference_batch on a mixed-size list)."""
+    blob = {}
+    for tag, (version, sizes) in FULLSIZE.items():
+        torch.manual_seed(0)
+        sd = to_torch(synthetic_state_dict(version, SEED))
+        model = ref_shim.build_reference(version, sd)
+        imgs = [synthetic_image(h, w, seed=500 + i) for i, (h, w) in enumerate(sizes)]
+        with torch.no_grad():
+            preds = model.inference_batch(imgs)
+        names = [k for k in PARAM_KEYS if k in preds[0]]
+        blob[f"fs_{tag}_param_names"] = np.array(names)
+        blob[f"fs_{tag}_n"] = np.array(len(sizes))
+        for k, (im, p) in enumerate(zip(imgs, preds)):
+            H, W = im.shape[:2]
+            pre = f"fs_{tag}_"
+            blob[f"{pre}in_u8_{k}"] = model.aug.apply_image(im)
+            blob[f"{pre}size_{k}"] = np.array([H, W])
+            g, l = p["pred_gravity"], p["pred_latitude"]
+            if g.shape[0] != 2:
+                blob[f"{pre}grav_argmax_{k}"] = g.argmax(0).to(torch.uint8).numpy()
+                blob[f"{pre}lat_argmax_{k}"] = l.argmax(0).to(torch.uint8).numpy()
+            else:
+                blob[f"{pre}grav_s2_{k}"] = g[:, ::2, ::2].numpy()
+                blob[f"{pre}lat_s2_{k}"] = l[:, ::2, ::2].numpy()
+            go, lo = p["pred_gravity_original"], p["pred_latitude_original"]
+            assert tuple(go.shape) == (2, H, W) and tuple(lo.shape) == (H, W)
+            blob[f"{pre}grav_s8_{k}"] = go[:, ::8, ::8].numpy()
+            blob[f"{pre}lat_s8_{k}"] = lo[::8, ::8].numpy()
+            rows, cols = [0, 1, H - 2, H - 1], [0, 1, W - 2, W - 1]
+            blob[f"{pre}grav_rows_{k}"] = go[:, rows, :].numpy()
+            blob[f"{pre}grav_cols_{k}"] = go[:, :, cols].numpy()
+            blob[f"{pre}lat_rows_{k}"] = lo[rows, :].numpy()
+            blob[f"{pre}lat_cols_{k}"] = lo[:, cols].numpy()
+            if names:
+                blob[f"{pre}params_{k}"] = np.array([float(p[n].reshape(-1)[0]) for n in names], dtype=np.float32)
+            print(f"  [fullsize {tag} img{k}] {H}x{W}", {n: float(p[n]) for n in names})
+    path = os.path.join(out_dir, "fullsize.npz")
+    np.savez_compressed(path, **blob)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     only = sys.argv[1:]
     if not only or "fields" in only:
         run_fields(out_dir)
+    if not only or "fullsize" in only:
+        run_fullsize(out_dir)
     for tag, (version, sizes) in CASES.items():
         if only and tag not in only:
             continue

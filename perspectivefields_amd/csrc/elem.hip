@@ -886,6 +886,60 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict
     o[0] = rs_clip8(s0); o[1] = rs_clip8(s1); o[2] = rs_clip8(s2);
   }
 }
+// The same two passes for up to ResizeBatch::MAX images per launch pair (blockIdx.y = image; per-image pointers, sizes and
+// coefficient tables travel in the kernel arguments): inference_batch's per-image resize loop as two launches.
+__device__ __forceinline__ void resize_h_pixels(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H, int W, int OW,
+                                                const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
+  const long total = (long)H * OW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xx = (int)(i % OW);
+    const long y = i / OW;
+    const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+    const int* k = kk + (long)xx * ksize;
+    const uint8_t* p = in + (y * W + xmin) * 3;
+    int s0 = 1 << (RS_PREC - 1), s1 = s0, s2 = s0;
+    for (int x = 0; x < n; ++x) {
+      const int w = k[x];
+      s0 += p[3 * x] * w; s1 += p[3 * x + 1] * w; s2 += p[3 * x + 2] * w;
+    }
+    uint8_t* o = out + i * 3;
+    o[0] = rs_clip8(s0); o[1] = rs_clip8(s1); o[2] = rs_clip8(s2);
+  }
+}
+__device__ __forceinline__ void resize_v_pixels(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int OW, int OH,
+                                                const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
+  const long total = (long)OH * OW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xx = (int)(i % OW);
+    const int yy = (int)(i / OW);
+    const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
+    const int* k = kk + (long)yy * ksize;
+    const uint8_t* p = in + ((long)ymin * OW + xx) * 3;
+    int s0 = 1 << (RS_PREC - 1), s1 = s0, s2 = s0;
+    for (int y = 0; y < n; ++y) {
+      const int w = k[y];
+      s0 += p[0] * w; s1 += p[1] * w; s2 += p[2] * w;
+      p += (long)OW * 3;
+    }
+    uint8_t* o = out + i * 3;
+    o[0] = rs_clip8(s0); o[1] = rs_clip8(s1); o[2] = rs_clip8(s2);
+  }
+}
+__global__ __launch_bounds__(256) void resize_h_batch_kernel(const ResizeBatch rb, int OW) {
+  const int k = blockIdx.y;
+  resize_h_pixels(rb.in[k], rb.tmp[k], rb.H[k], rb.W[k], OW, rb.bh[k], rb.kh[k], rb.ksh[k]);
+}
+__global__ __launch_bounds__(256) void resize_v_batch_kernel(const ResizeBatch rb, int OW, int OH) {
+  const int k = blockIdx.y;
+  resize_v_pixels(rb.tmp[k], rb.out[k], OW, OH, rb.bv[k], rb.kv[k], rb.ksv[k]);
+}
+void launch_resize_batch_u8(const ResizeBatch& rb, int OH, int OW, hipStream_t s) {
+  long mx = 1;
+  for (int k = 0; k < rb.n; ++k) mx = std::max(mx, (long)rb.H[k] * OW);
+  hipLaunchKernelGGL(resize_h_batch_kernel, dim3(grid_for(mx), rb.n), dim3(256), 0, s, rb, OW);
+  hipLaunchKernelGGL(resize_v_batch_kernel, dim3(grid_for((long)OH * OW), rb.n), dim3(256), 0, s, rb, OW, OH);
+}
+
 void launch_resize_u8(const uint8_t* in, int H, int W, uint8_t* tmp, uint8_t* out, int OH, int OW, const int* bh, const int* kh, int ksh,
                       const int* bv, const int* kv, int ksv, hipStream_t s) {
   hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for((long)H * OW)), dim3(256), 0, s, in, tmp, H, W, OW, bh, kh, ksh);

@@ -34,6 +34,9 @@ std::string fmt(const char* f, ...) {
 
 // ---- architecture constants (reference: mix_transformers.py:511-524, gravity_head.py:121-137, convnext.py:78-79)
 constexpr int NET = PF_NET_SIZE;
+static_assert((size_t)PF_MAX_BATCH * PF_NET_SIZE * PF_NET_SIZE * 64 * 4 <= 0x7fffffffull &&
+              (size_t)PF_MAX_BATCH * (PF_NET_SIZE / 2) * (PF_NET_SIZE / 2) * 256 * 4 <= 0x7fffffffull,
+              "PF_MAX_BATCH: every per-head activation must stay below 2 GiB (32-bit byte offsets, OOB marker 2^31)");
 const int MIT_DIMS[4] = {64, 128, 320, 512};
 const int MIT_HEADS[4] = {1, 2, 5, 8};
 const int MIT_DEPTHS[4] = {3, 4, 18, 3};
@@ -54,6 +57,8 @@ struct ConvW {
   float* b = nullptr;
   float* btab = nullptr;  // [9][Cout] border-case biases of a folded Linear->3x3 pair
   unsigned short* wsb = nullptr;  // weights split exactly into 3 bf16 planes (split-bf16 kernel), when Cin % 32 == 0
+  unsigned short* wh16 = nullptr; // split-f16 scheme: per-channel power-of-two scaled weights as two fp16 planes wh, wl
+  float* wh16_inv = nullptr;      //   and the inverse scale per output channel
   int Cout = 0, Cin = 0 /*padded*/, CinReal = 0, KH = 1, KW = 1, stride = 1, pad = 0, KWC = 0, KWCp = 0;
 };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-6f; };
@@ -191,6 +196,36 @@ std::vector<unsigned short> split_bf16x3(const std::vector<float>& w) {
   return o;
 }
 
+// Split-f16 weight planes (igemm_sb_impl.h, NT_F16X3).  Row n (one output channel, `per_row` packed values) is scaled by
+// S_n = 2^e with max|w S_n| in [2^13, 2^14) -- exact, and it keeps the low part wl = fp16(w S - wh) a NORMAL fp16 number
+// for every weight down to 2^-16 of the row maximum, and the product plane wh 2^-11 (made on the device) exact down to
+// 2^-17 of it.  Planes: [0] wh = fp16_rn(w S), [1] wl = fp16_rn(w S - wh); inv_scale[n] = 1 / S_n undoes the scale in the epilogue.
+struct F16Planes { std::vector<unsigned short> planes; std::vector<float> inv_scale; };
+F16Planes split_f16x2(const std::vector<float>& w, int Cout) {
+  const size_t n = w.size(), per_row = n / (size_t)Cout;
+  F16Planes o;
+  o.planes.resize(2 * n);
+  o.inv_scale.resize(Cout);
+  auto bits16 = [](_Float16 h) { unsigned short u; std::memcpy(&u, &h, 2); return u; };
+  for (int r = 0; r < Cout; ++r) {
+    float mx = 0.f;
+    for (size_t k = 0; k < per_row; ++k) mx = std::max(mx, std::fabs(w[r * per_row + k]));
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) { int ex; (void)std::frexp(mx, &ex); e = 14 - ex; }  // mx = m 2^ex, m in [0.5, 1)  ->  mx 2^e in [2^13, 2^14)
+    e = std::max(-100, std::min(100, e));
+    const float S = std::ldexp(1.0f, e);
+    o.inv_scale[r] = std::ldexp(1.0f, -e);
+    for (size_t k = 0; k < per_row; ++k) {
+      const float ws = w[r * per_row + k] * S;
+      const _Float16 hi = (_Float16)ws;
+      const _Float16 lo = (_Float16)(ws - (float)hi);
+      o.planes[r * per_row + k] = bits16(hi);
+      o.planes[n + r * per_row + k] = bits16(lo);
+    }
+  }
+  return o;
+}
+
 // Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR (triangle, support 1) filter, in double, so that
 // the integer tables are bit-identical to the ones PIL builds (reference path: perspectivefields.py:45 -> Image.resize).
 struct ResizeTable { int ksize = 0; std::vector<int> bounds, kk; int *d_bounds = nullptr, *d_kk = nullptr; };
@@ -240,14 +275,17 @@ struct pf_engine {
   std::vector<void*> dev_allocs;
   std::map<int, size_t> ws_cache;
   Profiler prof;
-  bool autotune = true;      // PF_AUTOTUNE=0: tile choice from the static cost model only
+  bool autotune = false;     // PF_AUTOTUNE=1: the first forward of every new batch size times all tile configs per conv shape (a 1-2 s stall).
+                             // Default off: tiles come from the shipped table (pf_load_tile_table, tuned/gfx950_tiles.txt) or the static
+                             // heuristic -- deterministic, no first-call latency cliff; pf_autotune stays available as an explicit call
   std::map<std::vector<int>, int> tile_cache;  // conv shape (+batch) -> fastest tile config, measured on this device
   std::map<int, bool> tuned_batches;
   std::map<int, ResizeTable> resize_tables;  // input extent -> tables for resizing that extent to NET
   std::map<int, size_t> scratch_off, scratch_elems;
   bool split_bf16 = true;    // PF_SPLIT_BF16=0: exact-fp32 MFMA kernels only (no split-bf16 tiles)
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
-  int nterms = 6;            // pf_set_precision / PF_PRECISION: 6 fp32-accurate (default), 3 = "bf16x3", 1 = "bf16" (reduced precision, not parity modes)
+  int nterms = NT_F16X3;     // pf_set_precision: NT_F16X3 = 2-way fp16 split, 3 MFMAs per product (default parity mode); 6 = exact 3-way bf16 split
+                             // (fp32-accurate, PF_PRECISION_FP32_BF16X6); 3 = "bf16x3", 1 = "bf16" (reduced precision, not parity modes)
   bool sba = false;          // PF_SBA=1: tensors that only feed GEMMs are stored as split-bf16 planes by their producers (sb_split.h);
                              // measured slower end to end (1.5x the bytes on HBM-bound layers), kept as an option -- DESIGN.md 4.2
 
@@ -291,9 +329,14 @@ struct pf_engine {
     return static_cast<unsigned short*>(d);
   }
   // packed fp32 weights -> device, plus the split-bf16 planes when the layer is eligible for igemm_sb
-  void upload_conv_weights(ConvW& c, const std::vector<float>& packed, int CinP) {
+  void upload_conv_weights(ConvW& c, const std::vector<float>& packed, int CinP, int Cout) {
     c.w = upload(packed);
-    if (split_bf16 && CinP % 32 == 0) c.wsb = upload_u16(split_bf16x3(packed));
+    if (split_bf16 && CinP % 32 == 0) {
+      c.wsb = upload_u16(split_bf16x3(packed));
+      const F16Planes f = split_f16x2(packed, Cout);
+      c.wh16 = upload_u16(f.planes);
+      c.wh16_inv = upload(f.inv_scale);
+    }
   }
   const HostTensor& get(const std::string& key, std::initializer_list<int64_t> shape) {
     auto it = host.find(key);
@@ -313,7 +356,7 @@ struct pf_engine {
     ConvW c;
     const int CinP = roundup(Cin, 4);
     const HostTensor& w = get(wkey, {Cout, Cin, K, K});
-    upload_conv_weights(c, pack_conv(w.data.data(), Cout, Cin, K, K, CinP, out_scale, &c.KWC, &c.KWCp), CinP);
+    upload_conv_weights(c, pack_conv(w.data.data(), Cout, Cin, K, K, CinP, out_scale, &c.KWC, &c.KWCp), CinP, Cout);
     if (bias_override) c.b = upload(*bias_override);
     else if (!bkey.empty()) {
       std::vector<float> b = get(bkey, {Cout}).data;
@@ -326,7 +369,7 @@ struct pf_engine {
   ConvW make_linear(const std::string& pfx, int N, int K, const double* out_scale = nullptr) {
     ConvW c;
     const HostTensor& w = get(pfx + ".weight", {N, K});
-    upload_conv_weights(c, pack_conv(w.data.data(), N, K, 1, 1, K, out_scale, &c.KWC, &c.KWCp), K);
+    upload_conv_weights(c, pack_conv(w.data.data(), N, K, 1, 1, K, out_scale, &c.KWC, &c.KWCp), K, N);
     std::vector<float> b = get(pfx + ".bias", {N}).data;
     if (out_scale) for (int n = 0; n < N; ++n) b[n] = (float)(b[n] * out_scale[n]);
     c.b = upload(b);
@@ -361,7 +404,7 @@ struct pf_engine {
         T[(size_t)o * 9 + t] = tb;
       }
     ConvW c;
-    upload_conv_weights(c, pack_conv(wf.data(), DEC_FEAT, C, 3, 3, C, nullptr, &c.KWC, &c.KWCp), C);
+    upload_conv_weights(c, pack_conv(wf.data(), DEC_FEAT, C, 3, 3, C, nullptr, &c.KWC, &c.KWCp), C, DEC_FEAT);
     std::vector<float> tab((size_t)9 * DEC_FEAT);
     for (int cy = 0; cy < 3; ++cy)
       for (int cx = 0; cx < 3; ++cx)
@@ -525,7 +568,7 @@ struct pf_engine {
     for (int g = 0; g < ngroups; ++g) {
       const ConvW& wg = *calls[g].w;
       ConvPtrs& q = p.g[g];
-      q.x = calls[g].x.f; q.x2 = calls[g].x2.f; q.w = wg.w; q.w_sb = wg.wsb; q.bias = wg.b; q.bias_tab = wg.btab;
+      q.x = calls[g].x.f; q.x2 = calls[g].x2.f; q.w = wg.w; q.w_sb = wg.wsb; q.w_h16 = wg.wh16; q.w_h16_inv_scale = wg.wh16_inv; q.bias = wg.b; q.bias_tab = wg.btab;
       q.res1 = calls[g].res1; q.res2 = calls[g].res2; q.y = calls[g].y.f;
       q.x_sb = calls[g].x.s.p; q.x2_sb = calls[g].x2.s.p; q.y_sb = calls[g].y.s.p;
     }
@@ -538,9 +581,10 @@ struct pf_engine {
     p.nterms = nterms;
     p.finish();
     int tile = -1;
-    if (autotune) {
+    {
       // operand formats are part of the key: a split-plane input changes which tile is fastest
-      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * (6 - nterms);
+      const int prec_code = nterms == NT_F16X3 ? 0 : (nterms == 6 ? 3 : (nterms == 3 ? 1 : 2));  // = PF_PRECISION_*
+      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * prec_code;
       const std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out, fmt_bits, p.act};
       auto it = tile_cache.find(key);
       if (it != tile_cache.end()) tile = it->second;
@@ -817,31 +861,35 @@ struct pf_engine {
     if (has_param) paramnet(c, B, pn, params);
   }
 
-  size_t workspace_bytes(int B) {
+  // with_scratch: plus the target of the tuning launches (largest conv output as fp32 + 3 bf16 planes) -- pf_autotune only
+  size_t workspace_bytes(int B, bool with_scratch = false) {
     auto it = ws_cache.find(B);
-    if (it != ws_cache.end()) return it->second;
-    Ctx c{nullptr, 4096, 0, 0, true, nullptr};
-    run(c, B, nullptr, true, nullptr, nullptr, nullptr);
-    const size_t scratch = autotune ? c.max_conv_out * 10 + 4096 : 0;  // largest conv output (fp32 + 3 bf16 planes), target of the tuning launches
-    const size_t need = c.peak + 4096 + scratch;
-    ws_cache[B] = need;
-    scratch_off[B] = c.peak;
-    scratch_elems[B] = c.max_conv_out;
-    return need;
+    if (it == ws_cache.end()) {
+      Ctx c{nullptr, 4096, 0, 0, true, nullptr};
+      run(c, B, nullptr, true, nullptr, nullptr, nullptr);
+      ws_cache[B] = c.peak + 4096;
+      scratch_off[B] = c.peak;
+      scratch_elems[B] = c.max_conv_out;
+      it = ws_cache.find(B);
+    }
+    return it->second + ((with_scratch || autotune) ? scratch_elems[B] * 10 + 4096 : 0);
   }
 
   int forward(int B, const void* in, bool is_u8, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, hipStream_t s, bool tune = false) {
     if (!finalized) return fail(PF_ERR_WEIGHTS, "pf_forward called before pf_finalize_weights");
     if (B <= 0 || !in || !pg || !pl || !ws) return fail(PF_ERR_ARG, "pf_forward: null pointer or batch <= 0");
     if (has_param && !params) return fail(PF_ERR_ARG, "pf_forward: d_params is required for a ParamNet architecture");
-    if ((long)B * NET * NET * 64 * 4 > 0x7fffffffL * 4L) return fail(PF_ERR_ARG, "pf_forward: batch too large for 32-bit tile indexing (max 81)");
-    const size_t need = workspace_bytes(B);
+    // The implicit-GEMM kernels address every activation with 32-bit BYTE offsets and use offset 2^31 as the "reads as
+    // zero" marker (igemm_common.h OOB): each per-head activation must stay below 2 GiB.  The largest are the
+    // 160x160x256 decoder map and the 320x320x64 map before conv_fuse_conv1: B * 26.2 MB  ->  B <= PF_MAX_BATCH (81).
+    if (B > PF_MAX_BATCH) return fail(PF_ERR_ARG, fmt("pf_forward: batch %d exceeds PF_MAX_BATCH = %d (32-bit byte offsets inside one activation); split the batch", B, PF_MAX_BATCH));
+    const size_t need = workspace_bytes(B, tune);
     if (ws_bytes < need) return fail(PF_ERR_WORKSPACE, fmt("workspace too small: %zu < %zu bytes", ws_bytes, need));
     if (hipSetDevice(device) != hipSuccess) return fail(PF_ERR_DEVICE, "hipSetDevice failed");
     uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255;
     Ctx c{s, base, 0, 0, false, nullptr};
     c.prof = prof.on ? &prof : nullptr;
-    if (tune && autotune) {
+    if (tune) {
       c.tuning = true;
       c.tune_scratch = reinterpret_cast<float*>(base + scratch_off[B]);
       c.tune_scratch_elems = scratch_elems[B];
@@ -894,7 +942,13 @@ struct TmpDev {  // test-entry-point helper: upload host weights, free on scope 
 
 extern "C" {
 
-const char* pf_version(void) { return "pf_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* pf_version(void) { return "pf_hip 0.2 (gfx950; split-f16 / split-bf16 / fp32 MFMA)"; }
+
+#ifndef PF_BUILD_DIGEST
+#define PF_BUILD_DIGEST "unknown"
+#endif
+// sha256 over csrc/ + include/ + flags at build time (perspectivefields_amd/build.py): lets the loader refuse a stale .so
+const char* pf_build_digest(void) { return PF_BUILD_DIGEST; }
 
 const char* pf_last_error(pf_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -911,8 +965,8 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;
-  if (const char* v = getenv("PF_PRECISION")) e->nterms = std::strcmp(v, "bf16") == 0 ? 1 : (std::strcmp(v, "bf16x3") == 0 ? 3 : 6);
   if (!e->split_bf16) e->sba = false;  // split planes are only read by the split-bf16 kernels
+  if (e->sba) e->nterms = 6;           // the split-plane activation format is the exact bf16 one
   tune_cache_load(e);
   *out = e;
   return PF_OK;
@@ -920,9 +974,10 @@ int pf_create(pf_handle* out, int device, int arch) {
 
 int pf_set_precision(pf_handle h, int mode) {
   if (!h) return PF_ERR_ARG;
-  if (mode != PF_PRECISION_FP32 && mode != PF_PRECISION_BF16X3 && mode != PF_PRECISION_BF16) return h->fail(PF_ERR_ARG, "pf_set_precision: unknown mode");
-  if (mode != PF_PRECISION_FP32 && !h->split_bf16) return h->fail(PF_ERR_ARG, "pf_set_precision: reduced precision needs the split-bf16 kernels (PF_SPLIT_BF16=0 is set)");
-  h->nterms = mode == PF_PRECISION_BF16 ? 1 : (mode == PF_PRECISION_BF16X3 ? 3 : 6);
+  if (mode < PF_PRECISION_FP32 || mode > PF_PRECISION_FP32_BF16X6) return h->fail(PF_ERR_ARG, "pf_set_precision: unknown mode");
+  if (mode != PF_PRECISION_FP32 && !h->split_bf16) return h->fail(PF_ERR_ARG, "pf_set_precision: this mode needs the split kernels (PF_SPLIT_BF16=0 is set)");
+  if (h->sba && mode == PF_PRECISION_FP32) mode = PF_PRECISION_FP32_BF16X6;  // PF_SBA=1: split-plane activations exist in the exact bf16 format only
+  h->nterms = mode == PF_PRECISION_BF16 ? 1 : (mode == PF_PRECISION_BF16X3 ? 3 : (mode == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
   return PF_OK;
 }
 
@@ -967,8 +1022,10 @@ int pf_output_info(pf_handle h, int* g, int* l, int* p) {
   return PF_OK;
 }
 
+int pf_max_batch(void) { return PF_MAX_BATCH; }
+
 size_t pf_workspace_bytes(pf_handle h, int batch) {
-  if (!h || batch <= 0) return 0;
+  if (!h || batch <= 0 || batch > PF_MAX_BATCH) return 0;
   const bool was = h->has_param;
   if (!h->finalized) {  // architecture-only estimate is allowed before weights are loaded
     h->has_param = h->arch != PF_ARCH_PERSNET_CLS;
@@ -997,42 +1054,63 @@ int pf_forward_f32(pf_handle h, int batch, const float* in, float* pg, float* pl
   return h->forward(batch, in, false, pg, pl, params, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
-// Optional on-disk tile cache (PF_TUNE_CACHE=<file>): lines "<12 key ints> <tile name>"; lets a profiled run skip the
-// tuning launches.  Entries are keyed by shape, so a stale file can only cost speed, never correctness.
-static void tune_cache_load(pf_engine* h) {
-  const char* path = getenv("PF_TUNE_CACHE");
-  if (!path) return;
-  FILE* f = fopen(path, "r");
-  if (!f) return;
-  char name[64];
-  int k[12];
-  while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %63s", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7], &k[8], &k[9], &k[10], &k[11], name) == 13) {
-    for (int t = 0; t < conv_num_tiles(); ++t)
-      if (std::strcmp(conv_tile_name(t), name) == 0) { h->tile_cache[std::vector<int>(k, k + 12)] = t; break; }
-  }
-  fclose(f);
-}
-static void tune_cache_save(pf_engine* h) {
-  const char* path = getenv("PF_TUNE_CACHE");
-  if (!path) return;
-  FILE* f = fopen(path, "w");
-  if (!f) return;
-  for (auto& kv : h->tile_cache) {
-    if (kv.second < 0) continue;
-    for (int v : kv.first) fprintf(f, "%d ", v);
-    fprintf(f, "%s\n", conv_tile_name(kv.second));
-  }
-  fclose(f);
-}
+// Optional on-disk tile cache (PF_TUNE_CACHE=<file>): read at pf_create, rewritten after every pf_autotune.
+static int tile_table_load(pf_engine* h, const char* path);
+static int tile_table_save(pf_engine* h, const char* path);
+static void tune_cache_load(pf_engine* h) { if (const char* path = getenv("PF_TUNE_CACHE")) (void)tile_table_load(h, path); }
+static void tune_cache_save(pf_engine* h) { if (const char* path = getenv("PF_TUNE_CACHE")) (void)tile_table_save(h, path); }
 
 int pf_autotune(pf_handle h, int batch, const uint8_t* in, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, void* stream) {
   if (!h) return PF_ERR_ARG;
   const int rc = h->forward(batch, in, true, pg, pl, params, ws, ws_bytes, static_cast<hipStream_t>(stream), true);
-  if (rc == PF_OK) { h->tuned_batches[batch * 8 + h->nterms] = true; tune_cache_save(h); }
+  if (rc == PF_OK) { h->tuned_batches[batch * 32 + h->nterms] = true; tune_cache_save(h); }
   return rc;
 }
 
-int pf_is_tuned(pf_handle h, int batch) { return (h && (!h->autotune || h->tuned_batches.count(batch * 8 + h->nterms))) ? 1 : 0; }
+int pf_is_tuned(pf_handle h, int batch) { return (h && (!h->autotune || h->tuned_batches.count(batch * 32 + h->nterms))) ? 1 : 0; }
+
+size_t pf_autotune_workspace_bytes(pf_handle h, int batch) {
+  if (!h || !h->finalized || batch <= 0 || batch > PF_MAX_BATCH) return 0;
+  return h->workspace_bytes(batch, true);
+}
+
+// Tile table files: one line per conv shape, "<12 key ints> <tile name>" (key = GEMM view, layout and precision of the
+// launch).  Entries are keyed by shape and name, so a stale file can only cost speed, never correctness.
+static int tile_table_load(pf_engine* h, const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  char name[64];
+  int k[12], n = 0;
+  while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %63s", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7], &k[8], &k[9], &k[10], &k[11], name) == 13) {
+    for (int t = 0; t < conv_num_tiles(); ++t)
+      if (std::strcmp(conv_tile_name(t), name) == 0) { h->tile_cache[std::vector<int>(k, k + 12)] = t; ++n; break; }
+  }
+  fclose(f);
+  return n;
+}
+static int tile_table_save(pf_engine* h, const char* path) {
+  FILE* f = fopen(path, "w");
+  if (!f) return -1;
+  int n = 0;
+  for (auto& kv : h->tile_cache) {
+    if (kv.second < 0) continue;
+    for (int v : kv.first) fprintf(f, "%d ", v);
+    fprintf(f, "%s\n", conv_tile_name(kv.second));
+    ++n;
+  }
+  fclose(f);
+  return n;
+}
+int pf_load_tile_table(pf_handle h, const char* path) {
+  if (!h || !path) return PF_ERR_ARG;
+  const int n = tile_table_load(h, path);
+  return n < 0 ? h->fail(PF_ERR_ARG, fmt("pf_load_tile_table: cannot read '%s'", path)) : n;
+}
+int pf_save_tile_table(pf_handle h, const char* path) {
+  if (!h || !path) return PF_ERR_ARG;
+  const int n = tile_table_save(h, path);
+  return n < 0 ? h->fail(PF_ERR_ARG, fmt("pf_save_tile_table: cannot write '%s'", path)) : n;
+}
 
 size_t pf_resize_workspace_bytes(int H, int W) { (void)W; return H > 0 ? (size_t)H * NET * 3 + 256 : 0; }
 
@@ -1046,6 +1124,37 @@ int pf_resize_bilinear_u8(pf_handle h, const uint8_t* d_img, int H, int W, uint8
   if (!th || !tv) return h->fail(PF_ERR_DEVICE, "pf_resize_bilinear_u8: could not upload coefficient tables");
   uint8_t* tmp = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
   launch_resize_u8(d_img, H, W, tmp, d_out, NET, NET, th->d_bounds, th->d_kk, th->ksize, tv->d_bounds, tv->d_kk, tv->ksize, static_cast<hipStream_t>(stream));
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return h->fail(PF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+  return PF_OK;
+}
+
+int pf_resize_batch_u8(pf_handle h, int B, const uint8_t* const* h_imgs, const int32_t* h_hw, uint8_t* d_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return PF_ERR_ARG;
+  if (B <= 0 || !h_imgs || !h_hw || !d_out) return h->fail(PF_ERR_ARG, "pf_resize_batch_u8: bad argument");
+  size_t need = 256;
+  for (int i = 0; i < B; ++i) {
+    if (!h_imgs[i] || h_hw[2 * i] <= 0 || h_hw[2 * i + 1] <= 0) return h->fail(PF_ERR_ARG, "pf_resize_batch_u8: bad image pointer or size");
+    need += ((size_t)h_hw[2 * i] * NET * 3 + 255) & ~(size_t)255;
+  }
+  if (!ws || ws_bytes < need) return h->fail(PF_ERR_WORKSPACE, fmt("pf_resize_batch_u8: workspace too small: %zu < %zu bytes", ws_bytes, need));
+  if (hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
+  uint8_t* tmp = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+  for (int i0 = 0; i0 < B; i0 += ResizeBatch::MAX) {
+    ResizeBatch rb;
+    rb.n = std::min(B - i0, (int)ResizeBatch::MAX);
+    for (int k = 0; k < rb.n; ++k) {
+      const int i = i0 + k, H = h_hw[2 * i], W = h_hw[2 * i + 1];
+      ResizeTable* th = h->resize_table(W);  // first use of an extent builds + uploads its table (blocking copy, once)
+      ResizeTable* tv = h->resize_table(H);
+      if (!th || !tv) return h->fail(PF_ERR_DEVICE, "pf_resize_batch_u8: could not upload coefficient tables");
+      rb.H[k] = H; rb.W[k] = W; rb.in[k] = h_imgs[i]; rb.tmp[k] = tmp; rb.out[k] = d_out + (size_t)i * NET * NET * 3;
+      rb.bh[k] = th->d_bounds; rb.kh[k] = th->d_kk; rb.ksh[k] = th->ksize;
+      rb.bv[k] = tv->d_bounds; rb.kv[k] = tv->d_kk; rb.ksv[k] = tv->ksize;
+      tmp += ((size_t)H * NET * 3 + 255) & ~(size_t)255;
+    }
+    launch_resize_batch_u8(rb, NET, NET, static_cast<hipStream_t>(stream));
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return h->fail(PF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
   return PF_OK;
@@ -1177,7 +1286,11 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   std::vector<float> packed = pack_conv(hw, Cout, Cin, KH, KW, Cin, nullptr, &p.KWC, &p.KWCp);
   p.g[0].w = tmp.up(packed);
   std::vector<unsigned short> sb;
-  if (Cin % 32 == 0) { sb = split_bf16x3(packed); p.g[0].w_sb = tmp.up_u16(sb); }
+  if (Cin % 32 == 0) {
+    sb = split_bf16x3(packed); p.g[0].w_sb = tmp.up_u16(sb);
+    const F16Planes f = split_f16x2(packed, Cout);
+    p.g[0].w_h16 = tmp.up_u16(f.planes); p.g[0].w_h16_inv_scale = tmp.up(f.inv_scale);
+  }
   p.g[0].bias = tmp.up(hb, Cout);
   p.g[0].x = x; p.g[0].x2 = x2; p.g[0].res1 = res1; p.g[0].res2 = res2; p.g[0].y = y;
   p.g[0].x_sb = x_planes; p.g[0].x2_sb = x2_planes; p.g[0].y_sb = y_planes;
@@ -1185,7 +1298,8 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.Cout = Cout; p.act = act; p.post_relu = post_relu; p.nchw_out = nchw_out;
-  p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : 6);
+  p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : (precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
+  if (x_planes || y_planes) p.nterms = p.nterms == NT_F16X3 ? 6 : p.nterms;  // split-plane operands exist in the bf16 formats only
   p.finish();
   if ((!x && !x_planes) || (!y && !y_planes) || (C2 > 0 && !x2 && !x2_planes)) { g_create_error = "pf_op_conv2d: missing input or output"; return PF_ERR_ARG; }
   // an explicit tile that cannot read / write split planes is an error; with fp32 operands an unusable tile id falls back to the cost model
@@ -1196,7 +1310,8 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   return rc;
 }
 
-int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt, float* ms_out) {
+int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt_prec, float* ms_out) {
+  const int fmt = fmt_prec & 15, precision = fmt_prec >> 4;  // low 4 bits: operand format, upper bits: PF_PRECISION_* of the split tiles
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
@@ -1205,12 +1320,16 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   p.KWC = K * Cin; p.KWCp = roundup(p.KWC, 32);
   p.B = B; p.H = H; p.W = W; p.C1 = Cin; p.C2 = 0; p.KH = K; p.KW = K; p.stride = stride; p.pad = pad;
   p.Cout = Cout; p.act = ACT_RELU; p.post_relu = 0; p.nchw_out = 0;
+  p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : (precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
+  if (fmt >= 1 && p.nterms == NT_F16X3) p.nterms = 6;
   p.finish();
   const size_t nx = (size_t)B * H * W * Cin, nw = (size_t)Cout * K * p.KWCp, ny = (size_t)p.M * Cout;
   float *dx = nullptr, *dw = nullptr, *dy = nullptr, *db = nullptr;
-  unsigned short *dsb = nullptr, *dxs = nullptr, *dys = nullptr;
+  unsigned short *dsb = nullptr, *dxs = nullptr, *dys = nullptr, *dh16 = nullptr;
+  float* dinv = nullptr;
   if (hipMalloc(&dx, nx * 4) != hipSuccess || hipMalloc(&dw, nw * 4) != hipSuccess || hipMalloc(&dy, ny * 4) != hipSuccess ||
-      hipMalloc(&db, (size_t)Cout * 4) != hipSuccess || hipMalloc(&dsb, nw * 10) != hipSuccess ||
+      hipMalloc(&db, (size_t)Cout * 4) != hipSuccess || hipMalloc(&dsb, nw * 10) != hipSuccess || hipMalloc(&dh16, nw * 4) != hipSuccess ||
+      hipMalloc(&dinv, (size_t)Cout * 4) != hipSuccess ||
       (fmt >= 1 && hipMalloc(&dxs, nx * 6) != hipSuccess) || (fmt >= 2 && hipMalloc(&dys, ny * 6) != hipSuccess)) { g_create_error = "pf_op_conv2d_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
   {  // uniform [-1,1) data (never zero-fill a bench: DVFS gives zeros a higher clock); activations filled on the device
     std::vector<float> hw(nw), hb(Cout);
@@ -1223,13 +1342,16 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
     (void)hipMemcpy(db, hb.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
     const std::vector<unsigned short> sb = split_bf16x3(hw);
     (void)hipMemcpy(dsb, sb.data(), nw * 10, hipMemcpyHostToDevice);
+    const F16Planes f = split_f16x2(hw, Cout);
+    (void)hipMemcpy(dh16, f.planes.data(), nw * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dinv, f.inv_scale.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
   }
   p.g[0].x = dx; p.g[0].w = dw; p.g[0].bias = db; p.g[0].y = dy;
-  if (Cin % 32 == 0) p.g[0].w_sb = dsb;
+  if (Cin % 32 == 0) { p.g[0].w_sb = dsb; p.g[0].w_h16 = dh16; p.g[0].w_h16_inv_scale = dinv; }
   // fmt 1: A operand as split planes (fp32 copy withheld); fmt 2: split planes in and out
   if (fmt >= 1) { launch_split_planes(dx, dxs, nx, (long)nx, nullptr); p.g[0].x_sb = dxs; p.x_sb_plane = nx; p.g[0].x = nullptr; }
   if (fmt >= 2) { p.g[0].y_sb = dys; p.y_sb_plane = ny; p.g[0].y = nullptr; }
-  if (!conv_tile_usable(p, tile_id) && tile_id >= 0) { *ms_out = -1.f; (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys); return PF_OK; }
+  if (!conv_tile_usable(p, tile_id) && tile_id >= 0) { *ms_out = -1.f; (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys); (void)hipFree(dh16); (void)hipFree(dinv); return PF_OK; }
   hipEvent_t a, b;
   (void)hipEventCreate(&a); (void)hipEventCreate(&b);
   launch_conv_tile(p, tile_id, nullptr);
@@ -1243,7 +1365,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   *ms_out = t / iters;
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys);
+  (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys); (void)hipFree(dh16); (void)hipFree(dinv);
   return rc;
 }
 

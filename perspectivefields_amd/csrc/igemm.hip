@@ -320,7 +320,8 @@ int pick_tile(const ConvParams& p) {
     g_forced_tile = e ? atoi(e) : -1;
   }
   if (g_forced_tile >= 0 && conv_tile_usable(p, g_forced_tile)) return g_forced_tile;
-  if (!conv_tile_usable(p, 2)) return kNumF32 + conv_sb_default_tile(p);  // split-plane input or output: split-bf16 family only
+  // the split kernels (3 or 6 MFMAs at the 16x bf16 / fp16 rate) beat the exact-fp32 MFMA wherever they can run
+  if (conv_sb_eligible(p) || !conv_tile_usable(p, 2)) return kNumF32 + conv_sb_default_tile(p);
   // MFMA-bound model: a CU works through its share of the blocks at the tile's intrinsic rate, so
   // time ~ ceil(blocks / 256 CUs) x (tile MFMA time + fill latency hidden by the resident blocks)
   int best = 2;

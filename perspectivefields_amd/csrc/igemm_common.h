@@ -47,7 +47,7 @@ __device__ __forceinline__ int xcd_tile_index(int nblk) {
 struct Tile2D { int b, oy0, ox0, tx, odd_shift; };  // odd_shift: cyclic column shift of the odd patch rows (LDS bank layout of the halo kernel)
 template <int BM, int BN, int WM, int WN, int SM, int SN, int NT, int SMEM_FLOATS>
 __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[SM][SN], float* Cs, int m0, int n0,
-                                              const Tile2D* t2 = nullptr) {
+                                              const Tile2D* t2 = nullptr, const float* oscale = nullptr /*[Cout] factor on the accumulators (split-f16 weight scale)*/) {
   constexpr int CROW = BN + 4;            // floats per staged row (keeps 16-B alignment, shifts banks)
   constexpr int CH_ROWS = WM * 32;        // rows per chunk: subtile row i of every wave row
   constexpr int F4_PER_ROW = BN / 4;
@@ -86,6 +86,7 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
       }
       const long o = (long)m * p.ldy + n;
       if (vec_ok) {
+        if (oscale) { const float4 sc = *reinterpret_cast<const float4*>(oscale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
         if (bsrc) { const float4 bb = *reinterpret_cast<const float4*>(bsrc + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
         if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         else if (p.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
@@ -97,7 +98,7 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
       } else {  // ragged channel count: scalar tail
         const float vv[4] = {v.x, v.y, v.z, v.w};
         for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-          float x = vv[e] + (bsrc ? bsrc[n + e] : 0.f);
+          float x = vv[e] * (oscale ? oscale[n + e] : 1.f) + (bsrc ? bsrc[n + e] : 0.f);
           if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
           else if (p.act == ACT_GELU) x = gelu_erf(x);
           if (P.res1) x += P.res1[o + e];

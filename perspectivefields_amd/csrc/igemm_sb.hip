@@ -26,6 +26,10 @@ bool conv_sb_eligible(const ConvParams& p) {
   if (p.nchw_out || (p.Cin % BK) != 0) return false;
   for (int g = 0; g < p.groups; ++g) {
     const ConvPtrs& q = p.g[g];
+    if (p.nterms == NT_F16X3) {  // split-f16: its own weight planes, fp32 activations in, fp32 out
+      if (!q.w_h16 || !q.w_h16_inv_scale || !q.x || q.x_sb || q.y_sb || !q.y || (p.C2 > 0 && !q.x2)) return false;
+      continue;
+    }
     if (!q.w_sb) return false;
     if (!q.x_sb && !q.x) return false;
     if (p.C2 > 0 && (q.x_sb ? !q.x2_sb : !q.x2)) return false;
@@ -33,20 +37,31 @@ bool conv_sb_eligible(const ConvParams& p) {
   return true;
 }
 
-// static choice for shapes the autotuner has not seen (and the only family that can read a split-plane input)
+bool conv_sbh_ok(const ConvParams& p);                                   // igemm_sbh.hip
+
+// Static choice for shapes the tile table (tuned/gfx950_tiles.txt) does not hold; follows what the per-shape tuning picks
+// (profiles/r01_tune_conv_*.txt): halo tiles for 3x3 / stride-1 convs on maps of 40^2 and more; otherwise the largest tile
+// that still gives every CU about two blocks, with a register prefetch ring (f2 / f3) when the K loop is deep.
 int conv_sb_default_tile(const ConvParams& p) {
-  if (p.Cout <= 32) return 5;
-  const long blocks128 = ((long)(p.M + 127) / 128) * ((p.Cout + 127) / 128) * p.groups;
-  if (p.Cout >= 128 && blocks128 >= 1024) return 0;
-  if (p.Cout <= 64 && (long)p.M * p.groups >= 262144) return 2;
-  return 1;
+  const long K = (long)p.KH * p.KWCp;
+  if (conv_sbh_ok(p) && p.Ho >= 40 && p.Wo >= 40) {
+    if (p.Cout <= 32) return kFirstH + 2;
+    if (p.Cout <= 64) return kFirstH + 1;
+    return p.Ho >= 80 ? kFirstH + 3 : kFirstH + 1;
+  }
+  if (p.Cout <= 32) return K >= 512 ? 10 : 5;
+  auto blocks = [&](int bm, int bn) { return ((long)(p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.groups; };
+  if (p.Cout >= 128 && blocks(256, 128) >= 768) return 3;
+  if (p.Cout >= 128 && blocks(128, 128) >= 512) return K >= 1024 ? 11 : 0;
+  if (blocks(128, 64) >= 512) return K >= 1024 ? 9 : 2;
+  return K >= 2048 ? 8 : (K >= 1024 ? 7 : 1);
 }
 
 
 void launch_conv_sb3(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb3.hip
 void launch_conv_sb1(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb1.hip
+void launch_conv_sbf(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sbf.hip (split-f16)
 
-bool conv_sbh_ok(const ConvParams& p);                                   // igemm_sbh.hip
 void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 
 bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) { return sb_tile < kFirstH || conv_sbh_ok(p); }
@@ -56,7 +71,8 @@ void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
     if (conv_sbh_ok(p)) { launch_conv_sbh(p, sb_tile - kFirstH, s); return; }
     sb_tile = conv_sb_default_tile(p);
   }
-  if (p.nterms == 3) launch_conv_sb3(p, sb_tile, s);
+  if (p.nterms == NT_F16X3) launch_conv_sbf(p, sb_tile, s);
+  else if (p.nterms == 3) launch_conv_sb3(p, sb_tile, s);
   else if (p.nterms == 1) launch_conv_sb1(p, sb_tile, s);
   else launch_conv_sb_nt<6>(p, sb_tile, s);
 }

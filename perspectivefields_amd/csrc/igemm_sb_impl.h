@@ -32,6 +32,13 @@
 namespace pf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// one 32x32x16 MFMA on 16-byte operand fragments: fp16 operands for the split-f16 scheme, bf16 otherwise
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 static constexpr int SB_ROW = BK;  // ushorts per LDS row: 64 bytes = four 16-byte pieces, no padding
 // Bank-conflict freedom comes from an XOR swizzle of the piece index with bits 2-3 of the row: a ds_read_b128
 // lane group covers 16 rows at one logical piece -> rows r, r+4, r+8, r+12 (same 16-byte slot mod 256 B) land on
@@ -61,7 +68,7 @@ __device__ __forceinline__ void split4_hm(const float4 v, uint2& h, uint2& m) {
 #define SB_W8_WAVES 4  // min waves per SIMD of the 256x128 / 128x256 8-wave tiles: 4 = two blocks per CU (<= 128 VGPRs)
 #endif
 template <int BM, int BN, int WM, int WN, int MODE, bool ASB, int PFD, int NTERM>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? (PFD == 1 ? 3 : 2) : ((WM * WN == 8 && BM * BN == 256 * 128 && NTERM == 6) ? SB_W8_WAVES : 1)) void igemm_sb_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? (PFD == 1 ? 3 : 2) : ((WM * WN == 8 && BM * BN == 256 * 128 && (NTERM == 6 || NTERM == NT_F16X3)) ? SB_W8_WAVES : 1)) void igemm_sb_kernel(const ConvParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int RPP = NT / 8;    // fp32 A rows staged per pass (8 threads x float4 = 32 floats)
   constexpr int RPB = NT / 4;    // bf16 rows staged per pass (4 threads x 16 B = 32 bf16): B, and A when ASB
@@ -70,18 +77,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   constexpr int A_ROWS = ASB ? (BM + RPB - 1) / RPB : BM / RPP;
   // NTERM partial products per element product: 6 = fp32-accurate (3 planes per operand), 3 = h*h + h*m + m*h (2 planes,
   // ~16 significant bits), 1 = plain bf16 (1 plane)
-  constexpr int NPL = NTERM == 6 ? 3 : (NTERM == 3 ? 2 : 1);
+  // NT_F16X3 (split-f16, the default parity scheme): a ~ ah + al 2^-11 (two fp16 planes, sb_split.h), weights pre-scaled per output
+  // channel and split as wh + wl (two fp16 planes in global memory); the third LDS plane wh2 = wh 2^-11 is made while
+  // staging, so that  ah wh + ah wl + al wh2  accumulates in ONE accumulator: 3 MFMAs per product.
+  constexpr bool F16 = NTERM == NT_F16X3;
+  static_assert(!(F16 && ASB), "the split-f16 scheme reads fp32 activations");
+  constexpr int NPL = F16 ? 2 : (NTERM == 6 ? 3 : (NTERM == 3 ? 2 : 1));  // A planes in LDS
+  constexpr int NPB = F16 ? 3 : NPL;                                      // B planes in LDS
+  constexpr int NPG = F16 ? 2 : NPL;                                      // B planes loaded from global memory
+  constexpr int NMF = F16 ? 3 : NTERM;                                    // MFMAs per element product
   constexpr int A_REGS = ASB ? A_ROWS * NPL : A_ROWS;  // float4 registers per staged A tile
   constexpr int B_ROWS = (BN + RPB - 1) / RPB;        // BN < RPB (N = 32 tiles): the upper threads stage no B rows
   static_assert(ASB ? (BM % RPB == 0 || BM < RPB) : BM % RPP == 0, "A tile rows must be a multiple of the staging pass");
   static_assert(BN % RPB == 0 || BN < RPB, "B tile rows must be a multiple of the staging pass");
   constexpr int PLANE_A = BM * SB_ROW, PLANE_B = BN * SB_ROW;  // ushorts
   constexpr int EPI_USHORTS = 2 * (WM * 32) * (BN + 4);        // epilogue staging chunk (igemm_common.h)
-  constexpr int OPER_USHORTS = NPL * (PLANE_A + PLANE_B);
+  constexpr int OPER_USHORTS = NPL * PLANE_A + NPB * PLANE_B;
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
   unsigned short* As = smem_u;                  // [NPL][BM][SB_ROW]
-  unsigned short* Bs = smem_u + NPL * PLANE_A;  // [NPL][BN][SB_ROW]
+  unsigned short* Bs = smem_u + NPL * PLANE_A;  // [NPB][BN][SB_ROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     rx[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
     rx2[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x2 ? P.x2 : P.x), 0, P.x2 ? p.x2_bytes : 0, 0x00020000);
   }
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_sb), 0, 5u * p.w_sb_plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(F16 ? P.w_h16 : P.w_sb), 0, (F16 ? 2u : 5u) * p.w_sb_plane_bytes, 0x00020000);
   int a_off1[A_ROWS], a_off2[A_ROWS];
   unsigned long long a_mask[A_ROWS];
 #pragma unroll
@@ -153,8 +168,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   }
 
   // weight planes in global memory: 0 h, 1 m, 2 l (truncation split), 3 round-to-nearest bf16, 4 round-to-nearest m
+  // (split-f16: its own two planes, 0 wh, 1 wl)
   constexpr int BPL[3] = {NTERM == 1 ? 3 : 0, NTERM == 3 ? 4 : 1, 2};
-  struct Raw { float4 a[A_REGS]; float4 b[B_ROWS][NPL]; };
+  struct Raw { float4 a[A_REGS]; float4 b[B_ROWS][NPG]; };
   Raw raw[PFD];
   const int nJ = p.KWCp / BK;
   const int nK = p.KH * nJ;
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i)
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl)
+      for (int pl = 0; pl < NPG; ++pl)
         R.b[i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)BPL[pl] * p.w_sb_plane_bytes : OOB);
   };
   auto store_tiles = [&](const Raw& R) {
@@ -213,7 +229,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
         }
       } else {
         uint2 h, m, l;
-        if (NTERM == 6) split4(R.a[i], h, m, l);
+        if (F16) split4_f16(R.a[i], h, m);
+        else if (NTERM == 6) split4(R.a[i], h, m, l);
         else if (NTERM == 3) split4_hm(R.a[i], h, m);
         else h = round4_bf16(R.a[i]);
         const int row = r0 + RPP * i;
@@ -227,8 +244,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     for (int i = 0; i < B_ROWS; ++i)
       if (BN % RPB == 0 || rb0 + RPB * i < BN) {
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
+        for (int pl = 0; pl < NPG; ++pl)
           *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = R.b[i][pl];
+        if (F16) *reinterpret_cast<float4*>(Bs + 2 * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = scale8_f16_2m11(R.b[i][0]);
       }
   };
 
@@ -250,26 +268,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
 #pragma unroll
     for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per K step; this lane's 8 k-values = piece 2c + hi
       const int po = ((2 * c + hi) ^ swz) * 8;
-      bf16x8 af[SM][NPL], bf[SN][NPL];
+      u32x4 af[SM][NPL], bf[SN][NPB];
 #pragma unroll
       for (int i = 0; i < SM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * PLANE_A + i * 32 * SB_ROW + po);
+        for (int pl = 0; pl < NPL; ++pl) af[i][pl] = *reinterpret_cast<const u32x4*>(Ab + pl * PLANE_A + i * 32 * SB_ROW + po);
 #pragma unroll
       for (int j = 0; j < SN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * PLANE_B + j * 32 * SB_ROW + po);
+        for (int pl = 0; pl < NPB; ++pl) bf[j][pl] = *reinterpret_cast<const u32x4*>(Bb + pl * PLANE_B + j * 32 * SB_ROW + po);
       // six partial products, smallest first; the (i, j) loop is innermost so that consecutive MFMAs never
       // depend on each other's accumulator
-      constexpr int TA[6] = {NTERM == 6 ? 2 : (NTERM == 3 ? 1 : 0), 0, NTERM == 6 ? 1 : 0, 1, 0, 0};  // plane of A: l h m m h h | m h h | h
-      constexpr int TB[6] = {0, NTERM == 6 ? 2 : (NTERM == 3 ? 1 : 0), NTERM == 6 ? 1 : 0, 0, 1, 0};  // plane of B: h l m h m h | h m h | h
+      //                                                                                                  split-f16: al ah ah
+      constexpr int TA[6] = {F16 ? 1 : (NTERM == 6 ? 2 : (NTERM == 3 ? 1 : 0)), 0, NTERM == 6 ? 1 : 0, 1, 0, 0};  // plane of A: l h m m h h | m h h | h
+      constexpr int TB[6] = {F16 ? 2 : 0, F16 ? 1 : (NTERM == 6 ? 2 : (NTERM == 3 ? 1 : 0)), NTERM == 6 ? 1 : 0, 0, 1, 0};  // plane of B: h l m h m h | h m h | h | wh2 wl wh
 #pragma unroll
-      for (int t6 = 0; t6 < NTERM; ++t6)
+      for (int t6 = 0; t6 < NMF; ++t6)
 #pragma unroll
         for (int i = 0; i < SM; ++i)
 #pragma unroll
           for (int j = 0; j < SN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<F16>(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j]);
     }
   };
 
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     __syncthreads();
   }
 
-  epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0);
+  epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0, nullptr, F16 ? P.w_h16_inv_scale : nullptr);
 }
 
 template <int BM, int BN, int WM, int WN, int PFD, int NT>
@@ -310,7 +329,10 @@ static void launch_sb_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const dim3 grid(tilesM * tilesN * p.groups), block(WM * WN * 64);
   const bool asb = p.g[0].x_sb != nullptr;
-  if (p.C2 > 0) {
+  if constexpr (NT == NT_F16X3) {  // fp32 activations only (conv_sb_eligible)
+    if (p.C2 > 0) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, false, PFD, NT>), grid, block, 0, s, p);
+    else          hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, false, PFD, NT>), grid, block, 0, s, p);
+  } else if (p.C2 > 0) {
     if (asb) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, true, PFD, NT>), grid, block, 0, s, p);
     else     hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, false, PFD, NT>), grid, block, 0, s, p);
   } else {

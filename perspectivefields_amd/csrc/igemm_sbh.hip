@@ -8,7 +8,7 @@
 // bank-conflict free under the instruction's non-contiguous lane groups).  Per 9 K steps the A side costs 23 KB of loads and 180 x 32 splits instead of 144 KB and
 // 1152 x 32; the weight tile (B) is staged per step as before.  The XOR piece swizzle is keyed on the halo row.
 // K order is (channel chunk, tap) instead of (tap, channel chunk): same products, different fp32 summation order.
-// fp32 operands, fp32-accurate mode (6 partial products) only.
+// fp32 operands; the two parity schemes: exact 3-way bf16 split (6 partial products) and 2-way fp16 split (3, the default).
 // Measured and not kept (profiles/r01_tune_conv_sbh.txt): 16 x 16 patches with 8 waves (ties the 8 x 16 / 4-wave form on
 // 256 -> 256 @80^2, loses elsewhere) and staging the weights of a whole kernel row per barrier pair (TPG = 3: the extra
 // LDS costs a resident block, 3-7 % slower).
@@ -20,10 +20,18 @@
 namespace pf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16h(const u32x4 a, const u32x4 b, const f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 static constexpr int H_ROW = BK;  // ushorts per LDS row (64 bytes)
 __device__ __forceinline__ int sbh_piece(int row, int piece) { return piece ^ ((row >> 2) & 3); }
 
-template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE, int TPG /*taps whose weights are staged together: 1 or 3 (one kernel row)*/>
+// SCH = 6: exact 3-way bf16 split, 6 MFMAs per product; SCH = NT_F16X3: 2-way fp16 split of the activations (2 LDS planes),
+// scaled weights wh + wl from global memory plus wh2 = wh 2^-11 made while staging (3 LDS planes), 3 MFMAs per product.
+template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE, int TPG /*taps whose weights are staged together: 1 or 3 (one kernel row)*/, int SCH>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
@@ -37,11 +45,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   constexpr int A_F4 = (H_ROWS * 8 + NT - 1) / NT;   // float4 loads per thread per halo chunk (6)
   constexpr int PLANE_A = H_ROWS * H_ROW, PLANE_B = BN * H_ROW;  // ushorts
   constexpr int EPI_USHORTS = 2 * (WM * 32) * (BN + 4);
-  constexpr int OPER_USHORTS = 3 * (PLANE_A + TPG * PLANE_B);
+  constexpr bool F16 = SCH == NT_F16X3;
+  constexpr int NPA = F16 ? 2 : 3, NPB = 3, NPG = F16 ? 2 : 3;  // A planes in LDS, B planes in LDS, B planes loaded from global memory
+  constexpr int OPER_USHORTS = NPA * PLANE_A + NPB * TPG * PLANE_B;
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
-  unsigned short* As = smem_u;                // [3][H_ROWS][H_ROW]
-  unsigned short* Bs = smem_u + 3 * PLANE_A;  // [TPG][3][BN][H_ROW]
+  unsigned short* As = smem_u;                  // [NPA][H_ROWS][H_ROW]
+  unsigned short* Bs = smem_u + NPA * PLANE_A;  // [TPG][3][BN][H_ROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x2 ? P.x2 : P.x), 0, P.x2 ? p.x2_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_sb), 0, 5u * p.w_sb_plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(F16 ? P.w_h16 : P.w_sb), 0, (F16 ? 2u : 5u) * p.w_sb_plane_bytes, 0x00020000);
 
   // ---- A halo staging: element e = tid + NT i -> (halo row e / 8, float4 e % 8 of the 32-channel chunk)
   unsigned a_off1[A_F4], a_off2[MODE == 2 ? A_F4 : 1];
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
     b_off[i] = (n < p.Cout && rb0 + RPB * i < BN) ? (unsigned)(n * 3 * p.KWCp + pc * 8) * 2u : OOB;
   }
 
-  float4 ra[A_F4], rb[TPG][B_ROWS][3];
+  float4 ra[A_F4], rb[TPG][B_ROWS][NPG];
   const int nC = p.Cin / BK;  // 32-channel chunks (x first, then x2 when concatenating)
 
   auto load_a = [&](int c) {  // chunk c (>= nC: nothing, out-of-range offsets)
@@ -118,11 +128,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
       const int e = tid + NT * i, hrow = e >> 3, c4 = e & 7;  // recomputed (cheaper than six more live registers)
       if (hrow < H_ROWS) {
         uint2 h, m, l;
-        split4(ra[i], h, m, l);
+        if (F16) split4_f16(ra[i], h, m);
+        else split4(ra[i], h, m, l);
         unsigned short* d = As + hrow * H_ROW + sbh_piece(hrow, c4 >> 1) * 8 + (c4 & 1) * 4;
         *reinterpret_cast<uint2*>(d) = h;
         *reinterpret_cast<uint2*>(d + PLANE_A) = m;
-        *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
+        if (!F16) *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
       }
     }
   };
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPG; ++pl)
           rb[u][i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes : OOB);
     }
   };
@@ -147,8 +158,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
       for (int i = 0; i < B_ROWS; ++i)
         if (BN % RPB == 0 || rb0 + RPB * i < BN) {
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
+          for (int pl = 0; pl < NPG; ++pl)
             *reinterpret_cast<float4*>(Bs + (u * 3 + pl) * PLANE_B + (rb0 + RPB * i) * H_ROW + sbh_piece(rb0 + RPB * i, pc) * 8) = rb[u][i][pl];
+          if (F16) *reinterpret_cast<float4*>(Bs + (u * 3 + 2) * PLANE_B + (rb0 + RPB * i) * H_ROW + sbh_piece(rb0 + RPB * i, pc) * 8) = scale8_f16_2m11(rb[u][i][0]);
         }
   };
 
@@ -183,28 +195,28 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
     const int toff = ky * H_HX + kx;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per K step; this lane's 8 k-values = piece 2c + hi
-      bf16x8 af[SM][3], bf[SN][3];
+      u32x4 af[SM][NPA], bf[SN][3];
 #pragma unroll
       for (int i = 0; i < SM; ++i) {
         const int row = hb[i] + toff;
         const unsigned short* ap = As + row * H_ROW + sbh_piece(row, 2 * c + hi) * 8;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANE_A);
+        for (int pl = 0; pl < NPA; ++pl) af[i][pl] = *reinterpret_cast<const u32x4*>(ap + pl * PLANE_A);
       }
       const int pob = ((2 * c + hi) ^ swz_b) * 8;
 #pragma unroll
       for (int j = 0; j < SN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + (slot * 3 + pl) * PLANE_B + j * 32 * H_ROW + pob);
-      constexpr int TA[6] = {2, 0, 1, 1, 0, 0};  // plane of A: l h m m h h
-      constexpr int TB[6] = {0, 2, 1, 0, 1, 0};  // plane of B: h l m h m h
+        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const u32x4*>(Bb + (slot * 3 + pl) * PLANE_B + j * 32 * H_ROW + pob);
+      constexpr int TA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};  // plane of A: l h m m h h | split-f16: al ah ah
+      constexpr int TB[6] = {F16 ? 2 : 0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};  // plane of B: h l m h m h | split-f16: wh2 wl wh
 #pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6)
+      for (int t6 = 0; t6 < (F16 ? 3 : 6); ++t6)
 #pragma unroll
         for (int i = 0; i < SM; ++i)
 #pragma unroll
           for (int j = 0; j < SN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16h<F16>(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j]);
     }
   };
 
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   }
 
   const Tile2D t2{bimg, oy0, ox0, H_TX, ODD_SHIFT};
-  epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2);
+  epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2, F16 ? P.w_h16_inv_scale : nullptr);
 }
 
 template <int H_TY, int H_TX, int BN, int WM, int WN, int TPG = 1>
@@ -238,16 +250,23 @@ static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(WM * WN * 64);
-  if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, TPG>), grid, block, 0, s, p);
-  else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, TPG>), grid, block, 0, s, p);
+  if (p.nterms == NT_F16X3) {
+    if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, TPG, NT_F16X3>), grid, block, 0, s, p);
+    else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, TPG, NT_F16X3>), grid, block, 0, s, p);
+  } else {
+    if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, TPG, 6>), grid, block, 0, s, p);
+    else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, TPG, 6>), grid, block, 0, s, p);
+  }
 }
 
 // 3x3 / stride 1 / pad 1, fp32 operands, fp32-accurate mode, channel counts multiples of 32
 bool conv_sbh_ok(const ConvParams& p) {
-  if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nterms != 6 || p.nchw_out) return false;
+  if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || (p.nterms != 6 && p.nterms != NT_F16X3) || p.nchw_out) return false;
   if ((p.C1 % BK) != 0 || (p.C2 % BK) != 0 || p.KWCp != p.KWC) return false;
-  for (int g = 0; g < p.groups; ++g)
-    if (!p.g[g].x || (p.C2 > 0 && !p.g[g].x2) || !p.g[g].w_sb) return false;
+  for (int g = 0; g < p.groups; ++g) {
+    if (!p.g[g].x || (p.C2 > 0 && !p.g[g].x2)) return false;
+    if (p.nterms == NT_F16X3 ? (!p.g[g].w_h16 || !p.g[g].w_h16_inv_scale || p.g[g].y_sb) : !p.g[g].w_sb) return false;
+  }
   return true;
 }
 

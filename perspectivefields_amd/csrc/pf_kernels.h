@@ -10,6 +10,7 @@
 namespace pf {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+static constexpr int NT_F16X3 = 23;  // ConvParams::nterms value of the split-f16 scheme
 
 // Implicit-GEMM convolution / GEMM on v_mfma_f32_32x32x2_f32.
 //   y[m][n] = post( act( sum_k A[m][k] * Wp[n][k] + bias[n] ) + res1[m][n] + res2[m][n] )
@@ -21,6 +22,10 @@ struct ConvPtrs {
   const float* w = nullptr;         // packed [Cout][KH][KWCp], KWCp = roundup(KW*Cin, 32), zero padded
   const unsigned short* w_sb = nullptr;  // same weights as 5 bf16 planes [5][Cout][KH][KWCp]: exact split h, m, l (h + m + l == w), then
                                          // round-to-nearest bf16(w) and round-to-nearest m for the reduced-precision modes
+  // split-f16 scheme (sb_split.h NT_F16X3): weights scaled per output channel by a power of two (row maximum in
+  // [2^13, 2^14)) as two fp16 planes [2][Cout][KH][KWCp]: wh = fp16(w S), wl = fp16(w S - wh); w_h16_inv_scale = 1 / S
+  const unsigned short* w_h16 = nullptr;
+  const float* w_h16_inv_scale = nullptr;  // [Cout]: applied to the accumulators before the bias
   const float* bias = nullptr;      // [Cout] or nullptr
   const float* bias_tab = nullptr;  // [9][Cout]: bias per 3x3 border case (folded Linear->conv), overrides bias
   const float* res1 = nullptr;      // [M][Cout] or nullptr (may alias y)
@@ -44,7 +49,8 @@ struct ConvParams {
   int post_relu;  // relu after the residual adds
   int ldy;        // row stride of y / res1 / res2 in floats (normally Cout)
   int nchw_out;   // 1: store y as [B][Cout][Ho*Wo] (API-visible logits), residuals unsupported
-  int nterms = 6; // split-bf16 kernel: partial products per element product -- 6 fp32-accurate (default), 3 (~16-bit operands), 1 (bf16)
+  int nterms = 6; // split kernels: partial products per element product -- NT_F16X3 (23): 2-way fp16 split, 3 products, fp32-class accuracy;
+                  // 6: exact 3-way bf16 split, 6 products (fp32-accurate); 3 (bf16, ~16-bit operands); 1 (plain bf16)
   unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)
   unsigned w_sb_plane_bytes;            // bytes of one bf16 weight plane
   size_t x_sb_plane = 0, x2_sb_plane = 0, y_sb_plane = 0;  // elements between consecutive planes of x_sb / x2_sb / y_sb
@@ -115,6 +121,19 @@ void launch_prep_f32_nchw(const float* in, float* out, int B, int HW, const floa
 // bit-exact PIL antialiased bilinear resize of one uint8 HxWx3 image to OHxOWx3 (two integer passes; tables from the host)
 void launch_resize_u8(const uint8_t* in, int H, int W, uint8_t* tmp, uint8_t* out, int OH, int OW, const int* bh, const int* kh, int ksh,
                       const int* bv, const int* kv, int ksv, hipStream_t s);
+
+// the same for up to ResizeBatch::MAX images in one launch pair (per-image pointers / sizes / tables in the kernel arguments)
+struct ResizeBatch {
+  static constexpr int MAX = 32;
+  int n;
+  int H[MAX], W[MAX], ksh[MAX], ksv[MAX];
+  const uint8_t* in[MAX];
+  uint8_t* tmp[MAX];
+  uint8_t* out[MAX];
+  const int* bh[MAX]; const int* kh[MAX];
+  const int* bv[MAX]; const int* kv[MAX];
+};
+void launch_resize_batch_u8(const ResizeBatch& rb, int OH, int OW, hipStream_t s);
 
 // regression prediction heads: 1x1 (32->2) + L2-normalise, 1x1 (32->1) + clamp; writes NCHW API outputs and the NHWC4 ParamNet input
 void launch_pred_regression(const float* tg, const float* tl, const float* wg, const float* bg, const float* wl, const float* bl,

@@ -28,6 +28,30 @@ __device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2
   l = make_uint2(sb_pack_hi16(lb[0], lb[1]), sb_pack_hi16(lb[2], lb[3]));
 }
 
+// ---- split-f16 scheme (NT_F16X3): x ~ hi + lo * 2^-11 with hi = fp16_rn(x), lo = fp16_rn((x - hi) * 2^11): 22-23 significant
+// bits in two fp16 values (representation error <= 2^-22 |x|).  |x| is clamped to the fp16 range (65504) first, so an
+// out-of-range activation saturates instead of turning into inf - inf; the scaled remainder is at most |x| / 2.
+typedef _Float16 sb_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4_f16(const float4 v, uint2& h, uint2& l) {
+  const float a[4] = {v.x, v.y, v.z, v.w};
+  _Float16 hh[4], ll[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float c = __builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);
+    hh[e] = (_Float16)c;
+    ll[e] = (_Float16)((c - (float)hh[e]) * 2048.f);
+  }
+  const sb_h2 h0 = {hh[0], hh[1]}, h1 = {hh[2], hh[3]}, l0 = {ll[0], ll[1]}, l1 = {ll[2], ll[3]};
+  h = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+  l = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+}
+// 8 fp16 values (one 16-byte piece) times 2^-11 (exact unless the result is subnormal): the third weight plane wh2 = wh * 2^-11
+__device__ __forceinline__ float4 scale8_f16_2m11(const float4 v) {
+  const sb_h2 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+  auto mul = [&](float f) { return __builtin_bit_cast(float, (sb_h2)(__builtin_bit_cast(sb_h2, f) * k)); };
+  return make_float4(mul(v.x), mul(v.y), mul(v.z), mul(v.w));
+}
+
 // store 4 consecutive elements (index idx, a multiple of 4) of an SBA tensor
 __device__ __forceinline__ void store_sb4(unsigned short* base, size_t plane_elems, size_t idx, const float4 v) {
   uint2 h, m, l;

@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpf_hip.so")
+TILE_TABLE = os.path.join(_HERE, "tuned", "gfx950_tiles.txt")  # per-shape tile choices measured on MI355X (scripts/gen_tile_table.py)
 NET = 320
 PARAMS_STRIDE = 8
 
@@ -31,13 +32,19 @@ _SIGNATURES = {
     "pf_load_tensor": (_c.c_int, [_P, _c.c_char_p, _P, _c.POINTER(_c.c_int64), _c.c_int]),
     "pf_finalize_weights": (_c.c_int, [_P]),
     "pf_output_info": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "pf_max_batch": (_c.c_int, []),
     "pf_workspace_bytes": (_c.c_size_t, [_P, _c.c_int]),
     "pf_forward_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_forward_f32": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_resize_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
     "pf_resize_bilinear_u8": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
+    "pf_resize_batch_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_autotune": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_is_tuned": (_c.c_int, [_P, _c.c_int]),
+    "pf_autotune_workspace_bytes": (_c.c_size_t, [_P, _c.c_int]),
+    "pf_load_tile_table": (_c.c_int, [_P, _c.c_char_p]),
+    "pf_save_tile_table": (_c.c_int, [_P, _c.c_char_p]),
+    "pf_build_digest": (_c.c_char_p, []),
     "pf_set_precision": (_c.c_int, [_P, _c.c_int]),
     "pf_postprocess": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
     "pf_postprocess_batch": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
@@ -76,23 +83,33 @@ def load_library(path: Optional[str] = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
-    if not os.path.exists(p) and path is None:
-        # in-tree build on first use when hipcc is present (one process builds, the others wait on the lock)
+    want = None
+    if path is None:
+        # The library must match the sources next to it: a stale .so after a csrc / header change would run ctypes calls with
+        # mismatched signatures.  Rebuild in-tree when hipcc is present (one process builds, the others wait on the lock);
+        # otherwise fail loudly.  PF_SKIP_DIGEST_CHECK=1 disables the comparison (deployments without the sources).
+        from . import build as _build
+
+        stamp = os.path.join(os.path.dirname(LIB_PATH), "libpf_hip.digest")
         try:
-            import fcntl
+            want = None if os.environ.get("PF_SKIP_DIGEST_CHECK") == "1" else _build._digest()
+        except OSError:
+            want = None  # sources not shipped
+        have = open(stamp).read() if os.path.exists(stamp) else None
+        if not os.path.exists(p) or (want is not None and have != want):
+            try:
+                import fcntl
 
-            from . import build as _build
-
-            os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-            with open(os.path.join(os.path.dirname(LIB_PATH), ".build.lock"), "w") as lk:
-                fcntl.flock(lk, fcntl.LOCK_EX)
-                if not os.path.exists(LIB_PATH):
-                    _build.build(verbose=False)
-        except Exception as e:  # no hipcc / build failure: fail loudly below
-            raise PfError(
-                f"{p} not found and could not be built ({e}); the HIP extension is required, there is no CPU fallback. "
-                "Build it with `python -m perspectivefields_amd.build` (needs hipcc)."
-            ) from e
+                os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+                with open(os.path.join(os.path.dirname(LIB_PATH), ".build.lock"), "w") as lk:
+                    fcntl.flock(lk, fcntl.LOCK_EX)
+                    _build.build(verbose=False)  # no-op when another process has just built it
+            except Exception as e:  # no hipcc / build failure: fail loudly
+                what = "not found" if not os.path.exists(p) else "is stale (built from different sources)"
+                raise PfError(
+                    f"{p} {what} and could not be built ({e}); the HIP extension is required, there is no CPU fallback. "
+                    "Build it with `python -m perspectivefields_amd.build` (needs hipcc)."
+                ) from e
     if not os.path.exists(p):
         raise PfError(f"{p} not found: the HIP extension is not built and there is no CPU fallback.")
     lib = ctypes.CDLL(p)
@@ -101,6 +118,9 @@ def load_library(path: Optional[str] = None):
         fn.restype = res
         fn.argtypes = args
     if path is None:
+        got = lib.pf_build_digest().decode()
+        if want is not None and got != want:
+            raise PfError(f"{p} was built from different sources (library digest {got[:12]}, sources {want[:12]}): rebuild with `python -m perspectivefields_amd.build --force`")
         _lib = lib
     return lib
 
@@ -147,6 +167,7 @@ class Engine:
         self._ws = None
         self._finalized = False
         self.precision = "fp32"
+        self.max_batch = int(self.lib.pf_max_batch())
         g, l, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self.lib.pf_output_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(p))
         self.gravity_channels, self.latitude_channels, self.param_outputs = g.value, l.value, p.value
@@ -174,12 +195,33 @@ class Engine:
             )
         _check(self.lib.pf_finalize_weights(self._h), self._h, "pf_finalize_weights")
         self._finalized = True
+        table = os.environ.get("PF_TILE_TABLE", TILE_TABLE)
+        if table and os.path.exists(table):
+            self.tile_table_entries = self.lib.pf_load_tile_table(self._h, table.encode())
 
-    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+    def autotune(self, batch: int, save_to: Optional[str] = None) -> None:
+        """Explicit one-time tile tuning for a batch size (pf_autotune: times every tile configuration of every conv /
+        GEMM shape on this device, ~1-2 s, synchronises).  Not needed for the shipped table's batch sizes."""
+        import torch
+
+        with torch.cuda.device(self.device):
+            x = torch.randint(0, 256, (batch, NET, NET, 3), dtype=torch.uint8, device=self.device)
+            pg = torch.empty((batch, self.gravity_channels, NET, NET), dtype=torch.float32, device=self.device)
+            pl = torch.empty((batch, self.latitude_channels, NET, NET), dtype=torch.float32, device=self.device)
+            params = torch.empty((batch, PARAMS_STRIDE), dtype=torch.float32, device=self.device) if self.param_outputs else None
+            ws = self._workspace(int(self.lib.pf_autotune_workspace_bytes(self._h, batch)))
+            rc = self.lib.pf_autotune(self._h, batch, x.data_ptr(), pg.data_ptr(), pl.data_ptr(),
+                                      params.data_ptr() if params is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr())
+        _check(rc, self._h, "pf_autotune")
+        if save_to:
+            _check(min(0, self.lib.pf_save_tile_table(self._h, save_to.encode())), self._h, "pf_save_tile_table")
+
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp32_bf16x6": 3}
 
     def set_precision(self, mode: str):
-        """Arithmetic of the dense contractions: 'fp32' (default; fp32-accurate, the parity mode), 'bf16x3' (three bf16
-        partial products, ~16-bit operands) or 'bf16' (plain bf16 operands).  See pf_set_precision in include/pf_hip.h."""
+        """Arithmetic of the dense contractions: 'fp32' (default, the parity mode: 2-way fp16 split, three MFMAs per
+        product), 'fp32_bf16x6' (exact 3-way bf16 split, six MFMAs: fp32-accurate for any input range), 'bf16x3' (three
+        bf16 partial products, ~16-bit operands) or 'bf16' (plain bf16 operands).  See pf_set_precision in include/pf_hip.h."""
         if mode not in self.PRECISIONS:
             raise PfError(f"unknown precision '{mode}' (expected one of {sorted(self.PRECISIONS)})")
         _check(self.lib.pf_set_precision(self._h, self.PRECISIONS[mode]), self._h, "pf_set_precision")
@@ -206,6 +248,8 @@ class Engine:
             raise PfError(f"input on {images.device}, engine on {self.device}")
         images = images.contiguous()
         B = images.shape[0]
+        if B > self.max_batch:
+            raise PfError(f"batch {B} exceeds PF_MAX_BATCH = {self.max_batch} per forward; split it (PerspectiveFields.inference_batch does)")
         if images.dtype == torch.uint8:
             if tuple(images.shape[1:]) != (NET, NET, 3):
                 raise PfError(f"uint8 input must be (B,{NET},{NET},3), got {tuple(images.shape)}")
@@ -243,6 +287,21 @@ class Engine:
             rc = self.lib.pf_resize_bilinear_u8(self._h, img_u8.data_ptr(), H, W, out_u8_320.data_ptr(),
                                                 self._rs_ws.data_ptr(), self._rs_ws.numel(), _stream_ptr())
         _check(rc, self._h, "pf_resize_bilinear_u8")
+
+    def resize_batch_into(self, imgs_u8, out_u8):
+        """The same for a list of (H_i,W_i,3) uint8 cuda tensors in two launches per 32 images: out_u8 (B,320,320,3) uint8 cuda."""
+        import torch
+
+        B = len(imgs_u8)
+        hw = [(int(t.shape[0]), int(t.shape[1])) for t in imgs_u8]
+        need = 256 + sum((h * NET * 3 + 255) // 256 * 256 for h, _ in hw)
+        if getattr(self, "_rs_ws", None) is None or self._rs_ws.numel() < need:
+            self._rs_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ptrs = (ctypes.c_void_p * B)(*[t.data_ptr() for t in imgs_u8])
+        hw_c = (ctypes.c_int32 * (2 * B))(*[v for s in hw for v in s])
+        with torch.cuda.device(self.device):
+            rc = self.lib.pf_resize_batch_u8(self._h, B, ptrs, hw_c, out_u8.data_ptr(), self._rs_ws.data_ptr(), self._rs_ws.numel(), _stream_ptr())
+        _check(rc, self._h, "pf_resize_batch_u8")
 
     PROFILE_CLASSES = ("igemm", "attention", "layernorm", "dwconv3x3_gelu", "dwconv7x7", "upsample2x", "other", "igemm_sb")
 

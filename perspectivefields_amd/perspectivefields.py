@@ -107,7 +107,9 @@ class PerspectiveFields(nn.Module):
 
     def _init_weights(self, weights=None):
         sd = _resolve_weights(self.version, weights)
-        self.load_state_dict(sd)
+        # a checkpoint FILE is loaded like the reference does (strict=False: extra entries tolerated, with a warning);
+        # state_dicts handed over in memory and the synthetic generator are held to the exact schema
+        self.load_state_dict(sd, strict=not (weights is None or (isinstance(weights, str) and not weights.startswith("synthetic"))))
 
     def state_dict(self, *args, **kwargs):  # checkpoint-format view (host copies)
         return OrderedDict((k, torch.as_tensor(np.asarray(v))) for k, v in self._state.items())
@@ -117,7 +119,15 @@ class PerspectiveFields(nn.Module):
         host = OrderedDict()
         for k, v in sd.items():
             host[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
-        validate_state_dict(self.version, host)  # always strict: silent partial loads are a reference bug source
+        # missing keys / wrong shapes are always fatal; keys this architecture does not have are fatal only when strict
+        # (the reference loads with strict=False, :185,192: zoo files may carry extra entries) and are dropped otherwise
+        extra = validate_state_dict(self.version, host, strict=strict)
+        if extra:
+            import warnings
+
+            warnings.warn(f"PerspectiveFields.load_state_dict: ignoring {len(extra)} checkpoint entries this architecture does not use: {extra[:4]}")
+            for k in extra:
+                host.pop(k)
         self._state = host
         self._engine = None
         return self
@@ -131,8 +141,7 @@ class PerspectiveFields(nn.Module):
         if self._engine is None or self._engine.device != dev:
             eng = Engine(self.arch["arch_id"], dev)
             eng.load_state_dict(self._state)
-            if self.precision != "fp32":
-                eng.set_precision(self.precision)
+            eng.set_precision(self.precision)  # always: the model's precision wins over any PF_PRECISION default of the library
             self._engine = eng
         return self._engine
 
@@ -152,10 +161,15 @@ class PerspectiveFields(nn.Module):
             sizes.append(tuple(int(v) for v in original.shape[:2]))
             resized.append(np.ascontiguousarray(original) if self.device_resize else self.aug.apply_image(np.ascontiguousarray(original)))
         if self.device_resize:
+            # one upload of all original images, then the whole batch resized in two launches per 32 images
             eng = self._get_engine()
+            flat = torch.from_numpy(np.concatenate([im.reshape(-1) for im in resized])).to(self.device)
+            views, o = [], 0
+            for im in resized:
+                views.append(flat[o:o + im.size].view(im.shape))
+                o += im.size
             batch = torch.empty((len(resized), NET_H, NET_W, 3), dtype=torch.uint8, device=self.device)
-            for i, im in enumerate(resized):
-                eng.resize_into(torch.from_numpy(im).to(self.device), batch[i])
+            eng.resize_batch_into(views, batch)
         else:
             batch = torch.from_numpy(np.stack(resized)).to(self.device, non_blocking=False)  # uint8 (B,320,320,3)
         return self._run(batch, sizes)
@@ -212,8 +226,7 @@ class PerspectiveFields(nn.Module):
                 dev_in = host[:nbytes].to(dev, non_blocking=True)  # one H2D per batch
                 if self.device_resize:
                     batch = torch.empty((len(resized), NET_H, NET_W, 3), dtype=torch.uint8, device=dev)
-                    for i, im in enumerate(resized):
-                        eng.resize_into(dev_in[offs[i]:offs[i] + im.size].view(im.shape), batch[i])
+                    eng.resize_batch_into([dev_in[offs[i]:offs[i] + im.size].view(im.shape) for i, im in enumerate(resized)], batch)
                 else:
                     batch = dev_in.view(len(resized), NET_H, NET_W, 3)
                 up_done = torch.cuda.Event()
@@ -263,8 +276,18 @@ class PerspectiveFields(nn.Module):
             return self._run(imgs, sizes)
 
     # -------------------------------------------------------------------- engine path
+    # images per engine forward: longer lists are processed in chunks (the reference accepts any list length; one
+    # pf_forward call is limited to PF_MAX_BATCH = 81 images by its 32-bit activation offsets, include/pf_hip.h)
+    MAX_CHUNK = 64
+
     def _run(self, batch, sizes) -> List[dict]:
         eng = self._get_engine()
+        chunk = max(1, min(int(os.environ.get("PF_MAX_CHUNK", self.MAX_CHUNK)), eng.max_batch))
+        if len(sizes) > chunk:
+            out: List[dict] = []
+            for i0 in range(0, len(sizes), chunk):
+                out.extend(self._run(batch[i0:i0 + chunk], sizes[i0:i0 + chunk]))
+            return out
         pg, pl, params = eng.forward(batch)
         results = []
         fields = eng.postprocess_batch(pg, pl, sizes)  # the reference's per-image post-process loop as one launch

@@ -148,8 +148,11 @@ def checkpoint_schema(version: str) -> "OrderedDict[str, tuple]":
 OPTIONAL_KEYS = ("ll_enc.bn1.num_batches_tracked",)
 
 
-def validate_state_dict(version: str, state_dict) -> None:
-    """Strict validation: every schema key present with the right shape, nothing extra."""
+def validate_state_dict(version: str, state_dict, strict: bool = True):
+    """Every schema key must be present with the right shape (always fatal: a partially initialised network is the
+    silent failure mode of the reference's strict=False load, perspectivefields.py:185,192).  Keys the architecture
+    does not have are an error when `strict`, otherwise they are returned so that the caller can drop them (real zoo
+    files may carry trainer state or unused heads)."""
     sch = checkpoint_schema(version)
     missing = [k for k in sch if k not in state_dict and k not in OPTIONAL_KEYS]
     extra = [k for k in state_dict if k not in sch]
@@ -158,9 +161,10 @@ def validate_state_dict(version: str, state_dict) -> None:
         for k in sch
         if k in state_dict and tuple(state_dict[k].shape) != tuple(sch[k])
     ]
-    if missing or extra or bad:
+    if missing or bad or (extra and strict):
         raise ValueError(
             f"checkpoint does not match schema for {version}: "
             f"missing={missing[:4]} ({len(missing)}), unexpected={extra[:4]} ({len(extra)}), "
             f"shape mismatches={bad[:4]} ({len(bad)})"
         )
+    return extra

@@ -1,0 +1,130 @@
+"""CPU emulation of a reduced-term split contraction across the WHOLE network (decision aid, test infrastructure only).
+
+Question: can the dense contractions run on fewer MFMAs than the 6-term exact bf16 split and stay
+inside the parity tolerances (up-vector 1-cos / latitude L1 1e-3, ParamNet scalars 1e-4) with >= 3x margin?
+
+Candidates:
+  f16x3  : operands as hi + lo * 2^-11, hi = fp16_rn(x), lo = fp16_rn((x - hi) * 2^11); products hi*hi + hi*lo + lo*hi
+           (3 x v_mfma_f32_32x32x16_f16).  Weights are scaled per output channel by a power of two so that the row
+           maximum sits in [2^13, 2^14) (exact; undone in the epilogue).
+  bf16x3 : the existing reduced mode (h, m of the bf16 truncation split; 3 products).
+
+The emulation replaces every dense conv / linear of the oracle whose input channel count is a multiple of 32 (the
+layers the split kernels serve) by: quantise both operands to what the scheme represents, contract in fp64 (the MFMA
+partial products are exact in fp32; accumulation noise is modelled by the plain fp32 oracle), drop the lo*lo term,
+round the result to fp32.  Everything else is the fp32 oracle.  Reported: scalar / field error of (a) the plain fp32
+oracle and (b) the emulated scheme against the float64 run of the oracle on the same inputs.
+
+    python scripts/emulate_split.py            # run from the repo root, CPU only (~2 min)
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import pf_oracle  # noqa: E402
+from perspectivefields_amd.config import arch_of, get_cfg  # noqa: E402
+from perspectivefields_amd.synth import synthetic_image, synthetic_state_dict, to_torch  # noqa: E402
+
+_conv2d, _linear = F.conv2d, F.linear
+SCHEME = "f16x3"
+
+
+def split_f16(x64):
+    """x (float64 holding fp32 values) -> (hi, lo_true) as float64: hi = fp16_rn(x), lo_true = fp16_rn((x-hi)*2^11)/2^11."""
+    x32 = x64.to(torch.float32)
+    hi = x32.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
+    lo = ((x32 - hi) * 2048.0).to(torch.float16).to(torch.float32)
+    return hi.double(), lo.double() / 2048.0
+
+
+def split_bf16_hm(x64):
+    x32 = x64.to(torch.float32)
+    h = (x32.view(torch.int32) & -65536).view(torch.float32)
+    m = (x32 - h).to(torch.bfloat16).to(torch.float32)
+    return h.double(), m.double()
+
+
+def weight_scale(w):
+    """per-output-channel power of two bringing max|w| into [2^13, 2^14)"""
+    mx = w.abs().flatten(1).max(dim=1).values.double()
+    e = torch.where(mx > 0, 13.0 - torch.floor(torch.log2(mx.clamp_min(1e-300))), torch.zeros_like(mx))
+    return torch.pow(torch.tensor(2.0, dtype=torch.float64), e)
+
+
+def contract(op, x, w, **kw):
+    xd, wd = x.double(), w.double()
+    if SCHEME == "f16x3":
+        s = weight_scale(w)
+        sh = [-1] + [1] * (w.dim() - 1)
+        xh, xl = split_f16(xd)
+        wh, wl = split_f16(wd * s.view(sh))
+        y = op(xh, wh, **kw) + op(xh, wl, **kw) + op(xl, wh, **kw)
+        shape = [1, -1, 1, 1] if op is _conv2d else [-1]
+        y = y / s.view(shape)
+    else:
+        xh, xm = split_bf16_hm(xd)
+        wh, wm = split_bf16_hm(wd)
+        y = op(xh, wh, **kw) + op(xh, wm, **kw) + op(xm, wh, **kw)
+    return y.to(torch.float32)
+
+
+def conv2d_q(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+    if groups != 1 or x.shape[1] % 32 != 0 or x.dtype != torch.float32:
+        return _conv2d(x, w, b, stride, padding, dilation, groups)
+    y = contract(_conv2d, x, w, stride=stride, padding=padding)
+    return y if b is None else y + b.view(1, -1, 1, 1)
+
+
+def linear_q(x, w, b=None):
+    if x.shape[-1] % 32 != 0 or x.dtype != torch.float32:
+        return _linear(x, w, b)
+    y = contract(_linear, x, w)
+    return y if b is None else y + b
+
+
+def run(sd, arch, imgs, mode):
+    global SCHEME
+    if mode in ("fp32", "fp64"):
+        F.conv2d, F.linear = _conv2d, _linear
+        dtype = torch.float64 if mode == "fp64" else torch.float32
+    else:
+        SCHEME = mode
+        F.conv2d, F.linear = conv2d_q, linear_q
+        dtype = torch.float32
+    try:
+        with torch.no_grad():
+            return pf_oracle.inference_batch(sd, arch, imgs, dtype)
+    finally:
+        F.conv2d, F.linear = _conv2d, _linear
+
+
+def main():
+    version = "Paramnet-360Cities-edina-centered"
+    sd = to_torch(synthetic_state_dict(version, 0))
+    arch = arch_of(get_cfg(version))
+    torch.set_num_threads(os.cpu_count() or 1)
+    imgs = [synthetic_image(640, 640, seed=1000 + i) for i in range(int(os.environ.get("N_IMG", "3")))]
+    keys = ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal")
+    truth = run(sd, arch, imgs, "fp64")
+    for mode in ("fp32", "f16x3", "bf16x3"):
+        res = run(sd, arch, imgs, mode)
+        dpar, dcos, dlat = 0.0, 0.0, 0.0
+        for r, t in zip(res, truth):
+            dpar = max(dpar, max(abs(float(r[k]) - float(t[k])) for k in keys))
+            g, go = r["pred_gravity_original"].double(), t["pred_gravity_original"].double()
+            c = 1.0 - (g * go).sum(0) / torch.sqrt((g * g).sum(0) * (go * go).sum(0))
+            dcos = max(dcos, float(c.max()))
+            dlat = max(dlat, float((r["pred_latitude_original"].double() - t["pred_latitude_original"].double()).abs().mean()))
+        print(f"{mode:7s} vs fp64: ParamNet max|d| {dpar:.3e} (tol 1e-4)   up 1-cos max {dcos:.3e} (tol 1e-3)   latitude L1 {dlat:.3e} deg (tol 1e-3)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -70,9 +70,11 @@ def test_conv2d_all_tiles(ops, case):
     ref = _ref_conv(x, w, b, stride, pad, x2)
     xd = x.cuda()
     x2d = x2.cuda() if x2 is not None else None
-    for tile in [-1] + list(range(len(ops.conv_tiles()))):
-        got = ops.conv2d(xd, w, b, stride=stride, pad=pad, x2=x2d, tile=tile)
-        _close(got, ref, 2e-5, f"{name} tile {tile}")
+    # both parity schemes of the split tiles: 0 = split-f16 (default), 3 = exact bf16 split (the fp32 tiles ignore it)
+    for precision in (0, 3):
+        for tile in [-1] + list(range(len(ops.conv_tiles()))):
+            got = ops.conv2d(xd, w, b, stride=stride, pad=pad, x2=x2d, tile=tile, precision=precision)
+            _close(got, ref, 2e-5, f"{name} tile {tile} precision {precision}")
 
 
 def test_split_planes_are_lossless(ops):
@@ -99,7 +101,7 @@ def test_conv2d_split_plane_operands(ops, case):
     sb = [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbh")]  # the halo tiles take fp32 operands only
     assert sb
     for tile in sb:
-        base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1)
+        base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, precision=3)  # the exact bf16 split (planes are its format)
         got_in = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True)
         assert torch.equal(got_in, base), f"{name} {names[tile]}: split-plane input differs from fp32 input"
         if Cout % 4 == 0:
@@ -112,6 +114,51 @@ def test_conv2d_split_plane_operands(ops, case):
     from perspectivefields_amd.engine import PfError
     with pytest.raises(PfError):
         ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=2, planes_in=True)
+
+
+def test_conv2d_split_f16_scheme(ops):
+    """The default parity scheme of the split tiles (2-way fp16 split, 3 MFMAs per product; include/pf_hip.h
+    PF_PRECISION_FP32) on every split tile incl. the halo tiles, against fp64:
+      * wide dynamic range (|x| over 2^+-12, per-channel weight magnitudes over 2^+-20: the per-channel power-of-two
+        weight scale) -- error within 4x of the exact bf16 split (PF_PRECISION_FP32_BF16X6) + an fp32-rounding floor;
+      * small activations (1e-3): relative accuracy kept; all-tiny tensors (1e-6, below the fp16 normal range): absolute
+        error 2^-36 per element only;
+      * |x| beyond the fp16 range saturates to +-65504 (finite output), everything below 65504 is exact-ish."""
+    B, H, W, C, Cout = 2, 12, 16, 256, 256
+    g = torch.Generator().manual_seed(123)
+    x = _rand((B, H, W, C), 80) * torch.exp2(torch.randint(-12, 13, (B, H, W, C), generator=g).float())
+    w = _rand((Cout, C, 3, 3), 81, 1.0 / math.sqrt(C * 9)) * torch.exp2(torch.randint(-20, 21, (Cout, 1, 1, 1), generator=g).float())
+    b = _rand((Cout,), 82, 0.1)
+    ref = _ref_conv(x, w, b, 1, 1)
+    scale = _ref_conv(x.abs(), w.abs(), None, 1, 1)  # sum |x||w|: the natural error scale of a dot product
+    xd = x.cuda()
+    names = ops.conv_tiles()
+    sb = [i for i, n in enumerate(names) if n.startswith("sb")]
+    assert any(names[i].startswith("sbh") for i in sb)
+    worst = 0.0
+    for tile in sb:
+        e16 = ((ops.conv2d(xd, w, b, pad=1, tile=tile, precision=0).double().cpu() - ref).abs() / scale).max().item()
+        e6 = ((ops.conv2d(xd, w, b, pad=1, tile=tile, precision=3).double().cpu() - ref).abs() / scale).max().item()
+        worst = max(worst, e16)
+        assert e16 <= 4 * e6 + 2.0 ** -22, (names[tile], e16, e6)
+        assert e16 <= 2.0 ** -20, (names[tile], e16)
+    print(f"[split-f16] worst |err| / sum|x||w| over {len(sb)} tiles: {worst:.2e} (2^-22 = {2.0 ** -22:.2e})")
+    # small / tiny activations (explicit split tile: tile -1 may pick any family)
+    t64 = names.index("sb64x64")
+    wt = _rand((64, 64, 1, 1), 84, 0.125)
+    for a_scale, rel in ((1e-3, 2.0 ** -20), (1e-6, 2.0 ** -14)):
+        xt = (_rand((1, 8, 8, 64), 83) * a_scale).cuda()
+        rt = _ref_conv(xt.cpu(), wt, None, 1, 0)
+        got = ops.conv2d(xt, wt, None, precision=0, tile=t64).double().cpu()
+        assert ((got - rt).abs() / _ref_conv(xt.cpu().abs(), wt.abs(), None, 1, 0)).max().item() <= rel, a_scale
+    # saturation at the fp16 range
+    xs = torch.zeros((1, 4, 4, 32)); xs[..., 0] = 1.0e6; xs[..., 1] = -70000.0; xs[..., 2] = 65000.0
+    ws = torch.zeros((32, 32, 1, 1)); ws[0, 0] = ws[1, 1] = ws[2, 2] = 1.0
+    ys = ops.conv2d(xs.cuda(), ws, None, precision=0, tile=t64).cpu()
+    assert torch.isfinite(ys).all()
+    assert torch.allclose(ys[..., 0], torch.tensor(65504.0)) and torch.allclose(ys[..., 1], torch.tensor(-65504.0)) and torch.allclose(ys[..., 2], torch.tensor(65000.0))
+    # ... while the exact bf16 split has no range restriction
+    assert torch.allclose(ops.conv2d(xs.cuda(), ws, None, precision=3, tile=t64).cpu()[..., 0], torch.tensor(1.0e6))
 
 
 @pytest.mark.parametrize("precision,tol", [(1, 2e-4), (2, 3e-2)], ids=["bf16x3", "bf16"])

@@ -39,3 +39,16 @@ def test_inference_with_device_resize_matches_host_resize(model):
         assert torch.equal(x["pred_gravity_original"], y["pred_gravity_original"])
         assert torch.equal(x["pred_latitude_original"], y["pred_latitude_original"])
         assert float(x["pred_roll"]) == float(y["pred_roll"])
+
+
+def test_batched_device_resize_is_bit_identical_to_pil(model):
+    """pf_resize_batch_u8: 40 mixed-size images (more than one 32-image launch pair) in one call, byte-identical to PIL."""
+    sizes = [(640, 640), (384, 512), (1024, 1365), (64, 48), (317, 2), (5, 700), (320, 320), (721, 900)] * 5
+    rng = np.random.default_rng(4242)
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    out = torch.empty((len(imgs), 320, 320, 3), dtype=torch.uint8, device="cuda")
+    model._get_engine().resize_batch_into([torch.from_numpy(im).cuda() for im in imgs], out)
+    got = out.cpu().numpy()
+    for i, im in enumerate(imgs):
+        ref = np.asarray(Image.fromarray(im).resize((320, 320), Image.BILINEAR))
+        assert np.array_equal(got[i], ref), (i, sizes[i], int((got[i] != ref).sum()))

@@ -195,6 +195,91 @@ def test_split_bf16_scheme_is_fp32_accurate():
     assert np.max(np.abs(six - ref)) <= 2 * np.max(np.abs(f32 - ref)) + 1e-12
 
 
+def test_split_f16_scheme_is_fp32_class():
+    """The default parity scheme of the split kernels (csrc/igemm_sb_impl.h, NT_F16X3): a ~ ah + al 2^-11 with two fp16
+    values, weights scaled per output channel by a power of two and split as wh + wl, three partial products
+    ah wh + ah wl + al (wh 2^-11) in ONE fp32 accumulator.  Emulated in numpy (fp16 rounding by numpy, products and sums
+    exact in float64): the per-product error is <= 3 * 2^-22 and the dot-product error stays at the level of a plain fp32
+    dot product -- for O(1) data, for per-channel weight magnitudes over 2^+-20 and for activations down to 1e-6."""
+    rng = np.random.default_rng(1)
+
+    def split_a(a):
+        a = np.clip(a.astype(np.float32), -65504, 65504)
+        hi = a.astype(np.float16)
+        lo = ((a - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64)
+
+    def split_w(w):  # rows = output channels
+        mx = np.abs(w).max(axis=1, keepdims=True)
+        e = np.where(mx > 0, 14 - np.frexp(mx)[1], 0)
+        S = np.ldexp(np.float32(1), e).astype(np.float32)
+        ws = (w * S).astype(np.float32)
+        assert np.array_equal(ws.astype(np.float64), w.astype(np.float64) * S.astype(np.float64)), "power-of-two scale must be exact"
+        hi = ws.astype(np.float16)
+        lo = (ws - hi.astype(np.float32)).astype(np.float16)
+        h2 = (hi * np.float16(2.0 ** -11)).astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64), h2.astype(np.float64), 1.0 / S.astype(np.float64)
+
+    for a_scale, w_spread in ((1.0, 0), (1.0, 20), (1e-3, 0), (300.0, 8)):
+        a = (rng.standard_normal((48, 2304)) * a_scale).astype(np.float32)
+        w = (rng.standard_normal((40, 2304)) / 48).astype(np.float32) * np.exp2(rng.integers(-w_spread, w_spread + 1, (40, 1))).astype(np.float32)
+        ah, al = split_a(a)
+        wh, wl, wh2, inv = split_w(w)
+        got = ((ah @ wh.T) + (ah @ wl.T) + (al @ wh2.T)) * inv.T
+        ref = a.astype(np.float64) @ w.astype(np.float64).T
+        scale = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T
+        err = np.max(np.abs(got - ref) / scale)
+        assert err <= 3 * 2.0 ** -22, (a_scale, w_spread, err)
+        f32 = (a @ w.T).astype(np.float64)
+        assert np.max(np.abs(got - ref) / scale) <= 4 * np.max(np.abs(f32 - ref) / scale) + 2.0 ** -24, (a_scale, w_spread)
+    # below the fp16 normal range (|a| < ~1.2e-4) the representation error becomes ABSOLUTE, 2^-36 per element (fp16 subnormal
+    # spacing of the scaled low part): harmless next to O(1) terms, a relative loss only for an all-tiny tensor
+    a = (rng.standard_normal((48, 2304)) * 1e-6).astype(np.float32)
+    w = (rng.standard_normal((40, 2304)) / 48).astype(np.float32)
+    ah, al = split_a(a)
+    wh, wl, wh2, inv = split_w(w)
+    got = ((ah @ wh.T) + (ah @ wl.T) + (al @ wh2.T)) * inv.T
+    ref = a.astype(np.float64) @ w.astype(np.float64).T
+    bound = 2.0 ** -35 * np.abs(w).astype(np.float64).sum(axis=1)[None, :] + 3 * 2.0 ** -22 * (np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T)
+    assert np.all(np.abs(got - ref) <= bound)
+    # representation: 22+ significant bits per operand, saturation at the fp16 range
+    x = (rng.standard_normal(100000) * np.exp(rng.uniform(-8, 8, 100000))).astype(np.float32)
+    x = x[(np.abs(x) >= 1.3e-4) & (np.abs(x) <= 65504)]
+    hi, lo = split_a(x)
+    assert np.max(np.abs(hi + lo / 2048 - x) / np.abs(x)) <= 2.0 ** -22
+    hi, lo = split_a(np.array([1e9, -1e9], dtype=np.float32))
+    assert np.array_equal(hi + lo / 2048, [65504.0, -65504.0])
+
+
+def test_load_state_dict_strictness():
+    """Missing keys / wrong shapes are always fatal; entries the architecture does not have are fatal when strict and
+    dropped with a warning otherwise (the reference loads its zoo files with strict=False, perspectivefields.py:185,192)."""
+    import warnings
+
+    from perspectivefields_amd import PerspectiveFields
+    from perspectivefields_amd.synth import synthetic_state_dict
+
+    v = "PersNet-360Cities"
+    sd = synthetic_state_dict(v, 0)
+    extra = dict(sd)
+    extra["trainer.iteration"] = np.zeros((1,), np.float32)
+    extra["param_net.backbone.head.bias"] = np.zeros((5,), np.float32)
+    with pytest.raises(ValueError):
+        PerspectiveFields(v, weights=extra)  # in-memory state_dicts are held to the exact schema
+    m = PerspectiveFields(v, weights="synthetic:0")
+    with pytest.raises(ValueError):
+        m.load_state_dict(extra)  # strict=True default
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        m.load_state_dict(extra, strict=False)
+    assert any("ignoring 2 checkpoint entries" in str(r.message) for r in rec)
+    assert "trainer.iteration" not in m.state_dict() and len(m.state_dict()) == len(sd)
+    short = dict(sd)
+    short.pop(next(iter(sd)))
+    with pytest.raises(ValueError):
+        m.load_state_dict(short, strict=False)  # a missing tensor is never tolerated
+
+
 def test_pil_resize_algorithm_restatement():
     """The integer two-pass filter that csrc (resize_coeffs + resize_h/v_kernel) implements, restated in numpy and
     checked bit-for-bit against PIL (the reference's host resize, perspectivefields.py:34-46)."""
@@ -329,10 +414,16 @@ def test_kernel_resources_static():
     assert all(r["lds"] <= 160 * 1024 for r in rows), [r for r in rows if r["lds"] > 160 * 1024]
     by = {r["kernel"]: r for r in rows}
     hot = [
+        # default parity scheme (split-f16, NT_F16X3 = 23) and the exact bf16 split (6)
+        "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 23>",
+        "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 23>", "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 23>",
+        "pf::igemm_sb_kernel<256, 256, 2, 4, 0, false, 1, 23>", "pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 23>",
+        "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1, 23>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 23>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 23>",
+        "pf::igemm_sbh_kernel<16, 16, 64, 4, 2, 0, 1, 23>",
         "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 6>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 6>",
         "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 6>", "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 6>",
         "pf::igemm_sb_kernel<256, 256, 2, 4, 0, false, 1, 6>",
-        "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1>",
+        "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1, 6>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 6>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 6>",
         "pf::sr_attention_kernel", "pf::dwconv7x7_lane_kernel<1, 3, 256, 0>", "pf::upsample2x_cell_kernel",
         "pf::dwconv3x3_gelu_direct_kernel<32, 8, 8, 0>", "pf::layernorm_kernel<64, 2>",
     ]

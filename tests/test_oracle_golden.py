@@ -112,3 +112,39 @@ def test_fields_from_params_restatement_matches_reference(golden_dir):
         assert up.shape == g[f"up_{i}"].shape == (int(h), int(w), 2)
         np.testing.assert_allclose(up, g[f"up_{i}"], rtol=0, atol=1e-9)
         np.testing.assert_allclose(lat, g[f"lat_{i}"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["centered", "persnet", "uncentered"])
+def test_oracle_at_baseline_sizes(tag, golden_dir):
+    """The oracle at the sizes BASELINE.json names (640x640; 384x512 / 1024x1365), against the unmodified reference's
+    outputs there (tests/golden/fullsize.npz): stride-8 grid plus the two outermost rows / columns of the post-processed
+    fields (the up-sampling clamp branches), 320^2 predictions, ParamNet scalars."""
+    from tests.parity import TOL_COS, one_minus_cos
+
+    g = np.load(os.path.join(golden_dir, "fullsize.npz"))
+    pre = f"fs_{tag}_"
+    n = int(g[pre + "n"])
+    version = CASES[tag]
+    arch = arch_of(get_cfg(version))
+    sd = to_torch(synthetic_state_dict(version, 0))
+    x = np.stack([g[f"{pre}in_u8_{k}"] for k in range(n)])
+    sizes = [tuple(int(v) for v in g[f"{pre}size_{k}"]) for k in range(n)]
+    with torch.no_grad():
+        res = pf_oracle.forward(sd, arch, x, sizes)
+    names = [str(v) for v in g[pre + "param_names"]]
+    for k, r in enumerate(res):
+        H, W = sizes[k]
+        up, lat = r["pred_gravity_original"].numpy(), r["pred_latitude_original"].numpy()
+        rows, cols = [0, 1, H - 2, H - 1], [0, 1, W - 2, W - 1]
+        for what, a, a_ref, b, b_ref in (
+            ("s8", up[:, ::8, ::8], g[f"{pre}grav_s8_{k}"], lat[::8, ::8], g[f"{pre}lat_s8_{k}"]),
+            ("rows", up[:, rows, :], g[f"{pre}grav_rows_{k}"], lat[rows, :], g[f"{pre}lat_rows_{k}"]),
+            ("cols", up[:, :, cols], g[f"{pre}grav_cols_{k}"], lat[:, cols], g[f"{pre}lat_cols_{k}"]),
+        ):
+            if arch["gravity_cls"]:
+                assert np.mean(one_minus_cos(a, a_ref) > TOL_COS) <= 5e-3 and np.mean(np.abs(b - b_ref) > 1e-3) <= 5e-3
+            else:
+                assert_fields_close(a, a_ref, b, b_ref, f"{tag} img{k} {H}x{W} {what}")
+        if names:
+            got = np.array([float(r[nm]) for nm in names])
+            np.testing.assert_allclose(got, g[f"{pre}params_{k}"], atol=TOL_PARAM, rtol=0)
