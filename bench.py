@@ -2,14 +2,20 @@
 
 A step = one pass of the hot path over one batch: 320x320 uint8 network inputs already resident
 in HBM -> MiT-B3 + both decoders + ParamNet (pf_forward_u8) -> post-process of every image to its
-original 640x640 size (pf_postprocess) -> per-image ParamNet scalars (+ all-gather of the
+original 640x640 size (pf_postprocess_batch) -> per-image ParamNet scalars (+ all-gather of the
 scalars over RCCL when N > 1).  Workload = BASELINE.json configs[2]: batch 32, 640x640,
 Paramnet-360Cities-edina-centered, random-init (seeded synthetic) weights, synthetic images.
-The host-side PIL resize (reference perspectivefields.py:201) happens before the timed region;
-its inclusive rate is reported separately (never as `value`).
+The reference's host-side PIL resize (perspectivefields.py:201) happens before the timed region.
+Reported next to `value` (never as `value`):
+  * `with_device_resize`: the same step starting from the ORIGINAL 640x640 uint8 images resident in HBM
+    (bit-exact device PIL resize, pf_resize_batch_u8, inside the timed region);
+  * `latency_ms`: batch-1 / batch-8 latency of the hot path (device resident) and of inference() / inference_batch()
+    from host numpy images;
+  * `parity`: one image of the LAST timed step checked against the CPU oracle after the timed loop.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    (--dry-run-cpu: the same control flow on CPU with a stub engine and the gloo backend -- tests/test_bench_dist_gloo.py)
 """
 from __future__ import annotations
 
@@ -27,12 +33,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense MFMA peak (spec; 2:1 sparsity NOT counted)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 dense MFMA peak (spec; 2:1 sparsity NOT counted)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 GFLOP_PER_IMAGE_REF = 213.44   # contraction FLOPs of the reference graph, Paramnet-centered
+MFMA_PER_PRODUCT = {"fp32": 3, "fp32_bf16x6": 6, "bf16x3": 3, "bf16": 1}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -40,13 +47,17 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=640, help="original image height = width")
     ap.add_argument("--version", default="Paramnet-360Cities-edina-centered")
-    ap.add_argument("--precision", default=os.environ.get("PF_PRECISION", "fp32"), choices=["fp32", "bf16x3", "bf16"],
-                    help="arithmetic of the dense contractions; fp32 (fp32-accurate) is the parity mode and the headline")
+    ap.add_argument("--precision", default="fp32", choices=list(MFMA_PER_PRODUCT),
+                    help="arithmetic of the dense contractions; fp32 (split-f16, fp32-class accuracy) is the parity mode and the headline; "
+                         "fp32_bf16x6 = exact bf16 split; bf16x3 / bf16 are reduced-precision modes (reported, never the headline)")
+    ap.add_argument("--autotune", type=int, default=0, help="1: time every tile configuration for this batch size before the warm-up (default: shipped tile table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--events-in-timed", type=int, default=1, help="bracket the dominant kernel with HIP events inside the timed region")
+    ap.add_argument("--no-extras", action="store_true", help="skip the device-resize figure, the latency numbers and the parity check")
+    ap.add_argument("--events-in-timed", type=int, default=1, help="bracket the kernels with HIP events inside the timed region")
     ap.add_argument("--event-steps", type=int, default=2, help="how many of the timed steps carry the per-launch HIP events (0 = all)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run-cpu", action="store_true", help="control-flow test: stub engine on CPU, gloo backend (no GPU, no numbers)")
+    return ap.parse_args(argv)
 
 
 def pmc_traffic():
@@ -95,45 +106,105 @@ def cpu_baseline(version, size, budget_s=12.0, max_images=12):
     }
 
 
-def main():
-    args = parse()
+def parity_check(version, resized_u8, size, out, index):
+    """One image of the last timed step against the CPU oracle (same 320x320 uint8 input, same synthetic checkpoint)."""
+    from oracle import pf_oracle
+    from perspectivefields_amd.config import arch_of, get_cfg
+    from perspectivefields_amd.synth import synthetic_state_dict, to_torch
+
+    pg, pl, outs, params = out
+    sd = to_torch(synthetic_state_dict(version, 0))
+    arch = arch_of(get_cfg(version))
+    with torch.no_grad():
+        ref = pf_oracle.forward(sd, arch, resized_u8[index:index + 1], [(size, size)])[0]
+    up, lat = outs[index]
+    g, go = up.double().cpu(), ref["pred_gravity_original"].double()
+    cosv = float((1.0 - (g * go).sum(0) / torch.sqrt((g * g).sum(0) * (go * go).sum(0))).max())
+    lat_l1 = float((lat.double().cpu() - ref["pred_latitude_original"].double()).abs().mean())
+    res = {"image_index": index, "up_1_minus_cos_max": cosv, "latitude_l1_deg": lat_l1, "tolerances": {"up_1_minus_cos": 1e-3, "latitude_l1": 1e-3, "paramnet": 1e-4}}
+    ok = cosv <= 1e-3 and lat_l1 <= 1e-3
+    if params is not None:
+        keys = ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal")
+        dpar = max(abs(float(params[index, j]) - float(ref[k])) for j, k in enumerate(keys))
+        res["paramnet_max_abs_delta"] = dpar
+        ok = ok and dpar <= 1e-4
+    res["ok"] = bool(ok)
+    return res
+
+
+class _StubEngine:
+    """--dry-run-cpu: stands in for the HIP engine so that the rank logic (shards, barrier, MAX over ranks, gather of
+    the scalars, rank-0-only JSON) can run under 2-process gloo on CPU.  Produces no numbers worth reading."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def forward(self, batch):
+        B = batch.shape[0]
+        time.sleep(0.002 * (1 + self.rank))  # ranks finish at different times: exercises the MAX reduction
+        params = (batch.reshape(B, -1)[:, :8].to(torch.float32) + self.rank).contiguous()
+        return torch.zeros((B, 2, 4, 4)), torch.zeros((B, 1, 4, 4)), params
+
+    def postprocess_batch(self, pg, pl, sizes):
+        return [(torch.zeros((2, 2, 2)), torch.zeros((2, 2))) for _ in sizes]
+
+
+def main(argv=None):
+    args = parse(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = args.dry_run_cpu
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+    if not dry:
+        torch.cuda.set_device(dev)
 
-    from perspectivefields_amd import PerspectiveFields
     from perspectivefields_amd.dist import gather_params
     from perspectivefields_amd.synth import synthetic_image
 
     precision = args.precision
-    model = PerspectiveFields(args.version, weights="synthetic:0", precision=precision).eval().to(dev)
     B, S = args.batch, args.size
     # per-rank shard of the global batch: synthetic images, host resize (outside the timed region)
     imgs = [synthetic_image(S, S, seed=1000 + rank * B + i) for i in range(min(B, 4))]
-    t_resize = time.perf_counter()
-    resized4 = [model.aug.apply_image(im) for im in imgs]
-    t_resize = (time.perf_counter() - t_resize) / len(imgs)
-    resized = np.stack([resized4[i % len(resized4)] for i in range(B)])
+    if dry:
+        model, eng = None, _StubEngine(rank)
+        t_resize = 0.0
+        resized = np.stack([np.full((8, 8, 3), (rank * B + i) % 251, dtype=np.uint8) for i in range(B)])
+    else:
+        from perspectivefields_amd import PerspectiveFields
+
+        model = PerspectiveFields(args.version, weights="synthetic:0", precision=precision).eval().to(dev)
+        t_resize = time.perf_counter()
+        resized4 = [model.aug.apply_image(im) for im in imgs]
+        t_resize = (time.perf_counter() - t_resize) / len(imgs)
+        resized = np.stack([resized4[i % len(resized4)] for i in range(B)])
+        eng = model._get_engine()
+        if args.autotune:
+            eng.autotune(B)
     batch = torch.from_numpy(resized).to(dev)
     sizes = [(S, S)] * B
-    eng = model._get_engine()
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
 
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def step():
         pg, pl, params = eng.forward(batch)
@@ -144,11 +215,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    use_events = bool(args.events_in_timed) and not args.no_roofline
+    use_events = bool(args.events_in_timed) and not args.no_roofline and not dry
     if use_events:
-        eng.profile_begin(classes=("igemm", "igemm_sb", "dwconv3x3_gelu", "dwconv7x7", "upsample2x"))
+        eng.profile_begin(classes=("igemm", "igemm_sb", "dwconv3x3_gelu", "dwconv7x7", "upsample2x", "layernorm", "attention"))
     ev_steps = args.steps if (args.event_steps <= 0 or args.event_steps > args.steps) else args.event_steps
     t0 = time.perf_counter()
+    out = None
     for i in range(args.steps):
         if use_events and i == ev_steps:
             eng.profile_pause()  # the remaining timed steps run without the event pairs (each costs the stream a few microseconds)
@@ -165,14 +237,17 @@ def main():
     dt = float(tmax.item())
     total_images = B * world * args.steps
     value = total_images / dt
+    gathered_rows = int(out[3].shape[0]) if out[3] is not None else 0
 
     if rank != 0:
         if world > 1:
             import torch.distributed as dist
 
+            dist.barrier()  # rank 0 may still be running its extras
             dist.destroy_process_group()
         return
 
+    nt = MFMA_PER_PRODUCT[precision]
     line = {
         "metric": "images/sec (640x640, Paramnet-360Cities)",
         "value": round(value, 2),
@@ -184,14 +259,19 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if precision == "fp32" else precision,
+        "dtype": {"fp32": "f32 (operands fp32 in HBM; contractions as 2-way fp16 split on the MFMA, fp32 accumulate, fp32-class accuracy)",
+                  "fp32_bf16x6": "f32 (exact 3-way bf16 split on the MFMA, fp32 accumulate)"}.get(precision, precision),
         "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[2]: batch {B}/GPU {S}x{S} {args.version}, fields + ParamNet, 320x320 network inputs resident in HBM, post-process to {S}x{S}",
             "global_batch": B * world, "image_size": [S, S], "parallelism": f"dp{world} (images sharded, all-gather of ParamNet scalars)",
-            "weights": "seeded synthetic checkpoint (no network for the trained .pth)",
+            "weights": "seeded synthetic checkpoint (no network for the trained .pth)", "precision": precision,
+            "tiles": "autotuned on this device before the warm-up" if args.autotune else "shipped tile table + static heuristic (no tuning)",
+            "gathered_param_rows": gathered_rows,
         },
     }
+    if dry:
+        line["data"] = "dry run (stub engine on CPU, gloo): control flow only, numbers are meaningless"
     if prof is not None:
         traffic, traffic_src = pmc_traffic()
         ig, sb = prof["igemm"], prof["igemm_sb"]
@@ -211,12 +291,12 @@ def main():
 
         objs = []
         if sb["ms"] > 0:
-            nt = {"fp32": 6, "bf16x3": 3, "bf16": 1}[precision]
+            what = {"fp32": "split-f16: 3 x v_mfma_f32_32x32x16_f16 per product, fp32-class accuracy",
+                    "fp32_bf16x6": "split-bf16: 6 x v_mfma_f32_32x32x16_bf16 per product, fp32-accurate"}.get(precision, f"split-bf16: {nt} x v_mfma_f32_32x32x16_bf16 per product, reduced precision")
             objs.append((sb["ms"], mfma_obj(
-                sb, f"pf::igemm_sb_kernel + pf::igemm_sbh_kernel (implicit-GEMM conv/GEMM, linear and 3x3 halo tiles; split-bf16: {nt} x v_mfma_f32_32x32x16_bf16 per product"
-                + (", fp32-accurate)" if nt == 6 else ", reduced precision)"),
-                BF16_MFMA_PEAK_TFLOPS, "achieved = algorithmic FLOPs (2*M*N*K) / time, priced against the DENSE bf16 MFMA peak; the kernel "
-                f"executes {nt} bf16 MFMA FLOPs per algorithmic FLOP (executed_mfma_tflops), i.e. its ceiling is 2500/{nt} = {2500.0 / nt:.1f} TFLOP/s", float(nt))))
+                sb, f"pf::igemm_sb_kernel + pf::igemm_sbh_kernel (implicit-GEMM conv/GEMM, linear and 3x3 halo tiles; {what})",
+                BF16_MFMA_PEAK_TFLOPS, "achieved = algorithmic FLOPs (2*M*N*K) / time, priced against the DENSE 16-bit MFMA peak; the kernel "
+                f"executes {nt} MFMA FLOPs per algorithmic FLOP (executed_mfma_tflops), i.e. its ceiling is 2500/{nt} = {2500.0 / nt:.1f} TFLOP/s", float(nt))))
         if ig["ms"] > 0:
             objs.append((ig["ms"], mfma_obj(
                 ig, "pf::igemm_kernel (implicit-GEMM conv/GEMM, exact fp32: v_mfma_f32_32x32x2_f32)",
@@ -225,7 +305,7 @@ def main():
         if objs:
             line["roofline"] = objs[0][1]          # dominant kernel by time
             line["roofline"]["traffic"] = traffic
-            line["roofline"]["traffic_unit"] = "HBM bytes per launch (all implicit-GEMM launches)"
+            line["roofline"]["traffic_unit"] = "HBM bytes per launch (dominant conv shape, rocprofv3 PMC)"
             line["roofline"]["traffic_source"] = traffic_src
             if len(objs) > 1:
                 line["roofline_second"] = objs[1][1]
@@ -234,8 +314,8 @@ def main():
                                          "vs_fp32_mfma_peak": round(tot_work / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                          "share_of_step_time": round(tot_ms / ev_steps / (1000.0 * dt / args.steps), 4)}
         # HBM-bound classes (north_star: ">= 60 % of the HBM roofline on the depthwise stages"): algorithmic bytes / event time
-        for cls, key, kernel in (("dwconv3x3_gelu", "roofline_dwconv3x3", "pf::dwconv3x3_gelu_direct_kernel"),
-                                 ("dwconv7x7", "roofline_dwconv7x7", "pf::dwconv7x7_lane_kernel"),
+        for cls, key, kernel in (("dwconv3x3_gelu", "roofline_dwconv3x3", "pf::dwconv3x3_gelu kernels"),
+                                 ("dwconv7x7", "roofline_dwconv7x7", "pf::dwconv7x7 kernels (+ fused LayerNorm where enabled)"),
                                  ("layernorm", "roofline_layernorm", "pf::layernorm_kernel"),
                                  ("upsample2x", "roofline_upsample2x", "pf::upsample2x_cell_kernel")):
             dw = prof[cls]
@@ -246,9 +326,78 @@ def main():
                     "traffic": None, "kernel": kernel, "launches_per_step": dw["launches"] // ev_steps,
                     "algorithmic_mb_per_step": round(dw["work"] / ev_steps / 1e6, 1), "ms_per_step": round(dw["ms"] / ev_steps, 3),
                 }
+        at = prof["attention"]
+        if at["ms"] > 0:
+            line["attention"] = {"achieved_tflops": round(at["work"] / (at["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(at["ms"] / ev_steps, 3),
+                                 "launches_per_step": at["launches"] // ev_steps}
         line["achieved_tflops_ref_graph"] = round(value / world * GFLOP_PER_IMAGE_REF / 1e3, 2)
     line["host_resize_ms_per_image"] = round(1000.0 * t_resize, 3)
-    if world == 1 and not args.no_cpu_baseline:
+
+    if not dry and not args.no_extras:
+        # ---- (1) parity of the timed configuration: one image of the LAST timed step against the CPU oracle
+        try:
+            line["parity"] = parity_check(args.version, resized, S, out, index=min(B - 1, 3))
+            line["parity_checked"] = bool(line["parity"]["ok"])
+        except Exception as e:  # the checker failing must not hide the measurement
+            line["parity"] = {"error": repr(e)}
+            line["parity_checked"] = False
+        # ---- (2) the same step starting from the original 640x640 uint8 images in HBM (device PIL resize inside the timed region)
+        try:
+            orig = [torch.from_numpy(imgs[i % len(imgs)]).to(dev) for i in range(B)]
+            u8 = torch.empty((B, 320, 320, 3), dtype=torch.uint8, device=dev)
+
+            def step_resize():
+                eng.resize_batch_into(orig, u8)
+                pg, pl, params = eng.forward(u8)
+                return eng.postprocess_batch(pg, pl, sizes)
+
+            for _ in range(2):
+                step_resize()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step_resize()
+            sync()
+            d1 = time.perf_counter() - t1
+            same = bool(torch.equal(u8, batch))
+            line["with_device_resize"] = {
+                "value": round(B * args.steps / d1, 2), "unit": "images/sec", "ms_per_step": round(1000.0 * d1 / args.steps, 3), "n_gpus": 1,
+                "workload": f"batch {B} ORIGINAL {S}x{S} uint8 images resident in HBM -> bit-exact PIL resize on the device (pf_resize_batch_u8) -> forward -> post-process",
+                "resized_bytes_identical_to_host_pil": same,
+            }
+        except Exception as e:
+            line["with_device_resize"] = {"error": repr(e)}
+        # ---- (3) latency of the reference's primary call pattern: inference(img) / small batches
+        try:
+            lat = {}
+            for b in (1, 8):
+                xb = batch[:b].contiguous()
+                sz = sizes[:b]
+                for _ in range(3):
+                    pg, pl, _p = eng.forward(xb)
+                    eng.postprocess_batch(pg, pl, sz)
+                sync()
+                n = 20
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    pg, pl, _p = eng.forward(xb)
+                    eng.postprocess_batch(pg, pl, sz)
+                    sync()
+                lat[f"b{b}_device_resident"] = round(1000.0 * (time.perf_counter() - t1) / n, 3)
+                host_imgs = [imgs[i % len(imgs)] for i in range(b)]
+                for _ in range(2):
+                    model.inference_batch(host_imgs)
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(8):
+                    model.inference_batch(host_imgs)
+                    sync()
+                lat[f"b{b}_host_images_pil_resize"] = round(1000.0 * (time.perf_counter() - t1) / 8, 3)
+            lat["note"] = "ms per call, synchronised after every call; device_resident = pf_forward_u8 + pf_postprocess_batch on 320x320 uint8 in HBM; host_images = inference_batch(list of 640x640 numpy images): host PIL resize + H2D + forward + post-process"
+            line["latency_ms"] = lat
+        except Exception as e:
+            line["latency_ms"] = {"error": repr(e)}
+    if world == 1 and not args.no_cpu_baseline and not dry:
         try:
             line["cpu_baseline"] = cpu_baseline(args.version, S)
         except Exception as e:  # the checker failing must not hide the measurement
@@ -257,6 +406,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -65,7 +65,8 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, p
            planes_in=False, planes_out=False, precision=0):
     """x: (B,H,W,C1) [+ x2: (B,H,W,C2) channel-concat]; weight: (Cout, C1+C2, KH, KW).  Returns (B,Ho,Wo,Cout) or NCHW.
     planes_in: hand the input(s) to the kernel as split-bf16 planes only; planes_out: take the output as planes
-    (returned merged back to fp32, which is exact).  precision: 0 fp32-accurate, 1 bf16x3, 2 bf16 (split-bf16 tiles)."""
+    (returned merged back to fp32, which is exact).  precision (split tiles): 0 split-f16 (default parity scheme), 3 exact bf16
+    split, 1 bf16x3, 2 bf16."""
     import torch
 
     lib = load_library()
@@ -174,12 +175,13 @@ def conv_tiles():
     return [lib.pf_op_conv_tile_name(i).decode() for i in range(lib.pf_op_num_conv_tiles())]
 
 
-def conv2d_bench(B, H, W, Cin, Cout, K, stride=1, pad=0, tile=-1, iters=10, device=0, fmt=0):
+def conv2d_bench(B, H, W, Cin, Cout, K, stride=1, pad=0, tile=-1, iters=10, device=0, fmt=0, precision=0):
     """Average ms per launch of one conv shape on random data (tuning aid).  fmt 0: fp32 in / out; 1: split-plane
-    input; 2: split-plane input and output.  Returns -1 when the tile cannot run the format."""
+    input; 2: split-plane input and output (the exact bf16 split).  precision: PF_PRECISION_* of the split tiles
+    (0 split-f16 default, 3 exact bf16 split, 1 bf16x3, 2 bf16).  Returns -1 when the tile cannot run the format."""
     lib = load_library()
     ms = ctypes.c_float()
-    _check(lib.pf_op_conv2d_bench(device, B, H, W, Cin, Cout, K, stride, pad, tile, iters, fmt, ctypes.byref(ms)), None, "pf_op_conv2d_bench")
+    _check(lib.pf_op_conv2d_bench(device, B, H, W, Cin, Cout, K, stride, pad, tile, iters, fmt + 16 * precision, ctypes.byref(ms)), None, "pf_op_conv2d_bench")
     return ms.value
 
 

@@ -6,17 +6,18 @@ from perspectivefields_amd import PerspectiveFields
 from perspectivefields_amd.synth import synthetic_image
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--version", default="Paramnet-360Cities-edina-centered")
-ap.add_argument("--out", default="gpurun_out/layers.txt")
+ap.add_argument("--out", default="gpurun_out/layers.txt"); ap.add_argument("--precision", default="fp32"); ap.add_argument("--autotune", type=int, default=0)
 a = ap.parse_args()
-m = PerspectiveFields(a.version, weights="synthetic:0").eval().cuda()
+m = PerspectiveFields(a.version, weights="synthetic:0", precision=a.precision).eval().cuda()
 eng = m._get_engine()
+if a.autotune: eng.autotune(a.batch)
 x = torch.from_numpy(np.stack([m.aug.apply_image(synthetic_image(640, 640, i % 4)) for i in range(a.batch)])).cuda()
 for _ in range(2): eng.forward(x)
 torch.cuda.synchronize()
 eng.profile_begin(); eng.forward(x); torch.cuda.synchronize(); tot = eng.profile_end(); recs = eng.profile_records()
 lines = []
 allms = sum(v["ms"] for v in tot.values())
-lines.append(f"batch {a.batch}: profiled classes total {allms:.2f} ms")
+lines.append(f"batch {a.batch} precision {a.precision} autotune {a.autotune}: profiled classes total {allms:.2f} ms")
 for k, v in tot.items():
     if v["launches"]:
         unit = "TFLOP/s" if k in ("igemm", "igemm_sb", "attention") else "GB/s"

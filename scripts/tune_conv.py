@@ -22,7 +22,8 @@ SHAPES = [
 tiles = ops.conv_tiles()
 # TUNE_SB=1: only the split-bf16 tiles, each with fp32 operands ("f") and with split-plane input + output ("p")
 SB_ONLY = os.environ.get("TUNE_SB", "0") == "1"
-out = [f"B={B}; tiles: " + ", ".join(f"{i}:{t}" for i, t in enumerate(tiles))]
+PREC = int(os.environ.get("TUNE_PREC", "0"))  # PF_PRECISION_* of the split tiles: 0 split-f16 (default), 3 exact bf16 split
+out = [f"B={B}; precision {PREC}; tiles: " + ", ".join(f"{i}:{t}" for i, t in enumerate(tiles))]
 ONLY = [t for t in os.environ.get("TUNE_ONLY", "").split(",") if t]
 for name, b, h, w, cin, cout, k, st, pd in SHAPES:
     if ONLY and not any(name.startswith(o) for o in ONLY):
@@ -41,7 +42,7 @@ for name, b, h, w, cin, cout, k, st, pd in SHAPES:
                 continue
             tf = []
             for fmt in (0, 2 if cout % 4 == 0 else 1):
-                ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=t, iters=iters, fmt=fmt)
+                ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=t, iters=iters, fmt=fmt, precision=3)
                 tf.append(flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
             bestf = max(bestf, (tf[0], tiles[t])); bestp = max(bestp, (tf[1], tiles[t]))
             line.append(f"{tiles[t]}:{tf[0]:5.1f}/{tf[1]:5.1f}")
@@ -49,15 +50,15 @@ for name, b, h, w, cin, cout, k, st, pd in SHAPES:
                    f"({(bestp[0]/bestf[0]-1)*100:+5.1f} %) | " + " ".join(line))
         continue
     for t in range(len(tiles)):
-        ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=t, iters=iters)
+        ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=t, iters=iters, precision=PREC)
         if ms <= 0:  # tile not usable for this shape
             continue
         res.append((flops / (ms * 1e-3) / 1e12, t, ms))
-    auto_ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=-1, iters=5)
+    auto_ms = ops.conv2d_bench(b, h, w, cin, cout, k, st, pd, tile=-1, iters=5, precision=PREC)
     best = max(res)
     out.append(f"{name:10s} M={b*ho*wo:8d} N={cout:5d} K={k*k*cin:6d}  best {tiles[best[1]]:10s} {best[0]:6.1f} TF {best[2]:7.3f} ms | auto {flops/(auto_ms*1e-3)/1e12:6.1f} TF | " +
                " ".join(f"{tiles[t]}:{tf:5.1f}" for tf, t, _ in sorted(res, key=lambda r: r[1])))
 txt = "\n".join(out)
 os.makedirs("gpurun_out", exist_ok=True)
-open("gpurun_out/tune_conv.txt", "w").write(txt + "\n")
+open(os.environ.get("TUNE_OUT", "gpurun_out/tune_conv.txt"), "w").write(txt + "\n")
 print(txt)
