@@ -141,7 +141,7 @@ def test_conv2d_split_f16_scheme(ops):
         e6 = ((ops.conv2d(xd, w, b, pad=1, tile=tile, precision=3).double().cpu() - ref).abs() / scale).max().item()
         worst = max(worst, e16)
         assert e16 <= 4 * e6 + 2.0 ** -22, (names[tile], e16, e6)
-        assert e16 <= 2.0 ** -20, (names[tile], e16)
+        assert e16 <= 2.0 ** -17, (names[tile], e16)  # (this data's fp32 accumulation error alone -- e6 -- reaches ~1e-6)
     print(f"[split-f16] worst |err| / sum|x||w| over {len(sb)} tiles: {worst:.2e} (2^-22 = {2.0 ** -22:.2e})")
     # small / tiny activations (explicit split tile: tile -1 may pick any family)
     t64 = names.index("sb64x64")
