@@ -206,8 +206,17 @@ int pf_op_layernorm(int device, const float* d_x, const float* h_gamma, const fl
 int pf_op_dwconv3x3_gelu(int device, const float* d_x, const float* h_weight /*[C][1][3][3]*/, const float* h_bias, float* d_y, int B, int H, int W, int C,
                          uint16_t* d_y_planes, long plane_elems, void* stream);
 int pf_op_dwconv7x7(int device, const float* d_x, const float* h_weight /*[C][1][7][7]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);
+/* the same with an explicit kernel: variant 3 = column-blocked streaming kernel (nc = 4 / 2 output columns per thread, nb = 2 / 3
+ * row buffers, th = rows per strip; 0 = automatic), 2 = one column per lane; and a timing loop on random data (avg ms per launch) */
+int pf_op_dwconv7x7_cfg(int device, const float* d_x, const float* h_weight, const float* h_bias, float* d_y, int B, int H, int W, int C,
+                        int variant, int nc, int nb, int th, void* stream);
+int pf_op_dwconv7x7_bench(int device, int variant, int nc, int nb, int th, int B, int H, int W, int C, int iters, float* ms_out);
 int pf_op_sr_attention(int device, const float* d_q, const float* d_kv, float* d_out, int B, int N, int M, int heads,
                        uint16_t* d_out_planes, long plane_elems, void* stream);
+/* explicit kernel: variant 1 = split-f16 MFMA (default of the forward), 0 = exact fp32 MFMA; iters > 0 additionally times
+ * `iters` launches (avg ms per launch in *ms_out; synchronises) */
+int pf_op_sr_attention_variant(int device, int variant, const float* d_q, const float* d_kv, float* d_out, int B, int N, int M, int heads,
+                               int iters, float* ms_out, void* stream);
 int pf_op_upsample2x(int device, const float* d_x, float* d_y, int B, int H, int W, int C, uint16_t* d_y_planes, long plane_elems, void* stream);
 int pf_op_num_conv_tiles(void);
 const char* pf_op_conv_tile_name(int tile_id);

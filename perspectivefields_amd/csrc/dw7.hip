@@ -16,6 +16,8 @@
 // flops per 8 bytes -- 0.09 ms (packed) / 0.18 ms (scalar) of VALU time per forward against 0.14 ms of HBM time at 8 TB/s.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "pf_kernels.h"
 
 namespace pf {
@@ -130,6 +132,152 @@ __global__ __launch_bounds__(MAXT) void dwconv7x7_lane_kernel(const float* __res
     if (t0 + r >= nrows) break;
     do_row(t0 + r, r);
   }
+}
+
+// ---- column-blocked form (default for the larger maps).  The lane kernel above issues 7 dword loads per output and lane:
+// with 4 waves per CU that is 112 texture-address cycles per 98 VALU cycles and row -- the kernel sits on the L1 / TA
+// request rate, which is why it did not react to occupancy, prefetch depth or packed FMAs.  Here a thread
+// owns NC ADJACENT output columns of one channel: a row costs NC + 6 loads for 49 NC FMAs (2.5 loads per output at NC = 4),
+// the x-overlap lives in registers instead of L1.  Same streaming structure otherwise: lane = channel (32 consecutive
+// channels = one 128-byte piece of a pixel), buffer loads with per-lane fixed offsets + scalar row offset (hardware range
+// check = zero padding), compile-time ring of 7 output-row accumulators x NC columns, loads NB - 1 rows ahead, branch-free
+// memory operations.  Taps whose output row lies outside the strip are skipped with block-uniform branches, so a strip's
+// six halo rows cost loads only, no FMAs.
+template <int NC /*adjacent output columns per thread*/, int NB /*row buffers*/, int DIAG = 0>
+__global__ __launch_bounds__(256) void dwconv7x7_cb_kernel(const float* __restrict__ x, const float* __restrict__ w49c,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int B, int H, int W, int C, int TH, int GB /*column groups per block*/) {
+  constexpr int NI = NC + 6;  // input columns per thread
+  const int groups = (W + NC - 1) / NC;
+  const int slabs = C / 32, tilesX = (groups + GB - 1) / GB, strips = (H + TH - 1) / TH;
+  const int nblk = B * strips * tilesX * slabs;
+  int t;
+  {  // XCD-aware order: the slabs / x-neighbours of one image region share an L2
+    const int b = blockIdx.x, qd = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    t = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+  }
+  const int slab = t % slabs; t /= slabs;
+  const int tx = t % tilesX; t /= tilesX;
+  const int st = t % strips; t /= strips;
+  const int b = t;
+  const int g = tx * GB + (int)threadIdx.x / 32;
+  const int c = slab * 32 + ((int)threadIdx.x & 31);
+  const int x0 = g * NC;
+  const bool g_ok = g < groups;
+  const int y0 = st * TH, y1 = min(y0 + TH, H);
+  float wk[49];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) wk[k] = w49c[(long)k * C + c];
+  const float bv = bias[c];
+  float* const xb = const_cast<float*>(x + (long)b * H * W * C);
+  float* const yb = y + (long)b * H * W * C;
+  const unsigned img_bytes = (unsigned)((long)H * W * C * 4);
+  unsigned voff[NI], voff_out[NC];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int ix = x0 - 3 + j;
+    voff[j] = (g_ok && (unsigned)ix < (unsigned)W) ? (unsigned)(ix * C + c) * 4u : 0x80000000u;
+  }
+#pragma unroll
+  for (int j = 0; j < NC; ++j) voff_out[j] = (g_ok && x0 + j < W) ? (unsigned)((x0 + j) * C + c) * 4u : 0x80000000u;
+  const unsigned row_bytes = (unsigned)(W * C) * 4u;
+  float acc[7][NC], in[NB][NI];
+#pragma unroll
+  for (int s = 0; s < 7; ++s)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) acc[s][j] = bv;
+  auto load_row = [&](int iy, float (&v)[NI]) {
+    const bool ok = (unsigned)iy < (unsigned)H;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(xb, 0, ok ? img_bytes : 0u, 0x00020000);
+    const unsigned soff = ok ? (unsigned)iy * row_bytes : 0u;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) v[j] = DIAG == 2 ? bv : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff[j], soff, 0));
+  };
+  // relative row tt: input row iy = y0 - 3 + tt feeds output rows oy = iy - ky + 3 (accumulator slot (tt - ky + 3) mod 7);
+  // after row tt the output row iy - 3 (slot (tt + 4) mod 7) is complete.  r = tt mod (7 NB) is a compile-time constant.
+  const int nrows = (y1 - y0) + 6;
+  auto do_row = [&](int tt, int r) {
+    const int iy = y0 - 3 + tt;
+    load_row(iy + NB - 1, in[(r + NB - 1) % NB]);  // prefetch; rows past the strip are loaded but never used
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      const int oy = iy - ky + 3;
+      if (oy >= y0 && oy < y1) {  // block-uniform; rows outside the image were loaded as zeros
+        constexpr int dummy = 0; (void)dummy;
+        const int s = (r - ky + 3 + 7 * NB) % 7;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          float a = acc[s][j];
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) a = fmaf(in[r % NB][j + kx], wk[ky * 7 + kx], a);
+          acc[s][j] = a;
+        }
+      }
+    }
+    const int oy = iy - 3;  // < y1 always (tt < nrows)
+    const bool st_ok = oy >= y0;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yb, 0, st_ok ? img_bytes : 0u, 0x00020000);
+    const unsigned soff = st_ok ? (unsigned)oy * row_bytes : 0u;
+    const int so = (r + 4) % 7;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      if (DIAG != 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[so][j]), ry, voff_out[j], soff, 0);
+      else if (tt == nrows - 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][j] + acc[1][j] + acc[2][j] + acc[3][j] + acc[4][j] + acc[5][j] + acc[6][j]), ry, voff_out[j], 0u, 0);
+      acc[so][j] = bv;
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < NB - 1; ++d) load_row(y0 - 3 + d, in[d]);
+  int t0 = 0;
+  for (; t0 + 7 * NB <= nrows; t0 += 7 * NB) {  // whole groups: no exit inside
+#pragma unroll
+    for (int r = 0; r < 7 * NB; ++r) do_row(t0 + r, r);
+  }
+#pragma unroll
+  for (int r = 0; r < 7 * NB; ++r) {  // straight-line tail
+    if (t0 + r >= nrows) break;
+    do_row(t0 + r, r);
+  }
+}
+
+template <int NC, int NB>
+static void launch_cb(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int TH, hipStream_t s) {
+  const int groups = (W + NC - 1) / NC;
+  int GB = 8;  // column groups per block (x 32 channels = threads); prefer an even divisor of `groups` (whole waves, no idle groups)
+  for (int cand : {8, 6, 4, 2}) if (groups % cand == 0) { GB = cand; break; }
+  if (groups % 2 != 0) GB = groups <= 8 ? groups : 8;
+  const long blocks = (long)B * ((H + TH - 1) / TH) * ((groups + GB - 1) / GB) * (C / 32);
+  static int diag = -1;
+  if (diag < 0) { const char* d = getenv("PF_DW7_DIAG"); diag = d ? atoi(d) : 0; }
+  if (diag == 1)      hipLaunchKernelGGL((dwconv7x7_cb_kernel<NC, NB, 1>), dim3((unsigned)blocks), dim3(GB * 32), 0, s, x, w49c, bias, y, B, H, W, C, TH, GB);
+  else if (diag == 2) hipLaunchKernelGGL((dwconv7x7_cb_kernel<NC, NB, 2>), dim3((unsigned)blocks), dim3(GB * 32), 0, s, x, w49c, bias, y, B, H, W, C, TH, GB);
+  else                hipLaunchKernelGGL((dwconv7x7_cb_kernel<NC, NB, 0>), dim3((unsigned)blocks), dim3(GB * 32), 0, s, x, w49c, bias, y, B, H, W, C, TH, GB);
+}
+
+// column-blocked kernel: NC / NB / strip height TH by map size (0 = automatic; scripts/tune_dw7.py measured the table);
+// PF_DW7_NC / PF_DW7_NB / PF_DW7_TH override the automatic choice
+void launch_dwconv7x7_cb_cfg(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int nc, int nb, int th, hipStream_t s) {
+  static int e_nc = -1, e_nb = 0, e_th = 0;
+  if (e_nc == -1) {
+    const char* a = getenv("PF_DW7_NC"); e_nc = a ? atoi(a) : 0;
+    const char* n = getenv("PF_DW7_NB"); e_nb = n ? atoi(n) : 0;
+    const char* t = getenv("PF_DW7_TH"); e_th = t ? atoi(t) : 0;
+  }
+  if (nc <= 0) nc = e_nc;
+  if (nb <= 0) nb = e_nb;
+  if (th <= 0) th = e_th;
+  const int NC = nc > 0 ? nc : (W >= 64 ? 4 : 2);
+  const int NB = nb > 0 ? nb : 3;
+  int TH = th > 0 ? std::min(th, H) : H;
+  if (th <= 0) {  // enough waves to fill the chip (256 CUs x 12-16 waves): waves = B x C x ceil(W / NC) / 64 x strips
+    const long per_strip = (long)B * C * ((W + NC - 1) / NC) / 64;
+    while (TH > 5 && per_strip * ((H + TH - 1) / TH) < 3072) TH = (TH + 1) / 2;
+  }
+  if (NC >= 4) { if (NB == 2) launch_cb<4, 2>(x, w49c, bias, y, B, H, W, C, TH, s); else launch_cb<4, 3>(x, w49c, bias, y, B, H, W, C, TH, s); }
+  else         { if (NB == 2) launch_cb<2, 2>(x, w49c, bias, y, B, H, W, C, TH, s); else launch_cb<2, 3>(x, w49c, bias, y, B, H, W, C, TH, s); }
+}
+void launch_dwconv7x7_cb(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+  launch_dwconv7x7_cb_cfg(x, w49c, bias, y, B, H, W, C, 0, 0, 0, s);
 }
 
 template <int CPL, int NB>

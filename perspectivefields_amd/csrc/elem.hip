@@ -432,13 +432,22 @@ __global__ __launch_bounds__(CQB * XB) void dwconv7x7_ring_kernel(const float* _
 
 // The default kernel (channels-per-lane, buffer loads, prefetch ring) lives in dw7.hip.
 void launch_dwconv7x7_lane(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
+void launch_dwconv7x7_cb(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
 
+void launch_dwconv7x7_cb_cfg(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int nc, int nb, int th, hipStream_t s);
 static int g_dw7_variant = -1;
+// explicit variant / column-blocked configuration (tests, tuning); variant < 0: the default path
+void launch_dwconv7x7_cfg(int variant, int nc, int nb, int th, const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+  if (variant == 3) { launch_dwconv7x7_cb_cfg(x, w49c, bias, y, B, H, W, C, nc, nb, th, s); return; }
+  if (variant == 2) { launch_dwconv7x7_lane(x, w49c, bias, y, B, H, W, C, s); return; }
+  launch_dwconv7x7(x, w49c, bias, y, B, H, W, C, s);
+}
 void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
   if (g_dw7_variant == -1) {
     const char* e = getenv("PF_DW7_VARIANT");
-    g_dw7_variant = e ? atoi(e) : 2;
+    g_dw7_variant = e ? atoi(e) : 3;  // 3: column-blocked streaming kernel (dw7.hip), 2: one column per lane, 1: ring, 0: LDS halo tile
   }
+  if (g_dw7_variant == 3) { launch_dwconv7x7_cb(x, w49c, bias, y, B, H, W, C, s); return; }
   if (g_dw7_variant == 2) { launch_dwconv7x7_lane(x, w49c, bias, y, B, H, W, C, s); return; }
   const int CQ = C / 4;
   if (g_dw7_variant == 0) {  // LDS halo-tile kernel (kept for A/B)

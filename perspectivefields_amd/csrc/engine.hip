@@ -1443,12 +1443,75 @@ int pf_op_dwconv7x7(int device, const float* x, const float* hw, const float* hb
   return rc;
 }
 
+int pf_op_dwconv7x7_cfg(int device, const float* x, const float* hw, const float* hb, float* y, int B, int H, int W, int C, int variant, int nc, int nb, int th, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (C % 96 != 0 && C % 32 != 0) { g_create_error = "pf_op_dwconv7x7_cfg: C must be a multiple of 32"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  launch_dwconv7x7_cfg(variant, nc, nb, th, x, tmp.up(pack_dw(hw, C, 7)), tmp.up(hb, C), y, B, H, W, C, s);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_dwconv7x7_bench(int device, int variant, int nc, int nb, int th, int B, int H, int W, int C, int iters, float* ms_out) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (C % 32 != 0 || iters <= 0 || !ms_out) { g_create_error = "pf_op_dwconv7x7_bench: bad argument"; return PF_ERR_ARG; }
+  const size_t n = (size_t)B * H * W * C;
+  float *dx = nullptr, *dy = nullptr, *dw = nullptr, *db = nullptr;
+  if (hipMalloc(&dx, n * 4) != hipSuccess || hipMalloc(&dy, n * 4) != hipSuccess || hipMalloc(&dw, (size_t)49 * C * 4) != hipSuccess ||
+      hipMalloc(&db, (size_t)C * 4) != hipSuccess) { g_create_error = "pf_op_dwconv7x7_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
+  launch_fill_random(dx, (long)n, 777u, 1.0f, nullptr);
+  launch_fill_random(dw, (long)49 * C, 778u, 0.15f, nullptr);
+  launch_fill_random(db, (long)C, 779u, 0.1f, nullptr);
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  launch_dwconv7x7_cfg(variant, nc, nb, th, dx, dw, db, dy, B, H, W, C, nullptr);
+  (void)hipEventRecord(a, nullptr);
+  for (int i = 0; i < iters; ++i) launch_dwconv7x7_cfg(variant, nc, nb, th, dx, dw, db, dy, B, H, W, C, nullptr);
+  (void)hipEventRecord(b, nullptr);
+  (void)hipEventSynchronize(b);
+  float t = 0.f;
+  (void)hipEventElapsedTime(&t, a, b);
+  *ms_out = t / iters;
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(db);
+  return rc;
+}
+
 int pf_op_sr_attention(int device, const float* q, const float* kv, float* out, int B, int N, int M, int heads, uint16_t* out_planes, long plane_elems, void* stream) {
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
   if (M <= 0 || M > 128) { g_create_error = "pf_op_sr_attention: kv length must be in 1..128"; return PF_ERR_ARG; }
   launch_sr_attention(q, kv, out, B, N, M, heads, static_cast<hipStream_t>(stream), out_planes, (size_t)plane_elems);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+}
+
+int pf_op_sr_attention_variant(int device, int variant, const float* q, const float* kv, float* out, int B, int N, int M, int heads, int iters, float* ms_out, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (M <= 0 || M > 128 || (variant != 0 && variant != 1)) { g_create_error = "pf_op_sr_attention_variant: kv length must be in 1..128, variant 0 or 1"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  launch_sr_attention_variant(variant, q, kv, out, B, N, M, heads, s);
+  if (iters > 0 && ms_out) {  // timing loop on the caller's data
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+    for (int i = 0; i < iters; ++i) launch_sr_attention_variant(variant, q, kv, out, B, N, M, heads, s);
+    (void)hipEventRecord(b, s);
+    (void)hipEventSynchronize(b);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, a, b);
+    *ms_out = t / iters;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  }
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
 }
 

@@ -15,7 +15,10 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {64, 64, 2, "sb64x64f2"}, {64, 64, 3, "sb64x64f3"}, {128, 64, 2, "sb128x64f2"}, {128, 32, 2, "sb128x32f2"},
                              {128, 128, 2, "sb128x128f2"},
                              // "sbh": 3x3 / stride 1 convs with an LDS-staged input halo tile, 8 x 16 output patch per block (igemm_sbh.hip)
-                             {128, 128, 0, "sbh128x128"}, {128, 64, 0, "sbh128x64"}, {128, 32, 0, "sbh128x32"}, {256, 64, 0, "sbh256x64w8"}};
+                             {128, 128, 0, "sbh128x128"}, {128, 64, 0, "sbh128x64"}, {128, 32, 0, "sbh128x32"}, {256, 64, 0, "sbh256x64w8"},
+                             // split-f16 scheme only: "d" = weights double-buffered in LDS (one barrier per tap), "t3" = weights of a kernel row per step
+                             {128, 128, 0, "sbhd128x128"}, {128, 64, 0, "sbhd128x64"}, {128, 32, 0, "sbhd128x32"}, {256, 64, 0, "sbhd256x64w8"},
+                             {256, 64, 0, "sbh256x64w8t3"}, {128, 64, 0, "sbh128x64t3"}};
 static constexpr int kFirstH = 12;  // index of the first "sbh" tile
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }
 const char* conv_sb_tile_name(int id) { return kSb[id].name; }
@@ -64,11 +67,12 @@ void launch_conv_sbf(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm
 
 void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 
-bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) { return sb_tile < kFirstH || conv_sbh_ok(p); }
+bool conv_sbh_tile_ok(const ConvParams& p, int h_tile);                  // igemm_sbh.hip
+bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) { return sb_tile < kFirstH || conv_sbh_tile_ok(p, sb_tile - kFirstH); }
 
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
   if (sb_tile >= kFirstH) {
-    if (conv_sbh_ok(p)) { launch_conv_sbh(p, sb_tile - kFirstH, s); return; }
+    if (conv_sbh_tile_ok(p, sb_tile - kFirstH)) { launch_conv_sbh(p, sb_tile - kFirstH, s); return; }
     sb_tile = conv_sb_default_tile(p);
   }
   if (p.nterms == NT_F16X3) launch_conv_sbf(p, sb_tile, s);

@@ -31,7 +31,8 @@ __device__ __forceinline__ int sbh_piece(int row, int piece) { return piece ^ ((
 
 // SCH = 6: exact 3-way bf16 split, 6 MFMAs per product; SCH = NT_F16X3: 2-way fp16 split of the activations (2 LDS planes),
 // scaled weights wh + wl from global memory plus wh2 = wh 2^-11 made while staging (3 LDS planes), 3 MFMAs per product.
-template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE, int TPG /*taps whose weights are staged together: 1 or 3 (one kernel row)*/, int SCH>
+template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE, int TPG /*taps whose weights are staged together: 1 or 3 (one kernel row)*/, int SCH,
+          bool DB = false /*two LDS buffers for the weights: the next tap's weights are stored while this tap is still being read -> one barrier per tap instead of two*/>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
@@ -47,11 +48,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   constexpr int EPI_USHORTS = 2 * (WM * 32) * (BN + 4);
   constexpr bool F16 = SCH == NT_F16X3;
   constexpr int NPA = F16 ? 2 : 3, NPB = 3, NPG = F16 ? 2 : 3;  // A planes in LDS, B planes in LDS, B planes loaded from global memory
-  constexpr int OPER_USHORTS = NPA * PLANE_A + NPB * TPG * PLANE_B;
+  static_assert(!DB || TPG == 1, "double-buffered weights: one tap per step");
+  constexpr int BBUF = NPB * TPG * PLANE_B;  // ushorts of one weight buffer
+  constexpr int OPER_USHORTS = NPA * PLANE_A + (DB ? 2 : 1) * BBUF;
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
   unsigned short* As = smem_u;                  // [NPA][H_ROWS][H_ROW]
-  unsigned short* Bs = smem_u + NPA * PLANE_A;  // [TPG][3][BN][H_ROW]
+  unsigned short* Bs0 = smem_u + NPA * PLANE_A;  // [DB ? 2 : 1][TPG][3][BN][H_ROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -151,7 +154,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
           rb[u][i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes : OOB);
     }
   };
-  auto store_b = [&]() {
+  auto store_b = [&](int buf = 0) {
+    unsigned short* Bs = Bs0 + (DB ? buf * BBUF : 0);
 #pragma unroll
     for (int u = 0; u < TPG; ++u)
 #pragma unroll
@@ -187,10 +191,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
     const int pr = ml / H_TX, pc0 = ml % H_TX;
     hb[i] = pr * H_HX + ((pr & 1) ? (pc0 + ODD_SHIFT) % H_TX : pc0);
   }
-  const unsigned short* Bb = Bs + (wn0 + l31) * H_ROW;
+  const unsigned short* Bb0 = Bs0 + (wn0 + l31) * H_ROW;
   const int swz_b = (l31 >> 2) & 3;
 
-  auto compute = [&](int tap, int slot /*position of this tap's weights in the staged group*/) {
+  auto compute = [&](int tap, int slot /*position of this tap's weights in the staged group*/, int buf = 0) {
+    const unsigned short* Bb = Bb0 + (DB ? buf * BBUF : 0);
     const int ky = tap / 3, kx = tap - 3 * ky;
     const int toff = ky * H_HX + kx;
 #pragma unroll
@@ -227,6 +232,23 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   store_b();
   __syncthreads();
   constexpr int NG = 9 / TPG;  // tap groups per chunk
+  if constexpr (DB) {
+    // weights of step q = 9 c + g live in LDS buffer q & 1: while the waves read buffer q & 1, the weights of step q + 1 (loaded
+    // at the start of this step) are stored into the other buffer -- nobody reads it since the barrier that ended step q - 1
+    int par = 0;
+    for (int c = 0; c < nC; ++c) {
+#pragma unroll
+      for (int g = 0; g < 9; ++g) {
+        if (g == 4) load_a(c + 1);
+        if (g + 1 < 9) load_b(c, g + 1); else load_b(c + 1, 0);
+        compute(g, 0, par);
+        store_b(par ^ 1);
+        if (g == 8 && c + 1 < nC) { __syncthreads(); store_a(); }  // every wave has read this chunk's halo
+        __syncthreads();
+        par ^= 1;
+      }
+    }
+  } else
   for (int c = 0; c < nC; ++c) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {  // unrolled: no branch around any load, the s_waitcnt counts stay exact
@@ -245,14 +267,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2, F16 ? P.w_h16_inv_scale : nullptr);
 }
 
-template <int H_TY, int H_TX, int BN, int WM, int WN, int TPG = 1>
+template <int H_TY, int H_TX, int BN, int WM, int WN, int TPG = 1, bool DB = false>
 static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(WM * WN * 64);
   if (p.nterms == NT_F16X3) {
-    if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, TPG, NT_F16X3>), grid, block, 0, s, p);
-    else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, TPG, NT_F16X3>), grid, block, 0, s, p);
+    if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, TPG, NT_F16X3, DB>), grid, block, 0, s, p);
+    else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, TPG, NT_F16X3, DB>), grid, block, 0, s, p);
+  } else if constexpr (TPG != 1 || DB) {
+    return;  // the t3 / double-buffered forms exist for the split-f16 scheme only (conv_sbh_tile_ok)
   } else {
     if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, TPG, 6>), grid, block, 0, s, p);
     else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, TPG, 6>), grid, block, 0, s, p);
@@ -270,12 +294,21 @@ bool conv_sbh_ok(const ConvParams& p) {
   return true;
 }
 
+// tiles 4.. (double-buffered weights "d", weights of a kernel row per step "t3") are built for the split-f16 scheme only
+bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) { return conv_sbh_ok(p) && (h_tile < 4 || p.nterms == NT_F16X3); }
+
 // ids = position among the "sbh" tiles of kSb[] (igemm_sb.hip)
 void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
   switch (h_tile) {
     case 0: launch_sbh_cfg<8, 16, 128, 2, 2>(p, s); break;
     case 1: launch_sbh_cfg<8, 16, 64, 2, 2>(p, s); break;
     case 2: launch_sbh_cfg<8, 16, 32, 4, 1>(p, s); break;
+    case 4: launch_sbh_cfg<8, 16, 128, 2, 2, 1, true>(p, s); break;
+    case 5: launch_sbh_cfg<8, 16, 64, 2, 2, 1, true>(p, s); break;
+    case 6: launch_sbh_cfg<8, 16, 32, 4, 1, 1, true>(p, s); break;
+    case 7: launch_sbh_cfg<16, 16, 64, 4, 2, 1, true>(p, s); break;
+    case 8: launch_sbh_cfg<16, 16, 64, 4, 2, 3>(p, s); break;
+    case 9: launch_sbh_cfg<8, 16, 64, 2, 2, 3>(p, s); break;
     default: launch_sbh_cfg<16, 16, 64, 4, 2>(p, s); break;  // 16 x 16 patch, 8 waves, two blocks per CU: weights staged once per 256 rows
   }
 }

@@ -101,10 +101,16 @@ void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c
                                    unsigned short* y_sb = nullptr, size_t sb_plane = 0);
 // depthwise 7x7 (pad 3) + bias, NHWC, w packed [49][C]
 void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
+// variant 3 = column-blocked streaming kernel with nc columns per thread (4 / 2), nb row buffers (2 / 3), strips of th rows (0 = automatic); 2 = one column per lane
+void launch_dwconv7x7_cfg(int variant, int nc, int nb, int th, const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
 
 // spatial-reduction attention: q [B][N][C], kv [B][M][2C] (k | v), out [B][N][C]; head_dim 64, M <= 128
 void launch_sr_attention(const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s,
                          unsigned short* out_sb = nullptr, size_t sb_plane = 0);
+
+// variant 1: split-f16 MFMA (default); 0: exact fp32 MFMA
+void launch_sr_attention_variant(int variant, const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s,
+                                 unsigned short* out_sb = nullptr, size_t sb_plane = 0);
 
 // bilinear x2 (align_corners=False), NHWC
 void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb = nullptr, size_t sb_plane = 0);

@@ -63,7 +63,10 @@ _SIGNATURES = {
     "pf_op_layernorm": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_long, _c.c_int, _c.c_float, _P, _c.c_long, _P]),
     "pf_op_dwconv3x3_gelu": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_long, _P]),
     "pf_op_dwconv7x7": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "pf_op_dwconv7x7_cfg": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "pf_op_dwconv7x7_bench": (_c.c_int, [_c.c_int] * 10 + [_c.POINTER(_c.c_float)]),
     "pf_op_sr_attention": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_long, _P]),
+    "pf_op_sr_attention_variant": (_c.c_int, [_c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_float), _P]),
     "pf_op_upsample2x": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_long, _P]),
     "pf_op_num_conv_tiles": (_c.c_int, []),
     "pf_op_conv_tile_name": (_c.c_char_p, [_c.c_int]),

@@ -131,7 +131,9 @@ def dwconv3x3_gelu(x, weight, bias, planes_out=False):
     return yp.merge() if planes_out else y
 
 
-def dwconv7x7(x, weight, bias):
+def dwconv7x7(x, weight, bias, variant=None, nc=0, nb=0, th=0):
+    """variant None: the default path; 3: column-blocked streaming kernel (nc columns per thread, nb row buffers, strips of th
+    rows; 0 = automatic); 2: one column per lane."""
     import torch
 
     lib = load_library()
@@ -139,8 +141,18 @@ def dwconv7x7(x, weight, bias):
     B, H, W, C = x.shape
     y = torch.empty_like(x)
     w, b = _np(weight), _np(bias)
-    _check(lib.pf_op_dwconv7x7(x.device.index, x.data_ptr(), _hp(w), _hp(b), y.data_ptr(), B, H, W, C, _stream_ptr()), None, "pf_op_dwconv7x7")
+    if variant is None:
+        _check(lib.pf_op_dwconv7x7(x.device.index, x.data_ptr(), _hp(w), _hp(b), y.data_ptr(), B, H, W, C, _stream_ptr()), None, "pf_op_dwconv7x7")
+    else:
+        _check(lib.pf_op_dwconv7x7_cfg(x.device.index, x.data_ptr(), _hp(w), _hp(b), y.data_ptr(), B, H, W, C, variant, nc, nb, th, _stream_ptr()), None, "pf_op_dwconv7x7_cfg")
     return y
+
+
+def dwconv7x7_bench(variant, B, H, W, C, nc=0, nb=0, th=0, iters=10, device=0):
+    lib = load_library()
+    ms = ctypes.c_float()
+    _check(lib.pf_op_dwconv7x7_bench(device, variant, nc, nb, th, B, H, W, C, iters, ctypes.byref(ms)), None, "pf_op_dwconv7x7_bench")
+    return ms.value
 
 
 def sr_attention(q, kv, heads, planes_out=False):
@@ -155,6 +167,20 @@ def sr_attention(q, kv, heads, planes_out=False):
     op = Planes(q.shape, q.device) if planes_out else None
     _check(lib.pf_op_sr_attention(q.device.index, q.data_ptr(), kv.data_ptr(), _dp(out), B, N, M, heads, *_pl(op), _stream_ptr()), None, "pf_op_sr_attention")
     return op.merge() if planes_out else out
+
+
+def sr_attention_variant(q, kv, heads, variant, iters=0):
+    """variant 1: split-f16 MFMA kernel (the forward's default), 0: exact fp32 MFMA.  iters > 0: returns (out, avg ms per launch)."""
+    import torch
+
+    lib = load_library()
+    q, kv = q.contiguous(), kv.contiguous()
+    B, N, C = q.shape
+    out = torch.empty_like(q)
+    ms = ctypes.c_float()
+    _check(lib.pf_op_sr_attention_variant(q.device.index, variant, q.data_ptr(), kv.data_ptr(), out.data_ptr(), B, N, kv.shape[1], heads, iters,
+                                          ctypes.byref(ms), _stream_ptr()), None, "pf_op_sr_attention_variant")
+    return (out, ms.value) if iters > 0 else out
 
 
 def upsample2x(x, planes_out=False):

@@ -90,20 +90,54 @@ def linear_q(x, w, b=None):
     return y if b is None else y + b
 
 
+def attention_q(w, x, H, W, heads, sr):
+    """mit_attention with both attention products on the split-f16 scheme (K and V scaled by 64 and split as hi + lo_true,
+    q * d^-0.5 and P split as hi + lo 2^-11): the planned MFMA form of csrc/attn.hip."""
+    B, N, C = x.shape
+    d = C // heads
+    q = F.linear(x, w("q.weight"), w("q.bias")).reshape(B, N, heads, d).transpose(1, 2)
+    if sr > 1:
+        xm = x.transpose(1, 2).reshape(B, C, H, W)
+        xr = F.conv2d(xm, w("sr.weight"), w("sr.bias"), stride=sr)
+        xr = xr.reshape(B, C, -1).transpose(1, 2)
+        xr = pf_oracle.layer_norm(xr, w("norm.weight"), w("norm.bias"), 1e-5)
+    else:
+        xr = x
+    kv = F.linear(xr, w("kv.weight"), w("kv.bias")).reshape(B, -1, 2, heads, d)
+    k = kv[:, :, 0].transpose(1, 2)
+    v = kv[:, :, 1].transpose(1, 2)
+
+    def mm(a, b_scaled64):  # a: activations split hi + lo/2048; b: (64 b) split hi + lo_true; the lo*lo term is dropped
+        ah, al = split_f16(a.double())
+        bh, bl = split_f16(b_scaled64.double() * 64.0)
+        return ((ah @ bh + ah @ bl + al @ bh) / 64.0).to(torch.float32)
+
+    a = mm(q * (d ** -0.5), k.transpose(-2, -1))
+    a = a.softmax(dim=-1)
+    o = mm(a, v).transpose(1, 2).reshape(B, N, C)
+    return F.linear(o, w("proj.weight"), w("proj.bias"))
+
+
+_attention = pf_oracle.mit_attention
+
+
 def run(sd, arch, imgs, mode):
     global SCHEME
     if mode in ("fp32", "fp64"):
         F.conv2d, F.linear = _conv2d, _linear
         dtype = torch.float64 if mode == "fp64" else torch.float32
     else:
-        SCHEME = mode
+        SCHEME = "f16x3" if mode.startswith("f16x3") else mode
         F.conv2d, F.linear = conv2d_q, linear_q
+        if mode == "f16x3+attn":
+            pf_oracle.mit_attention = attention_q
         dtype = torch.float32
     try:
         with torch.no_grad():
             return pf_oracle.inference_batch(sd, arch, imgs, dtype)
     finally:
         F.conv2d, F.linear = _conv2d, _linear
+        pf_oracle.mit_attention = _attention
 
 
 def main():
@@ -114,7 +148,7 @@ def main():
     imgs = [synthetic_image(640, 640, seed=1000 + i) for i in range(int(os.environ.get("N_IMG", "3")))]
     keys = ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal")
     truth = run(sd, arch, imgs, "fp64")
-    for mode in ("fp32", "f16x3", "bf16x3"):
+    for mode in ("fp32", "f16x3", "f16x3+attn", "bf16x3"):
         res = run(sd, arch, imgs, mode)
         dpar, dcos, dlat = 0.0, 0.0, 0.0
         for r, t in zip(res, truth):
@@ -123,7 +157,7 @@ def main():
             c = 1.0 - (g * go).sum(0) / torch.sqrt((g * g).sum(0) * (go * go).sum(0))
             dcos = max(dcos, float(c.max()))
             dlat = max(dlat, float((r["pred_latitude_original"].double() - t["pred_latitude_original"].double()).abs().mean()))
-        print(f"{mode:7s} vs fp64: ParamNet max|d| {dpar:.3e} (tol 1e-4)   up 1-cos max {dcos:.3e} (tol 1e-3)   latitude L1 {dlat:.3e} deg (tol 1e-3)", flush=True)
+        print(f"{mode:10s} vs fp64: ParamNet max|d| {dpar:.3e} (tol 1e-4)   up 1-cos max {dcos:.3e} (tol 1e-3)   latitude L1 {dlat:.3e} deg (tol 1e-3)", flush=True)
 
 
 if __name__ == "__main__":

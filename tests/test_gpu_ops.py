@@ -305,7 +305,14 @@ def test_dwconv7x7(ops, B, H, W, C):
     w = _rand((C, 1, 7, 7), 24, 0.15)
     b = _rand((C,), 25, 0.1)
     ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=3, groups=C).permute(0, 2, 3, 1).contiguous()
-    _close(ops.dwconv7x7(x.cuda(), w, b), ref, 1e-5, "dwconv7x7")
+    xd = x.cuda()
+    _close(ops.dwconv7x7(xd, w, b), ref, 1e-5, "dwconv7x7")
+    # every kernel / configuration: column-blocked (nc x nb x strip heights incl. one-strip and tiny strips), one column per lane
+    for nc in (4, 2):
+        for nb in (2, 3):
+            for th in (0, 1, 3, 7, H):
+                _close(ops.dwconv7x7(xd, w, b, variant=3, nc=nc, nb=nb, th=th), ref, 1e-5, f"dwconv7x7 cb nc{nc} nb{nb} th{th}")
+    _close(ops.dwconv7x7(xd, w, b, variant=2), ref, 1e-5, "dwconv7x7 lane")
 
 
 @pytest.mark.parametrize("B,N,heads,M", [(2, 6400, 1, 100), (1, 1600, 2, 100), (2, 400, 5, 100), (3, 100, 8, 100), (1, 70, 2, 37)])
@@ -318,7 +325,57 @@ def test_sr_attention(ops, B, N, heads, M):
     v = kv.double()[..., C:].reshape(B, M, heads, 64).transpose(1, 2)
     a = ((qh @ k.transpose(-2, -1)) * 0.125).softmax(-1)
     ref = (a @ v).transpose(1, 2).reshape(B, N, C)
-    _close(ops.sr_attention(q.cuda(), kv.cuda(), heads), ref, 1e-5, "sr attention")
+    _close(ops.sr_attention(q.cuda(), kv.cuda(), heads), ref, 2e-5, "sr attention")
+
+
+def _attention_bound(q, kv, heads):
+    """fp64 reference and a per-row error bound for the split-f16 kernel: a logit carries <= 3 * 2^-22 * sum_d |q_d k_d| / 8
+    (the split products) -> relative change of the softmax weights <= 2 delta; plus 2^-21 from the second product."""
+    B, N, C = q.shape
+    M = kv.shape[1]
+    qh = q.double().reshape(B, N, heads, 64).transpose(1, 2)
+    k = kv.double()[..., :C].reshape(B, M, heads, 64).transpose(1, 2)
+    v = kv.double()[..., C:].reshape(B, M, heads, 64).transpose(1, 2)
+    a = ((qh @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    ref = (a @ v).transpose(1, 2).reshape(B, N, C)
+    delta = 3 * 2.0 ** -22 * 0.125 * (qh.abs() @ k.abs().transpose(-2, -1)).max(-1).values  # (B, heads, N)
+    vmax = v.abs().amax(dim=(2, 3))  # (B, heads)
+    bound = (2 * delta + 2.0 ** -20) * vmax[:, :, None] + 1e-7
+    return ref, bound.transpose(1, 2)[..., None].expand(B, N, heads, 64).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("B,N,heads,M", [(2, 6400, 1, 100), (1, 1600, 2, 100), (2, 400, 5, 100), (3, 100, 8, 100), (1, 70, 2, 37), (1, 130, 1, 128), (1, 33, 1, 16)])
+def test_sr_attention_both_kernels(ops, B, N, heads, M):
+    """the split-f16 MFMA kernel (default) within its analytic bound, the exact-fp32 MFMA kernel at 1e-5, and the two agree"""
+    C = heads * 64
+    q = _rand((B, N, C), 26)
+    kv = _rand((B, M, 2 * C), 27)
+    ref, bound = _attention_bound(q, kv, heads)
+    f16 = ops.sr_attention_variant(q.cuda(), kv.cuda(), heads, 1).double().cpu()
+    f32 = ops.sr_attention_variant(q.cuda(), kv.cuda(), heads, 0).double().cpu()
+    assert torch.isfinite(f16).all()
+    worst = float(((f16 - ref).abs() / bound).max())
+    print(f"[attention split-f16 B{B} N{N} h{heads} M{M}] max err {float((f16 - ref).abs().max()):.2e} (ratio to bound {worst:.2f}); fp32 kernel {float((f32 - ref).abs().max()):.2e}")
+    assert worst <= 1.0
+    _close(f32, ref, 1e-5, "attention fp32 MFMA")
+    _close(f16, ref, 2e-5, "attention split-f16 (O(1) data)")
+
+
+def test_sr_attention_split_f16_extremes(ops):
+    """peaked rows (|logit| ~ 100), tiny and large K / V magnitudes, K / V beyond the +-1023 range of the scaled split
+    (saturates: finite output)"""
+    B, N, heads, M = 1, 64, 1, 100
+    q = _rand((B, N, 64), 28)
+    kv = _rand((B, M, 128), 29)
+    kv[0, 17, :64] = q[0, 5] * 6.0
+    q[0, 9] *= 30.0
+    kv[0, 40:60, 64:] *= 1e-4
+    kv[0, 60:70, 64:] *= 300.0
+    ref, bound = _attention_bound(q, kv, heads)
+    got = ops.sr_attention_variant(q.cuda(), kv.cuda(), heads, 1).double().cpu()
+    assert float(((got - ref).abs() / bound).max()) <= 1.0
+    kv[0, 3, 64:] = 5000.0
+    assert torch.isfinite(ops.sr_attention_variant(q.cuda(), kv.cuda(), heads, 1)).all()
 
 
 def test_sr_attention_spiked_row(ops):
@@ -330,7 +387,7 @@ def test_sr_attention_spiked_row(ops):
     q[0, 9] *= 30.0
     a = ((q.double() @ kv.double()[..., :64].transpose(-2, -1)) * 0.125).softmax(-1)
     ref = a @ kv.double()[..., 64:]
-    _close(ops.sr_attention(q.cuda(), kv.cuda(), heads), ref, 1e-5, "spiked attention")
+    _close(ops.sr_attention_variant(q.cuda(), kv.cuda(), heads, 0), ref, 1e-5, "spiked attention (exact fp32 MFMA kernel)")
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 10, 10, 256), (1, 80, 80, 256), (1, 160, 160, 64), (1, 3, 5, 8)])
