@@ -117,6 +117,13 @@ int pf_forward_u8(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_p
 int pf_forward_f32(pf_handle h, int batch, const float* d_images_f32, float* d_pred_gravity, float* d_pred_latitude,
                    float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Low-latency form of pf_forward_u8 for small batches: the ~430 launches of a forward are captured once per (batch, buffer
+ * set) into a hipGraph and replayed with one launch (host launch cost, not GPU time, bounds a batch-1 forward).  Same
+ * arguments and results; `stream` must be an explicit stream (not the legacy NULL stream); the graph is re-captured when
+ * any buffer pointer changes, so callers keep their buffers (the Python layer does). */
+int pf_forward_u8_graph(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_pred_gravity, float* d_pred_latitude,
+                        float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Device-side replacement of ResizeTransform.apply_image (perspectivefields.py:34-46,201): PIL's antialiased BILINEAR
  * resize of one uint8 [H][W][3] image to [320][320][3], bit-identical to PIL (integer two-pass filter; coefficient
  * tables built on the host exactly as Pillow does and cached per extent in the handle -- the first call for a new

@@ -158,9 +158,9 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------------------------
 // Split-f16 form (default): both products on v_mfma_f32_32x32x16_f16 with the 2-way fp16 split of the conv kernels
 // (igemm_sb_impl.h): 3 MFMAs per product at 16x the fp32-MFMA rate = 5.3x less matrix-core time, fp32-class accuracy
-// (scripts/emulate_split.py: no measurable change end to end).  K and V play the "weight" role: scaled by 64 (exact) and
-// split as hi + lo with lo = fp16(64 x - hi) UNSCALED, so that  qh kh + qh kl + ql (kh 2^-11)  accumulates in one
-// accumulator (|k|, |v| < 1023; entries below 2^-8 keep an absolute accuracy of 2^-31); q d^-0.5 and the probabilities
+// (scripts/emulate_split.py: no measurable change end to end).  K and V play the "weight" role: scaled by 16 (exact) and
+// split as hi + lo with lo = fp16(16 x - hi) UNSCALED, so that  qh kh + qh kl + ql (kh 2^-11)  accumulates in one
+// accumulator (|k|, |v| < 4094, saturating beyond; entries below 2^-6 keep an absolute accuracy of 2^-29); q d^-0.5 and the probabilities
 // are split as hi + lo 2^-11.  Same transposed formulation as above: S^T = K Q^T leaves a query's scores in one lane
 // pair, and P^T in accumulator layout feeds O^T = V^T P^T directly -- the MFMA k index of that product is then a fixed
 // PERMUTATION of the kv index (lane half hi, element e of 16-chunk cc  <->  kv = 16 cc + (e & 3) + 8 (e >> 2) + 4 hi), so
@@ -170,7 +170,7 @@ typedef _Float16 at_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int at_u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int AT_KS = 72;    // halfs per K row: 144 B -> 16 consecutive rows hit 16 distinct 16-byte slots (36 i mod 64)
 static constexpr int AT_VS = 136;   // halfs per V^T row: 128 kv positions + 8 (272 B = 68 words: 68 i mod 64 = 4 i)
-static constexpr float AT_KV_SCALE = 64.f;
+static constexpr float AT_KV_SCALE = 16.f;
 
 __device__ __forceinline__ unsigned at_pack(float a, float b) {
   const at_h2 v = {(_Float16)a, (_Float16)b};
@@ -201,9 +201,9 @@ __device__ __forceinline__ f32x16 at_mfma(const at_u32x4 a, const at_u32x4 b, co
 __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                                   float* __restrict__ out, unsigned short* __restrict__ out_sb, size_t sb_plane, int N, int M, int heads) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem_at[];
-  unsigned short* Kh = smem_at;              // [M][AT_KS]  hi of 64 K
+  unsigned short* Kh = smem_at;              // [M][AT_KS]  hi of 16 K
   unsigned short* Kl = Kh + M * AT_KS;       //             lo (unscaled remainder)
-  unsigned short* VTh = Kl + M * AT_KS;      // [64][AT_VS] hi of 64 V, transposed, kv in MFMA k order
+  unsigned short* VTh = Kl + M * AT_KS;      // [64][AT_VS] hi of 16 V, transposed, kv in MFMA k order
   unsigned short* VTl = VTh + HD * AT_VS;
   const int C = heads * HD;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
   }
   __syncthreads();
 
-  // ---- S^T[kv][q] * 64: kv blocks of 32 rows (rows past M read a clamped row and are masked below)
+  // ---- S^T[kv][q] * 16: kv blocks of 32 rows (rows past M read a clamped row and are masked below)
   f32x16 sacc[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
   }
 
   // ---- softmax over kv for query column (lane & 31); rows held by this lane: kv = 32 c + (r & 3) + 8 (r >> 2) + 4 hi.
-  //      The accumulators hold 64 x the scores: the 1/64 rides on the exp2 constant.
+  //      The accumulators hold 16 x the scores: the 1/16 rides on the exp2 constant.
   constexpr float L2E = 1.4426950408889634f / AT_KV_SCALE;
   float mx = -3.0e38f;
 #pragma unroll
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / (sum * AT_KV_SCALE);  // also undoes the scale of V
 
-  // ---- O^T[d][q] * 64 = sum_kv V^T[d][kv] P^T[kv][q]: chunk cc = registers 8 (cc & 1) .. + 7 of block cc >> 1
+  // ---- O^T[d][q] * 16 = sum_kv V^T[d][kv] P^T[kv][q]: chunk cc = registers 8 (cc & 1) .. + 7 of block cc >> 1
   f32x16 oacc[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)

@@ -266,12 +266,13 @@ void launch_dwconv7x7_cb_cfg(const float* x, const float* w49c, const float* bia
   if (nc <= 0) nc = e_nc;
   if (nb <= 0) nb = e_nb;
   if (th <= 0) th = e_th;
-  const int NC = nc > 0 ? nc : (W >= 64 ? 4 : 2);
-  const int NB = nb > 0 ? nb : 3;
-  int TH = th > 0 ? std::min(th, H) : H;
-  if (th <= 0) {  // enough waves to fill the chip (256 CUs x 12-16 waves): waves = B x C x ceil(W / NC) / 64 x strips
+  // measured on MI355X at B = 32 (profiles/r02_tune_dw7.txt): 80^2: nc4 nb2 th20, 40^2: nc4 nb2 th10, 20^2: nc4 nb2 th10, 10^2: nc2 nb3 th10
+  const int NC = nc > 0 ? nc : (W >= 20 ? 4 : 2);
+  const int NB = nb > 0 ? nb : (W >= 20 ? 2 : 3);
+  int TH = th > 0 ? std::min(th, H) : std::min(H, H >= 80 ? 20 : 10);
+  if (th <= 0) {  // small batches: more strips until the chip is full (256 CUs x 12-16 waves); waves = B x C x ceil(W / NC) / 64 x strips
     const long per_strip = (long)B * C * ((W + NC - 1) / NC) / 64;
-    while (TH > 5 && per_strip * ((H + TH - 1) / TH) < 3072) TH = (TH + 1) / 2;
+    while (TH > 5 && per_strip * ((H + TH - 1) / TH) < 2048) TH = (TH + 1) / 2;
   }
   if (NC >= 4) { if (NB == 2) launch_cb<4, 2>(x, w49c, bias, y, B, H, W, C, TH, s); else launch_cb<4, 3>(x, w49c, bias, y, B, H, W, C, TH, s); }
   else         { if (NB == 2) launch_cb<2, 2>(x, w49c, bias, y, B, H, W, C, TH, s); else launch_cb<2, 3>(x, w49c, bias, y, B, H, W, C, TH, s); }

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "pf_workspace_bytes": (_c.c_size_t, [_P, _c.c_int]),
     "pf_forward_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_forward_f32": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_forward_u8_graph": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_resize_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
     "pf_resize_bilinear_u8": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
     "pf_resize_batch_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _c.c_size_t, _P]),
@@ -171,6 +172,9 @@ class Engine:
         self._finalized = False
         self.precision = "fp32"
         self.max_batch = int(self.lib.pf_max_batch())
+        # batches up to this size replay a captured hipGraph (latency path: inference(img) / small lists); 0 disables
+        self.graph_max_batch = int(os.environ.get("PF_GRAPH_MAX_BATCH", "4"))
+        self._graph_bufs = {}
         g, l, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self.lib.pf_output_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(p))
         self.gravity_channels, self.latitude_channels, self.param_outputs = g.value, l.value, p.value
@@ -263,6 +267,8 @@ class Engine:
             fn = self.lib.pf_forward_f32
         else:
             raise PfError(f"unsupported input dtype {images.dtype}")
+        if images.dtype == torch.uint8 and B <= self.graph_max_batch and self.lib.pf_is_tuned(self._h, B):
+            return self._forward_graph(images)
         with torch.cuda.device(self.device):
             pg = torch.empty((B, self.gravity_channels, NET, NET), dtype=torch.float32, device=self.device)
             pl = torch.empty((B, self.latitude_channels, NET, NET), dtype=torch.float32, device=self.device)
@@ -277,6 +283,37 @@ class Engine:
             )
         _check(rc, self._h, "pf_forward")
         return pg, pl, params
+
+    def _forward_graph(self, images):
+        """Small batches: persistent input / output / workspace buffers + a hipGraph captured on first use
+        (pf_forward_u8_graph); the results are cloned, so the caller owns them as with forward()."""
+        import torch
+
+        B = images.shape[0]
+        bufs = self._graph_bufs.get(B)
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_graph_stream", None) is None:
+            self._graph_stream = torch.cuda.Stream(device=self.device)  # the legacy default stream cannot be captured
+        gs = self._graph_stream
+        with torch.cuda.device(self.device):
+            if bufs is None:
+                bufs = {
+                    "in": torch.empty((B, NET, NET, 3), dtype=torch.uint8, device=self.device),
+                    "pg": torch.empty((B, self.gravity_channels, NET, NET), dtype=torch.float32, device=self.device),
+                    "pl": torch.empty((B, self.latitude_channels, NET, NET), dtype=torch.float32, device=self.device),
+                    "params": torch.empty((B, PARAMS_STRIDE), dtype=torch.float32, device=self.device) if self.param_outputs else None,
+                    "ws": torch.empty(self.workspace_bytes(B), dtype=torch.uint8, device=self.device),
+                }
+                self._graph_bufs[B] = bufs
+            bufs["in"].copy_(images)
+            p = bufs["params"]
+            gs.wait_stream(cur)  # the input copy (and earlier readers of the persistent outputs) first
+            rc = self.lib.pf_forward_u8_graph(self._h, B, bufs["in"].data_ptr(), bufs["pg"].data_ptr(), bufs["pl"].data_ptr(),
+                                              p.data_ptr() if p is not None else None, bufs["ws"].data_ptr(), bufs["ws"].numel(),
+                                              ctypes.c_void_p(gs.cuda_stream))
+            _check(rc, self._h, "pf_forward_u8_graph")
+            cur.wait_stream(gs)
+            return bufs["pg"].clone(), bufs["pl"].clone(), (p.clone() if p is not None else None)
 
     def resize_into(self, img_u8, out_u8_320):
         """Bit-exact PIL BILINEAR resize on the device: img_u8 (H,W,3) uint8 cuda -> out_u8_320 (320,320,3) uint8 cuda view."""
