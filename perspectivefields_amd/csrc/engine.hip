@@ -289,9 +289,6 @@ struct pf_engine {
   // hipGraph replay of small-batch forwards (pf_forward_u8_graph): one graph per (batch, buffer set, precision)
   struct GraphEntry { std::vector<uintptr_t> key; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
-  int nstreams = 1;          // PF_STREAMS=2: halves of a batch on two internal streams (see split_streams)
-  hipStream_t aux[2] = {nullptr, nullptr};
-  hipEvent_t aux_ev[3] = {nullptr, nullptr, nullptr};
   bool sba = false;          // PF_SBA=1: tensors that only feed GEMMs are stored as split-bf16 planes by their producers (sb_split.h);
                              // measured slower end to end (1.5x the bytes on HBM-bound layers), kept as an option -- DESIGN.md 4.2
 
@@ -880,17 +877,6 @@ struct pf_engine {
     }
     return it->second + ((with_scratch || autotune) ? scratch_elems[B] * 10 + 4096 : 0);
   }
-  // Two-stream mode (PF_STREAMS=2, off by default): a batch of >= 2 * MIN_SPLIT images runs as two independent half-batch
-  // forwards on two internal HIP streams (images are independent units), joined back onto the caller's stream with
-  // events: the small launches of one half (MiT stages 3-4, ConvNeXt stages 2-3: one wave of blocks, a few us each) fill
-  // the ramp-up / tail of the other half's.  Results are those of two separate forwards of the halves.
-  static constexpr int MIN_SPLIT = 4;
-  bool split_streams(int B, bool tune) const { return nstreams == 2 && !tune && !autotune && !prof.on && B >= 2 * MIN_SPLIT; }
-  size_t forward_workspace_bytes(int B, bool tune) {
-    if (!split_streams(B, tune)) return workspace_bytes(B, tune);
-    return workspace_bytes(B / 2) + workspace_bytes(B - B / 2) + 512;
-  }
-
   int forward(int B, const void* in, bool is_u8, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, hipStream_t s, bool tune = false) {
     if (!finalized) return fail(PF_ERR_WEIGHTS, "pf_forward called before pf_finalize_weights");
     if (B <= 0 || !in || !pg || !pl || !ws) return fail(PF_ERR_ARG, "pf_forward: null pointer or batch <= 0");
@@ -899,37 +885,10 @@ struct pf_engine {
     // zero" marker (igemm_common.h OOB): each per-head activation must stay below 2 GiB.  The largest are the
     // 160x160x256 decoder map and the 320x320x64 map before conv_fuse_conv1: B * 26.2 MB  ->  B <= PF_MAX_BATCH (81).
     if (B > PF_MAX_BATCH) return fail(PF_ERR_ARG, fmt("pf_forward: batch %d exceeds PF_MAX_BATCH = %d (32-bit byte offsets inside one activation); split the batch", B, PF_MAX_BATCH));
-    const size_t need = forward_workspace_bytes(B, tune);
+    const size_t need = workspace_bytes(B, tune);
     if (ws_bytes < need) return fail(PF_ERR_WORKSPACE, fmt("workspace too small: %zu < %zu bytes", ws_bytes, need));
     if (hipSetDevice(device) != hipSuccess) return fail(PF_ERR_DEVICE, "hipSetDevice failed");
     uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255;
-    if (split_streams(B, tune)) {
-      if (!aux[0]) {
-        for (int k = 0; k < 2; ++k)
-          if (hipStreamCreateWithFlags(&aux[k], hipStreamNonBlocking) != hipSuccess) return fail(PF_ERR_DEVICE, "hipStreamCreate failed");
-        for (int k = 0; k < 3; ++k)
-          if (hipEventCreateWithFlags(&aux_ev[k], hipEventDisableTiming) != hipSuccess) return fail(PF_ERR_DEVICE, "hipEventCreate failed");
-      }
-      const int Bh[2] = {B / 2, B - B / 2};
-      const bool cls = arch == PF_ARCH_PERSNET_CLS;
-      const size_t npx = (size_t)NET * NET, cg = cls ? 73 : 2, cl = cls ? 180 : 1;
-      (void)hipEventRecord(aux_ev[0], s);
-      size_t woff = 0;
-      for (int k = 0; k < 2; ++k) {
-        (void)hipStreamWaitEvent(aux[k], aux_ev[0], 0);
-        const size_t i0 = k == 0 ? 0 : (size_t)Bh[0];
-        Ctx c{aux[k], base + woff, 0, 0, false, nullptr};
-        const void* in_k = is_u8 ? static_cast<const void*>(static_cast<const uint8_t*>(in) + i0 * npx * 3)
-                                 : static_cast<const void*>(static_cast<const float*>(in) + i0 * npx * 3);
-        run(c, Bh[k], in_k, is_u8, pg + i0 * cg * npx, pl + i0 * cl * npx, params ? params + i0 * PF_PARAMS_STRIDE : nullptr);
-        (void)hipEventRecord(aux_ev[1 + k], aux[k]);
-        (void)hipStreamWaitEvent(s, aux_ev[1 + k], 0);
-        woff += (workspace_bytes(Bh[k]) + 255) & ~(size_t)255;
-      }
-      const hipError_t e2 = hipGetLastError();
-      if (e2 != hipSuccess) return fail(PF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e2)));
-      return PF_OK;
-    }
     Ctx c{s, base, 0, 0, false, nullptr};
     c.prof = prof.on ? &prof : nullptr;
     if (tune) {
@@ -1008,7 +967,6 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;
-  if (const char* v = getenv("PF_STREAMS")) e->nstreams = atoi(v) == 2 ? 2 : 1;
   if (!e->split_bf16) e->sba = false;  // split planes are only read by the split-bf16 kernels
   if (e->sba) e->nterms = 6;           // the split-plane activation format is the exact bf16 one
   tune_cache_load(e);
@@ -1030,8 +988,6 @@ int pf_destroy(pf_handle h) {
   (void)hipSetDevice(h->device);
   for (void* d : h->dev_allocs) (void)hipFree(d);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-  for (int k = 0; k < 2; ++k) if (h->aux[k]) (void)hipStreamDestroy(h->aux[k]);
-  for (int k = 0; k < 3; ++k) if (h->aux_ev[k]) (void)hipEventDestroy(h->aux_ev[k]);
   delete h;
   return PF_OK;
 }
@@ -1083,7 +1039,7 @@ size_t pf_workspace_bytes(pf_handle h, int batch) {
       for (int s = 0; s < 4; ++s)
         if (h->cnx.blocks[s].empty()) h->cnx.blocks[s].resize(CNX_DEPTHS[s]);
   }
-  const size_t n = h->forward_workspace_bytes(batch, false);
+  const size_t n = h->workspace_bytes(batch);
   if (!h->finalized) {
     h->has_param = was;
     for (int s = 0; s < 4; ++s) { h->stages[s].blocks.clear(); h->cnx.blocks[s].clear(); }

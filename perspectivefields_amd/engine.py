@@ -172,8 +172,10 @@ class Engine:
         self._finalized = False
         self.precision = "fp32"
         self.max_batch = int(self.lib.pf_max_batch())
-        # batches up to this size replay a captured hipGraph (latency path: inference(img) / small lists); 0 disables
-        self.graph_max_batch = int(os.environ.get("PF_GRAPH_MAX_BATCH", "4"))
+        # Opt-in: batches up to this size replay a captured hipGraph (pf_forward_u8_graph).  Off by default -- measured on MI355X
+        # (profiles/r02_latency.md): a batch-1 forward is bound by the GPU-side latency of its ~430 dependent small kernels
+        # (6.4 ms eager, 6.8 ms replayed), not by host launch cost, so the replay buys nothing there.
+        self.graph_max_batch = int(os.environ.get("PF_GRAPH_MAX_BATCH", "0"))
         self._graph_bufs = {}
         g, l, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self.lib.pf_output_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(p))
