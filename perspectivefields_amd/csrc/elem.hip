@@ -486,10 +486,10 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float4* __restric
     const float4 v00 = base[((long)y0 * W + x0) * CQ], v01 = base[((long)y0 * W + x1) * CQ];
     const float4 v10 = base[((long)y1 * W + x0) * CQ], v11 = base[((long)y1 * W + x1) * CQ];
     float4 o;
-    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
-    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
-    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
-    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    o.x = bilerp2x(v00.x, v01.x, v10.x, v11.x, hx, lx, hy, ly);
+    o.y = bilerp2x(v00.y, v01.y, v10.y, v11.y, hx, lx, hy, ly);
+    o.z = bilerp2x(v00.z, v01.z, v10.z, v11.z, hx, lx, hy, ly);
+    o.w = bilerp2x(v00.w, v01.w, v10.w, v11.w, hx, lx, hy, ly);
     if (y) y[i] = o;
     if (y_sb) store_sb4(y_sb, sb_plane, (size_t)i * 4, o);
   }
@@ -555,10 +555,10 @@ __global__ __launch_bounds__(256) void upsample2x_cell_kernel(const float4* __re
       if (ox < 0 || ox >= Wo) continue;
       const float lx = jc < 0 ? 0.f : (dx ? 0.75f : 0.25f), hx = 1.f - lx;
       float4 o;
-      o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
-      o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
-      o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
-      o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+      o.x = bilerp2x(v00.x, v01.x, v10.x, v11.x, hx, lx, hy, ly);
+      o.y = bilerp2x(v00.y, v01.y, v10.y, v11.y, hx, lx, hy, ly);
+      o.z = bilerp2x(v00.z, v01.z, v10.z, v11.z, hx, lx, hy, ly);
+      o.w = bilerp2x(v00.w, v01.w, v10.w, v11.w, hx, lx, hy, ly);
       const long i = (((long)b * Ho + oy) * Wo + ox) * CQ + q;
       if (y) y[i] = o;
       if (y_sb) store_sb4(y_sb, sb_plane, (size_t)i * 4, o);

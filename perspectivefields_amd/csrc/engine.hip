@@ -283,6 +283,8 @@ struct pf_engine {
   std::map<int, ResizeTable> resize_tables;  // input extent -> tables for resizing that extent to NET
   std::map<int, size_t> scratch_off, scratch_elems;
   bool split_bf16 = true;    // PF_SPLIT_BF16=0: exact-fp32 MFMA kernels only (no split-bf16 tiles)
+  bool fuse_upsample = true; // PF_FUSE_UPSAMPLE=0: materialise the two largest bilinear x2 maps (160^2 x 256, 320^2 x 64 per head) instead of
+                             // interpolating them inside the consuming 3x3 convs' halo staging (split-f16 scheme only)
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
   int nterms = NT_F16X3;     // pf_set_precision: NT_F16X3 = 2-way fp16 split, 3 MFMAs per product (default parity mode); 6 = exact 3-way bf16 split
                              // (fp32-accurate, PF_PRECISION_FP32_BF16X6); 3 = "bf16x3", 1 = "bf16" (reduced precision, not parity modes)
@@ -559,7 +561,8 @@ struct pf_engine {
     const ConvW* w; Ten x; Ten y;
     const float* res1 = nullptr; const float* res2 = nullptr; Ten x2 = Ten();
   };
-  void conv_g(Ctx& c, int ngroups, const ConvCall* calls, int B, int H, int W, int act = ACT_NONE, int post_relu = 0, int C1 = -1, int nchw = 0) {
+  // ups: calls[].x is stored at half resolution (H/2 x W/2); the conv runs on its bilinear x2 up-sampling (ConvParams::ups)
+  void conv_g(Ctx& c, int ngroups, const ConvCall* calls, int B, int H, int W, int act = ACT_NONE, int post_relu = 0, int C1 = -1, int nchw = 0, int ups = 0) {
     const ConvW& w = *calls[0].w;
     if (c.dry) {
       const size_t Ho = (H + 2 * w.pad - w.KH) / w.stride + 1, Wo = (W + 2 * w.pad - w.KW) / w.stride + 1;
@@ -582,12 +585,13 @@ struct pf_engine {
     p.Cout = w.Cout; p.KWC = w.KWC; p.KWCp = w.KWCp;
     p.act = act; p.post_relu = post_relu; p.nchw_out = nchw;
     p.nterms = nterms;
+    p.ups = ups;
     p.finish();
     int tile = -1;
     {
       // operand formats are part of the key: a split-plane input changes which tile is fastest
       const int prec_code = nterms == NT_F16X3 ? 0 : (nterms == 6 ? 3 : (nterms == 3 ? 1 : 2));  // = PF_PRECISION_*
-      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * prec_code;
+      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * prec_code + 128 * ups;
       const std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out, fmt_bits, p.act};
       auto it = tile_cache.find(key);
       if (it != tile_cache.end()) tile = it->second;
@@ -726,11 +730,16 @@ struct pf_engine {
       if (want_f32) { a.f = c.alloc(2 * per_head); b.f = a.f + per_head; }
       if (want_sb) { a.s = c.alloc_sb(2 * per_head); b.s = a.s; b.s.p = a.s.p + per_head; }
     };
-    Ten up[4][2];
+    // The two largest bilinear x2 maps -- up[0] (160^2 x 256) feeding conv_fuse_conv0 and the 320^2 x 64 map feeding
+    // conv_fuse_conv1 (decode_head.py:284-286, gravity_head.py:170-172) -- are never materialised: the consuming 3x3 convs
+    // interpolate them while staging their input halo tiles (ConvParams::ups; same expression, bit-identical results).
+    const bool fuse_up = fuse_upsample && nterms == NT_F16X3 && split_bf16 && !S;
+    Ten up[4][2], qfin[2];
     for (int k = 3; k >= 0; --k) {
       const int h = NET >> (k + 2);
       // up[k] is a residual operand (fp32) for k >= 1 and conv0's input (split planes) for k == 0
-      pair((size_t)B * 4 * h * h * DEC_FEAT, !(S && k == 0), S && k == 0, up[k][0], up[k][1]);
+      if (k == 0 && fuse_up) pair((size_t)B * h * h * DEC_FEAT, true, false, qfin[0], qfin[1]);  // the 80^2 map conv0 up-samples on the fly
+      else pair((size_t)B * 4 * h * h * DEC_FEAT, !(S && k == 0), S && k == 0, up[k][0], up[k][1]);
     }
     for (int k = 3; k >= 0; --k) {
       const int h = NET >> (k + 2);
@@ -763,10 +772,11 @@ struct pf_engine {
       pair(M * DEC_FEAT, !S, S, t0, t1);
       ConvCall a[2] = {{&hg.r2c1[k], o0, t0}, {&hl.r2c1[k], o1, t1}};
       conv_g(c, 2, a, B, h, h, ACT_RELU);
-      pair(M * DEC_FEAT, true, false, q0, q1);
+      if (k == 0 && fuse_up) { q0 = qfin[0]; q1 = qfin[1]; }
+      else pair(M * DEC_FEAT, true, false, q0, q1);
       ConvCall b2[2] = {{&hg.r2c2[k], t0, q0, o0.f}, {&hl.r2c2[k], t1, q1, o1.f}};
       conv_g(c, 2, b2, B, h, h);                                              // RCU2 output, raw
-      if (!c.dry) {                                                           // decode_head.py:284-286
+      if (!c.dry && !(k == 0 && fuse_up)) {                                   // decode_head.py:284-286
         const Ten& u = up[k][0];
         ProfScope ps(c.prof, c.s, PC_UPSAMPLE, (8.0 + (u.f ? 32.0 : 0.0) + (u.s.p ? 48.0 : 0.0)) * M * DEC_FEAT);
         launch_upsample2x(q0.f, u.f, 2 * B, h, h, DEC_FEAT, c.s, u.s.p, u.s.plane);
@@ -776,15 +786,17 @@ struct pf_engine {
     const int h = NET / 2;
     Ten z0, z1, zu0, zu1;
     pair((size_t)B * h * h * 64, true, false, z0, z1);
-    ConvCall a[2] = {{&hg.conv0, up[0][0], z0, nullptr, nullptr, llf}, {&hl.conv0, up[0][1], z1, nullptr, nullptr, llf}};
-    conv_g(c, 2, a, B, h, h, ACT_RELU, 0, DEC_FEAT);                          // cat fused into the A gather (:170-171)
-    pair((size_t)B * NET * NET * 64, !S, S, zu0, zu1);
-    if (!c.dry) {
-      ProfScope ps(c.prof, c.s, PC_UPSAMPLE, (8.0 + (zu0.f ? 32.0 : 0.0) + (zu0.s.p ? 48.0 : 0.0)) * B * h * h * 64);
-      launch_upsample2x(z0.f, zu0.f, 2 * B, h, h, 64, c.s, zu0.s.p, zu0.s.plane);
+    ConvCall a[2] = {{&hg.conv0, fuse_up ? qfin[0] : up[0][0], z0, nullptr, nullptr, llf}, {&hl.conv0, fuse_up ? qfin[1] : up[0][1], z1, nullptr, nullptr, llf}};
+    conv_g(c, 2, a, B, h, h, ACT_RELU, 0, DEC_FEAT, 0, fuse_up ? 1 : 0);     // cat (and the x2 up-sampling) fused into the A gather (:170-171)
+    if (!fuse_up) {
+      pair((size_t)B * NET * NET * 64, !S, S, zu0, zu1);
+      if (!c.dry) {
+        ProfScope ps(c.prof, c.s, PC_UPSAMPLE, (8.0 + (zu0.f ? 32.0 : 0.0) + (zu0.s.p ? 48.0 : 0.0)) * B * h * h * 64);
+        launch_upsample2x(z0.f, zu0.f, 2 * B, h, h, 64, c.s, zu0.s.p, zu0.s.plane);
+      }
     }
-    ConvCall b2[2] = {{&hg.conv1, zu0, Ten(t32)}, {&hl.conv1, zu1, Ten(t32 + (size_t)B * NET * NET * 32)}};
-    conv_g(c, 2, b2, B, NET, NET, ACT_RELU);
+    ConvCall b2[2] = {{&hg.conv1, fuse_up ? z0 : zu0, Ten(t32)}, {&hl.conv1, fuse_up ? z1 : zu1, Ten(t32 + (size_t)B * NET * NET * 32)}};
+    conv_g(c, 2, b2, B, NET, NET, ACT_RELU, 0, -1, 0, fuse_up ? 1 : 0);
   }
 
   // ConvNeXt-T + heads of the ParamNets (convnext.py:140-152)
@@ -964,6 +976,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   e->device = device;
   e->arch = arch;
   if (const char* v = getenv("PF_FOLD_MLP")) e->fold_mlp = atoi(v) != 0;
+  if (const char* v = getenv("PF_FUSE_UPSAMPLE")) e->fuse_upsample = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;

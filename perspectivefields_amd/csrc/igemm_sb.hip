@@ -47,6 +47,7 @@ bool conv_sbh_ok(const ConvParams& p);                                   // igem
 // that still gives every CU about two blocks, with a register prefetch ring (f2 / f3) when the K loop is deep.
 int conv_sb_default_tile(const ConvParams& p) {
   const long K = (long)p.KH * p.KWCp;
+  if (p.ups) return kFirstH + (p.Cout <= 32 ? 2 : (p.Cout <= 64 ? 1 : 0));  // the only tiles that interpolate while staging
   if (conv_sbh_ok(p) && p.Ho >= 40 && p.Wo >= 40) {
     if (p.Cout <= 32) return kFirstH + 2;
     if (p.Cout <= 64) return kFirstH + 1;
@@ -68,7 +69,7 @@ void launch_conv_sbf(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm
 void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile);                  // igemm_sbh.hip
-bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) { return sb_tile < kFirstH || conv_sbh_tile_ok(p, sb_tile - kFirstH); }
+bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) { return sb_tile < kFirstH ? !p.ups : conv_sbh_tile_ok(p, sb_tile - kFirstH); }
 
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
   if (sb_tile >= kFirstH) {

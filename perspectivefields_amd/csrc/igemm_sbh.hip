@@ -32,7 +32,9 @@ __device__ __forceinline__ int sbh_piece(int row, int piece) { return piece ^ ((
 // SCH = 6: exact 3-way bf16 split, 6 MFMAs per product; SCH = NT_F16X3: 2-way fp16 split of the activations (2 LDS planes),
 // scaled weights wh + wl from global memory plus wh2 = wh 2^-11 made while staging (3 LDS planes), 3 MFMAs per product.
 template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE, int TPG /*taps whose weights are staged together: 1 or 3 (one kernel row)*/, int SCH,
-          bool DB = false /*two LDS buffers for the weights: the next tap's weights are stored while this tap is still being read -> one barrier per tap instead of two*/>
+          bool DB = false /*two LDS buffers for the weights: the next tap's weights are stored while this tap is still being read -> one barrier per tap instead of two*/,
+          bool UPS = false /*the first input x is stored at HALF resolution: the conv runs on its bilinear x2 up-sampling (decode_head.py:284-286,
+                             gravity_head.py:172), interpolated while the halo tile is staged -- the up-sampled tensor never exists in HBM*/>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
@@ -50,11 +52,17 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   constexpr int NPA = F16 ? 2 : 3, NPB = 3, NPG = F16 ? 2 : 3;  // A planes in LDS, B planes in LDS, B planes loaded from global memory
   static_assert(!DB || TPG == 1, "double-buffered weights: one tap per step");
   constexpr int BBUF = NPB * TPG * PLANE_B;  // ushorts of one weight buffer
-  constexpr int OPER_USHORTS = NPA * PLANE_A + (DB ? 2 : 1) * BBUF;
+  // UPS: the half-resolution SOURCE pixels under the halo tile (rows oy0/2 - 1 .. + H_TY/2 + 1, columns likewise; indices clamped
+  // into the map), one 32-channel chunk in fp32 -- staged once, every halo pixel then interpolates its 4 neighbours from LDS
+  constexpr int S_TY = H_TY / 2 + 2, S_TX = H_TX / 2 + 2, S_PIX = S_TY * S_TX;  // 6 x 10 for an 8 x 16 patch
+  constexpr int SRC_USHORTS = UPS ? S_PIX * BK * 2 : 0;
+  constexpr int S_F4 = UPS ? (S_PIX * 8 + NT - 1) / NT : 1;  // float4 loads per thread per source chunk (2)
+  constexpr int OPER_USHORTS = NPA * PLANE_A + (DB ? 2 : 1) * BBUF + SRC_USHORTS;
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
   unsigned short* As = smem_u;                  // [NPA][H_ROWS][H_ROW]
   unsigned short* Bs0 = smem_u + NPA * PLANE_A;  // [DB ? 2 : 1][TPG][3][BN][H_ROW]
+  float* Ss = reinterpret_cast<float*>(smem_u + NPA * PLANE_A + (DB ? 2 : 1) * BBUF);  // UPS: [S_PIX][BK] fp32 source tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -81,7 +89,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(F16 ? P.w_h16 : P.w_sb), 0, (F16 ? 2u : 5u) * p.w_sb_plane_bytes, 0x00020000);
 
   // ---- A halo staging: element e = tid + NT i -> (halo row e / 8, float4 e % 8 of the 32-channel chunk)
-  unsigned a_off1[A_F4], a_off2[MODE == 2 ? A_F4 : 1];
+  // UPS: x is at half resolution.  a_off1 then addresses this thread's SOURCE-tile elements (s_off), and a_ups[i] packs, for
+  // halo element i, the source-tile slots of its four neighbours and the weights: slot00 (bits 0-7), +1 column (bit 8), +1 row
+  // (bit 9), lx (bits 10-11), ly (bits 12-13) with 0 -> 0, 1 -> 0.25, 2 -> 0.75, valid (bit 14).  src = (dst + 0.5) / 2 - 0.5
+  // clamped at 0, neighbour clamped at the last row / column: exactly the stand-alone upsample2x kernels of elem.hip.
+  static_assert(!UPS || (TPG == 1 && !DB && (H_TY % 2) == 0 && (H_TX % 2) == 0), "fused up-sampling: plain tap loop, even patch");
+  unsigned a_off1[A_F4], a_off2[MODE == 2 ? A_F4 : 1], a_ups[UPS ? A_F4 : 1], s_off[S_F4];
+  const int hs = p.H >> 1, ws = p.W >> 1;
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
     const int e = tid + NT * i;
@@ -91,8 +105,22 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
     const bool in_tile = hrow < H_ROWS;
     const bool ok = in_tile && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     const int pix = (bimg * p.H + iy) * p.W + ix;
-    a_off1[i] = ok ? (unsigned)(pix * p.C1 * 4 + c4 * 16) : OOB;
+    if (UPS) {
+      const int y0 = iy <= 0 ? 0 : ((iy & 1) ? (iy - 1) >> 1 : (iy >> 1) - 1), x0 = ix <= 0 ? 0 : ((ix & 1) ? (ix - 1) >> 1 : (ix >> 1) - 1);
+      const unsigned ly = iy <= 0 ? 0u : ((iy & 1) ? 1u : 2u), lx = ix <= 0 ? 0u : ((ix & 1) ? 1u : 2u);
+      const int slot = (y0 - (oy0 / 2 - 1)) * S_TX + (x0 - (ox0 / 2 - 1));  // source tile origin (oy0/2 - 1, ox0/2 - 1)
+      a_ups[UPS ? i : 0] = (unsigned)(ok ? slot : 0) | (x0 < ws - 1 ? 0x100u : 0u) | (y0 < hs - 1 ? 0x200u : 0u) | (lx << 10) | (ly << 12) | (ok ? 0x4000u : 0u);
+      a_off1[i] = OOB;
+    } else {
+      a_off1[i] = ok ? (unsigned)(pix * p.C1 * 4 + c4 * 16) : OOB;
+    }
     if (MODE == 2) a_off2[i] = ok ? (unsigned)(pix * p.C2 * 4 + c4 * 16) : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < S_F4; ++j) {  // source-tile element e = tid + NT j -> (slot e / 8, float4 e % 8); coordinates clamped into the map
+    const int e = tid + NT * j, slot = e >> 3, c4 = e & 7;
+    const int sy = min(max(oy0 / 2 - 1 + slot / S_TX, 0), hs - 1), sx = min(max(ox0 / 2 - 1 + slot % S_TX, 0), ws - 1);
+    s_off[j] = (UPS && slot < S_PIX) ? (unsigned)(((bimg * hs + sy) * ws + sx) * p.C1 * 4 + c4 * 16) : OOB;
   }
   // ---- B staging: thread -> (row rb0 + RPB i, 16-byte piece pc of the 64-byte K chunk), three planes
   const int pc = tid & 3;
@@ -114,14 +142,57 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
     const unsigned coff = (unsigned)((first ? ci0 : ci0 - p.C1) * 4);
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      const unsigned base = (MODE != 2 || first) ? a_off1[i] : a_off2[MODE == 2 ? i : 0];
+      const unsigned base = (MODE != 2 || first) ? a_off1[i] : a_off2[MODE == 2 ? i : 0];  // UPS: a_off1 is out of range (x comes through load_src)
       const unsigned off = (live && base != OOB) ? base + coff : OOB;
+      if (UPS && MODE != 2) continue;
       if (MODE == 2) {
         const float4 v1 = buf_load16(rx, first ? off : OOB);
         const float4 v2 = buf_load16(rx2, first ? OOB : off);
         ra[i] = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);
       } else {
         ra[i] = buf_load16(rx, off);
+      }
+    }
+  };
+  // UPS: global loads of the next chunk's source tile (x chunks; out-of-range offsets for an x2 chunk) next to the plain halo
+  // loads of load_a (x2 chunks; out-of-range for an x chunk): both branch-free, one of the two returns zeros
+  float4 rs[S_F4];
+  auto load_src = [&](int c) {
+    const bool live = c < nC && c * BK < p.C1;
+    const unsigned coff = (unsigned)(c * BK * 4);
+#pragma unroll
+    for (int j = 0; j < S_F4; ++j) rs[j] = buf_load16(rx, (live && s_off[j] != OOB) ? s_off[j] + coff : OOB);
+  };
+  // source tile -> LDS, then every halo element of this thread = bilinear combination of four LDS values -> split -> A planes
+  auto store_a_ups = [&]() {
+#pragma unroll
+    for (int j = 0; j < S_F4; ++j) {
+      const int e = tid + NT * j;
+      if (e < S_PIX * 8) *reinterpret_cast<float4*>(Ss + e * 4) = rs[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int e = tid + NT * i, hrow = e >> 3, c4 = e & 7;
+      if (hrow < H_ROWS) {
+        const unsigned f = a_ups[UPS ? i : 0];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f & 0x4000u) {
+          const float* s00 = Ss + (f & 0xffu) * BK + c4 * 4;
+          const int dx = (f & 0x100u) ? BK : 0, dy = (f & 0x200u) ? S_TX * BK : 0;
+          const unsigned cx = (f >> 10) & 3u, cy = (f >> 12) & 3u;
+          const float lx = cx == 0 ? 0.f : (cx == 1 ? 0.25f : 0.75f), ly = cy == 0 ? 0.f : (cy == 1 ? 0.25f : 0.75f);
+          const float hx = 1.f - lx, hy = 1.f - ly;
+          const float4 v00 = *reinterpret_cast<const float4*>(s00), v01 = *reinterpret_cast<const float4*>(s00 + dx);
+          const float4 v10 = *reinterpret_cast<const float4*>(s00 + dy), v11 = *reinterpret_cast<const float4*>(s00 + dx + dy);
+          o = make_float4(bilerp2x(v00.x, v01.x, v10.x, v11.x, hx, lx, hy, ly), bilerp2x(v00.y, v01.y, v10.y, v11.y, hx, lx, hy, ly),
+                          bilerp2x(v00.z, v01.z, v10.z, v11.z, hx, lx, hy, ly), bilerp2x(v00.w, v01.w, v10.w, v11.w, hx, lx, hy, ly));
+        }
+        uint2 h, m;
+        split4_f16(o, h, m);
+        unsigned short* d = As + hrow * H_ROW + sbh_piece(hrow, c4 >> 1) * 8 + (c4 & 1) * 4;
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + PLANE_A) = m;
       }
     }
   };
@@ -227,8 +298,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
 
   // prologue: halo chunk 0 and the weights of the first tap group -> LDS
   load_a(0);
+  if constexpr (UPS) load_src(0);
   load_b(0, 0);
-  store_a();
+  if (UPS && 0 < p.C1) store_a_ups(); else store_a();
   store_b();
   __syncthreads();
   constexpr int NG = 9 / TPG;  // tap groups per chunk
@@ -252,13 +324,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   for (int c = 0; c < nC; ++c) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {  // unrolled: no branch around any load, the s_waitcnt counts stay exact
+      if (UPS && g == NG / 2) load_src(c + 1);
       if (g == NG / 2) load_a(c + 1);  // next halo chunk: in flight during the second half of this one
       if (g + 1 < NG) load_b(c, (g + 1) * TPG); else load_b(c + 1, 0);
 #pragma unroll
       for (int u = 0; u < TPG; ++u) compute(g * TPG + u, u);
       __syncthreads();  // every wave has read this group's weights (and, in the last group, this chunk's halo)
       store_b();
-      if (g == NG - 1 && c + 1 < nC) store_a();
+      if (g == NG - 1 && c + 1 < nC) {
+        if (UPS && (c + 1) * BK < p.C1) store_a_ups(); else store_a();  // block-uniform
+      }
       __syncthreads();
     }
   }
@@ -272,6 +347,13 @@ static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(WM * WN * 64);
+  if (p.ups) {  // conv_sbh_tile_ok: split-f16 scheme, 8 x 16 patch / 4-wave tiles, plain tap loop
+    if constexpr (H_TY == 8 && WM * WN == 4 && TPG == 1 && !DB) {
+      if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, 1, NT_F16X3, false, true>), grid, block, 0, s, p);
+      else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, 1, NT_F16X3, false, true>), grid, block, 0, s, p);
+    }
+    return;
+  }
   if (p.nterms == NT_F16X3) {
     if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, TPG, NT_F16X3, DB>), grid, block, 0, s, p);
     else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, TPG, NT_F16X3, DB>), grid, block, 0, s, p);
@@ -295,7 +377,12 @@ bool conv_sbh_ok(const ConvParams& p) {
 }
 
 // tiles 4.. (double-buffered weights "d", weights of a kernel row per step "t3") are built for the split-f16 scheme only
-bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) { return conv_sbh_ok(p) && (h_tile < 4 || p.nterms == NT_F16X3); }
+// fused up-sampling (p.ups): split-f16 scheme, tiles 0-2 (8 x 16 patch, 4 waves, plain tap loop)
+bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
+  if (!conv_sbh_ok(p)) return false;
+  if (p.ups) return h_tile < 3 && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
+  return h_tile < 4 || p.nterms == NT_F16X3;
+}
 
 // ids = position among the "sbh" tiles of kSb[] (igemm_sb.hip)
 void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {

@@ -49,6 +49,8 @@ struct ConvParams {
   int post_relu;  // relu after the residual adds
   int ldy;        // row stride of y / res1 / res2 in floats (normally Cout)
   int nchw_out;   // 1: store y as [B][Cout][Ho*Wo] (API-visible logits), residuals unsupported
+  int ups = 0;    // 1: x is stored at half resolution [B][H/2][W/2][C1]; the conv runs on its bilinear x2 up-sampling, interpolated
+                  // while the input halo is staged (3x3 halo tiles of the split-f16 scheme only; x2, if any, is at full resolution)
   int nterms = 6; // split kernels: partial products per element product -- NT_F16X3 (23): 2-way fp16 split, 3 products, fp32-class accuracy;
                   // 6: exact 3-way bf16 split, 6 products (fp32-accurate); 3 (bf16, ~16-bit operands); 1 (plain bf16)
   unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)
@@ -60,7 +62,7 @@ struct ConvParams {
     Ho = (H + 2 * pad - KH) / stride + 1;
     Wo = (W + 2 * pad - KW) / stride + 1;
     M = B * Ho * Wo;
-    x_bytes = (unsigned)((size_t)B * H * W * C1 * 4);
+    x_bytes = (unsigned)((size_t)B * (ups ? H / 2 : H) * (ups ? W / 2 : W) * C1 * 4);
     x2_bytes = (unsigned)((size_t)B * H * W * C2 * 4);
     w_bytes = (unsigned)((size_t)Cout * KH * KWCp * 4);
     w_sb_plane_bytes = (unsigned)((size_t)Cout * KH * KWCp * 2);

@@ -8,6 +8,15 @@
 
 namespace pf {
 
+// One output of the bilinear x2 up-sampling (align_corners = False): the same expression, with the roundings pinned by
+// explicit multiplies / fmas, in the stand-alone kernels (elem.hip) and in the halo staging of the fused conv (igemm_sbh.hip),
+// so that fused and unfused paths give bit-identical results.
+__device__ __forceinline__ float bilerp2x(float v00, float v01, float v10, float v11, float hx, float lx, float hy, float ly) {
+  const float t = fmaf(lx, v01, __fmul_rn(hx, v00));
+  const float b = fmaf(lx, v11, __fmul_rn(hx, v10));
+  return fmaf(ly, b, __fmul_rn(hy, t));
+}
+
 __device__ __forceinline__ unsigned sb_pack_hi16(unsigned lo_src, unsigned hi_src) { return (lo_src >> 16) | (hi_src & 0xffff0000u); }
 
 // exact 3-way truncation split of 4 floats -> three 8-byte groups of 4 bf16

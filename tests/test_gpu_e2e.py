@@ -300,3 +300,21 @@ def test_graph_replay_equals_eager_forward():
         assert torch.equal(pg0, pg1) and torch.equal(pl0, pl1) and torch.equal(pp0, pp1)
     assert torch.equal(other[0], eager[1][0]) and torch.equal(other[2], eager[1][2])
     assert not torch.equal(replay[0][0], replay[1][0])  # distinct inputs gave distinct, separately owned results
+
+
+@pytest.mark.parametrize("tag", ["centered", "persnet"])
+def test_fused_upsample_equals_materialised(tag, monkeypatch):
+    """Default: the 160^2 x 256 and 320^2 x 64 bilinear x2 maps are interpolated inside the halo staging of conv_fuse_conv0 /
+    conv_fuse_conv1 (ConvParams::ups) and never written to HBM.  PF_FUSE_UPSAMPLE=0 materialises them with the stand-alone
+    kernel.  Same expression with pinned roundings on both paths -> bit-identical network outputs."""
+    from perspectivefields_amd import PerspectiveFields
+
+    imgs = [synthetic_image(90, 120, seed=500 + i) for i in range(5)]
+    base = model(tag).inference_batch(imgs)
+    monkeypatch.setenv("PF_FUSE_UPSAMPLE", "0")
+    alt = PerspectiveFields(CASES[tag], weights="synthetic:0").eval().cuda().inference_batch(imgs)
+    for a, b in zip(base, alt):
+        assert torch.equal(a["pred_gravity"], b["pred_gravity"]) and torch.equal(a["pred_latitude"], b["pred_latitude"])
+        assert torch.equal(a["pred_latitude_original"], b["pred_latitude_original"])
+        if "pred_roll" in a:
+            assert float(a["pred_roll"]) == float(b["pred_roll"]) and float(a["pred_vfov"]) == float(b["pred_vfov"])
