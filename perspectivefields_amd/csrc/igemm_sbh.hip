@@ -142,9 +142,21 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
     const unsigned coff = (unsigned)((first ? ci0 : ci0 - p.C1) * 4);
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      const unsigned base = (MODE != 2 || first) ? a_off1[i] : a_off2[MODE == 2 ? i : 0];  // UPS: a_off1 is out of range (x comes through load_src)
+      if (UPS) {
+        // an x chunk: the first S_F4 registers carry this thread's part of the half-resolution SOURCE tile (store_a_ups); an x2
+        // chunk: the plain halo elements.  Branch-free: the load that does not apply goes to the out-of-range offset (zeros).
+        float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < S_F4) v1 = buf_load16(rx, (live && first && s_off[i < S_F4 ? i : 0] != OOB) ? s_off[i < S_F4 ? i : 0] + coff : OOB);
+        if (MODE == 2) {
+          const unsigned b2 = a_off2[MODE == 2 ? i : 0];
+          const float4 v2 = buf_load16(rx2, (live && !first && b2 != OOB) ? b2 + coff : OOB);
+          v1 = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);
+        }
+        ra[i] = v1;
+        continue;
+      }
+      const unsigned base = (MODE != 2 || first) ? a_off1[i] : a_off2[MODE == 2 ? i : 0];
       const unsigned off = (live && base != OOB) ? base + coff : OOB;
-      if (UPS && MODE != 2) continue;
       if (MODE == 2) {
         const float4 v1 = buf_load16(rx, first ? off : OOB);
         const float4 v2 = buf_load16(rx2, first ? OOB : off);
@@ -154,28 +166,20 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
       }
     }
   };
-  // UPS: global loads of the next chunk's source tile (x chunks; out-of-range offsets for an x2 chunk) next to the plain halo
-  // loads of load_a (x2 chunks; out-of-range for an x chunk): both branch-free, one of the two returns zeros
-  float4 rs[S_F4];
-  auto load_src = [&](int c) {
-    const bool live = c < nC && c * BK < p.C1;
-    const unsigned coff = (unsigned)(c * BK * 4);
-#pragma unroll
-    for (int j = 0; j < S_F4; ++j) rs[j] = buf_load16(rx, (live && s_off[j] != OOB) ? s_off[j] + coff : OOB);
-  };
   // source tile -> LDS, then every halo element of this thread = bilinear combination of four LDS values -> split -> A planes
   auto store_a_ups = [&]() {
 #pragma unroll
     for (int j = 0; j < S_F4; ++j) {
       const int e = tid + NT * j;
-      if (e < S_PIX * 8) *reinterpret_cast<float4*>(Ss + e * 4) = rs[j];
+      if (e < S_PIX * 8) *reinterpret_cast<float4*>(Ss + e * 4) = ra[j];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       const int e = tid + NT * i, hrow = e >> 3, c4 = e & 7;
       if (hrow < H_ROWS) {
-        const unsigned f = a_ups[UPS ? i : 0];
+        unsigned f = a_ups[UPS ? i : 0];
+        asm volatile("" : "+v"(f));  // keep the decode below inside the loop: hoisted, its addresses / weights cost ~40 VGPRs for the whole K loop
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (f & 0x4000u) {
           const float* s00 = Ss + (f & 0xffu) * BK + c4 * 4;
@@ -298,7 +302,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
 
   // prologue: halo chunk 0 and the weights of the first tap group -> LDS
   load_a(0);
-  if constexpr (UPS) load_src(0);
   load_b(0, 0);
   if (UPS && 0 < p.C1) store_a_ups(); else store_a();
   store_b();
@@ -324,7 +327,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   for (int c = 0; c < nC; ++c) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {  // unrolled: no branch around any load, the s_waitcnt counts stay exact
-      if (UPS && g == NG / 2) load_src(c + 1);
       if (g == NG / 2) load_a(c + 1);  // next halo chunk: in flight during the second half of this one
       if (g + 1 < NG) load_b(c, (g + 1) * TPG); else load_b(c + 1, 0);
 #pragma unroll

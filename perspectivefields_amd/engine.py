@@ -307,15 +307,21 @@ class Engine:
                     "ws": torch.empty(self.workspace_bytes(B), dtype=torch.uint8, device=self.device),
                 }
                 self._graph_bufs[B] = bufs
+            cur.wait_stream(gs)  # the previous replay (possibly issued from another stream) has finished reading the input buffer
             bufs["in"].copy_(images)
             p = bufs["params"]
-            gs.wait_stream(cur)  # the input copy (and earlier readers of the persistent outputs) first
+            if bufs.get("done") is not None:
+                gs.wait_event(bufs["done"])  # the previous caller's clones of the persistent outputs
+            gs.wait_stream(cur)  # the input copy
             rc = self.lib.pf_forward_u8_graph(self._h, B, bufs["in"].data_ptr(), bufs["pg"].data_ptr(), bufs["pl"].data_ptr(),
                                               p.data_ptr() if p is not None else None, bufs["ws"].data_ptr(), bufs["ws"].numel(),
                                               ctypes.c_void_p(gs.cuda_stream))
             _check(rc, self._h, "pf_forward_u8_graph")
             cur.wait_stream(gs)
-            return bufs["pg"].clone(), bufs["pl"].clone(), (p.clone() if p is not None else None)
+            out = bufs["pg"].clone(), bufs["pl"].clone(), (p.clone() if p is not None else None)
+            bufs["done"] = torch.cuda.Event()
+            bufs["done"].record(cur)
+            return out
 
     def resize_into(self, img_u8, out_u8_320):
         """Bit-exact PIL BILINEAR resize on the device: img_u8 (H,W,3) uint8 cuda -> out_u8_320 (320,320,3) uint8 cuda view."""
