@@ -190,9 +190,11 @@ int pf_fields_from_params(int device, const float* d_cam5, int H, int W, float* 
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels pf_forward runs) ----
  * NHWC fp32 device activations; weights are HOST pointers in the reference's layouts.
- * "planes": the engine's internal split-bf16 activation format -- an fp32 tensor stored losslessly as three bf16
- * planes (x == h + m + l exactly), plane k at `planes + k * plane_elems`, each laid out like the fp32 tensor.
- * Producers write it for tensors that only feed the split-bf16 GEMMs; every *_planes argument is optional (NULL). */
+ * "planes": the engine's internal split activation formats -- an fp32 tensor stored as planes of 16-bit values, plane k at
+ * `planes + k * (plane_elems & ~1)`, each laid out like the fp32 tensor.  Bit 0 of every *_plane_elems argument selects the
+ * format: 0 = three bf16 planes (x == h + m + l exactly; read by the bf16 schemes), 1 = two fp16 planes of the split-f16
+ * scheme (x ~ hi + lo 2^-11: what that scheme's GEMM computes from fp32 while staging; 4 bytes per element).
+ * Producers write them for tensors that only feed GEMMs (PF_SBA=1); every *_planes argument is optional (NULL). */
 int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, int W, int C1, int C2,
                  const float* h_weight /*[Cout][C1+C2][KH][KW]*/, const float* h_bias /*[Cout] or NULL*/,
                  int Cout, int KH, int KW, int stride, int pad, int act /*0 none 1 relu 2 gelu*/,
@@ -204,6 +206,7 @@ int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, 
  * fmt_prec = fmt + 16 * precision; fmt 0: fp32 in / out; 1: input as bf16 planes; 2: input and output as planes
  * (1 / 2: the exact bf16 split); precision = PF_PRECISION_* used by the split tiles */
 int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt_prec, float* ms_out);
+/* fp32 <-> planes in the format selected by bit 0 of plane_elems (the names are historical) */
 int pf_op_split_bf16(int device, const float* d_x, long n, uint16_t* d_planes, long plane_elems, void* stream);
 int pf_op_merge_bf16(int device, const uint16_t* d_planes, long plane_elems, long n, float* d_y, void* stream);
 /* times one depthwise-3x3+GELU launch variant on random data (0 = LDS halo tile, 1-4 = register-window direct, 99 = plain copy) */

@@ -105,10 +105,12 @@ struct Ctx {
     if (off > peak) peak = off;
     return reinterpret_cast<float*>(base + o);
   }
+  int sb_planes = 3;        // planes per split tensor: 3 (exact bf16 split) or 2 (split-f16 scheme; SbT::plane then carries SB_FMT_F16)
   SbT alloc_sb(size_t elems) {
     SbT t;
-    t.plane = (elems + 127) & ~(size_t)127;
-    t.p = reinterpret_cast<unsigned short*>(alloc((3 * t.plane * 2 + 3) / 4));
+    const size_t stride = (elems + 127) & ~(size_t)127;
+    t.p = reinterpret_cast<unsigned short*>(alloc((sb_planes * stride * 2 + 3) / 4));
+    t.plane = stride | (sb_planes == 2 ? SB_FMT_F16 : 0);
     return t;
   }
   // fp32 and / or split planes, as requested
@@ -611,7 +613,7 @@ struct pf_engine {
       if (p.g[g].y) p.g[g].y = c.tune_scratch + g * out_elems;
       if (p.g[g].y_sb) p.g[g].y_sb = sb_scratch + g * out_elems;
     }
-    p.y_sb_plane = c.tune_scratch_elems;
+    p.y_sb_plane = (c.tune_scratch_elems & ~(size_t)1) | (p0.y_sb_plane & 1);
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
     int best = -1;
@@ -721,7 +723,7 @@ struct pf_engine {
   // ReLU, decode_head.py:242-256): RCU(x) = conv2(relu(conv1(relu x))) + relu x.
   // With `sba` a conv's epilogue writes split planes for the next conv (and fp32 only where a residual add reads it).
   void heads_fwd(Ctx& c, int B, Ten feats[4], Ten llf, float* t32 /*[2][B][320][320][32]*/) {
-    const bool S = sba;
+    const bool S = sba && nterms != NT_F16X3;  // the 3x3 halo kernels of the decoder stage fp32 inputs: split-f16 planes only in MiT / ConvNeXt
     Head& hg = heads[0];
     Head& hl = heads[1];
     // a pair of per-head tensors, contiguous as [2][...] in fp32 and in every split plane
@@ -857,7 +859,8 @@ struct pf_engine {
     Ten feats[4];
     mit(c, B, x0, feats);
     // low-level encoder output: conv0's second (concatenated) input only
-    const Ten llf = c.ten((size_t)B * (NET / 2) * (NET / 2) * LL_CH, !sba, sba);
+    const bool Sh = sba && nterms != NT_F16X3;  // as in heads_fwd: the decoder's halo kernels read fp32
+    const Ten llf = c.ten((size_t)B * (NET / 2) * (NET / 2) * LL_CH, !Sh, Sh);
     conv(c, ll, Ten(x0), B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
     float* tg = c.alloc((size_t)2 * B * NET * NET * 32);
     float* tl = tg + (size_t)B * NET * NET * 32;
@@ -881,6 +884,7 @@ struct pf_engine {
     auto it = ws_cache.find(B);
     if (it == ws_cache.end()) {
       Ctx c{nullptr, 4096, 0, 0, true, nullptr};
+      c.sb_planes = nterms == NT_F16X3 ? 2 : 3;
       run(c, B, nullptr, true, nullptr, nullptr, nullptr);
       ws_cache[B] = c.peak + 4096;
       scratch_off[B] = c.peak;
@@ -902,6 +906,7 @@ struct pf_engine {
     if (hipSetDevice(device) != hipSuccess) return fail(PF_ERR_DEVICE, "hipSetDevice failed");
     uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255;
     Ctx c{s, base, 0, 0, false, nullptr};
+    c.sb_planes = nterms == NT_F16X3 ? 2 : 3;
     c.prof = prof.on ? &prof : nullptr;
     if (tune) {
       c.tuning = true;
@@ -981,7 +986,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;
   if (!e->split_bf16) e->sba = false;  // split planes are only read by the split-bf16 kernels
-  if (e->sba) e->nterms = 6;           // the split-plane activation format is the exact bf16 one
+
   tune_cache_load(e);
   *out = e;
   return PF_OK;
@@ -991,7 +996,7 @@ int pf_set_precision(pf_handle h, int mode) {
   if (!h) return PF_ERR_ARG;
   if (mode < PF_PRECISION_FP32 || mode > PF_PRECISION_FP32_BF16X6) return h->fail(PF_ERR_ARG, "pf_set_precision: unknown mode");
   if (mode != PF_PRECISION_FP32 && !h->split_bf16) return h->fail(PF_ERR_ARG, "pf_set_precision: this mode needs the split kernels (PF_SPLIT_BF16=0 is set)");
-  if (h->sba && mode == PF_PRECISION_FP32) mode = PF_PRECISION_FP32_BF16X6;  // PF_SBA=1: split-plane activations exist in the exact bf16 format only
+  h->ws_cache.clear();  // the split-plane activation format (2 fp16 / 3 bf16 planes) follows the scheme
   h->nterms = mode == PF_PRECISION_BF16 ? 1 : (mode == PF_PRECISION_BF16X3 ? 3 : (mode == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
   return PF_OK;
 }
@@ -1344,7 +1349,8 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.Cout = Cout; p.act = act; p.post_relu = post_relu; p.nchw_out = nchw_out;
   p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : (precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
-  if (x_planes || y_planes) p.nterms = p.nterms == NT_F16X3 ? 6 : p.nterms;  // split-plane operands exist in the bf16 formats only
+  // split-plane INPUT: the plane format (bit 0 of x_plane_elems, sb_split.h) fixes the scheme: fp16 planes <-> split-f16, bf16 planes <-> bf16 schemes
+  if (x_planes) p.nterms = (x_plane_elems & 1) ? NT_F16X3 : (p.nterms == NT_F16X3 ? 6 : p.nterms);
   p.finish();
   if ((!x && !x_planes) || (!y && !y_planes) || (C2 > 0 && !x2 && !x2_planes)) { g_create_error = "pf_op_conv2d: missing input or output"; return PF_ERR_ARG; }
   // an explicit tile that cannot read / write split planes is an error; with fp32 operands an unusable tile id falls back to the cost model
@@ -1366,7 +1372,6 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   p.B = B; p.H = H; p.W = W; p.C1 = Cin; p.C2 = 0; p.KH = K; p.KW = K; p.stride = stride; p.pad = pad;
   p.Cout = Cout; p.act = ACT_RELU; p.post_relu = 0; p.nchw_out = 0;
   p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : (precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
-  if (fmt >= 1 && p.nterms == NT_F16X3) p.nterms = 6;
   p.finish();
   const size_t nx = (size_t)B * H * W * Cin, nw = (size_t)Cout * K * p.KWCp, ny = (size_t)p.M * Cout;
   float *dx = nullptr, *dw = nullptr, *dy = nullptr, *db = nullptr;
@@ -1394,8 +1399,9 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   p.g[0].x = dx; p.g[0].w = dw; p.g[0].bias = db; p.g[0].y = dy;
   if (Cin % 32 == 0) { p.g[0].w_sb = dsb; p.g[0].w_h16 = dh16; p.g[0].w_h16_inv_scale = dinv; }
   // fmt 1: A operand as split planes (fp32 copy withheld); fmt 2: split planes in and out
-  if (fmt >= 1) { launch_split_planes(dx, dxs, nx, (long)nx, nullptr); p.g[0].x_sb = dxs; p.x_sb_plane = nx; p.g[0].x = nullptr; }
-  if (fmt >= 2) { p.g[0].y_sb = dys; p.y_sb_plane = ny; p.g[0].y = nullptr; }
+  const size_t fbit = p.nterms == NT_F16X3 ? SB_FMT_F16 : 0;  // plane format of the scheme under test (nx, ny are multiples of 4)
+  if (fmt >= 1) { launch_split_planes(dx, dxs, nx | fbit, (long)nx, nullptr); p.g[0].x_sb = dxs; p.x_sb_plane = nx | fbit; p.g[0].x = nullptr; }
+  if (fmt >= 2) { p.g[0].y_sb = dys; p.y_sb_plane = ny | fbit; p.g[0].y = nullptr; }
   if (!conv_tile_usable(p, tile_id) && tile_id >= 0) { *ms_out = -1.f; (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys); (void)hipFree(dh16); (void)hipFree(dinv); return PF_OK; }
   hipEvent_t a, b;
   (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -1572,7 +1578,7 @@ int pf_op_split_bf16(int device, const float* x, long n, uint16_t* planes, long 
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
-  if (!x || !planes || n <= 0 || (n & 3) || plane_elems < n) { g_create_error = "pf_op_split_bf16: n must be a positive multiple of 4 and plane_elems >= n"; return PF_ERR_ARG; }
+  if (!x || !planes || n <= 0 || (n & 3) || (plane_elems & ~1L) < n) { g_create_error = "pf_op_split_bf16: n must be a positive multiple of 4 and plane_elems >= n"; return PF_ERR_ARG; }
   launch_split_planes(x, planes, (size_t)plane_elems, n, static_cast<hipStream_t>(stream));
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
 }
@@ -1581,7 +1587,7 @@ int pf_op_merge_bf16(int device, const uint16_t* planes, long plane_elems, long 
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
-  if (!y || !planes || n <= 0 || (n & 3) || plane_elems < n) { g_create_error = "pf_op_merge_bf16: n must be a positive multiple of 4 and plane_elems >= n"; return PF_ERR_ARG; }
+  if (!y || !planes || n <= 0 || (n & 3) || (plane_elems & ~1L) < n) { g_create_error = "pf_op_merge_bf16: n must be a positive multiple of 4 and plane_elems >= n"; return PF_ERR_ARG; }
   launch_merge_planes(planes, (size_t)plane_elems, y, n, static_cast<hipStream_t>(stream));
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
 }

@@ -27,15 +27,17 @@ int conv_sb_tile_bn(int id) { return kSb[id].bn; }
 
 bool conv_sb_eligible(const ConvParams& p) {
   if (p.nchw_out || (p.Cin % BK) != 0) return false;
+  const bool f16 = p.nterms == NT_F16X3;
   for (int g = 0; g < p.groups; ++g) {
     const ConvPtrs& q = p.g[g];
-    if (p.nterms == NT_F16X3) {  // split-f16: its own weight planes, fp32 activations in, fp32 out
-      if (!q.w_h16 || !q.w_h16_inv_scale || !q.x || q.x_sb || q.y_sb || !q.y || (p.C2 > 0 && !q.x2)) return false;
-      continue;
+    if (f16 ? (!q.w_h16 || !q.w_h16_inv_scale) : !q.w_sb) return false;
+    if (q.x_sb) {  // split-plane input: its plane format (sb_split.h) must be the one this scheme multiplies
+      if (((p.x_sb_plane & SB_FMT_F16) != 0) != f16) return false;
+      if (p.C2 > 0 && (!q.x2_sb || ((p.x2_sb_plane & SB_FMT_F16) != 0) != f16)) return false;
+    } else {
+      if (!q.x || (p.C2 > 0 && !q.x2)) return false;
     }
-    if (!q.w_sb) return false;
-    if (!q.x_sb && !q.x) return false;
-    if (p.C2 > 0 && (q.x_sb ? !q.x2_sb : !q.x2)) return false;
+    if (!q.y && !q.y_sb) return false;
   }
   return true;
 }

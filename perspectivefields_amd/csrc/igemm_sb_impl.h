@@ -81,7 +81,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   // channel and split as wh + wl (two fp16 planes in global memory); the third LDS plane wh2 = wh 2^-11 is made while
   // staging, so that  ah wh + ah wl + al wh2  accumulates in ONE accumulator: 3 MFMAs per product.
   constexpr bool F16 = NTERM == NT_F16X3;
-  static_assert(!(F16 && ASB), "the split-f16 scheme reads fp32 activations");
   constexpr int NPL = F16 ? 2 : (NTERM == 6 ? 3 : (NTERM == 3 ? 2 : 1));  // A planes in LDS
   constexpr int NPB = F16 ? 3 : NPL;                                      // B planes in LDS
   constexpr int NPG = F16 ? 2 : NPL;                                      // B planes loaded from global memory
@@ -128,8 +127,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   if (ASB) {
 #pragma unroll
     for (int pl = 0; pl < (ASB ? NPL : 1); ++pl) {
-      rx[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.x_sb + pl * p.x_sb_plane), 0, p.x_bytes / 2, 0x00020000);
-      rx2[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.x2_sb ? P.x2_sb + pl * p.x2_sb_plane : P.x_sb), 0,
+      rx[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.x_sb + pl * (p.x_sb_plane & ~(size_t)1)), 0, p.x_bytes / 2, 0x00020000);
+      rx2[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.x2_sb ? P.x2_sb + pl * (p.x2_sb_plane & ~(size_t)1) : P.x_sb), 0,
                                                   P.x2_sb ? p.x2_bytes / 2 : 0, 0x00020000);
     }
   } else {
@@ -329,10 +328,7 @@ static void launch_sb_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const dim3 grid(tilesM * tilesN * p.groups), block(WM * WN * 64);
   const bool asb = p.g[0].x_sb != nullptr;
-  if constexpr (NT == NT_F16X3) {  // fp32 activations only (conv_sb_eligible)
-    if (p.C2 > 0) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, false, PFD, NT>), grid, block, 0, s, p);
-    else          hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, false, PFD, NT>), grid, block, 0, s, p);
-  } else if (p.C2 > 0) {
+  if (p.C2 > 0) {
     if (asb) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, true, PFD, NT>), grid, block, 0, s, p);
     else     hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, false, PFD, NT>), grid, block, 0, s, p);
   } else {

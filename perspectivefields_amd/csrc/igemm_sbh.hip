@@ -373,7 +373,7 @@ bool conv_sbh_ok(const ConvParams& p) {
   if ((p.C1 % BK) != 0 || (p.C2 % BK) != 0 || p.KWCp != p.KWC) return false;
   for (int g = 0; g < p.groups; ++g) {
     if (!p.g[g].x || (p.C2 > 0 && !p.g[g].x2)) return false;
-    if (p.nterms == NT_F16X3 ? (!p.g[g].w_h16 || !p.g[g].w_h16_inv_scale || p.g[g].y_sb) : !p.g[g].w_sb) return false;
+    if (p.nterms == NT_F16X3 ? (!p.g[g].w_h16 || !p.g[g].w_h16_inv_scale) : !p.g[g].w_sb) return false;
   }
   return true;
 }

@@ -11,6 +11,9 @@ namespace pf {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 static constexpr int NT_F16X3 = 23;  // ConvParams::nterms value of the split-f16 scheme
+// Split-plane tensors: every `plane` stride argument is (elements between consecutive planes, always even) | format bit:
+// 0 = three exact bf16 planes (x == h + m + l), SB_FMT_F16 = the two fp16 planes of the split-f16 scheme (sb_split.h)
+static constexpr size_t SB_FMT_F16 = 1;
 
 // Implicit-GEMM convolution / GEMM on v_mfma_f32_32x32x2_f32.
 //   y[m][n] = post( act( sum_k A[m][k] * Wp[n][k] + bias[n] ) + res1[m][n] + res2[m][n] )

@@ -6,6 +6,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "pf_kernels.h"
+
 namespace pf {
 
 // One output of the bilinear x2 up-sampling (align_corners = False): the same expression, with the roundings pinned by
@@ -61,8 +63,22 @@ __device__ __forceinline__ float4 scale8_f16_2m11(const float4 v) {
   return make_float4(mul(v.x), mul(v.y), mul(v.z), mul(v.w));
 }
 
-// store 4 consecutive elements (index idx, a multiple of 4) of an SBA tensor
-__device__ __forceinline__ void store_sb4(unsigned short* base, size_t plane_elems, size_t idx, const float4 v) {
+// ---- plane formats.  Every `plane` argument of the producers / consumers below is (elements between consecutive planes,
+// always even) | format bit:  0 = three exact bf16 planes (x == h + m + l),  SB_FMT_F16 = two fp16 planes of the split-f16
+// scheme (x ~ hi + lo 2^-11: the same two values the split-f16 GEMM would compute from the fp32 tensor while staging it,
+// 4 bytes per element like the fp32 tensor itself -- the consuming GEMM's A staging becomes a plain copy).
+// (SB_FMT_F16 is declared in pf_kernels.h)
+
+// store 4 consecutive elements (index idx, a multiple of 4) of a split-plane tensor
+__device__ __forceinline__ void store_sb4(unsigned short* base, size_t plane_fmt, size_t idx, const float4 v) {
+  const size_t plane_elems = plane_fmt & ~(size_t)1;
+  if (plane_fmt & SB_FMT_F16) {
+    uint2 h, l;
+    split4_f16(v, h, l);
+    *reinterpret_cast<uint2*>(base + idx) = h;
+    *reinterpret_cast<uint2*>(base + plane_elems + idx) = l;
+    return;
+  }
   uint2 h, m, l;
   split4(v, h, m, l);
   *reinterpret_cast<uint2*>(base + idx) = h;
@@ -70,7 +86,15 @@ __device__ __forceinline__ void store_sb4(unsigned short* base, size_t plane_ele
   *reinterpret_cast<uint2*>(base + 2 * plane_elems + idx) = l;
 }
 
-__device__ __forceinline__ float4 load_sb4(const unsigned short* base, size_t plane_elems, size_t idx) {
+__device__ __forceinline__ float4 load_sb4(const unsigned short* base, size_t plane_fmt, size_t idx) {
+  const size_t plane_elems = plane_fmt & ~(size_t)1;
+  if (plane_fmt & SB_FMT_F16) {  // hi + lo 2^-11 (the value the split-f16 GEMM works with; not the original fp32 bits)
+    const uint2 h = *reinterpret_cast<const uint2*>(base + idx);
+    const uint2 l = *reinterpret_cast<const uint2*>(base + plane_elems + idx);
+    auto f = [](unsigned w, int hi) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(hi ? (w >> 16) : (w & 0xffffu))); };
+    const float s = 0.00048828125f;
+    return make_float4(fmaf(f(l.x, 0), s, f(h.x, 0)), fmaf(f(l.x, 1), s, f(h.x, 1)), fmaf(f(l.y, 0), s, f(h.y, 0)), fmaf(f(l.y, 1), s, f(h.y, 1)));
+  }
   const uint2 h = *reinterpret_cast<const uint2*>(base + idx);
   const uint2 m = *reinterpret_cast<const uint2*>(base + plane_elems + idx);
   const uint2 l = *reinterpret_cast<const uint2*>(base + 2 * plane_elems + idx);

@@ -26,21 +26,24 @@ def _dp(t):
 
 
 class Planes:
-    """An fp32 tensor in the engine's split-bf16 activation format: three exact bf16 planes (include/pf_hip.h)."""
+    """An fp32 tensor in one of the engine's split activation formats (include/pf_hip.h): fmt "bf16x3" = three exact bf16
+    planes, "f16x2" = the two fp16 planes of the split-f16 scheme.  `plane_elems` carries the format in bit 0."""
 
-    def __init__(self, shape, device):
+    def __init__(self, shape, device, fmt="bf16x3"):
         import torch
 
         self.shape = tuple(shape)
+        self.fmt = fmt
         self.numel = int(np.prod(self.shape))
-        self.plane_elems = (self.numel + 127) // 128 * 128
-        self.data = torch.zeros(3 * self.plane_elems, dtype=torch.int16, device=device)
+        stride = (self.numel + 127) // 128 * 128
+        self.plane_elems = stride | (1 if fmt == "f16x2" else 0)
+        self.data = torch.zeros((2 if fmt == "f16x2" else 3) * stride, dtype=torch.int16, device=device)
 
     def data_ptr(self):
         return self.data.data_ptr()
 
     def merge(self):
-        """h + m + l in fp32 (exact)."""
+        """back to fp32: h + m + l (exact) or hi + lo 2^-11 (the value the split-f16 GEMM works with)."""
         import torch
 
         lib = load_library()
@@ -49,10 +52,10 @@ class Planes:
         return y
 
 
-def split_planes(x):
+def split_planes(x, fmt="bf16x3"):
     lib = load_library()
     x = x.contiguous()
-    pl = Planes(x.shape, x.device)
+    pl = Planes(x.shape, x.device, fmt)
     _check(lib.pf_op_split_bf16(x.device.index, x.data_ptr(), x.numel(), pl.data_ptr(), pl.plane_elems, _stream_ptr()), None, "pf_op_split_bf16")
     return pl
 
@@ -62,7 +65,7 @@ def _pl(planes):
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, post_relu=False, x2=None, nchw_out=False, tile=-1,
-           planes_in=False, planes_out=False, precision=0):
+           planes_in=False, planes_out=False, precision=0, planes_fmt="bf16x3"):
     """x: (B,H,W,C1) [+ x2: (B,H,W,C2) channel-concat]; weight: (Cout, C1+C2, KH, KW).  Returns (B,Ho,Wo,Cout) or NCHW.
     planes_in: hand the input(s) to the kernel as split-bf16 planes only; planes_out: take the output as planes
     (returned merged back to fp32, which is exact).  precision (split tiles): 0 split-f16 (default parity scheme), 3 exact bf16
@@ -82,9 +85,9 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, p
     shape = (B, Cout, Ho, Wo) if nchw_out else (B, Ho, Wo, Cout)
     b = _np(bias)
     x2 = x2.contiguous() if x2 is not None else None
-    xp = split_planes(x) if planes_in else None
-    x2p = split_planes(x2) if (planes_in and x2 is not None) else None
-    yp = Planes(shape, x.device) if planes_out else None
+    xp = split_planes(x, planes_fmt) if planes_in else None
+    x2p = split_planes(x2, planes_fmt) if (planes_in and x2 is not None) else None
+    yp = Planes(shape, x.device, planes_fmt) if planes_out else None
     y = None if planes_out else torch.empty(shape, dtype=torch.float32, device=x.device)
     rc = lib.pf_op_conv2d(
         x.device.index, None if planes_in else x.data_ptr(), None if planes_in else _dp(x2), B, H, W, C1, C2, _hp(w), _hp(b),

@@ -161,6 +161,30 @@ def test_conv2d_split_f16_scheme(ops):
     assert torch.allclose(ops.conv2d(xs.cuda(), ws, None, precision=3, tile=t64).cpu()[..., 0], torch.tensor(1.0e6))
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] % 32 == 0 and c[5] % 32 == 0], ids=[c[0] for c in CONV_CASES if c[4] % 32 == 0 and c[5] % 32 == 0])
+def test_conv2d_split_f16_plane_operands(ops, case):
+    """The split-f16 scheme fed with the two fp16 planes a producer kernel wrote (format bit 1, sb_split.h) instead of fp32:
+    the planes hold exactly what the GEMM's own staging would compute, so the results are bit-identical on every linear
+    split tile; plane OUTPUT is the fp32 result re-split (hi + lo 2^-11: within 2^-22 of it)."""
+    name, B, H, W, C1, C2, Cout, K, stride, pad = case
+    x = _rand((B, H, W, C1), 1).cuda()
+    x2 = _rand((B, H, W, C2), 2).cuda() if C2 else None
+    w = _rand((Cout, C1 + C2, K, K), 3, 1.0 / math.sqrt((C1 + C2) * K * K))
+    b = _rand((Cout,), 4, 0.1)
+    names = ops.conv_tiles()
+    for tile in [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbh")]:
+        base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, precision=0)
+        got_in = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_fmt="f16x2")
+        assert torch.equal(got_in, base), f"{name} {names[tile]}: fp16-plane input differs from fp32 input"
+        if Cout % 4 == 0:
+            got_io = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_out=True, planes_fmt="f16x2")
+            assert float(((got_io - base).abs() / (base.abs() + 1e-4)).max()) <= 2.0 ** -21, f"{name} {names[tile]}: fp16-plane output"
+    # round trip of the format itself: 22+ significant bits inside the fp16 range, saturation outside
+    v = _rand((4, 8, 8, 32), 5) * torch.exp2(torch.randint(-10, 12, (4, 8, 8, 32)).float())
+    back = ops.split_planes(v.cuda(), "f16x2").merge().cpu()
+    assert float(((back - v).abs() / v.abs().clamp_min(1e-3)).max()) <= 2.0 ** -22
+
+
 @pytest.mark.parametrize("precision,tol", [(1, 2e-4), (2, 3e-2)], ids=["bf16x3", "bf16"])
 def test_conv2d_reduced_precision_modes(ops, precision, tol):
     """The optional reduced-precision forms of the split-bf16 kernel (3 / 1 partial products instead of 6) on every
