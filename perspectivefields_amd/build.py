@@ -15,6 +15,10 @@ SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sb3.hip", "igemm_sb1.hip", "igemm
 # dw7.hip: the scalar one-channel-per-lane kernel must not be SLP-vectorised (see the file header)
 EXTRA_FLAGS = {"dw7.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
+# PF_TUNING_BUILD=1: also compile the measured-and-rejected kernel variants and the ablation (no-load / no-store) kernels that
+# the scripts under scripts/ can select; the product build carries the default path and its parity alternatives only
+if os.environ.get("PF_TUNING_BUILD", "0") == "1":
+    FLAGS.append("-DPF_TUNING_BUILD")
 
 
 def _hipcc() -> str:

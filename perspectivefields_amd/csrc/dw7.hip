@@ -249,9 +249,11 @@ static void launch_cb(const float* x, const float* w49c, const float* bias, floa
   const long blocks = (long)B * ((H + TH - 1) / TH) * ((groups + GB - 1) / GB) * (C / 32);
   static int diag = -1;
   if (diag < 0) { const char* d = getenv("PF_DW7_DIAG"); diag = d ? atoi(d) : 0; }
-  if (diag == 1)      hipLaunchKernelGGL((dwconv7x7_cb_kernel<NC, NB, 1>), dim3((unsigned)blocks), dim3(GB * 32), 0, s, x, w49c, bias, y, B, H, W, C, TH, GB);
-  else if (diag == 2) hipLaunchKernelGGL((dwconv7x7_cb_kernel<NC, NB, 2>), dim3((unsigned)blocks), dim3(GB * 32), 0, s, x, w49c, bias, y, B, H, W, C, TH, GB);
-  else                hipLaunchKernelGGL((dwconv7x7_cb_kernel<NC, NB, 0>), dim3((unsigned)blocks), dim3(GB * 32), 0, s, x, w49c, bias, y, B, H, W, C, TH, GB);
+#ifdef PF_TUNING_BUILD
+  if (diag == 1)      { hipLaunchKernelGGL((dwconv7x7_cb_kernel<NC, NB, 1>), dim3((unsigned)blocks), dim3(GB * 32), 0, s, x, w49c, bias, y, B, H, W, C, TH, GB); return; }
+  else if (diag == 2) { hipLaunchKernelGGL((dwconv7x7_cb_kernel<NC, NB, 2>), dim3((unsigned)blocks), dim3(GB * 32), 0, s, x, w49c, bias, y, B, H, W, C, TH, GB); return; }
+#endif
+  hipLaunchKernelGGL((dwconv7x7_cb_kernel<NC, NB, 0>), dim3((unsigned)blocks), dim3(GB * 32), 0, s, x, w49c, bias, y, B, H, W, C, TH, GB);
 }
 
 // column-blocked kernel: NC / NB / strip height TH by map size (0 = automatic; scripts/tune_dw7.py measured the table);
@@ -297,9 +299,11 @@ static void launch_lane(const float* x, const float* w49c, const float* bias, fl
   const long blocks = (long)B * ((H + TH - 1) / TH) * ((W + XB - 1) / XB) * (C / CPB);
   static int diag = -1;
   if (diag < 0) { const char* d = getenv("PF_DW7_DIAG"); diag = d ? atoi(d) : 0; }
-  if (diag == 1 && threads <= 256)      hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256, 1>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
-  else if (diag == 2 && threads <= 256) hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256, 2>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
-  else if (threads <= 256) hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
+#ifdef PF_TUNING_BUILD
+  if (diag == 1 && threads <= 256)      { hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256, 1>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB); return; }
+  else if (diag == 2 && threads <= 256) { hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256, 2>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB); return; }
+#endif
+  if (threads <= 256) hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 256>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
   else                hipLaunchKernelGGL((dwconv7x7_lane_kernel<CPL, NB, 1024>), dim3((unsigned)blocks), dim3(threads), 0, s, x, w49c, bias, y, B, H, W, C, TH, XB, CPB);
 }
 
@@ -311,9 +315,11 @@ void launch_dwconv7x7_lane(const float* x, const float* w49c, const float* bias,
     const char* t = getenv("PF_DW7_TH"); g_th = t ? atoi(t) : 0;
     const char* c = getenv("PF_DW7_CPB"); g_cpb = c ? atoi(c) : 0;
   }
-  if (g_cpl == 2) launch_lane<2, 3>(x, w49c, bias, y, B, H, W, C, g_th, 0, s);
-  else if (g_nb == 2) launch_lane<1, 2>(x, w49c, bias, y, B, H, W, C, g_th, g_cpb, s);
-  else launch_lane<1, 3>(x, w49c, bias, y, B, H, W, C, g_th, g_cpb, s);
+#ifdef PF_TUNING_BUILD
+  if (g_cpl == 2) { launch_lane<2, 3>(x, w49c, bias, y, B, H, W, C, g_th, 0, s); return; }
+  if (g_nb == 2) { launch_lane<1, 2>(x, w49c, bias, y, B, H, W, C, g_th, g_cpb, s); return; }
+#endif
+  launch_lane<1, 3>(x, w49c, bias, y, B, H, W, C, g_th, g_cpb, s);
 }
 
 }  // namespace pf

@@ -114,6 +114,7 @@ void launch_layernorm(const float* x, const float* g, const float* b, float* y, 
 static constexpr int DW3_T = 8;
 static constexpr int DW3_CQ = 32;  // channel quads per block (128 channels)
 
+#ifdef PF_TUNING_BUILD
 __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              unsigned short* __restrict__ y_sb, size_t sb_plane,
@@ -174,7 +175,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __rest
   }
 }
 
-// Variant without LDS: thread (channel quad q, column x) marches down a strip of rows keeping a 3x3 window of
+#endif  // PF_TUNING_BUILD
+
+// Default: no LDS -- thread (channel quad q, column x) marches down a strip of rows keeping a 3x3 window of
 // float4 in registers and fetching 3 new values per output straight from global memory; the x-1/x/x+1 overlap
 // between neighbouring lanes/waves is served by L1/L2, HBM sees each input once (plus strip halos).
 template <int CQB /*quads per block*/, int XB /*columns per block*/, int TH /*rows per strip*/, int DIAG = 0 /*1: no stores, 2: no loads (diagnostics)*/>
@@ -250,38 +253,47 @@ __global__ __launch_bounds__(CQB * XB) void dwconv3x3_gelu_direct_kernel(const f
   }
 }
 
+#ifdef PF_TUNING_BUILD
 __global__ __launch_bounds__(256) void copy_f4_kernel(const float4* __restrict__ x, float4* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = x[i];
 }
+#endif
 
 static int g_dw3_variant = -1;
 void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s,
                                    unsigned short* y_sb, size_t sb_plane) {
   const int CQ = C / 4;
+#ifdef PF_TUNING_BUILD  // measured-and-rejected variants + diagnostics: tuning builds only (PF_TUNING_BUILD=1 python -m perspectivefields_amd.build)
   if (variant == 0) {
     const int tilesX = (W + DW3_T - 1) / DW3_T, tilesY = (H + DW3_T - 1) / DW3_T;
     const long blocks = (long)B * tilesY * tilesX * (C / (DW3_CQ * 4));
     hipLaunchKernelGGL(dwconv3x3_gelu_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
+    return;
   } else if (variant == 1) {  // 32 quads x 8 columns, strips of 16 rows
     const long blocks = (long)B * ((H + 15) / 16) * ((W + 7) / 8) * (CQ / 32);
     hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
-  } else if (variant == 2) {  // 64 quads x 4 columns, strips of 16 rows
-    if (CQ % 64 != 0) return launch_dwconv3x3_gelu_variant(1, x, w9c, bias, y, B, H, W, C, s, y_sb, sb_plane);
-    const long blocks = (long)B * ((H + 15) / 16) * ((W + 3) / 4) * (CQ / 64);
-    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<64, 4, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
+    return;
   } else if (variant == 3) {  // 32 quads x 8 columns, strips of 40 rows
     const long blocks = (long)B * ((H + 39) / 40) * ((W + 7) / 8) * (CQ / 32);
     hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 40>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
-  } else if (variant == 4) {  // 32 quads x 8 columns, strips of 8 rows
-    const long blocks = (long)B * ((H + 7) / 8) * ((W + 7) / 8) * (CQ / 32);
-    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 8>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
+    return;
   } else if (variant == 51 || variant == 52) {  // diagnostics of variant 3: 51 = no stores, 52 = no loads
     const long blocks = (long)B * ((H + 39) / 40) * ((W + 7) / 8) * (CQ / 32);
     if (variant == 51) hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 40, 1>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
     else               hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 40, 2>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
-  } else {  // 99: plain copy of the same bytes (achievable streaming ceiling, diagnostic only)
+    return;
+  } else if (variant == 99) {  // plain copy of the same bytes (achievable streaming ceiling, diagnostic only)
     const long n = (long)B * H * W * CQ;
     hipLaunchKernelGGL(copy_f4_kernel, dim3(256 * 16), dim3(256), 0, s, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), n);
+    return;
+  }
+#endif
+  if (variant == 2 && CQ % 64 == 0) {  // 64 quads x 4 columns, strips of 16 rows (10^2 maps)
+    const long blocks = (long)B * ((H + 15) / 16) * ((W + 3) / 4) * (CQ / 64);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<64, 4, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
+  } else {  // 4 (default): 32 quads x 8 columns, strips of 8 rows
+    const long blocks = (long)B * ((H + 7) / 8) * ((W + 7) / 8) * (CQ / 32);
+    hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<32, 8, 8>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
   }
 }
 
@@ -303,6 +315,7 @@ void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, 
 // LDS (75 KB) + the 49x96 weights (18.8 KB); thread (q, row) accumulates its 8 outputs while
 // streaming the 7 input rows: each staged value is read once per thread and reused for up
 // to 7 outputs.
+#ifdef PF_TUNING_BUILD
 static constexpr int DW7_T = 8;
 static constexpr int DW7_CQ = 24;
 static constexpr int DW7_IN = DW7_T + 6;
@@ -430,7 +443,9 @@ __global__ __launch_bounds__(CQB * XB) void dwconv7x7_ring_kernel(const float* _
 }
 
 
-// The default kernel (channels-per-lane, buffer loads, prefetch ring) lives in dw7.hip.
+#endif  // PF_TUNING_BUILD
+
+// The default kernels (column-blocked / one column per lane streaming kernels) live in dw7.hip.
 void launch_dwconv7x7_lane(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
 void launch_dwconv7x7_cb(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
 
@@ -449,6 +464,7 @@ void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, floa
   }
   if (g_dw7_variant == 3) { launch_dwconv7x7_cb(x, w49c, bias, y, B, H, W, C, s); return; }
   if (g_dw7_variant == 2) { launch_dwconv7x7_lane(x, w49c, bias, y, B, H, W, C, s); return; }
+#ifdef PF_TUNING_BUILD
   const int CQ = C / 4;
   if (g_dw7_variant == 0) {  // LDS halo-tile kernel (kept for A/B)
     const int tilesX = (W + DW7_T - 1) / DW7_T, tilesY = (H + DW7_T - 1) / DW7_T;
@@ -461,6 +477,9 @@ void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, floa
     const long blocks = (long)B * ((H + 19) / 20) * ((W + 7) / 8) * (CQ / 24);
     hipLaunchKernelGGL((dwconv7x7_ring_kernel<24, 8, 20>), dim3((unsigned)blocks), dim3(192), 0, s, x, w49c, bias, y, B, H, W, C);
   }
+#else
+  launch_dwconv7x7_cb(x, w49c, bias, y, B, H, W, C, s);  // variants 0 / 1 (LDS halo tile, ring) exist in tuning builds only
+#endif
 }
 
 // --------------------------------------------------------------------------- bilinear x2

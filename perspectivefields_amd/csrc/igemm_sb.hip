@@ -16,9 +16,12 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {128, 128, 2, "sb128x128f2"},
                              // "sbh": 3x3 / stride 1 convs with an LDS-staged input halo tile, 8 x 16 output patch per block (igemm_sbh.hip)
                              {128, 128, 0, "sbh128x128"}, {128, 64, 0, "sbh128x64"}, {128, 32, 0, "sbh128x32"}, {256, 64, 0, "sbh256x64w8"},
+#ifdef PF_TUNING_BUILD
                              // split-f16 scheme only: "d" = weights double-buffered in LDS (one barrier per tap), "t3" = weights of a kernel row per step
                              {128, 128, 0, "sbhd128x128"}, {128, 64, 0, "sbhd128x64"}, {128, 32, 0, "sbhd128x32"}, {256, 64, 0, "sbhd256x64w8"},
-                             {256, 64, 0, "sbh256x64w8t3"}, {128, 64, 0, "sbh128x64t3"}};
+                             {256, 64, 0, "sbh256x64w8t3"}, {128, 64, 0, "sbh128x64t3"},
+#endif
+};
 static constexpr int kFirstH = 12;  // index of the first "sbh" tile
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }
 const char* conv_sb_tile_name(int id) { return kSb[id].name; }

@@ -383,7 +383,11 @@ bool conv_sbh_ok(const ConvParams& p) {
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
   if (!conv_sbh_ok(p)) return false;
   if (p.ups) return h_tile < 3 && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
+#ifdef PF_TUNING_BUILD
   return h_tile < 4 || p.nterms == NT_F16X3;
+#else
+  return h_tile < 4;
+#endif
 }
 
 // ids = position among the "sbh" tiles of kSb[] (igemm_sb.hip)
@@ -392,12 +396,14 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
     case 0: launch_sbh_cfg<8, 16, 128, 2, 2>(p, s); break;
     case 1: launch_sbh_cfg<8, 16, 64, 2, 2>(p, s); break;
     case 2: launch_sbh_cfg<8, 16, 32, 4, 1>(p, s); break;
+#ifdef PF_TUNING_BUILD  // measured, no gain (profiles/r02_negative_results.md)
     case 4: launch_sbh_cfg<8, 16, 128, 2, 2, 1, true>(p, s); break;
     case 5: launch_sbh_cfg<8, 16, 64, 2, 2, 1, true>(p, s); break;
     case 6: launch_sbh_cfg<8, 16, 32, 4, 1, 1, true>(p, s); break;
     case 7: launch_sbh_cfg<16, 16, 64, 4, 2, 1, true>(p, s); break;
     case 8: launch_sbh_cfg<16, 16, 64, 4, 2, 3>(p, s); break;
     case 9: launch_sbh_cfg<8, 16, 64, 2, 2, 3>(p, s); break;
+#endif
     default: launch_sbh_cfg<16, 16, 64, 4, 2>(p, s); break;  // 16 x 16 patch, 8 waves, two blocks per CU: weights staged once per 256 rows
   }
 }
