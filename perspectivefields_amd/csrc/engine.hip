@@ -338,7 +338,7 @@ struct pf_engine {
   // packed fp32 weights -> device, plus the split-bf16 planes when the layer is eligible for igemm_sb
   void upload_conv_weights(ConvW& c, const std::vector<float>& packed, int CinP, int Cout) {
     c.w = upload(packed);
-    if (split_bf16 && CinP % 32 == 0) {
+    if (split_bf16 && (CinP % 32 == 0 || CinP == 4)) {  // CinP == 4: the 3-channel stems (split-f16 "stem" form of igemm_sb_kernel)
       c.wsb = upload_u16(split_bf16x3(packed));
       const F16Planes f = split_f16x2(packed, Cout);
       c.wh16 = upload_u16(f.planes);
@@ -1336,7 +1336,7 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   std::vector<float> packed = pack_conv(hw, Cout, Cin, KH, KW, Cin, nullptr, &p.KWC, &p.KWCp);
   p.g[0].w = tmp.up(packed);
   std::vector<unsigned short> sb;
-  if (Cin % 32 == 0) {
+  if (Cin % 32 == 0 || Cin == 4) {
     sb = split_bf16x3(packed); p.g[0].w_sb = tmp.up_u16(sb);
     const F16Planes f = split_f16x2(packed, Cout);
     p.g[0].w_h16 = tmp.up_u16(f.planes); p.g[0].w_h16_inv_scale = tmp.up(f.inv_scale);
@@ -1397,7 +1397,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
     (void)hipMemcpy(dinv, f.inv_scale.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
   }
   p.g[0].x = dx; p.g[0].w = dw; p.g[0].bias = db; p.g[0].y = dy;
-  if (Cin % 32 == 0) { p.g[0].w_sb = dsb; p.g[0].w_h16 = dh16; p.g[0].w_h16_inv_scale = dinv; }
+  if (Cin % 32 == 0 || Cin == 4) { p.g[0].w_sb = dsb; p.g[0].w_h16 = dh16; p.g[0].w_h16_inv_scale = dinv; }
   // fmt 1: A operand as split planes (fp32 copy withheld); fmt 2: split planes in and out
   const size_t fbit = p.nterms == NT_F16X3 ? SB_FMT_F16 : 0;  // plane format of the scheme under test (nx, ny are multiples of 4)
   if (fmt >= 1) { launch_split_planes(dx, dxs, nx | fbit, (long)nx, nullptr); p.g[0].x_sb = dxs; p.x_sb_plane = nx | fbit; p.g[0].x = nullptr; }

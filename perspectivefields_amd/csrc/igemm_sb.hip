@@ -29,8 +29,10 @@ int conv_sb_tile_bm(int id) { return kSb[id].bm; }
 int conv_sb_tile_bn(int id) { return kSb[id].bn; }
 
 bool conv_sb_eligible(const ConvParams& p) {
-  if (p.nchw_out || (p.Cin % BK) != 0) return false;
   const bool f16 = p.nterms == NT_F16X3;
+  // stems (3 input channels padded to 4): split-f16 scheme, fp32 input, kernel rows of at most 8 taps (one 32-float chunk per row)
+  const bool stem = p.Cin == 4 && p.C2 == 0 && f16 && p.KWCp == BK && p.KH * p.KW <= 64 && !p.g[0].x_sb && (p.groups == 1 || !p.g[1].x_sb);
+  if (p.nchw_out || ((p.Cin % BK) != 0 && !stem)) return false;
   for (int g = 0; g < p.groups; ++g) {
     const ConvPtrs& q = p.g[g];
     if (f16 ? (!q.w_h16 || !q.w_h16_inv_scale) : !q.w_sb) return false;
@@ -74,7 +76,11 @@ void launch_conv_sbf(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm
 void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile);                  // igemm_sbh.hip
-bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) { return sb_tile < kFirstH ? !p.ups : conv_sbh_tile_ok(p, sb_tile - kFirstH); }
+bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
+  if (sb_tile >= kFirstH) return conv_sbh_tile_ok(p, sb_tile - kFirstH);
+  if (p.Cin == 4) return kSb[sb_tile].bm <= 128 && kSb[sb_tile].bn <= 128;  // stem form: built for the 4-wave tiles
+  return !p.ups;
+}
 
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
   if (sb_tile >= kFirstH) {

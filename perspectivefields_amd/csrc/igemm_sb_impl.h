@@ -150,7 +150,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     const int ox = rem - oy * p.Wo;
     const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
     const int pix = (b * p.H + iy0) * p.W + ix0;
-    a_off1[i] = pix * p.C1 * ESZ + (ASB ? pc : c4) * 16;
+    // MODE 1 (Cin == 4, the 3-channel stems padded to 4): a float4 is one PIXEL, the 32-float K chunk = 8 taps of one kernel row,
+    // this thread's tap (kx = chunk offset / 4 + c4) is added per K step
+    a_off1[i] = pix * p.C1 * ESZ + (MODE == 1 ? 0 : (ASB ? pc : c4) * 16);
     a_off2[i] = pix * p.C2 * ESZ + (ASB ? pc : c4) * 16;
     unsigned long long mk = 0;
     if (ok)
@@ -184,10 +186,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     const int bit = (ky * p.KW + kx) & 63;
     const bool first = MODE != 2 || ci0 < p.C1;
     const int toff = ((ky * p.W + kx) * (first ? p.C1 : p.C2) + (first ? ci0 : ci0 - p.C1)) * ESZ;
+    const int j1 = j0 + c4 * 4, kx1 = j1 >> 2;  // MODE 1: this thread's own tap of the chunk
+    const int bit1 = (ky * p.KW + kx1) & 63, toff1 = (ky * p.W + kx1) * 16;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-      const bool valid = live && ((a_mask[i] >> bit) & 1ull);
-      const unsigned off = valid ? (unsigned)((first ? a_off1[i] : a_off2[i]) + toff) : OOB;
+      const bool valid = MODE == 1 ? (live && j1 < p.KWC && ((a_mask[i] >> bit1) & 1ull)) : (live && ((a_mask[i] >> bit) & 1ull));
+      const unsigned off = valid ? (unsigned)((first ? a_off1[i] : a_off2[i]) + (MODE == 1 ? toff1 : toff)) : OOB;
       if (ASB) {
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
@@ -328,7 +332,9 @@ static void launch_sb_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const dim3 grid(tilesM * tilesN * p.groups), block(WM * WN * 64);
   const bool asb = p.g[0].x_sb != nullptr;
-  if (p.C2 > 0) {
+  if (p.Cin == 4) {  // stems (conv_sb_eligible: fp32 input, no concat)
+    if constexpr (NT == NT_F16X3 && (BN <= 128 && BM <= 128)) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 1, false, PFD, NT>), grid, block, 0, s, p);
+  } else if (p.C2 > 0) {
     if (asb) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, true, PFD, NT>), grid, block, 0, s, p);
     else     hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, false, PFD, NT>), grid, block, 0, s, p);
   } else {
