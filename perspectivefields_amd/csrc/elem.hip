@@ -647,9 +647,9 @@ __global__ __launch_bounds__(256) void pred_regression_kernel(const float4* __re
   const float bg0 = bg[0], bg1 = bg[1], bl0 = bl[0];
   for (long pix = ((long)blockIdx.x * 256 + threadIdx.x) >> 3; pix < npix; pix += ((long)gridDim.x * 256) >> 3) {
     const float4 a = tg[pix * 8 + sub], c = tl[pix * 8 + sub];
-    float g0 = (a.x * wg0.x + a.y * wg0.y) + (a.z * wg0.z + a.w * wg0.w);
-    float g1 = (a.x * wg1.x + a.y * wg1.y) + (a.z * wg1.z + a.w * wg1.w);
-    float l0 = (c.x * wl0.x + c.y * wl0.y) + (c.z * wl0.z + c.w * wl0.w);
+    float g0 = head_dot4(a, wg0);
+    float g1 = head_dot4(a, wg1);
+    float l0 = head_dot4(c, wl0);
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) {
       g0 += __shfl_xor(g0, o, 8);
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void pred_regression_kernel(const float4* __re
     }
     if (sub == 0) {
       g0 += bg0; g1 += bg1; l0 += bl0;
-      const float nrm = fmaxf(sqrtf(g0 * g0 + g1 * g1), 1e-12f);  // F.normalize eps
+      const float nrm = fmaxf(sqrtf(fmaf(g1, g1, __fmul_rn(g0, g0))), 1e-12f);  // F.normalize eps
       g0 /= nrm; g1 /= nrm;
       l0 = fminf(fmaxf(l0, -1.f), 1.f);
       const long b = pix / HW, r = pix - b * HW;

@@ -285,6 +285,7 @@ struct pf_engine {
   std::map<int, ResizeTable> resize_tables;  // input extent -> tables for resizing that extent to NET
   std::map<int, size_t> scratch_off, scratch_elems;
   bool split_bf16 = true;    // PF_SPLIT_BF16=0: exact-fp32 MFMA kernels only (no split-bf16 tiles)
+  bool fuse_pred = true;     // PF_FUSE_PRED=0: keep the 32-channel 320x320 maps and run the regression prediction heads as their own kernel
   bool fuse_upsample = true; // PF_FUSE_UPSAMPLE=0: materialise the two largest bilinear x2 maps (160^2 x 256, 320^2 x 64 per head) instead of
                              // interpolating them inside the consuming 3x3 convs' halo staging (split-f16 scheme only)
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
@@ -562,6 +563,8 @@ struct pf_engine {
   struct ConvCall {  // one problem of a (possibly grouped) conv launch
     const ConvW* w; Ten x; Ten y;
     const float* res1 = nullptr; const float* res2 = nullptr; Ten x2 = Ten();
+    // fused regression prediction head (ConvPtrs::head_*): kind 1 gravity, 2 latitude
+    int head_kind = 0; const float* head_w = nullptr; const float* head_b = nullptr; float* head_out = nullptr; float* head_pn = nullptr;
   };
   // ups: calls[].x is stored at half resolution (H/2 x W/2); the conv runs on its bilinear x2 up-sampling (ConvParams::ups)
   void conv_g(Ctx& c, int ngroups, const ConvCall* calls, int B, int H, int W, int act = ACT_NONE, int post_relu = 0, int C1 = -1, int nchw = 0, int ups = 0) {
@@ -579,6 +582,7 @@ struct pf_engine {
       q.x = calls[g].x.f; q.x2 = calls[g].x2.f; q.w = wg.w; q.w_sb = wg.wsb; q.w_h16 = wg.wh16; q.w_h16_inv_scale = wg.wh16_inv; q.bias = wg.b; q.bias_tab = wg.btab;
       q.res1 = calls[g].res1; q.res2 = calls[g].res2; q.y = calls[g].y.f;
       q.x_sb = calls[g].x.s.p; q.x2_sb = calls[g].x2.s.p; q.y_sb = calls[g].y.s.p;
+      q.head_kind = calls[g].head_kind; q.head_w = calls[g].head_w; q.head_b = calls[g].head_b; q.head_out = calls[g].head_out; q.head_pn = calls[g].head_pn;
     }
     p.x_sb_plane = calls[0].x.s.plane; p.x2_sb_plane = calls[0].x2.s.plane; p.y_sb_plane = calls[0].y.s.plane;
     p.B = B; p.H = H; p.W = W;
@@ -593,7 +597,7 @@ struct pf_engine {
     {
       // operand formats are part of the key: a split-plane input changes which tile is fastest
       const int prec_code = nterms == NT_F16X3 ? 0 : (nterms == 6 ? 3 : (nterms == 3 ? 1 : 2));  // = PF_PRECISION_*
-      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * prec_code + 128 * ups;
+      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * prec_code + 128 * ups + 256 * (calls[0].head_kind ? 1 : 0);
       const std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out, fmt_bits, p.act};
       auto it = tile_cache.find(key);
       if (it != tile_cache.end()) tile = it->second;
@@ -722,7 +726,9 @@ struct pf_engine {
   // Stored tensors are post-ReLU wherever every consumer applies ReLU first (ResidualConvUnit's in-place
   // ReLU, decode_head.py:242-256): RCU(x) = conv2(relu(conv1(relu x))) + relu x.
   // With `sba` a conv's epilogue writes split planes for the next conv (and fp32 only where a residual add reads it).
-  void heads_fwd(Ctx& c, int B, Ten feats[4], Ten llf, float* t32 /*[2][B][320][320][32]*/) {
+  // pred_fused(): the regression heads' 1x1 prediction convs run inside conv_fuse_conv1's epilogue (no 32-channel map in HBM)
+  bool pred_fused() const { return fuse_pred && arch != PF_ARCH_PERSNET_CLS && nterms == NT_F16X3 && split_bf16; }
+  void heads_fwd(Ctx& c, int B, Ten feats[4], Ten llf, float* t32 /*[2][B][320][320][32], unused when the heads are fused*/, float* pg, float* pl, float* pn) {
     const bool S = sba && nterms != NT_F16X3;  // the 3x3 halo kernels of the decoder stage fp32 inputs: split-f16 planes only in MiT / ConvNeXt
     Head& hg = heads[0];
     Head& hl = heads[1];
@@ -797,7 +803,11 @@ struct pf_engine {
         launch_upsample2x(z0.f, zu0.f, 2 * B, h, h, 64, c.s, zu0.s.p, zu0.s.plane);
       }
     }
-    ConvCall b2[2] = {{&hg.conv1, fuse_up ? z0 : zu0, Ten(t32)}, {&hl.conv1, fuse_up ? z1 : zu1, Ten(t32 + (size_t)B * NET * NET * 32)}};
+    ConvCall b2[2] = {{&hg.conv1, fuse_up ? z0 : zu0, Ten(t32)}, {&hl.conv1, fuse_up ? z1 : zu1, Ten(t32 ? t32 + (size_t)B * NET * NET * 32 : nullptr)}};
+    if (pred_fused()) {
+      b2[0].head_kind = 1; b2[0].head_w = hg.predw; b2[0].head_b = hg.predb; b2[0].head_out = pg; b2[0].head_pn = pn;
+      b2[1].head_kind = 2; b2[1].head_w = hl.predw; b2[1].head_b = hl.predb; b2[1].head_out = pl; b2[1].head_pn = pn;
+    }
     conv_g(c, 2, b2, B, NET, NET, ACT_RELU, 0, -1, 0, fuse_up ? 1 : 0);
   }
 
@@ -862,11 +872,12 @@ struct pf_engine {
     const bool Sh = sba && nterms != NT_F16X3;  // as in heads_fwd: the decoder's halo kernels read fp32
     const Ten llf = c.ten((size_t)B * (NET / 2) * (NET / 2) * LL_CH, !Sh, Sh);
     conv(c, ll, Ten(x0), B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
-    float* tg = c.alloc((size_t)2 * B * NET * NET * 32);
-    float* tl = tg + (size_t)B * NET * NET * 32;
+    const bool pf = pred_fused();
+    float* tg = pf ? nullptr : c.alloc((size_t)2 * B * NET * NET * 32);
+    float* tl = pf ? nullptr : tg + (size_t)B * NET * NET * 32;
     float* pn = has_param ? c.alloc((size_t)B * NET * NET * 4) : nullptr;
     const size_t mk = c.mark();
-    heads_fwd(c, B, feats, llf, tg);
+    heads_fwd(c, B, feats, llf, tg, pg, pl, pn);
     c.release(mk);
     if (arch == PF_ARCH_PERSNET_CLS) {
       // 1x1 convs to 73 / 180 logits, stored NCHW because the logits are API-visible (gravity_head.py:259)
@@ -874,7 +885,7 @@ struct pf_engine {
       conv(c, heads[1].predcls, Ten(tl), B, NET, NET, Ten(pl), ACT_NONE, nullptr, nullptr, 0, Ten(), -1, 1);
       return;
     }
-    if (!c.dry)
+    if (!c.dry && !pf)
       launch_pred_regression(tg, tl, heads[0].predw, heads[0].predb, heads[1].predw, heads[1].predb, pg, pl, pn, B, NET * NET, c.s);
     if (has_param) paramnet(c, B, pn, params);
   }
@@ -982,6 +993,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   e->arch = arch;
   if (const char* v = getenv("PF_FOLD_MLP")) e->fold_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_UPSAMPLE")) e->fuse_upsample = atoi(v) != 0;
+  if (const char* v = getenv("PF_FUSE_PRED")) e->fuse_pred = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;

@@ -93,6 +93,33 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
         if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         if (p.post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if constexpr (BN == 32) {
+          if (P.head_kind) {  // block-uniform.  The 8 lanes idx % 8 = 0..7 hold the 32 channels of one pixel (same row -> same branch)
+            const int sub = cq;  // channels 4 sub .. 4 sub + 3
+            const float4 w0 = reinterpret_cast<const float4*>(P.head_w)[sub];
+            float d0 = head_dot4(v, w0), d1 = 0.f;
+            if (P.head_kind == 1) d1 = head_dot4(v, reinterpret_cast<const float4*>(P.head_w)[8 + sub]);
+#pragma unroll
+            for (int sh = 4; sh > 0; sh >>= 1) { d0 += __shfl_xor(d0, sh, 8); d1 += __shfl_xor(d1, sh, 8); }
+            if (sub == 0) {
+              const int b_img = m / HoWo;
+              const int r = m - b_img * HoWo;
+              if (P.head_kind == 1) {
+                d0 += P.head_b[0]; d1 += P.head_b[1];
+                const float nrm = fmaxf(sqrtf(fmaf(d1, d1, __fmul_rn(d0, d0))), 1e-12f);  // F.normalize eps (same expression as pred_regression_kernel)
+                d0 /= nrm; d1 /= nrm;
+                P.head_out[((long)b_img * 2) * HoWo + r] = d0;
+                P.head_out[((long)b_img * 2 + 1) * HoWo + r] = d1;
+                if (P.head_pn) *reinterpret_cast<float2*>(P.head_pn + (long)m * 4) = make_float2(d0, d1);
+              } else {
+                d0 = fminf(fmaxf(d0 + P.head_b[0], -1.f), 1.f);
+                P.head_out[m] = d0;
+                if (P.head_pn) *reinterpret_cast<float2*>(P.head_pn + (long)m * 4 + 2) = make_float2(d0, 0.f);
+              }
+            }
+            continue;
+          }
+        }
         if (P.y) *reinterpret_cast<float4*>(P.y + o) = v;
         if (P.y_sb) store_sb4(P.y_sb, p.y_sb_plane, (size_t)o, v);  // split once here instead of per (tap, n-tile) in the consumer
       } else {  // ragged channel count: scalar tail

@@ -42,7 +42,7 @@ bool conv_sb_eligible(const ConvParams& p) {
     } else {
       if (!q.x || (p.C2 > 0 && !q.x2)) return false;
     }
-    if (!q.y && !q.y_sb) return false;
+    if (!q.y && !q.y_sb && !q.head_kind) return false;
   }
   return true;
 }
@@ -77,6 +77,7 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile);                  // igemm_sbh.hip
 bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
+  if (p.g[0].head_kind && (kSb[sb_tile].bn != 32 || p.Cout != 32)) return false;  // the fused prediction head lives in the BN = 32 epilogue
   if (sb_tile >= kFirstH) return conv_sbh_tile_ok(p, sb_tile - kFirstH);
   if (p.Cin == 4) return kSb[sb_tile].bm <= 128 && kSb[sb_tile].bn <= 128;  // stem form: built for the 4-wave tiles
   return !p.ups;

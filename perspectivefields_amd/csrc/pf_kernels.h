@@ -34,6 +34,15 @@ struct ConvPtrs {
   const float* res1 = nullptr;      // [M][Cout] or nullptr (may alias y)
   const float* res2 = nullptr;      // [M][Cout] or nullptr
   float* y = nullptr;               // [M][ldy], or nullptr when only the split planes are wanted
+  // Fused regression prediction head (Cout == 32, tiles with BN == 32 only): instead of storing the 32-channel map, the
+  // epilogue applies the 1x1 head to every pixel -- kind 1: linear_pred_gravity (32 -> 2) + F.normalize (gravity_head.py:117,
+  // 190-193), kind 2: linear_pred_latitude (32 -> 1) + clamp(-1, 1) (latitude_head.py:118,189-192) -- and writes the NCHW
+  // API output head_out plus its components of the ParamNet input head_pn ([M] float4: g0, g1, lat, 0; may be nullptr)
+  int head_kind = 0;
+  const float* head_w = nullptr;    // [nout][32]
+  const float* head_b = nullptr;    // [nout]
+  float* head_out = nullptr;        // [B][nout][Ho*Wo]
+  float* head_pn = nullptr;
   // split-bf16 activation format (sb_split.h): plane 0 of the same NHWC tensors as three exact bf16 planes.  When x_sb
   // is set the split-bf16 kernel copies its A operand instead of splitting it (x / x2 may then be nullptr).
   const unsigned short* x_sb = nullptr;

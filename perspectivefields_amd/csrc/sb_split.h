@@ -19,6 +19,12 @@ __device__ __forceinline__ float bilerp2x(float v00, float v01, float v10, float
   return fmaf(ly, b, __fmul_rn(hy, t));
 }
 
+// 4-term partial dot product of the regression prediction heads: the same expression (roundings pinned) in the stand-alone
+// kernel (elem.hip pred_regression_kernel) and in the fused conv epilogue (igemm_common.h), so that both paths agree bitwise
+__device__ __forceinline__ float head_dot4(const float4 a, const float4 w) {
+  return fmaf(a.y, w.y, __fmul_rn(a.x, w.x)) + fmaf(a.w, w.w, __fmul_rn(a.z, w.z));
+}
+
 __device__ __forceinline__ unsigned sb_pack_hi16(unsigned lo_src, unsigned hi_src) { return (lo_src >> 16) | (hi_src & 0xffff0000u); }
 
 // exact 3-way truncation split of 4 floats -> three 8-byte groups of 4 bf16

@@ -318,3 +318,20 @@ def test_fused_upsample_equals_materialised(tag, monkeypatch):
         assert torch.equal(a["pred_latitude_original"], b["pred_latitude_original"])
         if "pred_roll" in a:
             assert float(a["pred_roll"]) == float(b["pred_roll"]) and float(a["pred_vfov"]) == float(b["pred_vfov"])
+
+
+def test_fused_prediction_heads_equal_standalone_kernel(monkeypatch):
+    """Default: linear_pred_gravity + F.normalize / linear_pred_latitude + clamp run inside conv_fuse_conv1's epilogue (the
+    32-channel 320x320 maps never reach HBM).  PF_FUSE_PRED=0 stores them and runs pred_regression_kernel.  Same expressions
+    with pinned roundings -> bit-identical fields and ParamNet scalars."""
+    from perspectivefields_amd import PerspectiveFields
+
+    imgs = [synthetic_image(90, 120, seed=600 + i) for i in range(5)]
+    for tag in ("centered", "uncentered"):
+        base = model(tag).inference_batch(imgs)
+        monkeypatch.setenv("PF_FUSE_PRED", "0")
+        alt = PerspectiveFields(CASES[tag], weights="synthetic:0").eval().cuda().inference_batch(imgs)
+        monkeypatch.delenv("PF_FUSE_PRED")
+        for a, b in zip(base, alt):
+            assert torch.equal(a["pred_gravity"], b["pred_gravity"]) and torch.equal(a["pred_latitude"], b["pred_latitude"])
+            assert float(a["pred_roll"]) == float(b["pred_roll"]) and float(a["pred_pitch"]) == float(b["pred_pitch"])
