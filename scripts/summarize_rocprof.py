@@ -1,5 +1,5 @@
 """Aggregates rocprofv3 CSVs (kernel trace + PMC passes) per kernel name -> gpurun_out/rocprof_summary.{json,md}."""
-import csv, glob, json, os, re, sys
+import csv, glob, json, math, os, re, sys
 from collections import defaultdict
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
@@ -59,21 +59,25 @@ shapes = {}
 for f in glob.glob(os.path.join(root, "rocprof_trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if "igemm_sbh" not in r["Kernel_Name"]: continue
-        k = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]))
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        # launches of one kernel + grid can still differ in K (e.g. 256 -> 256 and the folded 64 -> 256 conv at 80^2): split by duration octave
+        k = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]), int(round(math.log2(max(us, 1.0)))))
         e = shapes.setdefault(k, {"calls": 0, "us": 0.0})
-        e["calls"] += 1; e["us"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        e["calls"] += 1; e["us"] += us
 for d in glob.glob(os.path.join(root, "rocprof_pmc_*")):
     if not os.path.isdir(d): continue
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if "igemm_sbh" not in r["Kernel_Name"]: continue
-            k = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
+            us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            k = (short(r["Kernel_Name"]), int(r["Grid_Size"]), int(round(math.log2(max(us, 1.0)))))
             e = shapes.setdefault(k, {"calls": 0, "us": 0.0}).setdefault("pmc", {}).setdefault(r["Counter_Name"], [0.0, 0])
             e[0] += float(r["Counter_Value"]); e[1] += 1
 rows_s = []
-for (k, grid), v in shapes.items():
+for (k, grid, octave), v in shapes.items():
+    if not v["calls"]: continue  # a duration octave seen only under the counters (profiled runs clock a little lower)
     p = {c: s / max(n, 1) for c, (s, n) in v.get("pmc", {}).items()}
-    row = {"kernel": k, "grid": grid, "calls": v["calls"], "avg_us": round(v["us"] / max(v["calls"], 1), 2), "total_us": round(v["us"], 1)}
+    row = {"kernel": k, "grid": grid, "duration_octave_us": 2 ** octave, "calls": v["calls"], "avg_us": round(v["us"] / max(v["calls"], 1), 2), "total_us": round(v["us"], 1)}
     if "FETCH_SIZE" in p and "WRITE_SIZE" in p: row["hbm_bytes_per_launch"] = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
     if "TCC_HIT_sum" in p and "TCC_MISS_sum" in p: row["l2_hit_rate"] = p["TCC_HIT_sum"] / max(p["TCC_HIT_sum"] + p["TCC_MISS_sum"], 1)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in p and p.get("GRBM_GUI_ACTIVE", 0) > 0: row["mfma_busy_frac"] = p["SQ_VALU_MFMA_BUSY_CYCLES"] / (p["GRBM_GUI_ACTIVE"] / 8.0 * 1024)
