@@ -253,19 +253,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
       }
   };
 
-  // Small tiles have only SM * SN = 1 or 2 accumulators per wave: with one set, consecutive MFMAs of a K step would all (or every
-  // second one) wait for the previous result (PMC, profiles/r02_pmc_gemm_shapes.txt: 35 % of the wave cycles in issue stalls on the
-  // 64x64 / 128x64 tiles).  The partial products of a chunk therefore go to NSET independent accumulator sets, summed before the epilogue.
-  constexpr int NSET = SM * SN == 1 ? 3 : (SM * SN == 2 ? 2 : 1);
-  f32x16 accs[NSET][SM][SN];
+  f32x16 acc[SM][SN];
 #pragma unroll
-  for (int q = 0; q < NSET; ++q)
+  for (int i = 0; i < SM; ++i)
 #pragma unroll
-    for (int i = 0; i < SM; ++i)
+    for (int j = 0; j < SN; ++j)
 #pragma unroll
-      for (int j = 0; j < SN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accs[q][i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int wm0 = (wave / WN) * (SM * 32);
   const int wn0 = (wave % WN) * (SN * 32);
@@ -297,7 +291,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
         for (int i = 0; i < SM; ++i)
 #pragma unroll
           for (int j = 0; j < SN; ++j)
-            accs[t6 % NSET][i][j] = mfma16<F16>(af[i][TA[t6]], bf[j][TB[t6]], accs[t6 % NSET][i][j]);
+            acc[i][j] = mfma16<F16>(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j]);
     }
   };
 
@@ -330,13 +324,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     __syncthreads();
   }
 
-  f32x16 (&acc)[SM][SN] = accs[0];
-#pragma unroll
-  for (int q = 1; q < NSET; ++q)
-#pragma unroll
-    for (int i = 0; i < SM; ++i)
-#pragma unroll
-      for (int j = 0; j < SN; ++j) acc[i][j] += accs[q][i][j];
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0, nullptr, F16 ? P.w_h16_inv_scale : nullptr);
 }
 

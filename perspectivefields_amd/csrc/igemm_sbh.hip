@@ -243,18 +243,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
         }
   };
 
-  // independent accumulator sets for the tiles with one or two 32x32 sub-tiles per wave (see igemm_sb_impl.h); the 8-wave tile
-  // sits at its 128-VGPR cap and keeps one set
-  constexpr int NSET = SM * SN == 1 ? 3 : ((SM * SN == 2 && WM * WN == 4) ? 2 : 1);
-  f32x16 accs[NSET][SM][SN];
+  f32x16 acc[SM][SN];
 #pragma unroll
-  for (int q = 0; q < NSET; ++q)
+  for (int i = 0; i < SM; ++i)
 #pragma unroll
-    for (int i = 0; i < SM; ++i)
+    for (int j = 0; j < SN; ++j)
 #pragma unroll
-      for (int j = 0; j < SN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accs[q][i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // GEMM row -> patch pixel: rows 16 k .. 16 k + 15 are patch row k; ODD patch rows are rotated by ODD_SHIFT columns.
   // ds_read_b128 is serviced in the non-contiguous lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: with the plain
@@ -301,7 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
         for (int i = 0; i < SM; ++i)
 #pragma unroll
           for (int j = 0; j < SN; ++j)
-            accs[t6 % NSET][i][j] = mfma16h<F16>(af[i][TA[t6]], bf[j][TB[t6]], accs[t6 % NSET][i][j]);
+            acc[i][j] = mfma16h<F16>(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j]);
     }
   };
 
@@ -345,13 +340,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
     }
   }
 
-  f32x16 (&acc)[SM][SN] = accs[0];
-#pragma unroll
-  for (int q = 1; q < NSET; ++q)
-#pragma unroll
-    for (int i = 0; i < SM; ++i)
-#pragma unroll
-      for (int j = 0; j < SN; ++j) acc[i][j] += accs[q][i][j];
   const Tile2D t2{bimg, oy0, ox0, H_TX, ODD_SHIFT};
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2, F16 ? P.w_h16_inv_scale : nullptr);
 }
