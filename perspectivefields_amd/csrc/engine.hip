@@ -569,9 +569,21 @@ struct pf_engine {
   // ups: calls[].x is stored at half resolution (H/2 x W/2); the conv runs on its bilinear x2 up-sampling (ConvParams::ups)
   void conv_g(Ctx& c, int ngroups, const ConvCall* calls, int B, int H, int W, int act = ACT_NONE, int post_relu = 0, int C1 = -1, int nchw = 0, int ups = 0) {
     const ConvW& w = *calls[0].w;
+    const size_t Ho_ = (H + 2 * w.pad - w.KH) / w.stride + 1, Wo_ = (W + 2 * w.pad - w.KW) / w.stride + 1;
+    // split-K scratch (conv_splitk_factor: deep-K launches with too few tiles for 256 CUs -- the MiT spatial-reduction convs); decided
+    // from the shape and the call's operand set, so that the workspace dry run takes the same decision
+    int splitk = 1;
+    {
+      bool plain = !nchw && !ups && w.Cin % 32 == 0 && w.KWCp > 0;
+      for (int g = 0; g < ngroups; ++g)
+        if (calls[g].head_kind || calls[g].w->btab || calls[g].res2 || calls[g].y.s.p || !calls[g].y.f || calls[g].x.s.p) plain = false;
+      if (plain && split_bf16) splitk = conv_splitk_shape((long)B * Ho_ * Wo_, w.Cout, w.KH, w.KWCp, ngroups);
+    }
+    const size_t mk_part = c.mark();
+    float* part = splitk > 1 ? c.alloc((size_t)splitk * ngroups * B * Ho_ * Wo_ * w.Cout) : nullptr;
+    struct Rel { Ctx& c; size_t m; ~Rel() { c.release(m); } } rel{c, mk_part};  // stream order makes the reuse safe
     if (c.dry) {
-      const size_t Ho = (H + 2 * w.pad - w.KH) / w.stride + 1, Wo = (W + 2 * w.pad - w.KW) / w.stride + 1;
-      c.max_conv_out = std::max(c.max_conv_out, (size_t)ngroups * B * Ho * Wo * w.Cout);
+      c.max_conv_out = std::max(c.max_conv_out, (size_t)ngroups * B * Ho_ * Wo_ * w.Cout);
       return;
     }
     ConvParams p;
@@ -593,6 +605,10 @@ struct pf_engine {
     p.nterms = nterms;
     p.ups = ups;
     p.finish();
+    if (part) {
+      p.splitk = splitk;
+      for (int g = 0; g < ngroups; ++g) p.g[g].partial = part + (size_t)g * splitk * p.M * p.Cout;
+    }
     int tile = -1;
     {
       // operand formats are part of the key: a split-plane input changes which tile is fastest
@@ -1367,6 +1383,13 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   if ((!x && !x_planes) || (!y && !y_planes) || (C2 > 0 && !x2 && !x2_planes)) { g_create_error = "pf_op_conv2d: missing input or output"; return PF_ERR_ARG; }
   // an explicit tile that cannot read / write split planes is an error; with fp32 operands an unusable tile id falls back to the cost model
   if (tile_id >= 0 && !conv_tile_usable(p, tile_id) && (x_planes || y_planes)) { g_create_error = "pf_op_conv2d: tile config cannot run this operand format"; return PF_ERR_ARG; }
+  {  // split-K by the engine's rule (scratch for the partial sums from a temporary allocation)
+    const int S = conv_splitk_factor(p);
+    if (S > 1) {
+      void* d = nullptr;
+      if (hipMalloc(&d, (size_t)S * p.M * p.Cout * 4) == hipSuccess) { tmp.p.push_back(d); p.g[0].partial = static_cast<float*>(d); p.splitk = S; }
+    }
+  }
   launch_conv_tile(p, tile_id, s);
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);

@@ -1,5 +1,7 @@
 // Split-bf16 implicit GEMM, fp32-accurate form (6 partial products): tile table, eligibility and dispatch by precision.
 // Kernel: igemm_sb_impl.h.
+#include <algorithm>
+
 #include "igemm_sb_impl.h"
 
 namespace pf {
@@ -83,7 +85,58 @@ bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
   return !p.ups;
 }
 
-void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s) {
+static int g_splitk_env = -2;  // PF_SPLITK=0 disables split-K, N > 1 forces the factor (tuning aid)
+// shape-only part (the engine's workspace dry run uses it before any pointer exists): deep K (>= 32 steps of 32) and at most 300
+// tiles of 64x64, i.e. barely one block per CU -- enough slices for ~1024 blocks, each keeping >= 8 K steps
+int conv_splitk_shape(long M, int Cout, int KH, int KWCp, int groups) {
+  if (g_splitk_env == -2) { const char* e = getenv("PF_SPLITK"); g_splitk_env = e ? atoi(e) : -1; }
+  if (g_splitk_env == 0 || (Cout & 3)) return 1;
+  const int nK = KH * (KWCp / BK);
+  const long blocks64 = ((M + 63) / 64) * ((Cout + 63) / 64) * groups;
+  if (nK < 32 || blocks64 > 300) return 1;
+  int S = g_splitk_env > 1 ? g_splitk_env : (int)std::min<long>(8, 1024 / blocks64);
+  while (S > 1 && nK / S < 8) --S;
+  return S;
+}
+int conv_splitk_factor(const ConvParams& p) {
+  if (p.nchw_out || p.ups || (p.Cin % BK) != 0 || !conv_sb_eligible(p)) return 1;
+  for (int g = 0; g < p.groups; ++g)
+    if (p.g[g].head_kind || p.g[g].bias_tab || p.g[g].res2 || p.g[g].y_sb || !p.g[g].y) return 1;
+  return conv_splitk_shape(p.M, p.Cout, p.KH, p.KWCp, p.groups);
+}
+
+// y = post(act(oscale * sum_s partial[s] + bias) + res1), 4 outputs per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ partial, int S, long mn4, int n4, const float4* __restrict__ oscale,
+                                                            const float4* __restrict__ bias, int act, const float4* __restrict__ res1, int post_relu, float4* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (long)gridDim.x * 256) {
+    float4 v = partial[i];
+    for (int k = 1; k < S; ++k) { const float4 q = partial[(long)k * mn4 + i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    const int c = (int)(i % n4);
+    if (oscale) { const float4 q = oscale[c]; v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
+    if (bias) { const float4 q = bias[c]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    if (act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+    if (res1) { const float4 q = res1[i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    if (post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    y[i] = v;
+  }
+}
+
+void launch_conv_sb(const ConvParams& p0, int sb_tile, hipStream_t s) {
+  ConvParams p = p0;
+  // split-K only on the linear tiles, with scratch from the caller and 16-byte rows
+  if (p.splitk > 1 && (sb_tile >= kFirstH || !p.g[0].partial || (p.groups > 1 && !p.g[1].partial) || (p.Cout & 3) || p.ldy != p.Cout)) p.splitk = 1;
+  struct Reduce { const ConvParams& p; hipStream_t s; ~Reduce() {
+    if (p.splitk <= 1) return;
+    const long mn4 = (long)p.M * p.Cout / 4;
+    const unsigned blocks = (unsigned)std::min<long>((mn4 + 255) / 256, 4096);
+    for (int g = 0; g < p.groups; ++g) {
+      const ConvPtrs& q = p.g[g];
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(q.partial), p.splitk, mn4, p.Cout / 4,
+                         reinterpret_cast<const float4*>(p.nterms == NT_F16X3 ? q.w_h16_inv_scale : nullptr), reinterpret_cast<const float4*>(q.bias), p.act,
+                         reinterpret_cast<const float4*>(q.res1), p.post_relu, reinterpret_cast<float4*>(q.y));
+    }
+  } } reduce_after{p, s};
   if (sb_tile >= kFirstH) {
     if (conv_sbh_tile_ok(p, sb_tile - kFirstH)) { launch_conv_sbh(p, sb_tile - kFirstH, s); return; }
     sb_tile = conv_sb_default_tile(p);

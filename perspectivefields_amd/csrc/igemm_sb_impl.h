@@ -106,7 +106,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int tilesM = (p.M + BM - 1) / BM;
   const int nblk1 = tilesM * tilesN;
-  int t = xcd_tile_index(nblk1 * p.groups);
+  // split-K (ConvParams::splitk = S > 1, deep-K launches with too few tiles to fill the chip): the grid holds S copies of the
+  // tile set, copy `sidx` contracts K steps [sidx nK / S, (sidx + 1) nK / S) and stores raw sums to P.partial[sidx]
+  const int S = p.splitk > 1 ? p.splitk : 1;
+  int t = xcd_tile_index(nblk1 * p.groups * S);
+  const int sidx = t / (nblk1 * p.groups);
+  t -= sidx * nblk1 * p.groups;
   const bool g1 = t >= nblk1;
   if (g1) t -= nblk1;
   const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
@@ -174,7 +179,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   struct Raw { float4 a[A_REGS]; float4 b[B_ROWS][NPG]; };
   Raw raw[PFD];
   const int nJ = p.KWCp / BK;
-  const int nK = p.KH * nJ;
+  const int nK_all = p.KH * nJ;
+  const int it0 = (int)((long)sidx * nK_all / S), nK = (int)((long)(sidx + 1) * nK_all / S);  // this block's K steps [it0, nK)
 
   // branch-free: a step at or past nK loads from the out-of-range offset (zeros, never stored)
   auto load_tiles = [&](int it, Raw& R) {
@@ -297,14 +303,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
 
   // prologue: tiles 0 .. PFD-1 in flight, tile 0 -> LDS (tile k lives in register set k % PFD)
 #pragma unroll
-  for (int d = 0; d < PFD; ++d) load_tiles(d, raw[d]);
+  for (int d = 0; d < PFD; ++d) load_tiles(it0 + d, raw[d]);
   store_tiles(raw[0]);
   __syncthreads();
   // Main loop: whole groups of PFD steps with no exit inside, so that the loop header sees ONE load order and the
   // compiler's s_waitcnt analysis keeps the partial vmcnt(N) waits (an exit inside the group rejoins the back edge
   // with a different order and every PFD-th store then drains all loads).  The last 1..PFD tiles are already in
   // flight when the loop ends and are consumed by the straight-line tail.
-  int it = 0;
+  int it = it0;
   for (; it + PFD < nK; it += PFD) {
 #pragma unroll
     for (int d = 0; d < PFD; ++d) {
@@ -324,13 +330,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     __syncthreads();
   }
 
+  if (S > 1) {  // raw partial sums; scale, bias, activation and residual are applied by splitk_reduce_kernel
+    ConvParams pp = p;
+    pp.act = ACT_NONE; pp.post_relu = 0;
+    ConvPtrs Q;
+    Q.y = P.partial + (size_t)sidx * p.M * p.ldy;
+    epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(pp, Q, acc, reinterpret_cast<float*>(smem_u), m0, n0);
+    return;
+  }
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0, nullptr, F16 ? P.w_h16_inv_scale : nullptr);
 }
 
 template <int BM, int BN, int WM, int WN, int PFD, int NT>
 static void launch_sb_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
-  const dim3 grid(tilesM * tilesN * p.groups), block(WM * WN * 64);
+  const dim3 grid(tilesM * tilesN * p.groups * (p.splitk > 1 ? p.splitk : 1)), block(WM * WN * 64);
   const bool asb = p.g[0].x_sb != nullptr;
   if (p.Cin == 4) {  // stems (conv_sb_eligible: fp32 input, no concat)
     if constexpr (NT == NT_F16X3 && (BN <= 128 && BM <= 128)) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 1, false, PFD, NT>), grid, block, 0, s, p);

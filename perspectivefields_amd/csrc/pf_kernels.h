@@ -38,6 +38,7 @@ struct ConvPtrs {
   // epilogue applies the 1x1 head to every pixel -- kind 1: linear_pred_gravity (32 -> 2) + F.normalize (gravity_head.py:117,
   // 190-193), kind 2: linear_pred_latitude (32 -> 1) + clamp(-1, 1) (latitude_head.py:118,189-192) -- and writes the NCHW
   // API output head_out plus its components of the ParamNet input head_pn ([M] float4: g0, g1, lat, 0; may be nullptr)
+  float* partial = nullptr;         // split-K: [splitk][M][ldy] raw partial sums (fp32 scratch owned by the caller)
   int head_kind = 0;
   const float* head_w = nullptr;    // [nout][32]
   const float* head_b = nullptr;    // [nout]
@@ -61,6 +62,8 @@ struct ConvParams {
   int post_relu;  // relu after the residual adds
   int ldy;        // row stride of y / res1 / res2 in floats (normally Cout)
   int nchw_out;   // 1: store y as [B][Cout][Ho*Wo] (API-visible logits), residuals unsupported
+  int splitk = 1; // > 1: K is contracted in `splitk` slices by separate blocks (linear split tiles only) into g[].partial, then reduced with
+                  // the epilogue (scale, bias, activation, res1, post_relu) by splitk_reduce_kernel -- deterministic (fixed summation order)
   int ups = 0;    // 1: x is stored at half resolution [B][H/2][W/2][C1]; the conv runs on its bilinear x2 up-sampling, interpolated
                   // while the input halo is staged (3x3 halo tiles of the split-f16 scheme only; x2, if any, is at full resolution)
   int nterms = 6; // split kernels: partial products per element product -- NT_F16X3 (23): 2-way fp16 split, 3 products, fp32-class accuracy;
@@ -100,6 +103,10 @@ bool conv_sb_eligible(const ConvParams& p);
 bool conv_sb_tile_ok(const ConvParams& p, int sb_tile);  // per-tile restrictions (the pipelined "sbd" tiles: fp32 operands, fp32-accurate mode)
 int conv_sb_default_tile(const ConvParams& p);
 void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s);
+// split-K factor for a launch (1 = none): deep-K shapes whose 64x64 tiling gives too few blocks for 256 CUs (the MiT spatial-
+// reduction convs: 3 200 rows, K up to 4 096); the caller allocates g[].partial = splitk * M * ldy floats and sets ConvParams::splitk
+int conv_splitk_factor(const ConvParams& p);
+int conv_splitk_shape(long M, int Cout, int KH, int KWCp, int groups);  // its shape-only part
 const char* conv_tile_name(int tile_id);
 
 // rows x C LayerNorm (biased variance), y may alias x

@@ -335,3 +335,23 @@ def test_fused_prediction_heads_equal_standalone_kernel(monkeypatch):
         for a, b in zip(base, alt):
             assert torch.equal(a["pred_gravity"], b["pred_gravity"]) and torch.equal(a["pred_latitude"], b["pred_latitude"])
             assert float(a["pred_roll"]) == float(b["pred_roll"]) and float(a["pred_pitch"]) == float(b["pred_pitch"])
+
+
+def test_split_k_agrees_with_single_pass(monkeypatch):
+    """Deep-K launches with too few tiles for 256 CUs (the MiT spatial-reduction convs: 100 x B rows, K up to 4 096) contract K
+    in slices by separate blocks + a deterministic reduce (ConvParams::splitk).  PF_SPLITK=0 disables it: same results up to
+    fp32 summation order, far inside the parity tolerances; and the split path itself is run-to-run deterministic."""
+    from perspectivefields_amd import PerspectiveFields
+
+    imgs = [synthetic_image(72, 96, seed=700 + i) for i in range(3)]
+    base = model("centered").inference_batch(imgs)
+    again = model("centered").inference_batch(imgs)
+    monkeypatch.setenv("PF_SPLITK", "0")
+    alt = PerspectiveFields(CASES["centered"], weights="synthetic:0").eval().cuda().inference_batch(imgs)
+    for a, b, c2 in zip(base, alt, again):
+        assert torch.equal(a["pred_gravity"], c2["pred_gravity"]) and float(a["pred_roll"]) == float(c2["pred_roll"])
+        c = one_minus_cos(a["pred_gravity"].cpu().numpy(), b["pred_gravity"].cpu().numpy()).max()
+        e = l1(a["pred_latitude"].cpu().numpy(), b["pred_latitude"].cpu().numpy())
+        d = max(abs(float(a[k]) - float(b[k])) for k in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
+        print(f"[split-K vs single pass] 1-cos {c:.2e} latL1 {e:.2e} param {d:.2e}")
+        assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
