@@ -201,7 +201,7 @@ int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, 
                  const float* d_res1, const float* d_res2, int post_relu, int nchw_out, int tile_id /*-1 auto*/,
                  float* d_y /*may be NULL when d_y_planes is given*/,
                  const uint16_t* d_x_planes /*replaces d_x*/, long x_plane_elems, const uint16_t* d_x2_planes, long x2_plane_elems,
-                 uint16_t* d_y_planes, long y_plane_elems, int precision /*PF_PRECISION_*: split tiles only*/, void* stream);
+                 uint16_t* d_y_planes, long y_plane_elems, int precision /*PF_PRECISION_* (split tiles only); + 16: no split-K (otherwise applied by the engine's rule)*/, void* stream);
 /* times `iters` launches of one conv shape on random data with tile config `tile_id` (-1 auto); avg ms per launch.
  * fmt_prec = fmt + 16 * precision; fmt 0: fp32 in / out; 1: input as bf16 planes; 2: input and output as planes
  * (1 / 2: the exact bf16 split); precision = PF_PRECISION_* used by the split tiles */

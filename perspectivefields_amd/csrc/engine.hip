@@ -1352,7 +1352,9 @@ const char* pf_op_conv_tile_name(int id) { return conv_tile_name(id); }
 int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int W, int C1, int C2, const float* hw, const float* hb,
                  int Cout, int KH, int KW, int stride, int pad, int act, const float* res1, const float* res2, int post_relu,
                  int nchw_out, int tile_id, float* y, const uint16_t* x_planes, long x_plane_elems, const uint16_t* x2_planes,
-                 long x2_plane_elems, uint16_t* y_planes, long y_plane_elems, int precision, void* stream) {
+                 long x2_plane_elems, uint16_t* y_planes, long y_plane_elems, int precision_flags, void* stream) {
+  const int precision = precision_flags & 15;
+  const bool allow_splitk = !(precision_flags & 16);
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
@@ -1384,7 +1386,7 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   // an explicit tile that cannot read / write split planes is an error; with fp32 operands an unusable tile id falls back to the cost model
   if (tile_id >= 0 && !conv_tile_usable(p, tile_id) && (x_planes || y_planes)) { g_create_error = "pf_op_conv2d: tile config cannot run this operand format"; return PF_ERR_ARG; }
   {  // split-K by the engine's rule (scratch for the partial sums from a temporary allocation)
-    const int S = conv_splitk_factor(p);
+    const int S = allow_splitk ? conv_splitk_factor(p) : 1;
     if (S > 1) {
       void* d = nullptr;
       if (hipMalloc(&d, (size_t)S * p.M * p.Cout * 4) == hipSuccess) { tmp.p.push_back(d); p.g[0].partial = static_cast<float*>(d); p.splitk = S; }

@@ -23,6 +23,7 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {128, 128, 0, "sbhd128x128"}, {128, 64, 0, "sbhd128x64"}, {128, 32, 0, "sbhd128x32"}, {256, 64, 0, "sbhd256x64w8"},
                              {256, 64, 0, "sbh256x64w8t3"}, {128, 64, 0, "sbh128x64t3"},
 #endif
+                             {256, 32, 0, "sbh256x32"},  // split-f16 scheme: 16 x 16 patch, N = 32, 4 waves
 };
 static constexpr int kFirstH = 12;  // index of the first "sbh" tile
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }

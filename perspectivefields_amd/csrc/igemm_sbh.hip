@@ -350,7 +350,7 @@ static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(WM * WN * 64);
   if (p.ups) {  // conv_sbh_tile_ok: split-f16 scheme, 8 x 16 patch / 4-wave tiles, plain tap loop
-    if constexpr (H_TY == 8 && WM * WN == 4 && TPG == 1 && !DB) {
+    if constexpr (WM * WN == 4 && TPG == 1 && !DB) {
       if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, 1, NT_F16X3, false, true>), grid, block, 0, s, p);
       else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, 1, NT_F16X3, false, true>), grid, block, 0, s, p);
     }
@@ -382,7 +382,13 @@ bool conv_sbh_ok(const ConvParams& p) {
 // fused up-sampling (p.ups): split-f16 scheme, tiles 0-2 (8 x 16 patch, 4 waves, plain tap loop)
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
   if (!conv_sbh_ok(p)) return false;
-  if (p.ups) return h_tile < 3 && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
+#ifdef PF_TUNING_BUILD
+  constexpr int kWide32 = 10;  // "sbh256x32": after the tuning-only tiles
+#else
+  constexpr int kWide32 = 4;
+#endif
+  if (p.ups) return (h_tile < 3 || h_tile == kWide32) && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
+  if (h_tile == kWide32) return p.nterms == NT_F16X3;
 #ifdef PF_TUNING_BUILD
   return h_tile < 4 || p.nterms == NT_F16X3;
 #else
@@ -396,7 +402,11 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
     case 0: launch_sbh_cfg<8, 16, 128, 2, 2>(p, s); break;
     case 1: launch_sbh_cfg<8, 16, 64, 2, 2>(p, s); break;
     case 2: launch_sbh_cfg<8, 16, 32, 4, 1>(p, s); break;
-#ifdef PF_TUNING_BUILD  // measured, no gain (profiles/r02_negative_results.md)
+#ifndef PF_TUNING_BUILD
+    case 4: launch_sbh_cfg<16, 16, 32, 4, 1>(p, s); break;  // "sbh256x32": 16 x 16 patch for the N = 32 layer (twice the MFMAs per barrier)
+#else
+    case 10: launch_sbh_cfg<16, 16, 32, 4, 1>(p, s); break;
+    // measured, no gain (profiles/r02_negative_results.md)
     case 4: launch_sbh_cfg<8, 16, 128, 2, 2, 1, true>(p, s); break;
     case 5: launch_sbh_cfg<8, 16, 64, 2, 2, 1, true>(p, s); break;
     case 6: launch_sbh_cfg<8, 16, 32, 4, 1, 1, true>(p, s); break;

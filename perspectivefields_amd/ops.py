@@ -65,11 +65,11 @@ def _pl(planes):
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, post_relu=False, x2=None, nchw_out=False, tile=-1,
-           planes_in=False, planes_out=False, precision=0, planes_fmt="bf16x3"):
+           planes_in=False, planes_out=False, precision=0, planes_fmt="bf16x3", splitk=True):
     """x: (B,H,W,C1) [+ x2: (B,H,W,C2) channel-concat]; weight: (Cout, C1+C2, KH, KW).  Returns (B,Ho,Wo,Cout) or NCHW.
     planes_in: hand the input(s) to the kernel as split-bf16 planes only; planes_out: take the output as planes
     (returned merged back to fp32, which is exact).  precision (split tiles): 0 split-f16 (default parity scheme), 3 exact bf16
-    split, 1 bf16x3, 2 bf16."""
+    split, 1 bf16x3, 2 bf16.  splitk=False: never contract K in slices (the engine's split-K rule applies otherwise)."""
     import torch
 
     lib = load_library()
@@ -92,7 +92,7 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, act=0, res1=None, res2=None, p
     rc = lib.pf_op_conv2d(
         x.device.index, None if planes_in else x.data_ptr(), None if planes_in else _dp(x2), B, H, W, C1, C2, _hp(w), _hp(b),
         Cout, KH, KW, stride, pad, act, _dp(res1), _dp(res2), int(post_relu), int(nchw_out), tile, _dp(y),
-        *_pl(xp), *_pl(x2p), *_pl(yp), precision, _stream_ptr(),
+        *_pl(xp), *_pl(x2p), *_pl(yp), precision + (0 if splitk else 16), _stream_ptr(),
     )
     _check(rc, None, "pf_op_conv2d")
     return yp.merge() if planes_out else y

@@ -101,11 +101,12 @@ def test_conv2d_split_plane_operands(ops, case):
     sb = [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbh")]  # the halo tiles take fp32 operands only
     assert sb
     for tile in sb:
-        base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, precision=3)  # the exact bf16 split (planes are its format)
-        got_in = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True)
+        # (splitk=False: split-K, which only fp32-in / fp32-out launches use, changes the summation order)
+        base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, precision=3, splitk=False)  # the exact bf16 split (planes are its format)
+        got_in = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, splitk=False)
         assert torch.equal(got_in, base), f"{name} {names[tile]}: split-plane input differs from fp32 input"
         if Cout % 4 == 0:
-            got_io = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_out=True)
+            got_io = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_out=True, splitk=False)
             assert torch.equal(got_io, base), f"{name} {names[tile]}: split-plane output differs"
     # automatic tile choice with plane operands only (no fp32 tile can run) + oracle check
     got = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, planes_in=True, planes_out=Cout % 4 == 0)
@@ -173,11 +174,11 @@ def test_conv2d_split_f16_plane_operands(ops, case):
     b = _rand((Cout,), 4, 0.1)
     names = ops.conv_tiles()
     for tile in [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbh")]:
-        base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, precision=0)
-        got_in = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_fmt="f16x2")
+        base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, precision=0, splitk=False)
+        got_in = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_fmt="f16x2", splitk=False)
         assert torch.equal(got_in, base), f"{name} {names[tile]}: fp16-plane input differs from fp32 input"
         if Cout % 4 == 0:
-            got_io = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_out=True, planes_fmt="f16x2")
+            got_io = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_out=True, planes_fmt="f16x2", splitk=False)
             assert float(((got_io - base).abs() / (base.abs() + 1e-4)).max()) <= 2.0 ** -21, f"{name} {names[tile]}: fp16-plane output"
     # round trip of the format itself: 22+ significant bits inside the fp16 range, saturation outside
     v = _rand((4, 8, 8, 32), 5) * torch.exp2(torch.randint(-10, 12, (4, 8, 8, 32)).float())
