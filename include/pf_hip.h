@@ -205,16 +205,26 @@ int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, 
 /* times `iters` launches of one conv shape on random data with tile config `tile_id` (-1 auto); avg ms per launch.
  * fmt_prec = fmt + 16 * precision; fmt 0: fp32 in / out; 1: input as bf16 planes; 2: input and output as planes
  * (1 / 2: the exact bf16 split); precision = PF_PRECISION_* used by the split tiles */
+/* y = act(Linear(LayerNorm(x))) + res1 with the LayerNorm fused into the GEMM (ConvParams::ln: row statistics accumulated while the rows are
+ * staged, gamma / beta folded into the weights / bias here on the host) -- the engine's form of mix_transformers.py:200 (norm2 -> fc1),
+ * :123-126 (sr norm -> kv) and convnext.py:50-51 (norm -> pwconv1).  K % 32 == 0, N % 4 == 0; tile_id as pf_op_conv2d (linear split tiles only). */
+int pf_op_linear_ln(int device, const float* d_x, long rows, int K, const float* h_weight /*[N][K]*/, const float* h_bias, const float* h_gamma, const float* h_beta,
+                    float eps, int N, int act, const float* d_res1, int tile_id, float* d_y, int precision, void* stream);
 int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt_prec, float* ms_out);
 /* fp32 <-> planes in the format selected by bit 0 of plane_elems (the names are historical) */
 int pf_op_split_bf16(int device, const float* d_x, long n, uint16_t* d_planes, long plane_elems, void* stream);
 int pf_op_merge_bf16(int device, const uint16_t* d_planes, long plane_elems, long n, float* d_y, void* stream);
-/* times one depthwise-3x3+GELU launch variant on random data (0 = LDS halo tile, 1-4 = register-window direct, 99 = plain copy) */
+/* times one depthwise-3x3+GELU launch variant on random data (0 = LDS halo tile, 1-4 = register-window direct, 99 = plain copy; 0, 1, 3, 99: tuning builds only;
+ * 1000 + 100 s + 10 t + c: multi-column kernel, block shape s, strip height t, (columns, prefetch) code c -- elem.hip) */
 int pf_op_dwconv3x3_bench(int device, int variant, int B, int H, int W, int C, int iters, float* ms_out);
 int pf_op_layernorm(int device, const float* d_x, const float* h_gamma, const float* h_beta, float* d_y, long rows, int C, float eps,
                     uint16_t* d_y_planes, long plane_elems, void* stream);
 int pf_op_dwconv3x3_gelu(int device, const float* d_x, const float* h_weight /*[C][1][3][3]*/, const float* h_bias, float* d_y, int B, int H, int W, int C,
                          uint16_t* d_y_planes, long plane_elems, void* stream);
+/* the same with an explicit kernel variant (pf_op_dwconv3x3_bench's ids; >= 1000: multi-column / prefetching kernel, falls back to the
+ * default when the shape does not fit its block) */
+int pf_op_dwconv3x3_gelu_cfg(int device, const float* d_x, const float* h_weight, const float* h_bias, float* d_y, int B, int H, int W, int C,
+                             uint16_t* d_y_planes, long plane_elems, int variant, void* stream);
 int pf_op_dwconv7x7(int device, const float* d_x, const float* h_weight /*[C][1][7][7]*/, const float* h_bias, float* d_y, int B, int H, int W, int C, void* stream);
 /* the same with an explicit kernel: variant 3 = column-blocked streaming kernel (nc = 4 / 2 output columns per thread, nb = 2 / 3
  * row buffers, th = rows per strip; 0 = automatic), 2 = one column per lane; and a timing loop on random data (avg ms per launch) */

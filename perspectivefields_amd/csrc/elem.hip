@@ -28,6 +28,7 @@ __device__ __forceinline__ float gelu_fast(float v) {
   return 0.5f * v * (1.0f + er);
 }
 typedef float f32x2e __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
@@ -253,11 +254,162 @@ __global__ __launch_bounds__(CQB * XB) void dwconv3x3_gelu_direct_kernel(const f
   }
 }
 
+// Multi-column form with a row prefetch.  The kernel above keeps 3 x 16 bytes per lane in flight and then waits for them
+// (the row it loads is the row it needs next): with 16 waves per CU that is ~49 KB in flight per CU, i.e. by Little's law
+// ~4.8 TB/s at the ~2.5 us loaded HBM latency -- exactly what its loads-only ablation measures.  Here a thread owns NC adjacent
+// columns of one channel quad (NC + 2 loads per row for NC outputs instead of 3 per output) and loads row oy + 1 + PF while it
+// computes row oy from rows loaded earlier: (1 + PF) x (NC + 2) x 16 bytes per lane in flight.  Same tap order as above:
+// bit-identical results.  Row buffers rotate by name (the loop is unrolled over the 3 + PF buffers).
+template <int CQB /*quads per block*/, int XB /*threads along x*/, int TH /*rows per strip*/, int NC /*columns per thread*/, int PF /*rows loaded ahead*/, bool SB = false /*split-plane output (y_sb) instead of / next to fp32*/>
+__global__ __launch_bounds__(CQB * XB, (NC + 2) * (3 + PF) < 16 ? 4 : 3) void dwconv3x3_gelu_mc_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
+                                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                                     unsigned short* __restrict__ y_sb, size_t sb_plane,
+                                                                     int B, int H, int W, int C) {
+  constexpr int NB = 3 + PF, NL = NC + 2;
+  const int CQ = C >> 2;
+  const int slabs = CQ / CQB, tilesX = (W + XB * NC - 1) / (XB * NC), strips = (H + TH - 1) / TH;
+  const int nblk = B * strips * tilesX * slabs;
+  int t;
+  {
+    const int b = blockIdx.x, qd = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    t = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+  }
+  const int slab = t % slabs; t /= slabs;
+  const int tx = t % tilesX; t /= tilesX;
+  const int st = t % strips; t /= strips;
+  const int b = t;
+  const int q = slab * CQB + threadIdx.x % CQB;
+  const int ox = (tx * XB + threadIdx.x / CQB) * NC;
+  if (ox >= W) return;
+  const int y0 = st * TH, y1 = min(y0 + TH, H);
+  // one buffer descriptor per image (an image of the largest hidden map is 6.5 MB): 32-bit byte offsets, a column outside the map
+  // or a row outside it / past the strip's halo row gets an out-of-range offset (loads return zeros, stores are dropped) -- no
+  // 64-bit address arithmetic and no branch around any memory instruction
+  const unsigned img_bytes = (unsigned)H * W * C * 4u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)b * H * W * C, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((SB && !y) ? const_cast<float*>(x) : y + (size_t)b * H * W * C, 0, (SB && !y) ? 0 : img_bytes, 0x00020000);
+  const long ybase = (long)b * H * W * CQ;  // float4 index of (b, 0, 0, 0): split-plane output only
+  float4 wk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const float4*>(w9c)[(long)k * CQ + q];
+  const float4 bv = reinterpret_cast<const float4*>(bias)[q];
+  unsigned coff[NL];  // byte offset of (row 0, column ox - 1 + j, quad q); 2^30 (>= any image) when the column is outside the map
+#pragma unroll
+  for (int j = 0; j < NL; ++j) coff[j] = (unsigned)(ox - 1 + j) < (unsigned)W ? (unsigned)((ox - 1 + j) * CQ + q) * 16u : 0x40000000u;
+  const unsigned row_bytes = (unsigned)W * C * 4u;
+  auto load_row = [&](int iy, float4 (&row)[NL]) {
+    const unsigned rb = ((unsigned)iy < (unsigned)H && iy <= y1) ? (unsigned)iy * row_bytes : 0x80000000u;  // block-uniform
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const u32x4e v = __builtin_amdgcn_raw_buffer_load_b128(rx, rb + coff[j], 0, 0);
+      row[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  };
+  auto lo = [](const float4& v) { return f32x2e{v.x, v.y}; };
+  auto hi = [](const float4& v) { return f32x2e{v.z, v.w}; };
+  auto emit = [&](int oy, const float4 (&tr)[NL], const float4 (&mr)[NL], const float4 (&br)[NL]) {
+    const unsigned rb = (unsigned)oy * row_bytes;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      f32x2e a0 = lo(bv), a1 = hi(bv);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        a0 = __builtin_elementwise_fma(lo(tr[k + c]), lo(wk[c]), a0);     a1 = __builtin_elementwise_fma(hi(tr[k + c]), hi(wk[c]), a1);
+        a0 = __builtin_elementwise_fma(lo(mr[k + c]), lo(wk[3 + c]), a0); a1 = __builtin_elementwise_fma(hi(mr[k + c]), hi(wk[3 + c]), a1);
+        a0 = __builtin_elementwise_fma(lo(br[k + c]), lo(wk[6 + c]), a0); a1 = __builtin_elementwise_fma(hi(br[k + c]), hi(wk[6 + c]), a1);
+      }
+      const float4 a = make_float4(gelu_fast(a0.x), gelu_fast(a0.y), gelu_fast(a1.x), gelu_fast(a1.y));
+      if (!SB || y) {
+        const u32x4e v = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, ry, rb + coff[k + 1], 0, 0);  // column outside the map: dropped
+      }
+      if (SB && coff[k + 1] != 0x40000000u) store_sb4(y_sb, sb_plane, (size_t)(ybase + ((long)oy * W + ox + k) * CQ + q) * 4, a);
+    }
+  };
+  float4 R[NB][NL];
+#pragma unroll
+  for (int k = 0; k < 2 + PF; ++k) load_row(y0 - 1 + k, R[k]);  // rows y0 - 1 .. y0 + PF
+  int oy = y0;
+  for (; oy + NB <= y1; oy += NB) {  // whole groups: no branch around any load
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      load_row(oy + u + 1 + PF, R[(u + 2 + PF) % NB]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the issue order: hipcc otherwise hoists the loads of the whole group (and spills)
+      emit(oy + u, R[u % NB], R[(u + 1) % NB], R[(u + 2) % NB]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll 1
+  for (; oy < y1; ++oy) {  // fewer than 3 + PF rows left: rolled, buffers rotate by register moves
+    load_row(oy + 1 + PF, R[NB - 1]);
+    emit(oy, R[0], R[1], R[2]);
+#pragma unroll
+    for (int k = 0; k + 1 < NB; ++k)
+#pragma unroll
+      for (int j = 0; j < NL; ++j) R[k][j] = R[k + 1][j];
+  }
+}
+
 #ifdef PF_TUNING_BUILD
 __global__ __launch_bounds__(256) void copy_f4_kernel(const float4* __restrict__ x, float4* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = x[i];
 }
 #endif
+
+template <int CQB, int XB, int TH, int NC, int PF>
+static bool launch_dw3_mc(const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb, size_t sb_plane) {
+  const int CQ = C / 4;
+  if (CQ % CQB != 0 || W % (XB * NC) != 0) return false;
+  const long blocks = (long)B * ((H + TH - 1) / TH) * (W / (XB * NC)) * (CQ / CQB);
+  if (y_sb) hipLaunchKernelGGL((dwconv3x3_gelu_mc_kernel<CQB, XB, TH, NC, PF, true>), dim3((unsigned)blocks), dim3(CQB * XB), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
+  else      hipLaunchKernelGGL((dwconv3x3_gelu_mc_kernel<CQB, XB, TH, NC, PF, false>), dim3((unsigned)blocks), dim3(CQB * XB), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
+  return true;
+}
+// code = 100 shape + 10 strip + np.  shape (quads x x-threads per block): 0 = 32 x 8, 1 = 64 x 4, 2 = 64 x 2, 3 = 64 x 5; strip: 8 / 16 / 40 rows;
+// np (columns per thread, rows loaded ahead): 0 (1, 1), 1 (2, 0), 2 (2, 1), 3 (2, 2), 4 (1, 2).  The product build carries the three forms the
+// sweep picked (profiles/r02_tune_dw3_mc.txt); everything else is a tuning build (PF_TUNING_BUILD=1) -- unknown codes return false (-> default).
+#define PF_DW3_ARGS x, w9c, bias, y, B, H, W, C, s, y_sb, sb_plane
+#ifdef PF_TUNING_BUILD
+template <int CQB, int XB, int TH>
+static bool launch_dw3_mc_np(int np, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb, size_t sb_plane) {
+  switch (np) {
+    case 0: return launch_dw3_mc<CQB, XB, TH, 1, 1>(PF_DW3_ARGS);
+    case 1: return launch_dw3_mc<CQB, XB, TH, 2, 0>(PF_DW3_ARGS);
+    case 2: return launch_dw3_mc<CQB, XB, TH, 2, 1>(PF_DW3_ARGS);
+    case 3: return launch_dw3_mc<CQB, XB, TH, 2, 2>(PF_DW3_ARGS);
+    case 4: return launch_dw3_mc<CQB, XB, TH, 1, 2>(PF_DW3_ARGS);
+    default: return false;
+  }
+}
+template <int CQB, int XB>
+static bool launch_dw3_mc_th(int th, int np, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb, size_t sb_plane) {
+  switch (th) {
+    case 0: return launch_dw3_mc_np<CQB, XB, 8>(np, PF_DW3_ARGS);
+    case 1: return launch_dw3_mc_np<CQB, XB, 16>(np, PF_DW3_ARGS);
+    case 2: return launch_dw3_mc_np<CQB, XB, 40>(np, PF_DW3_ARGS);
+    default: return false;
+  }
+}
+#endif
+static bool launch_dw3_mc_variant(int code, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb, size_t sb_plane) {
+#ifdef PF_TUNING_BUILD
+  const int shape = code / 100, th = (code / 10) % 10, np = code % 10;
+  switch (shape) {
+    case 0: return launch_dw3_mc_th<32, 8>(th, np, PF_DW3_ARGS);
+    case 1: return launch_dw3_mc_th<64, 4>(th, np, PF_DW3_ARGS);
+    case 2: return launch_dw3_mc_th<64, 2>(th, np, PF_DW3_ARGS);
+    case 3: return launch_dw3_mc_th<64, 5>(th, np, PF_DW3_ARGS);
+    default: return false;
+  }
+#else
+  switch (code) {
+    case 223: return launch_dw3_mc<64, 2, 40, 2, 2>(PF_DW3_ARGS);  // 80^2 maps: 4 columns x 64 quads per 128-thread block, two rows ahead
+    case 100: return launch_dw3_mc<64, 4, 8, 1, 1>(PF_DW3_ARGS);   // 40^2 / 20^2
+    case 314: return launch_dw3_mc<64, 5, 16, 1, 2>(PF_DW3_ARGS);  // 10^2
+    default: return false;
+  }
+#endif
+}
 
 static int g_dw3_variant = -1;
 void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s,
@@ -288,6 +440,10 @@ void launch_dwconv3x3_gelu_variant(int variant, const float* x, const float* w9c
     return;
   }
 #endif
+  if (variant >= 1000) {  // multi-column / prefetching kernel: 1000 + 100 block shape + 10 strip height + (columns, prefetch) code
+    if (launch_dw3_mc_variant(variant - 1000, x, w9c, bias, y, B, H, W, C, s, y_sb, sb_plane)) return;
+    variant = H >= 16 ? 4 : 2;
+  }
   if (variant == 2 && CQ % 64 == 0) {  // 64 quads x 4 columns, strips of 16 rows (10^2 maps)
     const long blocks = (long)B * ((H + 15) / 16) * ((W + 3) / 4) * (CQ / 64);
     hipLaunchKernelGGL((dwconv3x3_gelu_direct_kernel<64, 4, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, w9c, bias, y, y_sb, sb_plane, B, H, W, C);
@@ -305,7 +461,13 @@ void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, 
   }
   // default: register-window kernel; strip height / block shape by map size (scripts/tune_dw.py, profiles/r01_tune_dw_v2.txt:
   // 8-row strips win or tie at 80^2 .. 20^2 now that the GELU is branch-free; 64-quad blocks at 10^2)
-  const int v = g_dw3_variant >= 0 ? g_dw3_variant : (H >= 16 ? 4 : 2);
+  // r02: the multi-column / prefetching kernel where the map fits one of its block shapes (sweep: profiles/r02_tune_dw3_mc.txt), else as before
+  int v = g_dw3_variant >= 0 ? g_dw3_variant : (H >= 16 ? 4 : 2);
+  if (g_dw3_variant < 0 && (C / 4) % 64 == 0) {
+    if (W >= 64 && W % 4 == 0) v = 1223;
+    else if (W >= 16 && W % 4 == 0) v = 1100;
+    else if (W % 5 == 0) v = 1314;
+  }
   launch_dwconv3x3_gelu_variant(v, x, w9c, bias, y, B, H, W, C, s, y_sb, sb_plane);
 }
 

@@ -59,6 +59,8 @@ struct ConvW {
   unsigned short* wsb = nullptr;  // weights split exactly into 3 bf16 planes (split-bf16 kernel), when Cin % 32 == 0
   unsigned short* wh16 = nullptr; // split-f16 scheme: per-channel power-of-two scaled weights as two fp16 planes wh, wl
   float* wh16_inv = nullptr;      //   and the inverse scale per output channel
+  float* ln_s = nullptr;          // fused input LayerNorm (ConvParams::ln): column sums of the gamma-folded weights; nullptr = no fusion
+  float ln_eps = 0.f;
   int Cout = 0, Cin = 0 /*padded*/, CinReal = 0, KH = 1, KW = 1, stride = 1, pad = 0, KWC = 0, KWCp = 0;
 };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-6f; };
@@ -228,6 +230,23 @@ F16Planes split_f16x2(const std::vector<float>& w, int Cout) {
   return o;
 }
 
+// LayerNorm folded into the Linear that consumes it (ConvParams::ln), in fp64:
+//   Linear(LN(x)) = rstd (x - mean) . (W gamma) + (b + W beta)  ->  W'[n][k] = W[n][k] gamma[k], bias' = b + W beta, colsum[n] = sum_k W'[n][k]
+void fold_ln_linear(const float* w, const float* b, const float* g, const float* be, int N, int K, std::vector<float>* wf, std::vector<float>* bf, std::vector<float>* cs) {
+  wf->resize((size_t)N * K); bf->resize(N); cs->resize(N);
+  for (int n = 0; n < N; ++n) {
+    double sb = b ? (double)b[n] : 0.0, sc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double wv = w[(size_t)n * K + k];
+      const float wg = (float)(wv * (double)g[k]);
+      (*wf)[(size_t)n * K + k] = wg;
+      sc += (double)wg;  // the sum of the weights the kernel really multiplies
+      sb += wv * (double)be[k];
+    }
+    (*bf)[n] = (float)sb; (*cs)[n] = (float)sc;
+  }
+}
+
 // Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR (triangle, support 1) filter, in double, so that
 // the integer tables are bit-identical to the ones PIL builds (reference path: perspectivefields.py:45 -> Image.resize).
 struct ResizeTable { int ksize = 0; std::vector<int> bounds, kk; int *d_bounds = nullptr, *d_kk = nullptr; };
@@ -288,6 +307,9 @@ struct pf_engine {
   bool fuse_pred = true;     // PF_FUSE_PRED=0: keep the 32-channel 320x320 maps and run the regression prediction heads as their own kernel
   bool fuse_upsample = true; // PF_FUSE_UPSAMPLE=0: materialise the two largest bilinear x2 maps (160^2 x 256, 320^2 x 64 per head) instead of
                              // interpolating them inside the consuming 3x3 convs' halo staging (split-f16 scheme only)
+  bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
+                             // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
+                             // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
   int nterms = NT_F16X3;     // pf_set_precision: NT_F16X3 = 2-way fp16 split, 3 MFMAs per product (default parity mode); 6 = exact 3-way bf16 split
                              // (fp32-accurate, PF_PRECISION_FP32_BF16X6); 3 = "bf16x3", 1 = "bf16" (reduced precision, not parity modes)
@@ -374,12 +396,24 @@ struct pf_engine {
     c.Cout = Cout; c.Cin = CinP; c.CinReal = Cin; c.KH = c.KW = K; c.stride = stride; c.pad = pad;
     return c;
   }
-  ConvW make_linear(const std::string& pfx, int N, int K, const double* out_scale = nullptr) {
+  // ln_pfx != "" (and fuse_ln): the LayerNorm `ln_pfx` in front of this Linear is folded into it (fold_ln_linear)
+  ConvW make_linear(const std::string& pfx, int N, int K, const double* out_scale = nullptr, const std::string& ln_pfx = "", float ln_eps = 0.f) {
     ConvW c;
     const HostTensor& w = get(pfx + ".weight", {N, K});
-    upload_conv_weights(c, pack_conv(w.data.data(), N, K, 1, 1, K, out_scale, &c.KWC, &c.KWCp), K, N);
     std::vector<float> b = get(pfx + ".bias", {N}).data;
-    if (out_scale) for (int n = 0; n < N; ++n) b[n] = (float)(b[n] * out_scale[n]);
+    if (!ln_pfx.empty() && fuse_ln && K % 32 == 0 && N % 4 == 0) {
+      const std::vector<float>& g = get(ln_pfx + ".weight", {K}).data;
+      const std::vector<float>& be = get(ln_pfx + ".bias", {K}).data;
+      std::vector<float> wf, bf, cs;
+      fold_ln_linear(w.data.data(), b.data(), g.data(), be.data(), N, K, &wf, &bf, &cs);
+      b = bf;
+      upload_conv_weights(c, pack_conv(wf.data(), N, K, 1, 1, K, nullptr, &c.KWC, &c.KWCp), K, N);
+      c.ln_s = upload(cs);
+      c.ln_eps = ln_eps;
+    } else {
+      upload_conv_weights(c, pack_conv(w.data.data(), N, K, 1, 1, K, out_scale, &c.KWC, &c.KWCp), K, N);
+      if (out_scale) for (int n = 0; n < N; ++n) b[n] = (float)(b[n] * out_scale[n]);
+    }
     c.b = upload(b);
     c.Cout = N; c.Cin = K; c.CinReal = K; c.KH = c.KW = 1; c.stride = 1; c.pad = 0;
     return c;
@@ -489,14 +523,17 @@ struct pf_engine {
         MitBlock mb;
         mb.n1 = make_ln(b + ".norm1", C, 1e-6f);  // mit_b3 norm_layer eps (:519)
         mb.n2 = make_ln(b + ".norm2", C, 1e-6f);
-        mb.q = make_linear(b + ".attn.q", C, C);
-        mb.kv = make_linear(b + ".attn.kv", 2 * C, C);
+        // fused LayerNorms (fuse_ln): with spatial reduction norm1 also feeds the sr conv (several pixels per GEMM row) and stays a kernel;
+        // without it (stage 4) q and kv are its only consumers.  The sr norm feeds kv only, norm2 feeds fc1 only.
+        const bool sr1 = MIT_SR[s] == 1;
+        mb.q = make_linear(b + ".attn.q", C, C, nullptr, sr1 ? b + ".norm1" : "", 1e-6f);
+        mb.kv = make_linear(b + ".attn.kv", 2 * C, C, nullptr, sr1 ? b + ".norm1" : b + ".attn.norm", sr1 ? 1e-6f : 1e-5f);
         mb.proj = make_linear(b + ".attn.proj", C, C);
         if (MIT_SR[s] > 1) {
           mb.sr = make_conv(b + ".attn.sr.weight", b + ".attn.sr.bias", C, C, MIT_SR[s], MIT_SR[s], 0);
           mb.srn = make_ln(b + ".attn.norm", C, 1e-5f);  // Attention.norm default eps (:89)
         }
-        mb.fc1 = make_linear(b + ".mlp.fc1", 4 * C, C);
+        mb.fc1 = make_linear(b + ".mlp.fc1", 4 * C, C, nullptr, b + ".norm2", 1e-6f);
         mb.dw = make_dw(b + ".mlp.dwconv.dwconv", 4 * C, 3);
         mb.fc2 = make_linear(b + ".mlp.fc2", C, 4 * C);
         stages[s].blocks.push_back(mb);
@@ -542,7 +579,7 @@ struct pf_engine {
           CnxBlock cb;
           cb.dw = make_dw(b + ".dwconv", C, 7);
           cb.n = make_ln(b + ".norm", C, 1e-6f);
-          cb.pw1 = make_linear(b + ".pwconv1", 4 * C, C);
+          cb.pw1 = make_linear(b + ".pwconv1", 4 * C, C, nullptr, b + ".norm", 1e-6f);
           // layer scale gamma folded into pwconv2 (convnext.py:54-55: x = gamma * x)
           const std::vector<float>& gm = get(b + ".gamma", {C}).data;
           std::vector<double> sc(gm.begin(), gm.end());
@@ -574,7 +611,7 @@ struct pf_engine {
     // from the shape and the call's operand set, so that the workspace dry run takes the same decision
     int splitk = 1;
     {
-      bool plain = !nchw && !ups && w.Cin % 32 == 0 && w.KWCp > 0;
+      bool plain = !nchw && !ups && !w.ln_s && w.Cin % 32 == 0 && w.KWCp > 0;
       for (int g = 0; g < ngroups; ++g)
         if (calls[g].head_kind || calls[g].w->btab || calls[g].res2 || calls[g].y.s.p || !calls[g].y.f || calls[g].x.s.p) plain = false;
       if (plain && split_bf16) splitk = conv_splitk_shape((long)B * Ho_ * Wo_, w.Cout, w.KH, w.KWCp, ngroups);
@@ -594,6 +631,7 @@ struct pf_engine {
       q.x = calls[g].x.f; q.x2 = calls[g].x2.f; q.w = wg.w; q.w_sb = wg.wsb; q.w_h16 = wg.wh16; q.w_h16_inv_scale = wg.wh16_inv; q.bias = wg.b; q.bias_tab = wg.btab;
       q.res1 = calls[g].res1; q.res2 = calls[g].res2; q.y = calls[g].y.f;
       q.x_sb = calls[g].x.s.p; q.x2_sb = calls[g].x2.s.p; q.y_sb = calls[g].y.s.p;
+      q.ln_colsum = wg.ln_s;
       q.head_kind = calls[g].head_kind; q.head_w = calls[g].head_w; q.head_b = calls[g].head_b; q.head_out = calls[g].head_out; q.head_pn = calls[g].head_pn;
     }
     p.x_sb_plane = calls[0].x.s.plane; p.x2_sb_plane = calls[0].x2.s.plane; p.y_sb_plane = calls[0].y.s.plane;
@@ -604,6 +642,7 @@ struct pf_engine {
     p.act = act; p.post_relu = post_relu; p.nchw_out = nchw;
     p.nterms = nterms;
     p.ups = ups;
+    p.ln = w.ln_s ? 1 : 0; p.ln_eps = w.ln_eps;
     p.finish();
     if (part) {
       p.splitk = splitk;
@@ -614,8 +653,9 @@ struct pf_engine {
       // operand formats are part of the key: a split-plane input changes which tile is fastest
       const int prec_code = nterms == NT_F16X3 ? 0 : (nterms == 6 ? 3 : (nterms == 3 ? 1 : 2));  // = PF_PRECISION_*
       const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * prec_code + 128 * ups + 256 * (calls[0].head_kind ? 1 : 0);
-      const std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out, fmt_bits, p.act};
+      std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out, fmt_bits + 512 * p.ln, p.act};
       auto it = tile_cache.find(key);
+      if (it == tile_cache.end() && p.ln && !(c.tuning && c.tune_scratch)) { key[10] = fmt_bits; it = tile_cache.find(key); }  // table without the fused form: same shape's tile
       if (it != tile_cache.end()) tile = it->second;
       else if (c.tuning && c.tune_scratch) { tile = tune_conv(p, c); tile_cache[key] = tile; }
     }
@@ -704,13 +744,22 @@ struct pf_engine {
       const Ten h2 = c.ten(M * 4 * C, !S, S);
       for (MitBlock& mb : st.blocks) {
         // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
-        ln(c, mb.n1, x, xn, M);
-        gemm(c, mb.q, xn, M, Ten(qb));
         if (sr > 1) {
+          ln(c, mb.n1, x, xn, M);
+          gemm(c, mb.q, xn, M, Ten(qb));
           conv(c, mb.sr, xn, B, Ho, Wo, Ten(srb));
-          ln(c, mb.srn, srb, srn, Mkv);
-          gemm(c, mb.kv, srn, Mkv, Ten(kvb));
+          if (mb.kv.ln_s) {
+            gemm(c, mb.kv, Ten(srb), Mkv, Ten(kvb));  // LayerNorm(sr conv) inside the kv GEMM
+          } else {
+            ln(c, mb.srn, srb, srn, Mkv);
+            gemm(c, mb.kv, srn, Mkv, Ten(kvb));
+          }
+        } else if (mb.q.ln_s && mb.kv.ln_s) {
+          gemm(c, mb.q, Ten(x), M, Ten(qb));          // norm1 inside both of its consumers
+          gemm(c, mb.kv, Ten(x), M, Ten(kvb));
         } else {
+          ln(c, mb.n1, x, xn, M);
+          gemm(c, mb.q, xn, M, Ten(qb));
           gemm(c, mb.kv, xn, M, Ten(kvb));
         }
         if (!c.dry) {
@@ -719,8 +768,12 @@ struct pf_engine {
         }
         gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
         // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
-        ln(c, mb.n2, x, xn, M);
-        gemm(c, mb.fc1, xn, M, Ten(hb));
+        if (mb.fc1.ln_s) {
+          gemm(c, mb.fc1, Ten(x), M, Ten(hb));        // norm2 inside fc1
+        } else {
+          ln(c, mb.n2, x, xn, M);
+          gemm(c, mb.fc1, xn, M, Ten(hb));
+        }
         if (!c.dry) {
           ProfScope ps(c.prof, c.s, PC_DW3, (4.0 + (h2.f ? 4.0 : 0.0) + (h2.s.p ? 6.0 : 0.0)) * M * 4 * C);  // read + write of the hidden map
           launch_dwconv3x3_gelu(hb, mb.dw.w, mb.dw.b, h2.f, B, Ho, Wo, 4 * C, c.s, h2.s.p, h2.s.plane);
@@ -863,8 +916,12 @@ struct pf_engine {
           ProfScope ps(c.prof, c.s, PC_DW7, 8.0 * M * C);
           launch_dwconv7x7(y, cb.dw.w, cb.dw.b, d, B, h, h, C, c.s);
         }
-        ln(c, cb.n, d, dn, M);
-        gemm(c, cb.pw1, dn, M, hb, ACT_GELU);
+        if (cb.pw1.ln_s) {
+          gemm(c, cb.pw1, Ten(d), M, hb, ACT_GELU);   // block norm inside pwconv1
+        } else {
+          ln(c, cb.n, d, dn, M);
+          gemm(c, cb.pw1, dn, M, hb, ACT_GELU);
+        }
         gemm(c, cb.pw2, hb, M, Ten(y), ACT_NONE, y);  // y += gamma * pwconv2(...)  (gamma folded)
       }
       c.release(mk);
@@ -1010,10 +1067,12 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FOLD_MLP")) e->fold_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_UPSAMPLE")) e->fuse_upsample = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_PRED")) e->fuse_pred = atoi(v) != 0;
+  if (const char* v = getenv("PF_FUSE_LN")) e->fuse_ln = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;
   if (!e->split_bf16) e->sba = false;  // split planes are only read by the split-bf16 kernels
+  if (!e->split_bf16 || e->sba) e->fuse_ln = false;  // the fused form lives in the split GEMM kernels and reads fp32 rows
 
   tune_cache_load(e);
   *out = e;
@@ -1398,6 +1457,37 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   return rc;
 }
 
+int pf_op_linear_ln(int device, const float* x, long rows, int K, const float* hw, const float* hb, const float* hgamma, const float* hbeta, float eps, int N,
+                    int act, const float* res1, int tile_id, float* y, int precision, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (K % 32 != 0 || N % 4 != 0 || !x || !y || !hw || !hgamma || !hbeta || rows <= 0) { g_create_error = "pf_op_linear_ln: K must be a multiple of 32, N of 4"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  ConvParams p;
+  std::vector<float> wf, bf, cs;
+  fold_ln_linear(hw, hb, hgamma, hbeta, N, K, &wf, &bf, &cs);
+  std::vector<float> packed = pack_conv(wf.data(), N, K, 1, 1, K, nullptr, &p.KWC, &p.KWCp);
+  p.g[0].w = tmp.up(packed);
+  std::vector<unsigned short> sb = split_bf16x3(packed);
+  p.g[0].w_sb = tmp.up_u16(sb);
+  const F16Planes f = split_f16x2(packed, N);
+  p.g[0].w_h16 = tmp.up_u16(f.planes); p.g[0].w_h16_inv_scale = tmp.up(f.inv_scale);
+  p.g[0].bias = tmp.up(bf); p.g[0].ln_colsum = tmp.up(cs);
+  p.g[0].x = x; p.g[0].res1 = res1; p.g[0].y = y;
+  p.B = 1; p.H = (int)rows; p.W = 1; p.C1 = K; p.C2 = 0; p.KH = p.KW = 1; p.stride = 1; p.pad = 0;
+  p.Cout = N; p.act = act; p.post_relu = 0; p.nchw_out = 0;
+  p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : (precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
+  p.ln = 1; p.ln_eps = eps;
+  p.finish();
+  if (tile_id >= 0 && !conv_tile_usable(p, tile_id)) { g_create_error = "pf_op_linear_ln: tile config cannot run the fused LayerNorm form"; return PF_ERR_ARG; }
+  launch_conv_tile(p, tile_id, s);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
 int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt_prec, float* ms_out) {
   const int fmt = fmt_prec & 15, precision = fmt_prec >> 4;  // low 4 bits: operand format, upper bits: PF_PRECISION_* of the split tiles
   std::string err;
@@ -1513,6 +1603,19 @@ int pf_op_dwconv3x3_gelu(int device, const float* x, const float* hw, const floa
   hipStream_t s = static_cast<hipStream_t>(stream);
   TmpDev tmp;
   launch_dwconv3x3_gelu(x, tmp.up(pack_dw(hw, C, 3)), tmp.up(hb, C), y, B, H, W, C, s, y_planes, (size_t)plane_elems);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_dwconv3x3_gelu_cfg(int device, const float* x, const float* hw, const float* hb, float* y, int B, int H, int W, int C, uint16_t* y_planes, long plane_elems, int variant, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (C % 128 != 0) { g_create_error = "pf_op_dwconv3x3_gelu_cfg: C must be a multiple of 128"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  launch_dwconv3x3_gelu_variant(variant, x, tmp.up(pack_dw(hw, C, 3)), tmp.up(hb, C), y, B, H, W, C, s, y_planes, (size_t)plane_elems);
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);
   return rc;

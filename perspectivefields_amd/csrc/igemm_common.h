@@ -47,7 +47,8 @@ __device__ __forceinline__ int xcd_tile_index(int nblk) {
 struct Tile2D { int b, oy0, ox0, tx, odd_shift; };  // odd_shift: cyclic column shift of the odd patch rows (LDS bank layout of the halo kernel)
 template <int BM, int BN, int WM, int WN, int SM, int SN, int NT, int SMEM_FLOATS>
 __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[SM][SN], float* Cs, int m0, int n0,
-                                              const Tile2D* t2 = nullptr, const float* oscale = nullptr /*[Cout] factor on the accumulators (split-f16 weight scale)*/) {
+                                              const Tile2D* t2 = nullptr, const float* oscale = nullptr /*[Cout] factor on the accumulators (split-f16 weight scale)*/,
+                                              const float* ln_stat = nullptr /*LDS [BM][2]: (mean, rstd) of the block's input rows -- fused input LayerNorm (ConvParams::ln)*/) {
   constexpr int CROW = BN + 4;            // floats per staged row (keeps 16-B alignment, shifts banks)
   constexpr int CH_ROWS = WM * 32;        // rows per chunk: subtile row i of every wave row
   constexpr int F4_PER_ROW = BN / 4;
@@ -68,7 +69,8 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
     __syncthreads();
     for (int idx = tid; idx < CH_ROWS * F4_PER_ROW; idx += NT) {
       const int row_l = idx / F4_PER_ROW, cq = idx - row_l * F4_PER_ROW;
-      int m = m0 + (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
+      const int lm0 = (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
+      int m = m0 + lm0;
       const int n = n0 + cq * 4;
       if (t2) {
         const int lm = m - m0, ry = lm / t2->tx, rx = lm - ry * t2->tx;
@@ -87,6 +89,11 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
       const long o = (long)m * p.ldy + n;
       if (vec_ok) {
         if (oscale) { const float4 sc = *reinterpret_cast<const float4*>(oscale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+        if (ln_stat) {  // y = rstd (x W' - mean colsum) (+ bias below): LayerNorm of the input rows, gamma / beta folded into W' / bias
+          const float mu = ln_stat[2 * lm0], rs = ln_stat[2 * lm0 + 1];
+          const float4 cs = *reinterpret_cast<const float4*>(P.ln_colsum + n);
+          v.x = rs * fmaf(-mu, cs.x, v.x); v.y = rs * fmaf(-mu, cs.y, v.y); v.z = rs * fmaf(-mu, cs.z, v.z); v.w = rs * fmaf(-mu, cs.w, v.w);
+        }
         if (bsrc) { const float4 bb = *reinterpret_cast<const float4*>(bsrc + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
         if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         else if (p.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }

@@ -81,6 +81,12 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile);                  // igemm_sbh.hip
 bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
   if (p.g[0].head_kind && (kSb[sb_tile].bn != 32 || p.Cout != 32)) return false;  // the fused prediction head lives in the BN = 32 epilogue
+  if (p.ln) {  // fused input LayerNorm: linear tiles, 1x1, fp32 rows, the whole row inside one block's K loop
+    if (sb_tile >= kFirstH || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.C2 > 0 || (p.Cin % BK) != 0 || (p.Cout & 3) || p.splitk > 1 || p.ups) return false;
+    for (int g = 0; g < p.groups; ++g)
+      if (!p.g[g].ln_colsum || p.g[g].x_sb || !p.g[g].x) return false;
+    return true;
+  }
   if (sb_tile >= kFirstH) return conv_sbh_tile_ok(p, sb_tile - kFirstH);
   if (p.Cin == 4) return kSb[sb_tile].bm <= 128 && kSb[sb_tile].bn <= 128;  // stem form: built for the 4-wave tiles
   return !p.ups;
@@ -100,7 +106,7 @@ int conv_splitk_shape(long M, int Cout, int KH, int KWCp, int groups) {
   return S;
 }
 int conv_splitk_factor(const ConvParams& p) {
-  if (p.nchw_out || p.ups || (p.Cin % BK) != 0 || !conv_sb_eligible(p)) return 1;
+  if (p.nchw_out || p.ups || p.ln || (p.Cin % BK) != 0 || !conv_sb_eligible(p)) return 1;
   for (int g = 0; g < p.groups; ++g)
     if (p.g[g].head_kind || p.g[g].bias_tab || p.g[g].res2 || p.g[g].y_sb || !p.g[g].y) return 1;
   return conv_splitk_shape(p.M, p.Cout, p.KH, p.KWCp, p.groups);
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
 void launch_conv_sb(const ConvParams& p0, int sb_tile, hipStream_t s) {
   ConvParams p = p0;
   // split-K only on the linear tiles, with scratch from the caller and 16-byte rows
-  if (p.splitk > 1 && (sb_tile >= kFirstH || !p.g[0].partial || (p.groups > 1 && !p.g[1].partial) || (p.Cout & 3) || p.ldy != p.Cout)) p.splitk = 1;
+  if (p.splitk > 1 && (sb_tile >= kFirstH || p.ln || !p.g[0].partial || (p.groups > 1 && !p.g[1].partial) || (p.Cout & 3) || p.ldy != p.Cout)) p.splitk = 1;
   struct Reduce { const ConvParams& p; hipStream_t s; ~Reduce() {
     if (p.splitk <= 1) return;
     const long mn4 = (long)p.M * p.Cout / 4;

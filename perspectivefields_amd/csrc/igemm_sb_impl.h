@@ -67,7 +67,11 @@ __device__ __forceinline__ void split4_hm(const float4 v, uint2& h, uint2& m) {
 #ifndef SB_W8_WAVES
 #define SB_W8_WAVES 4  // min waves per SIMD of the 256x128 / 128x256 8-wave tiles: 4 = two blocks per CU (<= 128 VGPRs)
 #endif
-template <int BM, int BN, int WM, int WN, int MODE, bool ASB, int PFD, int NTERM>
+// LNF: LayerNorm of the input rows fused into a 1x1 layer (ConvParams::ln).  The staging threads subtract a per-row pivot (the
+// row's first element: LayerNorm is shift invariant, and the shifted row has no large common offset left to cancel), accumulate
+// sum / sum of squares of what they stage, and the epilogue applies  y = rstd (acc - mean colsum) + bias  -- the normalised tensor
+// is never written or read (mix_transformers.py:200, :123-126; convnext.py:50-51).
+template <int BM, int BN, int WM, int WN, int MODE, bool ASB, int PFD, int NTERM, bool LNF = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? (PFD == 1 ? 3 : 2) : ((WM * WN == 8 && BM * BN == 256 * 128 && (NTERM == 6 || NTERM == NT_F16X3)) ? SB_W8_WAVES : 1)) void igemm_sb_kernel(const ConvParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int RPP = NT / 8;    // fp32 A rows staged per pass (8 threads x float4 = 32 floats)
@@ -93,7 +97,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   constexpr int EPI_USHORTS = 2 * (WM * 32) * (BN + 4);        // epilogue staging chunk (igemm_common.h)
   constexpr int OPER_USHORTS = NPL * PLANE_A + NPB * PLANE_B;
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
-  __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
+  static_assert(!LNF || (!ASB && MODE == 0), "fused LayerNorm: fp32 rows, no concat");
+  __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS + (LNF ? 4 * BM : 0)];  // + [BM] (mean, rstd) of the rows
   unsigned short* As = smem_u;                  // [NPL][BM][SB_ROW]
   unsigned short* Bs = smem_u + NPL * PLANE_A;  // [NPB][BN][SB_ROW]
 
@@ -226,6 +231,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
       for (int pl = 0; pl < NPG; ++pl)
         R.b[i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)BPL[pl] * p.w_sb_plane_bytes : OOB);
   };
+  float ln_piv[LNF ? A_ROWS : 1], ln_s1[LNF ? A_ROWS : 1], ln_s2[LNF ? A_ROWS : 1];
+#pragma unroll
+  for (int i = 0; i < (LNF ? A_ROWS : 1); ++i) ln_piv[i] = ln_s1[i] = ln_s2[i] = 0.f;
   auto store_tiles = [&](const Raw& R) {
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -238,10 +246,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
         }
       } else {
         uint2 h, m, l;
-        if (F16) split4_f16(R.a[i], h, m);
-        else if (NTERM == 6) split4(R.a[i], h, m, l);
-        else if (NTERM == 3) split4_hm(R.a[i], h, m);
-        else h = round4_bf16(R.a[i]);
+        float4 av = R.a[i];
+        if (LNF) {
+          const float pv = ln_piv[LNF ? i : 0];
+          av = make_float4(av.x - pv, av.y - pv, av.z - pv, av.w - pv);
+          ln_s1[LNF ? i : 0] += (av.x + av.y) + (av.z + av.w);
+          ln_s2[LNF ? i : 0] = fmaf(av.x, av.x, fmaf(av.y, av.y, fmaf(av.z, av.z, fmaf(av.w, av.w, ln_s2[LNF ? i : 0]))));
+        }
+        if (F16) split4_f16(av, h, m);
+        else if (NTERM == 6) split4(av, h, m, l);
+        else if (NTERM == 3) split4_hm(av, h, m);
+        else h = round4_bf16(av);
         const int row = r0 + RPP * i;
         unsigned short* d = As + row * SB_ROW + sb_piece(row, c4 >> 1) * 8 + (c4 & 1) * 4;
         *reinterpret_cast<uint2*>(d) = h;
@@ -304,6 +319,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   // prologue: tiles 0 .. PFD-1 in flight, tile 0 -> LDS (tile k lives in register set k % PFD)
 #pragma unroll
   for (int d = 0; d < PFD; ++d) load_tiles(it0 + d, raw[d]);
+  if constexpr (LNF) {  // pivot = channel 0 of the row, held by the thread with c4 == 0 of the row's 8 staging lanes
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) ln_piv[i] = __shfl(raw[0].a[i].x, lane & ~7);
+  }
   store_tiles(raw[0]);
   __syncthreads();
   // Main loop: whole groups of PFD steps with no exit inside, so that the loop header sees ONE load order and the
@@ -330,6 +349,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     __syncthreads();
   }
 
+  float* ln_stat = reinterpret_cast<float*>(smem_u + SMEM_USHORTS);  // [BM][2]: mean of the shifted row, rstd
+  if constexpr (LNF) {
+    const float invK = 1.0f / (float)p.Cin;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      float a = ln_s1[i], b = ln_s2[i];
+#pragma unroll
+      for (int sh = 1; sh < 8; sh <<= 1) { a += __shfl_xor(a, sh); b += __shfl_xor(b, sh); }
+      const float mu = a * invK;
+      const float var = fmaxf(fmaf(-mu, mu, b * invK), 0.f);
+      if (c4 == 0) { ln_stat[2 * (r0 + RPP * i)] = mu; ln_stat[2 * (r0 + RPP * i) + 1] = 1.0f / sqrtf(var + p.ln_eps); }
+    }
+  }
   if (S > 1) {  // raw partial sums; scale, bias, activation and residual are applied by splitk_reduce_kernel
     ConvParams pp = p;
     pp.act = ACT_NONE; pp.post_relu = 0;
@@ -338,7 +370,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(pp, Q, acc, reinterpret_cast<float*>(smem_u), m0, n0);
     return;
   }
-  epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0, nullptr, F16 ? P.w_h16_inv_scale : nullptr);
+  epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0, nullptr, F16 ? P.w_h16_inv_scale : nullptr,
+                                                              LNF ? ln_stat : nullptr);
 }
 
 template <int BM, int BN, int WM, int WN, int PFD, int NT>
@@ -351,6 +384,8 @@ static void launch_sb_cfg(const ConvParams& p, hipStream_t s) {
   } else if (p.C2 > 0) {
     if (asb) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, true, PFD, NT>), grid, block, 0, s, p);
     else     hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 2, false, PFD, NT>), grid, block, 0, s, p);
+  } else if (p.ln) {  // conv_sb_tile_ok: fp32 rows, 1x1, no concat
+    hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, false, PFD, NT, true>), grid, block, 0, s, p);
   } else {
     if (asb) hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, true, PFD, NT>), grid, block, 0, s, p);
     else     hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, false, PFD, NT>), grid, block, 0, s, p);

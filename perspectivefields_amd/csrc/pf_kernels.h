@@ -38,6 +38,10 @@ struct ConvPtrs {
   // epilogue applies the 1x1 head to every pixel -- kind 1: linear_pred_gravity (32 -> 2) + F.normalize (gravity_head.py:117,
   // 190-193), kind 2: linear_pred_latitude (32 -> 1) + clamp(-1, 1) (latitude_head.py:118,189-192) -- and writes the NCHW
   // API output head_out plus its components of the ParamNet input head_pn ([M] float4: g0, g1, lat, 0; may be nullptr)
+  // Fused LayerNorm of the INPUT rows (ConvParams::ln, 1x1 layers whose K loop covers the whole row): the weights carry the LayerNorm
+  // gamma (W'[n][k] = W[n][k] gamma[k]), bias = b + W beta, and ln_colsum[n] = sum_k W'[n][k]; the kernel contracts the raw rows,
+  // accumulates their mean / variance while staging them and applies  y = rstd (acc - mean colsum) + bias  in the epilogue
+  const float* ln_colsum = nullptr; // [Cout]
   float* partial = nullptr;         // split-K: [splitk][M][ldy] raw partial sums (fp32 scratch owned by the caller)
   int head_kind = 0;
   const float* head_w = nullptr;    // [nout][32]
@@ -66,6 +70,9 @@ struct ConvParams {
                   // the epilogue (scale, bias, activation, res1, post_relu) by splitk_reduce_kernel -- deterministic (fixed summation order)
   int ups = 0;    // 1: x is stored at half resolution [B][H/2][W/2][C1]; the conv runs on its bilinear x2 up-sampling, interpolated
                   // while the input halo is staged (3x3 halo tiles of the split-f16 scheme only; x2, if any, is at full resolution)
+  int ln = 0;     // 1: LayerNorm over the Cin input channels fused into this 1x1 layer (ConvPtrs::ln_colsum; linear split tiles, fp32 input,
+                  // no concat, no split-K): mix_transformers.py:200 (norm2 -> fc1), :123-126 (sr norm -> kv), convnext.py:50-51 (norm -> pwconv1)
+  float ln_eps = 0.f;
   int nterms = 6; // split kernels: partial products per element product -- NT_F16X3 (23): 2-way fp16 split, 3 products, fp32-class accuracy;
                   // 6: exact 3-way bf16 split, 6 products (fp32-accurate); 3 (bf16, ~16-bit operands); 1 (plain bf16)
   unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)

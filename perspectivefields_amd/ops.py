@@ -108,6 +108,22 @@ def linear(x, weight, bias=None, act=0, res1=None, tile=-1):
     return y.reshape(*x.shape[:-1], w.shape[0])
 
 
+def linear_ln(x, weight, bias, gamma, beta, eps, act=0, res1=None, tile=-1, precision=0):
+    """act(Linear(LayerNorm(x))) + res1 with the LayerNorm fused into the GEMM (pf_op_linear_ln).  x: (..., K); weight (N, K)."""
+    import torch
+
+    lib = load_library()
+    x = x.contiguous()
+    K = x.shape[-1]
+    rows = x.numel() // K
+    w, b, g, be = _np(weight), _np(bias), _np(gamma), _np(beta)
+    N = w.shape[0]
+    y = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
+    _check(lib.pf_op_linear_ln(x.device.index, x.data_ptr(), rows, K, _hp(w), _hp(b), _hp(g), _hp(be), float(eps), N, act, _dp(res1), tile, y.data_ptr(), precision,
+                               _stream_ptr()), None, "pf_op_linear_ln")
+    return y
+
+
 def layernorm(x, gamma, beta, eps, planes_out=False):
     import torch
 
@@ -121,7 +137,8 @@ def layernorm(x, gamma, beta, eps, planes_out=False):
     return yp.merge() if planes_out else y
 
 
-def dwconv3x3_gelu(x, weight, bias, planes_out=False):
+def dwconv3x3_gelu(x, weight, bias, planes_out=False, variant=None):
+    """variant None: the default path; otherwise an explicit kernel (pf_op_dwconv3x3_bench's ids)."""
     import torch
 
     lib = load_library()
@@ -130,6 +147,9 @@ def dwconv3x3_gelu(x, weight, bias, planes_out=False):
     y = None if planes_out else torch.empty_like(x)
     yp = Planes(x.shape, x.device) if planes_out else None
     w, b = _np(weight), _np(bias)
+    if variant is not None:
+        _check(lib.pf_op_dwconv3x3_gelu_cfg(x.device.index, x.data_ptr(), _hp(w), _hp(b), _dp(y), B, H, W, C, *_pl(yp), int(variant), _stream_ptr()), None, "pf_op_dwconv3x3_gelu_cfg")
+        return yp.merge() if planes_out else y
     _check(lib.pf_op_dwconv3x3_gelu(x.device.index, x.data_ptr(), _hp(w), _hp(b), _dp(y), B, H, W, C, *_pl(yp), _stream_ptr()), None, "pf_op_dwconv3x3_gelu")
     return yp.merge() if planes_out else y
 

@@ -171,6 +171,28 @@ def test_folded_and_unfolded_mlp_agree(monkeypatch):
         assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
 
 
+@pytest.mark.parametrize("case", ["centered", "uncentered"])
+def test_fused_layernorm_agrees_with_layernorm_kernels(monkeypatch, case):
+    """Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1, sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt
+    norm -> pwconv1) runs inside those GEMMs (row statistics from the staging threads, gamma / beta folded into the weights).
+    PF_FUSE_LN=0 runs every LayerNorm as its own kernel.  Same mathematics, different roundings: far inside the tolerances."""
+    from perspectivefields_amd import PerspectiveFields
+
+    imgs = [synthetic_image(72, 96, seed=85 + i) for i in range(3)]
+    base = model(case).inference_batch(imgs)
+    monkeypatch.setenv("PF_FUSE_LN", "0")
+    alt_model = PerspectiveFields(CASES[case], weights="synthetic:0").eval().cuda()
+    alt = alt_model.inference_batch(imgs)
+    for i, (a, b) in enumerate(zip(base, alt)):
+        c = one_minus_cos(a["pred_gravity"].cpu().numpy(), b["pred_gravity"].cpu().numpy()).max()
+        e = l1(a["pred_latitude"].cpu().numpy(), b["pred_latitude"].cpu().numpy())
+        keys = [k for k, v in a.items() if k.startswith("pred_") and (v.numel() == 1 if hasattr(v, "numel") else isinstance(v, (int, float)))]
+        assert len(keys) >= 4
+        d = max(abs(float(a[k]) - float(b[k])) for k in keys)
+        print(f"[fused LN vs LN kernels {case} img{i}] 1-cos {c:.2e} latL1 {e:.2e} param {d:.2e} ({len(keys)} scalars)")
+        assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
+
+
 def test_split_plane_activations_agree_with_fp32_activations(monkeypatch):
     """PF_SBA=1 stores GEMM-only tensors as split-bf16 planes written by their producers; the default keeps every GEMM
     input in fp32 and splits inside the GEMM.  The planes are lossless, so the two engines differ only through the

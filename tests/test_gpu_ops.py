@@ -294,6 +294,40 @@ def test_linear(ops, K, N, rows):
     _close(ops.linear(x.cuda(), w, b, res1=r.cuda()), ref + r.double(), 3e-5, "linear+res")
 
 
+@pytest.mark.parametrize("K,N,rows", [(64, 256, 300), (320, 1280, 257), (320, 640, 100), (512, 1024, 129), (96, 384, 200), (768, 3072, 33), (128, 512, 1000)])
+def test_linear_with_fused_layernorm(ops, K, N, rows):
+    """Linear(LayerNorm(x)) with the LayerNorm inside the GEMM (ConvParams::ln): every linear split tile and every contraction scheme,
+    rows with a large common offset (the per-row pivot must keep the one-pass variance and the mean correction accurate), GELU and
+    residual epilogues.  Oracle: torch fp64."""
+    x = _rand((rows, K), 31, 1.5)
+    x = x + 40.0 * _rand((rows, 1), 32)          # per-row offsets up to 40 sigma
+    x[3] = 0.0                                    # a constant row: variance 0 -> rstd = eps^-1/2, output = bias term
+    w = _rand((N, K), 33, 1.0 / math.sqrt(K))
+    b = _rand((N,), 34, 0.1)
+    g = 1 + _rand((K,), 35, 0.3)
+    be = _rand((K,), 36, 0.2)
+    r = _rand((rows, N), 37)
+    for eps in (1e-6, 1e-5):
+        xn = F.layer_norm(x.double(), (K,), g.double(), be.double(), eps)
+        ref = F.linear(xn, w.double(), b.double())
+        xd = x.cuda()
+        _close(ops.linear_ln(xd, w, b, g, be, eps), ref, 5e-5, "linear_ln")
+        _close(ops.linear_ln(xd, w, b, g, be, eps, act=2), pf_oracle.gelu(ref), 5e-5, "linear_ln+gelu")
+        _close(ops.linear_ln(xd, w, b, g, be, eps, res1=r.cuda()), ref + r.double(), 5e-5, "linear_ln+res")
+    tiles = ops.conv_tiles()
+    ref = F.linear(F.layer_norm(x.double(), (K,), g.double(), be.double(), 1e-6), w.double(), b.double())
+    ran = 0
+    for t, name in enumerate(tiles):
+        if not name.startswith("sb") or name.startswith("sbh"):
+            with pytest.raises(Exception):
+                ops.linear_ln(x.cuda(), w, b, g, be, 1e-6, tile=t)   # exact-fp32 and halo tiles do not carry the fused form: loud
+            continue
+        for prec, tol in ((0, 5e-5), (3, 5e-5)):
+            _close(ops.linear_ln(x.cuda(), w, b, g, be, 1e-6, tile=t, precision=prec), ref, tol, f"linear_ln tile {name} precision {prec}")
+            ran += 1
+    assert ran >= 20
+
+
 def test_mfma_operand_orientation(ops):
     """A = I-like check with an ASYMMETRIC B: catches a row/col swap of the MFMA C layout."""
     K = N = 64
@@ -314,14 +348,26 @@ def test_layernorm(ops, C, eps):
     _close(ops.layernorm(x.cuda(), g, b, eps), ref, 1e-5, f"layernorm C={C}")
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 80, 80, 256), (1, 40, 40, 512), (2, 20, 20, 1280), (3, 10, 10, 2048), (1, 9, 13, 128)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 80, 80, 256), (1, 40, 40, 512), (2, 20, 20, 1280), (3, 10, 10, 2048), (1, 9, 13, 128), (2, 11, 16, 128), (1, 21, 20, 256)])
 def test_dwconv3x3_gelu(ops, B, H, W, C):
     x = _rand((B, H, W, C), 20)
     w = _rand((C, 1, 3, 3), 21, 0.4)
     b = _rand((C,), 22, 0.1)
     ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1, groups=C)
     ref = pf_oracle.gelu(ref).permute(0, 2, 3, 1).contiguous()
-    _close(ops.dwconv3x3_gelu(x.cuda(), w, b), ref, 1e-5, "dwconv3x3+gelu")
+    xd = x.cuda()
+    y0 = ops.dwconv3x3_gelu(xd, w, b)
+    _close(y0, ref, 1e-5, "dwconv3x3+gelu")
+    # multi-column / prefetching kernel (elem.hip dwconv3x3_gelu_mc_kernel): every (block shape, strip height, columns x prefetch)
+    # the shape fits -- same tap order, so bit-identical to the one-column kernel; also with split-plane output
+    for shape, (cqb, xb) in enumerate(((32, 8), (64, 4), (64, 2), (64, 5))):
+        for code, (nc, pf) in enumerate(((1, 1), (2, 0), (2, 1), (2, 2), (1, 2))):
+            if (C // 4) % cqb or W % (xb * nc):
+                continue
+            for th in range(3):
+                v = 1000 + 100 * shape + 10 * th + code
+                assert torch.equal(ops.dwconv3x3_gelu(xd, w, b, variant=v), y0), f"dwconv3x3 mc variant {v}"
+            assert torch.equal(ops.dwconv3x3_gelu(xd, w, b, variant=1000 + 100 * shape + code, planes_out=True), ops.dwconv3x3_gelu(xd, w, b, planes_out=True)), "dwconv3x3 mc planes"
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 80, 80, 96), (1, 40, 40, 192), (2, 20, 20, 384), (3, 10, 10, 768), (1, 2, 2, 768), (1, 5, 11, 96)])

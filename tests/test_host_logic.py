@@ -415,20 +415,23 @@ def test_kernel_resources_static():
     by = {r["kernel"]: r for r in rows}
     hot = [
         # default parity scheme (split-f16, NT_F16X3 = 23) and the exact bf16 split (6)
-        "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 23>",
-        "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 23>", "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 23>",
-        "pf::igemm_sb_kernel<256, 256, 2, 4, 0, false, 1, 23>", "pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 23>",
+        "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23, false>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 23, false>",
+        "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 23, false>", "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 23, false>",
+        "pf::igemm_sb_kernel<256, 256, 2, 4, 0, false, 1, 23, false>", "pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 23, false>",
         "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1, 23, false, false>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 23, false, false>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 23, false, false>",
         "pf::igemm_sbh_kernel<16, 16, 64, 4, 2, 0, 1, 23, false, false>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 2, 1, 23, false, true>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 23, false, true>", "pf::sr_attention_f16_kernel", "pf::dwconv7x7_cb_kernel<4, 3, 0>", "pf::dwconv7x7_cb_kernel<2, 3, 0>",
-        "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 6>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 6>",
-        "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 6>", "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 6>",
-        "pf::igemm_sb_kernel<256, 256, 2, 4, 0, false, 1, 6>",
+        "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 6, false>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 6, false>",
+        "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 6, false>", "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 6, false>",
+        "pf::igemm_sb_kernel<256, 256, 2, 4, 0, false, 1, 6, false>",
         "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1, 6, false, false>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 6, false, false>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 6, false, false>",
         "pf::sr_attention_kernel", "pf::dwconv7x7_lane_kernel<1, 3, 256, 0>", "pf::upsample2x_cell_kernel",
         "pf::dwconv3x3_gelu_direct_kernel<32, 8, 8, 0>", "pf::layernorm_kernel<64, 2>",
+        # r02: multi-column depthwise 3x3 (the three shipped forms) and the fused-LayerNorm GEMM forms of the 4-wave tiles
+        "pf::dwconv3x3_gelu_mc_kernel<64, 2, 40, 2, 2, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 4, 8, 1, 1, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 5, 16, 1, 2, false>",
+        "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23, true>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 2, 23, true>", "pf::igemm_sb_kernel<128, 256, 2, 4, 0, false, 1, 23, true>",
     ]
     for k in hot:
         assert k in by, (k, [n for n in by if n.startswith(k.split("<")[0])][:4])
         assert by[k]["spill"] == 0 and by[k]["scratch"] == 0, by[k]
     # the two-blocks-per-CU 8-wave tiles trade a handful of spilled registers for the second resident block
-    assert by["pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 6>"]["vgpr"] <= 128
+    assert by["pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 6, false>"]["vgpr"] <= 128
