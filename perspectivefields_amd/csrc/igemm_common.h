@@ -145,4 +145,66 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
   }
 }
 
+// Direct epilogue for TRANSPOSED accumulators.  With the MFMA operands swapped (weights as the instruction's A operand, pixels as B)
+// the 32x32 C/D layout puts GEMM row m = lane & 31 and, per register group g = r >> 2, the four CONSECUTIVE output channels
+// n = 8 g + 4 (lane >> 5) + (r & 3) into one lane: every lane owns float4s of its own output row and can apply scale / LayerNorm
+// correction / bias / activation / residuals and store 16 bytes straight from registers -- no LDS staging, no barriers (the LDS form
+// above costs 2 barriers, 16 SN ds_write_b32 and SN/.. ds_read_b128 per lane and 32-row chunk).  A store instruction covers 32 rows x
+// 32 bytes; the four groups of a subtile complete each row's 128-byte line.  Same operation order as epilogue_nhwc: bit-identical.
+template <int SM, int SN>
+__device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[SM][SN], int mw0 /*first row of this wave's tile*/,
+                                                int nw0 /*first column*/, int ml0 /*mw0 - m0: row inside the block tile*/, const float* oscale, const float* ln_stat) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int HoWo = p.Ho * p.Wo;
+  const bool vec_ok = (p.Cout & 3) == 0 && (p.ldy & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < SM; ++i) {
+    const int m = mw0 + i * 32 + l31;
+    if (m >= p.M) continue;
+    float mu = 0.f, rs = 1.f;
+    if (ln_stat) { mu = ln_stat[2 * (ml0 + i * 32 + l31)]; rs = ln_stat[2 * (ml0 + i * 32 + l31) + 1]; }
+    const float* bsrc = P.bias;
+    if (P.bias_tab) {
+      const int rem = m % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
+      bsrc = P.bias_tab + (cy * 3 + cx) * p.Cout;
+    }
+#pragma unroll
+    for (int j = 0; j < SN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nw0 + j * 32 + 8 * g + 4 * hi;
+        if (n >= p.Cout) continue;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        const long o = (long)m * p.ldy + n;
+        if (vec_ok) {
+          if (oscale) { const float4 sc = *reinterpret_cast<const float4*>(oscale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+          if (ln_stat) {
+            const float4 cs = *reinterpret_cast<const float4*>(P.ln_colsum + n);
+            v.x = rs * fmaf(-mu, cs.x, v.x); v.y = rs * fmaf(-mu, cs.y, v.y); v.z = rs * fmaf(-mu, cs.z, v.z); v.w = rs * fmaf(-mu, cs.w, v.w);
+          }
+          if (bsrc) { const float4 bb = *reinterpret_cast<const float4*>(bsrc + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+          if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          else if (p.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+          if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+          if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+          if (p.post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (P.y) *reinterpret_cast<float4*>(P.y + o) = v;
+          if (P.y_sb) store_sb4(P.y_sb, p.y_sb_plane, (size_t)o, v);
+        } else {  // ragged channel count: scalar tail
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+            float x = vv[e] * (oscale ? oscale[n + e] : 1.f) + (bsrc ? bsrc[n + e] : 0.f);
+            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+            else if (p.act == ACT_GELU) x = gelu_erf(x);
+            if (P.res1) x += P.res1[o + e];
+            if (P.res2) x += P.res2[o + e];
+            if (p.post_relu) x = fmaxf(x, 0.f);
+            P.y[o + e] = x;
+          }
+        }
+      }
+  }
+}
+
 }  // namespace pf

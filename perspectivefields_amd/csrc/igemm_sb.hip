@@ -24,6 +24,9 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {256, 64, 0, "sbh256x64w8t3"}, {128, 64, 0, "sbh128x64t3"},
 #endif
                              {256, 32, 0, "sbh256x32"},  // split-f16 scheme: 16 x 16 patch, N = 32, 4 waves
+#ifdef PF_TUNING_BUILD
+                             {256, 256, 0, "sbh256x256w8"}, {256, 256, 0, "sbhd256x256w8"},  // split-f16 scheme: 16 x 16 patch x all 256 output channels, 8 waves (rejected)
+#endif
 };
 static constexpr int kFirstH = 12;  // index of the first "sbh" tile
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }

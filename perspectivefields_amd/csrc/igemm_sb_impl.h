@@ -82,11 +82,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   // NTERM partial products per element product: 6 = fp32-accurate (3 planes per operand), 3 = h*h + h*m + m*h (2 planes,
   // ~16 significant bits), 1 = plain bf16 (1 plane)
   // NT_F16X3 (split-f16, the default parity scheme): a ~ ah + al 2^-11 (two fp16 planes, sb_split.h), weights pre-scaled per output
-  // channel and split as wh + wl (two fp16 planes in global memory); the third LDS plane wh2 = wh 2^-11 is made while
-  // staging, so that  ah wh + ah wl + al wh2  accumulates in ONE accumulator: 3 MFMAs per product.
+  // channel and split as wh + wl (two fp16 planes in global memory); the third operand wh2 = wh 2^-11 is made from the
+  // wh fragment in registers, so that  ah wh + ah wl + al wh2  accumulates in ONE accumulator: 3 MFMAs per product.
   constexpr bool F16 = NTERM == NT_F16X3;
+  // DIRECT: MFMA operands swapped (transposed accumulators) + register epilogue (igemm_common.h epilogue_direct) on the 64 x 64 tiles, i.e. the
+  // small-M / latency-bound layers (+2...7 % there, profiles/r02_tune_conv_v3_direct_epilogue.txt).  The larger tiles keep the LDS-staged
+  // epilogue: their layers are write-heavy (M >= 51 200, short K) and the 32-byte store granules of the direct form cost them 5-20 %
+  constexpr bool DIRECT = BM == 64 && BN == 64;
   constexpr int NPL = F16 ? 2 : (NTERM == 6 ? 3 : (NTERM == 3 ? 2 : 1));  // A planes in LDS
-  constexpr int NPB = F16 ? 3 : NPL;                                      // B planes in LDS
+  constexpr int NPB = NPL;                                                // B planes in LDS (split-f16: wh, wl; wh2 = wh 2^-11 is made in registers
+                                                                          // from the wh fragment -- 4 v_pk_mul_f16 instead of an LDS plane, its stores and its reads)
   constexpr int NPG = F16 ? 2 : NPL;                                      // B planes loaded from global memory
   constexpr int NMF = F16 ? 3 : NTERM;                                    // MFMAs per element product
   constexpr int A_REGS = ASB ? A_ROWS * NPL : A_ROWS;  // float4 registers per staged A tile
@@ -270,7 +275,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
 #pragma unroll
         for (int pl = 0; pl < NPG; ++pl)
           *reinterpret_cast<float4*>(Bs + pl * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = R.b[i][pl];
-        if (F16) *reinterpret_cast<float4*>(Bs + 2 * PLANE_B + (rb0 + RPB * i) * SB_ROW + sb_piece(rb0 + RPB * i, pc) * 8) = scale8_f16_2m11(R.b[i][0]);
       }
   };
 
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
 #pragma unroll
     for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per K step; this lane's 8 k-values = piece 2c + hi
       const int po = ((2 * c + hi) ^ swz) * 8;
-      u32x4 af[SM][NPL], bf[SN][NPB];
+      u32x4 af[SM][NPL], bf[SN][F16 ? 3 : NPB];
 #pragma unroll
       for (int i = 0; i < SM; ++i)
 #pragma unroll
@@ -301,6 +305,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
       for (int j = 0; j < SN; ++j)
 #pragma unroll
         for (int pl = 0; pl < NPB; ++pl) bf[j][pl] = *reinterpret_cast<const u32x4*>(Bb + pl * PLANE_B + j * 32 * SB_ROW + po);
+      if constexpr (F16) {
+#pragma unroll
+        for (int j = 0; j < SN; ++j) bf[j][2] = __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, bf[j][0])));
+      }
       // six partial products, smallest first; the (i, j) loop is innermost so that consecutive MFMAs never
       // depend on each other's accumulator
       //                                                                                                  split-f16: al ah ah
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
         for (int i = 0; i < SM; ++i)
 #pragma unroll
           for (int j = 0; j < SN; ++j)
-            acc[i][j] = mfma16<F16>(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j]);
+            acc[i][j] = DIRECT ? mfma16<F16>(bf[j][TB[t6]], af[i][TA[t6]], acc[i][j]) : mfma16<F16>(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j]);
     }
   };
 
@@ -367,11 +375,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     pp.act = ACT_NONE; pp.post_relu = 0;
     ConvPtrs Q;
     Q.y = P.partial + (size_t)sidx * p.M * p.ldy;
-    epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(pp, Q, acc, reinterpret_cast<float*>(smem_u), m0, n0);
+    if constexpr (DIRECT) epilogue_direct<SM, SN>(pp, Q, acc, m0 + wm0, n0 + wn0, wm0, nullptr, nullptr);
+    else epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(pp, Q, acc, reinterpret_cast<float*>(smem_u), m0, n0);
     return;
   }
-  epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0, nullptr, F16 ? P.w_h16_inv_scale : nullptr,
-                                                              LNF ? ln_stat : nullptr);
+  if constexpr (DIRECT) {
+    if constexpr (LNF) __syncthreads();  // the row statistics written above
+    epilogue_direct<SM, SN>(p, P, acc, m0 + wm0, n0 + wn0, wm0, F16 ? P.w_h16_inv_scale : nullptr, LNF ? ln_stat : nullptr);
+  } else {
+    epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0, nullptr, F16 ? P.w_h16_inv_scale : nullptr,
+                                                                LNF ? ln_stat : nullptr);
+  }
 }
 
 template <int BM, int BN, int WM, int WN, int PFD, int NT>

@@ -35,7 +35,7 @@ template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE,
           bool DB = false /*two LDS buffers for the weights: the next tap's weights are stored while this tap is still being read -> one barrier per tap instead of two*/,
           bool UPS = false /*the first input x is stored at HALF resolution: the conv runs on its bilinear x2 up-sampling (decode_head.py:284-286,
                              gravity_head.py:172), interpolated while the halo tile is staged -- the up-sampled tensor never exists in HBM*/>
-__global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
   constexpr int BM = H_TY * H_TX;
@@ -49,7 +49,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   constexpr int PLANE_A = H_ROWS * H_ROW, PLANE_B = BN * H_ROW;  // ushorts
   constexpr int EPI_USHORTS = 2 * (WM * 32) * (BN + 4);
   constexpr bool F16 = SCH == NT_F16X3;
-  constexpr int NPA = F16 ? 2 : 3, NPB = 3, NPG = F16 ? 2 : 3;  // A planes in LDS, B planes in LDS, B planes loaded from global memory
+  // A planes in LDS, B planes in LDS, B planes loaded from global memory.  split-f16: the third weight operand wh2 = wh 2^-11 is made in
+  // REGISTERS from the wh fragment (4 v_pk_mul_f16 per fragment -- the VALU has slack, the LDS pipe does not): 2 LDS planes, 2 of every
+  // 14 (SN = 1) / 4 of every 20 (SN = 2) fragment reads and a third of the weight-staging LDS writes less than with a staged wh2 plane
+  constexpr int NPA = F16 ? 2 : 3, NPB = F16 ? 2 : 3, NPG = F16 ? 2 : 3;
   static_assert(!DB || TPG == 1, "double-buffered weights: one tap per step");
   constexpr int BBUF = NPB * TPG * PLANE_B;  // ushorts of one weight buffer
   // UPS: the half-resolution SOURCE pixels under the halo tile (rows oy0/2 - 1 .. + H_TY/2 + 1, columns likewise; indices clamped
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
   unsigned short* As = smem_u;                  // [NPA][H_ROWS][H_ROW]
-  unsigned short* Bs0 = smem_u + NPA * PLANE_A;  // [DB ? 2 : 1][TPG][3][BN][H_ROW]
+  unsigned short* Bs0 = smem_u + NPA * PLANE_A;  // [DB ? 2 : 1][TPG][NPB][BN][H_ROW]
   float* Ss = reinterpret_cast<float*>(smem_u + NPA * PLANE_A + (DB ? 2 : 1) * BBUF);  // UPS: [S_PIX][BK] fp32 source tile
 
   const int tid = threadIdx.x;
@@ -238,8 +241,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
         if (BN % RPB == 0 || rb0 + RPB * i < BN) {
 #pragma unroll
           for (int pl = 0; pl < NPG; ++pl)
-            *reinterpret_cast<float4*>(Bs + (u * 3 + pl) * PLANE_B + (rb0 + RPB * i) * H_ROW + sbh_piece(rb0 + RPB * i, pc) * 8) = rb[u][i][pl];
-          if (F16) *reinterpret_cast<float4*>(Bs + (u * 3 + 2) * PLANE_B + (rb0 + RPB * i) * H_ROW + sbh_piece(rb0 + RPB * i, pc) * 8) = scale8_f16_2m11(rb[u][i][0]);
+            *reinterpret_cast<float4*>(Bs + (u * NPB + pl) * PLANE_B + (rb0 + RPB * i) * H_ROW + sbh_piece(rb0 + RPB * i, pc) * 8) = rb[u][i][pl];
         }
   };
 
@@ -285,9 +287,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 4 : 2) void igemm_sbh_
       }
       const int pob = ((2 * c + hi) ^ swz_b) * 8;
 #pragma unroll
-      for (int j = 0; j < SN; ++j)
+      for (int j = 0; j < SN; ++j) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const u32x4*>(Bb + (slot * 3 + pl) * PLANE_B + j * 32 * H_ROW + pob);
+        for (int pl = 0; pl < NPB; ++pl) bf[j][pl] = *reinterpret_cast<const u32x4*>(Bb + (slot * NPB + pl) * PLANE_B + j * 32 * H_ROW + pob);
+        if (F16) bf[j][2] = __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, bf[j][0])));
+      }
       constexpr int TA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};  // plane of A: l h m m h h | split-f16: al ah ah
       constexpr int TB[6] = {F16 ? 2 : 0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};  // plane of B: h l m h m h | split-f16: wh2 wl wh
 #pragma unroll
@@ -388,7 +392,7 @@ bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
   constexpr int kWide32 = 4;
 #endif
   if (p.ups) return (h_tile < 3 || h_tile == kWide32) && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
-  if (h_tile == kWide32) return p.nterms == NT_F16X3;
+  if (h_tile >= kWide32) return p.nterms == NT_F16X3;  // sbh256x32 (and, in tuning builds, the whole-N tiles sbh256x256w8 / sbhd256x256w8)
 #ifdef PF_TUNING_BUILD
   return h_tile < 4 || p.nterms == NT_F16X3;
 #else
@@ -406,6 +410,12 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
     case 4: launch_sbh_cfg<16, 16, 32, 4, 1>(p, s); break;  // "sbh256x32": 16 x 16 patch for the N = 32 layer (twice the MFMAs per barrier)
 #else
     case 10: launch_sbh_cfg<16, 16, 32, 4, 1>(p, s); break;
+    // whole N = 256 per block (256 x 256 / 8-wave geometry, wave tile 128 x 64): the halo is staged and split ONCE per patch instead of once
+    // per n-tile, 0.58 fragment reads per MFMA instead of 1.17 -- but one block per CU at 256 VGPRs (33 / 52 spilled) with the plain
+    // two-barrier tap loop: 258 / 221 TF vs 294 TF for sbh256x64w8 on 256 -> 256 @80^2 (profiles/r02_negative_results.md).  "d" = weights
+    // double-buffered in LDS
+    case 11: launch_sbh_cfg<16, 16, 256, 2, 4>(p, s); break;
+    case 12: launch_sbh_cfg<16, 16, 256, 2, 4, 1, true>(p, s); break;
     // measured, no gain (profiles/r02_negative_results.md)
     case 4: launch_sbh_cfg<8, 16, 128, 2, 2, 1, true>(p, s); break;
     case 5: launch_sbh_cfg<8, 16, 64, 2, 2, 1, true>(p, s); break;
