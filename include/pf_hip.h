@@ -210,6 +210,11 @@ int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, 
  * :123-126 (sr norm -> kv) and convnext.py:50-51 (norm -> pwconv1).  K % 32 == 0, N % 4 == 0; tile_id as pf_op_conv2d (linear split tiles only). */
 int pf_op_linear_ln(int device, const float* d_x, long rows, int K, const float* h_weight /*[N][K]*/, const float* h_bias, const float* h_gamma, const float* h_beta,
                     float eps, int N, int act, const float* d_res1, int tile_id, float* d_y, int precision, void* stream);
+/* One ConvNeXt block MLP in one kernel (cnx_mlp.hip): y += ls * pwconv2(GELU(pwconv1(LayerNorm(d)))), convnext.py:49-58; C = 96 or 192, weights
+ * in the reference's shapes (pwconv1 [4C][C], pwconv2 [C][4C], layer scale ls [C]); y is read (residual) and written.  iters > 0 additionally times
+ * `iters` launches (avg ms in *ms_out; y is then garbage). */
+int pf_op_cnx_mlp(int device, const float* d_d, float* d_y, long rows, int C, const float* h_w1, const float* h_b1, const float* h_ln_gamma, const float* h_ln_beta,
+                  float eps, const float* h_w2, const float* h_b2, const float* h_layer_scale, int iters, float* ms_out, void* stream);
 int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt_prec, float* ms_out);
 /* fp32 <-> planes in the format selected by bit 0 of plane_elems (the names are historical) */
 int pf_op_split_bf16(int device, const float* d_x, long n, uint16_t* d_planes, long plane_elems, void* stream);

@@ -72,7 +72,7 @@ struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
   float* predw = nullptr; float* predb = nullptr; int nout = 0;
 };
-struct CnxBlock { DwW dw; LNW n; ConvW pw1, pw2; };
+struct CnxBlock { DwW dw; LNW n; ConvW pw1, pw2; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused MLP (cnx_mlp.hip), when built */ };
 struct Cnx { ConvW stem, ds[3]; LNW stemn, dsn[3], norm; std::vector<CnxBlock> blocks[4]; float* headw = nullptr; float* headb = nullptr; int nout = 0; };
 
 // Split-bf16 activation tensor (sb_split.h): three exact bf16 planes `plane` elements apart.
@@ -247,6 +247,50 @@ void fold_ln_linear(const float* w, const float* b, const float* g, const float*
   }
 }
 
+// Weights of the fused ConvNeXt block MLP (cnx_mlp.hip) in MFMA fragment order, split-f16 scheme (split_f16x2's scaling), fp64 folds:
+//   W1'[j][c] = W1[j][c] gamma[c], b1' = b1 + W1 beta, cs1[j] = sum_c W1'[j][c]   (LayerNorm folded, as fold_ln_linear)
+//   W2'[n][j] = ls[n] W2[n][j],    b2' = ls[n] b2[n]                                 (layer scale folded, convnext.py:54-55)
+// chunk t (32 hidden units): W1 part [s][plane][lane][8] = W1s[32 t + (lane & 31)][(lane >> 5) C/2 + 8 s + e],
+//                            W2 part [q][u][plane][lane][8] = W2s[32 q + (lane & 31)][32 t + 16 u + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)]
+// tab: inv1[H], cs1[H], b1'[H], inv2[C], b2'[C]
+void cnx_mlp_pack(const float* w1, const float* b1, const float* g, const float* be, const float* w2, const float* b2, const float* ls, int C,
+                  std::vector<unsigned short>* wpk, std::vector<float>* tab) {
+  const int H = 4 * C, S1 = C / 16, Q = C / 32, NCH = H / 32;
+  std::vector<float> w1f, b1f, cs1;
+  fold_ln_linear(w1, b1, g, be, H, C, &w1f, &b1f, &cs1);
+  std::vector<float> w2f((size_t)C * H), b2f(C);
+  for (int n = 0; n < C; ++n) {
+    for (int j = 0; j < H; ++j) w2f[(size_t)n * H + j] = (float)((double)w2[(size_t)n * H + j] * (double)ls[n]);
+    b2f[n] = (float)((double)b2[n] * (double)ls[n]);
+  }
+  const F16Planes p1 = split_f16x2(w1f, H), p2 = split_f16x2(w2f, C);
+  const size_t n1 = w1f.size(), n2 = w2f.size();
+  const size_t CH1 = (size_t)S1 * 2 * 512, CH2 = (size_t)Q * 2 * 2 * 512, CHUNK = CH1 + CH2;
+  wpk->assign((size_t)NCH * CHUNK, 0);
+  for (int t = 0; t < NCH; ++t) {
+    unsigned short* o = wpk->data() + (size_t)t * CHUNK;
+    for (int s = 0; s < S1; ++s)
+      for (int pl = 0; pl < 2; ++pl)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int row = 32 * t + (lane & 31), col = (lane >> 5) * (C / 2) + 8 * s + e;
+            o[((size_t)(s * 2 + pl) * 64 + lane) * 8 + e] = p1.planes[pl * n1 + (size_t)row * C + col];
+          }
+    o += CH1;
+    for (int q = 0; q < Q; ++q)
+      for (int u = 0; u < 2; ++u)
+        for (int pl = 0; pl < 2; ++pl)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const int row = 32 * q + (lane & 31), col = 32 * t + 16 * u + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+              o[((size_t)((q * 2 + u) * 2 + pl) * 64 + lane) * 8 + e] = p2.planes[pl * n2 + (size_t)row * H + col];
+            }
+  }
+  tab->resize((size_t)3 * H + 2 * C);
+  for (int j = 0; j < H; ++j) { (*tab)[j] = p1.inv_scale[j]; (*tab)[H + j] = cs1[j]; (*tab)[2 * H + j] = b1f[j]; }
+  for (int n = 0; n < C; ++n) { (*tab)[3 * H + n] = p2.inv_scale[n]; (*tab)[3 * H + C + n] = b2f[n]; }
+}
+
 // Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR (triangle, support 1) filter, in double, so that
 // the integer tables are bit-identical to the ones PIL builds (reference path: perspectivefields.py:45 -> Image.resize).
 struct ResizeTable { int ksize = 0; std::vector<int> bounds, kk; int *d_bounds = nullptr, *d_kk = nullptr; };
@@ -310,6 +354,8 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
+  bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
+                             // the one-kernel MLP (cnx_mlp.hip, hidden map in registers only); split-f16 scheme only
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
   int nterms = NT_F16X3;     // pf_set_precision: NT_F16X3 = 2-way fp16 split, 3 MFMAs per product (default parity mode); 6 = exact 3-way bf16 split
                              // (fp32-accurate, PF_PRECISION_FP32_BF16X6); 3 = "bf16x3", 1 = "bf16" (reduced precision, not parity modes)
@@ -584,6 +630,15 @@ struct pf_engine {
           const std::vector<float>& gm = get(b + ".gamma", {C}).data;
           std::vector<double> sc(gm.begin(), gm.end());
           cb.pw2 = make_linear(b + ".pwconv2", C, 4 * C, sc.data());
+          if (fuse_cnx_mlp && cnx_mlp_preferred(C)) {
+            std::vector<unsigned short> wpk;
+            std::vector<float> tab;
+            cnx_mlp_pack(get(b + ".pwconv1.weight", {4 * C, C}).data.data(), get(b + ".pwconv1.bias", {4 * C}).data.data(), get(b + ".norm.weight", {C}).data.data(),
+                         get(b + ".norm.bias", {C}).data.data(), get(b + ".pwconv2.weight", {C, 4 * C}).data.data(), get(b + ".pwconv2.bias", {C}).data.data(), gm.data(), C,
+                         &wpk, &tab);
+            cb.mlp_w = upload_u16(wpk);
+            cb.mlp_tab = upload(tab);
+          }
           cnx.blocks[s].push_back(cb);
         }
       }
@@ -916,6 +971,13 @@ struct pf_engine {
           ProfScope ps(c.prof, c.s, PC_DW7, 8.0 * M * C);
           launch_dwconv7x7(y, cb.dw.w, cb.dw.b, d, B, h, h, C, c.s);
         }
+        if (cb.mlp_w && nterms == NT_F16X3) {         // norm + pwconv1 + GELU + pwconv2 + layer scale + residual in one kernel
+          if (!c.dry) {
+            ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * 2.0 * M * (double)C * 4 * C, (int)M, C, 8 * C, 1);
+            launch_cnx_mlp(d, y, cb.mlp_w, cb.mlp_tab, M, C, cb.n.eps, c.s);
+          }
+          continue;
+        }
         if (cb.pw1.ln_s) {
           gemm(c, cb.pw1, Ten(d), M, hb, ACT_GELU);   // block norm inside pwconv1
         } else {
@@ -1068,11 +1130,13 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_UPSAMPLE")) e->fuse_upsample = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_PRED")) e->fuse_pred = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_LN")) e->fuse_ln = atoi(v) != 0;
+  if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;
   if (!e->split_bf16) e->sba = false;  // split planes are only read by the split-bf16 kernels
   if (!e->split_bf16 || e->sba) e->fuse_ln = false;  // the fused form lives in the split GEMM kernels and reads fp32 rows
+  if (!e->split_bf16 || e->sba) e->fuse_cnx_mlp = false;
 
   tune_cache_load(e);
   *out = e;
@@ -1483,6 +1547,37 @@ int pf_op_linear_ln(int device, const float* x, long rows, int K, const float* h
   p.finish();
   if (tile_id >= 0 && !conv_tile_usable(p, tile_id)) { g_create_error = "pf_op_linear_ln: tile config cannot run the fused LayerNorm form"; return PF_ERR_ARG; }
   launch_conv_tile(p, tile_id, s);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_cnx_mlp(int device, const float* d, float* y, long rows, int C, const float* w1, const float* b1, const float* lng, const float* lnb, float eps,
+                  const float* w2, const float* b2, const float* ls, int iters, float* ms_out, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (!cnx_mlp_supported(C) || !d || !y || rows <= 0) { g_create_error = "pf_op_cnx_mlp: C must be 96 or 192"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  std::vector<unsigned short> wpk;
+  std::vector<float> tab;
+  cnx_mlp_pack(w1, b1, lng, lnb, w2, b2, ls, C, &wpk, &tab);
+  const unsigned short* dw = tmp.up_u16(wpk);
+  const float* dt = tmp.up(tab);
+  launch_cnx_mlp(d, y, dw, dt, rows, C, eps, s);
+  if (iters > 0 && ms_out) {  // timing loop (y keeps accumulating: values are meaningless afterwards)
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+    for (int i = 0; i < iters; ++i) launch_cnx_mlp(d, y, dw, dt, rows, C, eps, s);
+    (void)hipEventRecord(b, s);
+    (void)hipEventSynchronize(b);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, a, b);
+    *ms_out = t / iters;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  }
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);
   return rc;

@@ -196,6 +196,11 @@ void launch_postprocess_batch(PostBatch& pb, int h, int w, int lat_is_sin, hipSt
 void launch_nearest_nhwc4(const float* x, float* y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
 
 // ConvNeXt tail: global average pool -> LN(C) -> Linear(C->nout); out [B][nout]
+// Fused ConvNeXt block MLP (cnx_mlp.hip): y += ls * pwconv2(GELU(pwconv1(LayerNorm(d)))) for C = 96 / 192, hidden map in registers only.
+// wpk / tab: packed by cnx_mlp_pack (engine.hip)
+bool cnx_mlp_supported(int C);
+bool cnx_mlp_preferred(int C);  // the stages where the engine uses it
+void launch_cnx_mlp(const float* d, float* y, const unsigned short* wpk, const float* tab, long M, int C, float eps, hipStream_t s);
 void launch_gap_ln_head(const float* x, const float* g, const float* b, const float* w, const float* hb, float* out, int B, int HW, int C, int nout, float eps, hipStream_t s);
 
 // camera parameters {roll, elevation (rad), focal_rel, cx_rel, cy_rel} (device) -> up [2][H][W], latitude [H][W] degrees

@@ -124,6 +124,20 @@ def linear_ln(x, weight, bias, gamma, beta, eps, act=0, res1=None, tile=-1, prec
     return y
 
 
+def cnx_mlp(d, y, w1, b1, ln_gamma, ln_beta, eps, w2, b2, layer_scale, iters=0):
+    """One ConvNeXt block MLP in one kernel: returns y + layer_scale * pwconv2(GELU(pwconv1(LayerNorm(d)))) (y is not modified: a copy is
+    updated).  d, y: (rows, C) on the GPU, C = 96 or 192.  iters > 0: returns (result of the first launch is lost) the average ms per launch."""
+    lib = load_library()
+    d = d.contiguous()
+    out = y.contiguous().clone()
+    rows, C = d.shape
+    ms = ctypes.c_float()
+    a = [_np(v) for v in (w1, b1, ln_gamma, ln_beta, w2, b2, layer_scale)]
+    _check(lib.pf_op_cnx_mlp(d.device.index, d.data_ptr(), out.data_ptr(), rows, C, _hp(a[0]), _hp(a[1]), _hp(a[2]), _hp(a[3]), float(eps), _hp(a[4]), _hp(a[5]), _hp(a[6]),
+                             iters, ctypes.byref(ms), _stream_ptr()), None, "pf_op_cnx_mlp")
+    return ms.value if iters > 0 else out
+
+
 def layernorm(x, gamma, beta, eps, planes_out=False):
     import torch
 

@@ -328,6 +328,31 @@ def test_linear_with_fused_layernorm(ops, K, N, rows):
     assert ran >= 20
 
 
+@pytest.mark.parametrize("C,rows", [(96, 128), (96, 1000), (96, 6400), (192, 300), (192, 1600)])
+def test_convnext_block_mlp_fused(ops, C, rows):
+    """cnx_mlp.hip: y + ls * pwconv2(GELU(pwconv1(LayerNorm(d)))) in one kernel (hidden map in registers) vs torch fp64 (convnext.py:49-58).
+    Rows with large common offsets, a constant row, ragged row count (tail block)."""
+    d = _rand((rows, C), 41, 1.5) + 30.0 * _rand((rows, 1), 42)
+    d[5] = 2.0
+    y = _rand((rows, C), 43)
+    w1 = _rand((4 * C, C), 44, 1.0 / math.sqrt(C))
+    b1 = _rand((4 * C,), 45, 0.1)
+    g = 1 + _rand((C,), 46, 0.3)
+    be = _rand((C,), 47, 0.2)
+    w2 = _rand((C, 4 * C), 48, 1.0 / math.sqrt(4 * C))
+    b2 = _rand((C,), 49, 0.1)
+    ls = _rand((C,), 50, 0.5)
+    xn = F.layer_norm(d.double(), (C,), g.double(), be.double(), 1e-6)
+    h = pf_oracle.gelu(F.linear(xn, w1.double(), b1.double()))
+    ref = y.double() + ls.double() * F.linear(h, w2.double(), b2.double())
+    got = ops.cnx_mlp(d.cuda(), y.cuda(), w1, b1, g, be, 1e-6, w2, b2, ls)
+    _close(got, ref, 5e-5, f"fused ConvNeXt MLP C={C}")
+    # and against the two-GEMM form it replaces (LayerNorm-fused pwconv1 + pwconv2 with the layer scale folded): same scheme, ~1e-6
+    hid = ops.linear_ln(d.cuda(), w1, b1, g, be, 1e-6, act=2)
+    two = ops.linear(hid, w2 * ls[:, None], b2 * ls, res1=y.cuda())
+    _close(got, two.double().cpu(), 2e-5, f"fused ConvNeXt MLP vs two GEMMs C={C}")
+
+
 def test_mfma_operand_orientation(ops):
     """A = I-like check with an ASYMMETRIC B: catches a row/col swap of the MFMA C layout."""
     K = N = 64
