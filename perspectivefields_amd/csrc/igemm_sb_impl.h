@@ -236,9 +236,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
       for (int pl = 0; pl < NPG; ++pl)
         R.b[i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)BPL[pl] * p.w_sb_plane_bytes : OOB);
   };
-  float ln_piv[LNF ? A_ROWS : 1], ln_s1[LNF ? A_ROWS : 1], ln_s2[LNF ? A_ROWS : 1];
+  // statistics in packed fp32 (v_pk_add_f32 / v_pk_fma_f32: two lanes of the sum per instruction -- VALU instructions are paid in MFMA issue time,
+  // profiles/r02_cnx_mlp.md): 6 instead of 12 VALU instructions per staged float4
+  typedef float lnf2 __attribute__((ext_vector_type(2)));
+  float ln_piv[LNF ? A_ROWS : 1];
+  lnf2 ln_s1[LNF ? A_ROWS : 1], ln_s2[LNF ? A_ROWS : 1];
 #pragma unroll
-  for (int i = 0; i < (LNF ? A_ROWS : 1); ++i) ln_piv[i] = ln_s1[i] = ln_s2[i] = 0.f;
+  for (int i = 0; i < (LNF ? A_ROWS : 1); ++i) { ln_piv[i] = 0.f; ln_s1[i] = lnf2{0.f, 0.f}; ln_s2[i] = lnf2{0.f, 0.f}; }
   auto store_tiles = [&](const Raw& R) {
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -254,9 +258,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
         float4 av = R.a[i];
         if (LNF) {
           const float pv = ln_piv[LNF ? i : 0];
-          av = make_float4(av.x - pv, av.y - pv, av.z - pv, av.w - pv);
-          ln_s1[LNF ? i : 0] += (av.x + av.y) + (av.z + av.w);
-          ln_s2[LNF ? i : 0] = fmaf(av.x, av.x, fmaf(av.y, av.y, fmaf(av.z, av.z, fmaf(av.w, av.w, ln_s2[LNF ? i : 0]))));
+          const lnf2 a0 = lnf2{av.x, av.y} - lnf2{pv, pv}, a1 = lnf2{av.z, av.w} - lnf2{pv, pv};
+          av = make_float4(a0.x, a0.y, a1.x, a1.y);
+          ln_s1[LNF ? i : 0] = (ln_s1[LNF ? i : 0] + a0) + a1;
+          ln_s2[LNF ? i : 0] = __builtin_elementwise_fma(a1, a1, __builtin_elementwise_fma(a0, a0, ln_s2[LNF ? i : 0]));
         }
         if (F16) split4_f16(av, h, m);
         else if (NTERM == 6) split4(av, h, m, l);
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     const float invK = 1.0f / (float)p.Cin;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-      float a = ln_s1[i], b = ln_s2[i];
+      float a = ln_s1[i].x + ln_s1[i].y, b = ln_s2[i].x + ln_s2[i].y;
 #pragma unroll
       for (int sh = 1; sh < 8; sh <<= 1) { a += __shfl_xor(a, sh); b += __shfl_xor(b, sh); }
       const float mu = a * invK;
