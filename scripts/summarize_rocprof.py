@@ -49,7 +49,7 @@ for k, v in out["kernels"].items():
         # SQ_VALU_MFMA_BUSY_CYCLES: 64 per v_mfma_f32_32x32x2_f32, summed over all SIMDs
         v["mfma_busy_frac"] = p["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / (p["GRBM_GUI_ACTIVE"]["sum"] / 8.0 * 1024)  # GRBM counter is summed over the 8 XCDs; 1024 SIMDs
 # class aggregate matching bench.py's `roofline` object (all split-bf16 implicit-GEMM launches: linear + halo tiles)
-cls = [v["trace"] for k, v in out["kernels"].items() if k.startswith("pf::igemm_sb") and "trace" in v]  # igemm_sb_kernel<*> and igemm_sbh_kernel<*>
+cls = [v["trace"] for k, v in out["kernels"].items() if (k.startswith("pf::igemm_sb") or k.startswith("pf::cnx_mlp")) and "trace" in v]  # igemm_sb_kernel<*>, igemm_sbh_kernel<*>, cnx_mlp_kernel
 if cls:
     n, us = sum(t["calls"] for t in cls), sum(t["total_us"] for t in cls)
     out["split_bf16_igemm_class"] = {"calls": n, "total_us": round(us, 1), "avg_us": round(us / n, 2),
@@ -104,7 +104,7 @@ for k, v in rows[:40]:
 if "split_bf16_igemm_class" in out:
     c = out["split_bf16_igemm_class"]
     md.append("")
-    md.append(f"split (fp16 / bf16) implicit GEMM as one class (pf::igemm_sb_kernel<*> + pf::igemm_sbh_kernel = bench.py's `roofline` kernel): "
+    md.append(f"split (fp16 / bf16) implicit GEMM as one class (pf::igemm_sb_kernel<*> + pf::igemm_sbh_kernel + pf::cnx_mlp_kernel = bench.py's `split_gemm_class`): "
               f"{c['calls']} calls, {c['total_us']} us, avg {c['avg_us']} us per launch, {c['pct']} % of kernel time")
 md.append("")
 md.append("3x3 halo kernels by launch shape (kernel, grid size):")
