@@ -198,8 +198,10 @@ __device__ __forceinline__ f32x16 at_mfma(const at_u32x4 a, const at_u32x4 b, co
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(at_f16x8, a), __builtin_bit_cast(at_f16x8, b), c, 0, 0, 0);
 }
 
+// QT: query tiles of 128 rows per block -- K / V of a (batch, head) are staged (fetched, split, V transposed) once per block, so a block that walks
+// QT tiles amortises that staging QT-fold (it costs about as much as one tile's two products); the launcher picks QT so that the grid still fills the chip
 __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* __restrict__ q, const float* __restrict__ kv,
-                                                                  float* __restrict__ out, unsigned short* __restrict__ out_sb, size_t sb_plane, int N, int M, int heads) {
+                                                                  float* __restrict__ out, unsigned short* __restrict__ out_sb, size_t sb_plane, int N, int M, int heads, int QT) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem_at[];
   unsigned short* Kh = smem_at;              // [M][AT_KS]  hi of 16 K
   unsigned short* Kl = Kh + M * AT_KS;       //             lo (unscaled remainder)
@@ -244,8 +246,11 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
     }
   }
 
+  __syncthreads();
+  for (int qt = 0; qt < QT; ++qt) {
   // ---- this lane's query row (clamped; out-of-range rows are computed but not stored): B fragments of S^T = K Q^T
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = (blockIdx.x * QT + qt) * 128 + wave * 32;
+  if (q0 >= N) break;  // wave-uniform; no barrier below
   const int qrow = q0 + l31;
   const int qr = qrow < N ? qrow : N - 1;
   const float* qp = q + ((long)b * N + qr) * C + h * HD + 8 * hi;
@@ -256,7 +261,6 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
     const float a[8] = {v0.x * 0.125f, v0.y * 0.125f, v0.z * 0.125f, v0.w * 0.125f, v1.x * 0.125f, v1.y * 0.125f, v1.z * 0.125f, v1.w * 0.125f};  // d^-0.5, exact
     at_split8<true>(a, qh[t], ql[t]);
   }
-  __syncthreads();
 
   // ---- S^T[kv][q] * 16: kv blocks of 32 rows (rows past M read a clamped row and are masked below)
   f32x16 sacc[4];
@@ -359,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
         if (out_sb) store_sb4(out_sb, sb_plane, o, v);
       }
   }
+  }  // query tiles
 }
 
 static int g_attn_variant = -1;  // PF_ATTN_VARIANT: 1 = split-f16 MFMA (default), 0 = exact fp32 MFMA
@@ -366,7 +371,14 @@ void launch_sr_attention_variant(int variant, const float* q, const float* kv, f
   const dim3 grid((N + 127) / 128, heads, B);
   if (variant == 1) {
     const size_t lds = ((size_t)2 * M * AT_KS + (size_t)2 * HD * AT_VS) * sizeof(unsigned short);
-    hipLaunchKernelGGL(sr_attention_f16_kernel, grid, dim3(256), lds, s, q, kv, out, out_sb, sb_plane, N, M, heads);
+    // query tiles per block: doubled while the grid keeps >= 300 blocks (sweep profiles/r02_tune_attn_qt.txt: stage 1 best at 4, stages 2 / 3 at 2; PF_ATTN_QT overrides)
+    static const int qt_env = [] { const char* e = getenv("PF_ATTN_QT"); return e ? atoi(e) : 0; }();
+    const int tiles = (N + 127) / 128;
+    int QT = 1;
+    if (qt_env > 0) QT = qt_env;
+    else while (QT < 8 && QT * 2 <= tiles && (long)((tiles + 2 * QT - 1) / (2 * QT)) * heads * B >= 300) QT *= 2;
+    const dim3 gridq((tiles + QT - 1) / QT, heads, B);
+    hipLaunchKernelGGL(sr_attention_f16_kernel, gridq, dim3(256), lds, s, q, kv, out, out_sb, sb_plane, N, M, heads, QT);
   } else {
     const size_t lds = (size_t)M * (K_ROW + HD) * sizeof(float);
     hipLaunchKernelGGL(sr_attention_kernel, grid, dim3(256), lds, s, q, kv, out, out_sb, sb_plane, N, M, heads);
