@@ -215,6 +215,11 @@ int pf_op_linear_ln(int device, const float* d_x, long rows, int K, const float*
  * `iters` launches (avg ms in *ms_out; y is then garbage). */
 int pf_op_cnx_mlp(int device, const float* d_d, float* d_y, long rows, int C, const float* h_w1, const float* h_b1, const float* h_ln_gamma, const float* h_ln_beta,
                   float eps, const float* h_w2, const float* h_b2, const float* h_layer_scale, int iters, float* ms_out, void* stream);
+/* One MiT block Mlp in one kernel (mit_mlp.hip): y = x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))), mix_transformers.py:49-56,200,497-508; x, y: (B, Hs, Ws, C) NHWC
+ * token maps in DIFFERENT buffers, C = 64 or 128; weights in the reference's shapes (fc1 [4C][C], dwconv [4C][1][3][3], fc2 [C][4C]).  iters > 0 additionally
+ * times `iters` launches (avg ms in *ms_out). */
+int pf_op_mit_mlp(int device, const float* d_x, float* d_y, int B, int Hs, int Ws, int C, const float* h_fc1_w, const float* h_fc1_b, const float* h_ln_gamma,
+                  const float* h_ln_beta, float eps, const float* h_dw_w, const float* h_dw_b, const float* h_fc2_w, const float* h_fc2_b, int iters, float* ms_out, void* stream);
 int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int tile_id, int iters, int fmt_prec, float* ms_out);
 /* fp32 <-> planes in the format selected by bit 0 of plane_elems (the names are historical) */
 int pf_op_split_bf16(int device, const float* d_x, long n, uint16_t* d_planes, long plane_elems, void* stream);

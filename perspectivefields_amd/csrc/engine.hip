@@ -66,7 +66,7 @@ struct ConvW {
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-6f; };
 struct DwW { float* w = nullptr; float* b = nullptr; int C = 0; };
 
-struct MitBlock { LNW n1, n2, srn; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; };
+struct MitBlock { LNW n1, n2, srn; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */ };
 struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
 struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
@@ -291,6 +291,44 @@ void cnx_mlp_pack(const float* w1, const float* b1, const float* g, const float*
   for (int n = 0; n < C; ++n) { (*tab)[3 * H + n] = p2.inv_scale[n]; (*tab)[3 * H + C + n] = b2f[n]; }
 }
 
+// Weights of the fused MiT block Mlp (mit_mlp.hip), one chunk of mit_mlp_chunk_bytes(C) per 32 hidden units t (layout: the kernel's header):
+// LayerNorm (norm2) folded into fc1 as fold_ln_linear, split-f16 planes in MFMA fragment order, depthwise taps [ky * 3 + kx][hidden] + bias.
+void mit_mlp_pack(const float* w1, const float* b1, const float* g, const float* be, const float* wdw /*[H][1][3][3]*/, const float* bdw, const float* w2, const float* b2,
+                  int C, std::vector<unsigned short>* wpk, std::vector<float>* tab2) {
+  const int H = 4 * C, S1 = C / 16, Q = C / 32, NCH = H / 32;
+  std::vector<float> w1f, b1f, cs1;
+  fold_ln_linear(w1, b1, g, be, H, C, &w1f, &b1f, &cs1);
+  std::vector<float> w2v(w2, w2 + (size_t)C * H);
+  const F16Planes p1 = split_f16x2(w1f, H), p2 = split_f16x2(w2v, C);
+  const size_t n1 = w1f.size(), n2 = w2v.size();
+  const size_t chunk_us = (size_t)mit_mlp_chunk_bytes(C) / 2, w1_us = (size_t)S1 * 2 * 512, w2_us = (size_t)Q * 2 * 2 * 512;
+  wpk->assign((size_t)NCH * chunk_us, 0);
+  for (int t = 0; t < NCH; ++t) {
+    unsigned short* o = wpk->data() + (size_t)t * chunk_us;
+    for (int s = 0; s < S1; ++s)
+      for (int pl = 0; pl < 2; ++pl)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e)
+            o[((size_t)(s * 2 + pl) * 64 + lane) * 8 + e] = p1.planes[pl * n1 + (size_t)(32 * t + (lane & 31)) * C + (lane >> 5) * (C / 2) + 8 * s + e];
+    o += w1_us;
+    for (int q = 0; q < Q; ++q)
+      for (int u = 0; u < 2; ++u)
+        for (int pl = 0; pl < 2; ++pl)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e)
+              o[((size_t)((q * 2 + u) * 2 + pl) * 64 + lane) * 8 + e] = p2.planes[pl * n2 + (size_t)(32 * q + (lane & 31)) * H + 32 * t + 16 * u + 8 * (lane >> 5) + e];
+    float* tb = reinterpret_cast<float*>(o + w2_us);  // inv1[32], cs1[32], b1[32], taps [9][32], dw bias [32]
+    for (int j = 0; j < 32; ++j) {
+      const int hd = 32 * t + j;
+      tb[j] = p1.inv_scale[hd]; tb[32 + j] = cs1[hd]; tb[64 + j] = b1f[hd];
+      for (int k = 0; k < 9; ++k) tb[96 + k * 32 + j] = wdw[(size_t)hd * 9 + k];
+      tb[96 + 9 * 32 + j] = bdw[hd];
+    }
+  }
+  tab2->resize((size_t)2 * C);
+  for (int n = 0; n < C; ++n) { (*tab2)[n] = p2.inv_scale[n]; (*tab2)[C + n] = b2[n]; }
+}
+
 // Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR (triangle, support 1) filter, in double, so that
 // the integer tables are bit-identical to the ones PIL builds (reference path: perspectivefields.py:45 -> Image.resize).
 struct ResizeTable { int ksize = 0; std::vector<int> bounds, kk; int *d_bounds = nullptr, *d_kk = nullptr; };
@@ -354,6 +392,8 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
+  bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
+                             // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
   bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
                              // the one-kernel MLP (cnx_mlp.hip, hidden map in registers only); split-f16 scheme only
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
@@ -582,6 +622,16 @@ struct pf_engine {
         mb.fc1 = make_linear(b + ".mlp.fc1", 4 * C, C, nullptr, b + ".norm2", 1e-6f);
         mb.dw = make_dw(b + ".mlp.dwconv.dwconv", 4 * C, 3);
         mb.fc2 = make_linear(b + ".mlp.fc2", C, 4 * C);
+        if (fuse_mit_mlp && mit_mlp_preferred(C)) {
+          std::vector<unsigned short> wpk;
+          std::vector<float> tab2;
+          mit_mlp_pack(get(b + ".mlp.fc1.weight", {4 * C, C}).data.data(), get(b + ".mlp.fc1.bias", {4 * C}).data.data(), get(b + ".norm2.weight", {C}).data.data(),
+                       get(b + ".norm2.bias", {C}).data.data(), get(b + ".mlp.dwconv.dwconv.weight", {4 * C, 1, 3, 3}).data.data(),
+                       get(b + ".mlp.dwconv.dwconv.bias", {4 * C}).data.data(), get(b + ".mlp.fc2.weight", {C, 4 * C}).data.data(), get(b + ".mlp.fc2.bias", {C}).data.data(), C,
+                       &wpk, &tab2);
+          mb.mlp_w = upload_u16(wpk);
+          mb.mlp_tab = upload(tab2);
+        }
         stages[s].blocks.push_back(mb);
       }
       stages[s].norm = make_ln("backbone.norm" + std::to_string(s + 1), C, 1e-6f);
@@ -783,6 +833,9 @@ struct pf_engine {
       const int Ho = (H + 2 * MIT_PP[s] - MIT_PK[s]) / MIT_PS[s] + 1, Wo = (W + 2 * MIT_PP[s] - MIT_PK[s]) / MIT_PS[s] + 1;
       const long N = (long)Ho * Wo, M = (long)B * N;
       float* x = c.alloc(M * C);  // token stream, updated in place by the residual epilogues
+      // the fused Mlp (mit_mlp.hip) reads the halo rows of neighbouring blocks: it writes a second buffer and the two swap roles
+      const bool fused_mlp = !st.blocks.empty() && st.blocks[0].mlp_w && nterms == NT_F16X3;
+      float* xalt = fused_mlp ? c.alloc(M * C) : nullptr;
       const SbT xs = S ? c.alloc_sb(M * C) : SbT();  // split copy of the stage output (next patch embed + decoder)
       conv(c, st.pe, cur, B, H, W, Ten(x));
       ln(c, st.pen, x, Ten(x), M);
@@ -823,6 +876,14 @@ struct pf_engine {
         }
         gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
         // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
+        if (fused_mlp && mb.mlp_w) {                  // norm2 + fc1 + depthwise 3x3 + GELU + fc2 + residual in one kernel, x -> xalt
+          if (!c.dry) {
+            ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * 2.0 * M * (double)C * 4 * C, (int)M, C, 8 * C, 9);
+            launch_mit_mlp(x, xalt, mb.mlp_w, mb.mlp_tab, B, Ho, Wo, C, mb.n2.eps, c.s);
+          }
+          std::swap(x, xalt);
+          continue;
+        }
         if (mb.fc1.ln_s) {
           gemm(c, mb.fc1, Ten(x), M, Ten(hb));        // norm2 inside fc1
         } else {
@@ -1131,12 +1192,14 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_PRED")) e->fuse_pred = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_LN")) e->fuse_ln = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
+  if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;
   if (!e->split_bf16) e->sba = false;  // split planes are only read by the split-bf16 kernels
   if (!e->split_bf16 || e->sba) e->fuse_ln = false;  // the fused form lives in the split GEMM kernels and reads fp32 rows
   if (!e->split_bf16 || e->sba) e->fuse_cnx_mlp = false;
+  if (!e->split_bf16 || e->sba) e->fuse_mit_mlp = false;
 
   tune_cache_load(e);
   *out = e;
@@ -1547,6 +1610,37 @@ int pf_op_linear_ln(int device, const float* x, long rows, int K, const float* h
   p.finish();
   if (tile_id >= 0 && !conv_tile_usable(p, tile_id)) { g_create_error = "pf_op_linear_ln: tile config cannot run the fused LayerNorm form"; return PF_ERR_ARG; }
   launch_conv_tile(p, tile_id, s);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_mit_mlp(int device, const float* x, float* y, int B, int Hs, int Ws, int C, const float* w1, const float* b1, const float* lng, const float* lnb, float eps,
+                  const float* wdw, const float* bdw, const float* w2, const float* b2, int iters, float* ms_out, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (!mit_mlp_supported(C) || !x || !y || x == y || B <= 0) { g_create_error = "pf_op_mit_mlp: C must be 64 or 128, x and y different buffers"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  std::vector<unsigned short> wpk;
+  std::vector<float> tab2;
+  mit_mlp_pack(w1, b1, lng, lnb, wdw, bdw, w2, b2, C, &wpk, &tab2);
+  const unsigned short* dw = tmp.up_u16(wpk);
+  const float* dt = tmp.up(tab2);
+  launch_mit_mlp(x, y, dw, dt, B, Hs, Ws, C, eps, s);
+  if (iters > 0 && ms_out) {
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+    for (int i = 0; i < iters; ++i) launch_mit_mlp(x, y, dw, dt, B, Hs, Ws, C, eps, s);
+    (void)hipEventRecord(b, s);
+    (void)hipEventSynchronize(b);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, a, b);
+    *ms_out = t / iters;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  }
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);
   return rc;

@@ -1,0 +1,272 @@
+// Fused MiT block Mlp for gfx950:  y = x + fc2( GELU( dwconv3x3( fc1( LayerNorm(x) ) ) ) )   (mix_transformers.py:49-56 Mlp.forward, :200 the
+// residual, :497-508 DWConv), for the two large stages (C = 64 @80x80, C = 128 @40x40).  The 4C-wide hidden map never goes to HBM.
+//
+// As three kernels (LayerNorm-fused fc1, depthwise 3x3 + GELU, fc2) the block moves the hidden map four times (210 MB each at stage 1 and batch 32)
+// and every one of the three is bound by that traffic.  Here a block of 4 waves owns a TY x TX patch of pixels of one image:
+//   * GEMM 1 runs on the patch PLUS its one-pixel halo (HY x HX pixels, RT1 row tiles of 32): the rows (minus a per-row pivot) live in registers as
+//     split-f16 fragments for the whole kernel, their LayerNorm statistics come from the same registers;
+//   * per chunk of 32 hidden units: GEMM 1 (transposed form: weights = MFMA A operand) -> LayerNorm correction + bias in registers -> the hidden
+//     values of the halo pixels to LDS (fp32; pixels outside the image are ZERO: the depthwise conv pads the hidden map, not the input) -> barrier ->
+//     every thread computes the 3x3 depthwise sum + bias + erf-GELU for HPT hidden units of one interior pixel from nine LDS rows, splits the result
+//     into fp16 hi / lo and writes it as the B operand of GEMM 2 -> barrier -> GEMM 2 accumulates y^T (channels x pixels) in registers;
+//   * weights of a chunk (W1 rows, W2 columns, depthwise taps, per-hidden-unit tables) stream through LDS in fragment order by LDS-DMA, double-buffered;
+//     the DMA of chunk t + 1 is issued after the first barrier of chunk t and waited for before its second one;
+//   * epilogue: y = acc * inv_scale + bias + x for the patch's pixels (float4 per lane: transposed accumulators).
+// x and y must be different buffers (neighbouring blocks read each other's rows as halo): the engine ping-pongs the token stream.
+// Contractions: the split-f16 scheme of igemm_sb_impl.h (three fp16 MFMAs per product, fp32-class accuracy).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "igemm_common.h"
+#include "sb_split.h"
+
+namespace pf {
+
+typedef _Float16 mm_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mm_mfma(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mm_f16x8, a), __builtin_bit_cast(mm_f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 mm_scale(const u32x4 w) { return __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, w))); }
+
+// Chunk layout (mit_mlp_pack in engine.hip), CHUNK_BYTES per 32 hidden units, fp16 fragments lane-major (64 lanes x 8 values = 1 KB each):
+//   [0, S1 * 2 KB)                      W1: [s][plane hi / lo][lane][8] = W1s[32 t + (lane & 31)][(lane >> 5) C/2 + 8 s + e]      (S1 = C / 16)
+//   [.., + Q * 2 * 2 KB)                W2: [q][u][plane][lane][8]      = W2s[32 q + (lane & 31)][32 t + 16 u + 8 (lane >> 5) + e]  (Q = C / 32)
+//   then 13 x 32 floats                 inv1, cs1, b1 (LayerNorm-folded fc1), depthwise taps [9][32], depthwise bias   (chunk padded to a multiple of 1 KB)
+// tab2: inv2[C], b2[C]
+template <int C> struct MitMlpCfg {
+  static constexpr int S1 = C / 16, Q = C / 32;
+  static constexpr int W1_BYTES = S1 * 2 * 1024, W2_BYTES = Q * 2 * 2 * 1024, TAB_FLOATS = 13 * 32;
+  static constexpr int USED_BYTES = W1_BYTES + W2_BYTES + TAB_FLOATS * 4;       // multiple of 16
+  static constexpr int CHUNK_BYTES = ((USED_BYTES + 1023) / 1024) * 1024;      // stride of a chunk in global memory and of a buffer in LDS
+};
+
+template <int C, int TY, int TX>
+__global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const float* __restrict__ x, float* __restrict__ y, const unsigned short* __restrict__ wpk,
+                                                                      const float* __restrict__ tab2, int B, int Hs, int Ws, float eps) {
+  typedef MitMlpCfg<C> Cfg;
+  constexpr int H = 4 * C, S1 = Cfg::S1, Q = Cfg::Q, NCH = H / 32;
+  constexpr int HY = TY + 2, HX = TX + 2, NHALO = HY * HX, RT1 = (NHALO + 31) / 32, NINT = TY * TX, RT2 = NINT / 32;
+  constexpr int T1 = (RT1 + 3) / 4;                 // GEMM-1 row tiles per wave (wave w: tiles w, w + 4)
+  constexpr int TPP = 256 / NINT, HPT = 32 / TPP;   // depthwise phase: threads per interior pixel, hidden units per thread
+  constexpr int HS = 36;                            // floats per hidden row in LDS (144 B: 16 consecutive rows hit distinct 16-byte bank groups)
+  static_assert(NINT % 32 == 0 && RT2 * Q == 8 && 256 % NINT == 0 && HPT % 8 == 0 && NCH % 2 == 0, "geometry");
+  constexpr int CHUNK = Cfg::CHUNK_BYTES;
+  constexpr int HBUF_BYTES = RT1 * 32 * HS * 4, H2_BYTES = NINT * 64 * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CHUNK + HBUF_BYTES + H2_BYTES];
+  float* Hbuf = reinterpret_cast<float*>(smem + 2 * CHUNK);                          // [RT1 * 32][HS] hidden values of the halo pixels (one chunk)
+  unsigned short* H2 = reinterpret_cast<unsigned short*>(smem + 2 * CHUNK + HBUF_BYTES);  // [2 planes][NINT][32] fp16, 64-byte rows, XOR piece swizzle
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tilesX = (Ws + TX - 1) / TX, tilesY = (Hs + TY - 1) / TY;
+  int bid = blockIdx.x;
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY; bid /= tilesY;
+  const int b = bid;
+  const int y0 = ty * TY, x0 = tx * TX;
+  const float* xb = x + (size_t)b * Hs * Ws * C;
+
+  // ---- weight chunks by LDS-DMA (inline asm: hipcc would wait for the DMA in front of the next ds_read, cnx_mlp.hip)
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+  auto dma_w = [&](int t, int buf) {
+    const char* src = reinterpret_cast<const char*>(wpk) + (size_t)t * CHUNK + tid * 16;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * CHUNK + wave * 1024));
+#pragma unroll
+    for (int j = 0; j < (Cfg::USED_BYTES + 4095) / 4096; ++j) {
+      if (4096 * (j + 1) <= Cfg::USED_BYTES || tid * 16 + 4096 * j < Cfg::USED_BYTES) {  // last round: only the lanes that still have a piece
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src + 4096 * j), "s"(dst + 4096u * j) : "memory");
+      }
+    }
+  };
+  dma_w(0, 0);
+
+  // ---- this wave's GEMM-1 rows (halo pixels): split-f16 fragments + LayerNorm statistics, held for the whole kernel
+  u32x4 xh[T1][S1], xl[T1][S1];
+  float mu[T1], rs[T1];
+  bool rok[T1];
+#pragma unroll
+  for (int k = 0; k < T1; ++k) {
+    const int tile = wave + 4 * k;
+    const int r = tile * 32 + l31;                       // halo pixel index
+    const int hy = r / HX, hx = r - hy * HX;
+    const int py = y0 - 1 + hy, px = x0 - 1 + hx;
+    rok[k] = tile < RT1 && r < NHALO && (unsigned)py < (unsigned)Hs && (unsigned)px < (unsigned)Ws;
+    const int cy = min(max(py, 0), Hs - 1), cx = min(max(px, 0), Ws - 1);  // a valid row for the loads; its hidden values are zeroed below
+    const float4* src = reinterpret_cast<const float4*>(xb + ((size_t)cy * Ws + cx) * C + hi * (C / 2));
+    float4 v[2 * S1];
+#pragma unroll
+    for (int j = 0; j < 2 * S1; ++j) v[j] = src[j];
+    const float piv = __shfl(v[0].x, l31);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * S1; ++j) {
+      v[j] = make_float4(v[j].x - piv, v[j].y - piv, v[j].z - piv, v[j].w - piv);
+      s1 += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+      s2 = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, s2))));
+    }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    mu[k] = s1 * (1.0f / C);
+    rs[k] = 1.0f / sqrtf(fmaxf(fmaf(-mu[k], mu[k], s2 * (1.0f / C)), 0.f) + eps);
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      uint2 h0, l0, h1, l1;
+      split4_f16(v[2 * s], h0, l0);
+      split4_f16(v[2 * s + 1], h1, l1);
+      xh[k][s] = u32x4{h0.x, h0.y, h1.x, h1.y};
+      xl[k][s] = u32x4{l0.x, l0.y, l1.x, l1.y};
+    }
+  }
+
+  // GEMM-2 sub-tiles of this wave: s = 2 wave, 2 wave + 1 -> (row tile s / Q, channel tile s % Q); two accumulators
+  f32x16 acc2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
+  const int rt2 = (2 * wave) / Q, q0 = (2 * wave) % Q;  // both sub-tiles share the row tile (Q is even)
+
+  // depthwise phase: thread -> (interior pixel dp, hidden units dh0 .. dh0 + HPT - 1 of the chunk)
+  const int dp = tid / TPP, dh0 = (tid % TPP) * HPT;
+  const int dpy = dp / TX, dpx = dp - dpy * TX;
+  const int hc = (dpy + 1) * HX + dpx + 1;  // halo index of the pixel itself
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // chunk 0 in LDS
+
+  auto step = [&](int t, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    const unsigned char* cb = smem + BUF * CHUNK;
+    const unsigned short* w1f = reinterpret_cast<const unsigned short*>(cb) + lane * 8;
+    const unsigned short* w2f = reinterpret_cast<const unsigned short*>(cb + Cfg::W1_BYTES) + lane * 8;
+    const float* tb = reinterpret_cast<const float*>(cb + Cfg::W1_BYTES + Cfg::W2_BYTES);  // inv1[32], cs1[32], b1[32], taps [9][32], dw bias [32]
+    // ---- GEMM 1 (transposed): hidden[32] x rows[32] per owned row tile, then LayerNorm correction + bias, zero outside the image, -> Hbuf
+#pragma unroll
+    for (int k = 0; k < T1; ++k) {
+      if (wave + 4 * k < RT1) {  // wave-uniform
+        f32x16 a1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a1[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < S1; ++s) {
+          const u32x4 wh = *reinterpret_cast<const u32x4*>(w1f + (s * 2) * 512);
+          const u32x4 wl = *reinterpret_cast<const u32x4*>(w1f + (s * 2 + 1) * 512);
+          a1 = mm_mfma(mm_scale(wh), xl[k][s], a1);
+          a1 = mm_mfma(wl, xh[k][s], a1);
+          a1 = mm_mfma(wh, xh[k][s], a1);
+        }
+        float* hrow = Hbuf + ((wave + 4 * k) * 32 + l31) * HS + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int hl = 8 * g + 4 * hi;  // hidden unit of the chunk
+          const float4 iv = *reinterpret_cast<const float4*>(tb + hl), cs = *reinterpret_cast<const float4*>(tb + 32 + hl), bb = *reinterpret_cast<const float4*>(tb + 64 + hl);
+          float4 a;
+          a.x = rs[k] * fmaf(-mu[k], cs.x, a1[4 * g] * iv.x) + bb.x; a.y = rs[k] * fmaf(-mu[k], cs.y, a1[4 * g + 1] * iv.y) + bb.y;
+          a.z = rs[k] * fmaf(-mu[k], cs.z, a1[4 * g + 2] * iv.z) + bb.z; a.w = rs[k] * fmaf(-mu[k], cs.w, a1[4 * g + 3] * iv.w) + bb.w;
+          if (!rok[k]) a = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(hrow + 8 * g) = a;
+        }
+      }
+    }
+    __syncthreads();  // (A) hidden values of the whole halo tile in Hbuf; every wave is past GEMM 2 of the previous chunk
+    if (t + 1 < NCH) dma_w(t + 1, 1 - BUF);  // that buffer was last read by chunk t - 1
+    // ---- depthwise 3x3 + bias + GELU for HPT hidden units of one interior pixel; fp16 split -> H2 (B operand of GEMM 2)
+    {
+      typedef float mm_f2 __attribute__((ext_vector_type(2)));
+      mm_f2 acc[HPT / 2];  // v_pk_fma_f32: two hidden units per instruction
+#pragma unroll
+      for (int j = 0; j < HPT / 4; ++j) {
+        const float4 bv = *reinterpret_cast<const float4*>(tb + 96 + 9 * 32 + dh0 + 4 * j);
+        acc[2 * j] = mm_f2{bv.x, bv.y}; acc[2 * j + 1] = mm_f2{bv.z, bv.w};
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)    // tap order of the stand-alone kernel (elem.hip): (ky, kx) = (0, c), (1, c), (2, c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* hr = Hbuf + (hc + (ky - 1) * HX + (c - 1)) * HS + dh0;
+          const float* wt = tb + 96 + (ky * 3 + c) * 32 + dh0;
+#pragma unroll
+          for (int j = 0; j < HPT / 4; ++j) {
+            const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * j), wv = *reinterpret_cast<const float4*>(wt + 4 * j);
+            acc[2 * j] = __builtin_elementwise_fma(mm_f2{hv.x, hv.y}, mm_f2{wv.x, wv.y}, acc[2 * j]);
+            acc[2 * j + 1] = __builtin_elementwise_fma(mm_f2{hv.z, hv.w}, mm_f2{wv.z, wv.w}, acc[2 * j + 1]);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < HPT / 8; ++j) {
+        const float4 g0 = make_float4(gelu_erf(acc[4 * j].x), gelu_erf(acc[4 * j].y), gelu_erf(acc[4 * j + 1].x), gelu_erf(acc[4 * j + 1].y));
+        const float4 g1 = make_float4(gelu_erf(acc[4 * j + 2].x), gelu_erf(acc[4 * j + 2].y), gelu_erf(acc[4 * j + 3].x), gelu_erf(acc[4 * j + 3].y));
+        uint2 h0, l0, h1, l1;
+        split4_f16(g0, h0, l0);
+        split4_f16(g1, h1, l1);
+        const int piece = ((dh0 >> 3) + j) ^ ((dp >> 2) & 3);
+        *reinterpret_cast<u32x4*>(H2 + dp * 32 + piece * 8) = u32x4{h0.x, h0.y, h1.x, h1.y};
+        *reinterpret_cast<u32x4*>(H2 + NINT * 32 + dp * 32 + piece * 8) = u32x4{l0.x, l0.y, l1.x, l1.y};
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of chunk t + 1
+    __syncthreads();  // (B) H2 complete; weights of chunk t + 1 visible to every wave
+    // ---- GEMM 2 (transposed): channels[32] x pixels[32], two channel tiles of one row tile per wave
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int prow = rt2 * 32 + l31;
+      const int piece = (2 * u + hi) ^ ((prow >> 2) & 3);
+      const u32x4 hh = *reinterpret_cast<const u32x4*>(H2 + prow * 32 + piece * 8);
+      const u32x4 hl = *reinterpret_cast<const u32x4*>(H2 + NINT * 32 + prow * 32 + piece * 8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u32x4 wh = *reinterpret_cast<const u32x4*>(w2f + (((q0 + j) * 2 + u) * 2) * 512);
+        const u32x4 wl = *reinterpret_cast<const u32x4*>(w2f + (((q0 + j) * 2 + u) * 2 + 1) * 512);
+        acc2[j] = mm_mfma(mm_scale(wh), hl, acc2[j]);
+        acc2[j] = mm_mfma(wl, hh, acc2[j]);
+        acc2[j] = mm_mfma(wh, hh, acc2[j]);
+      }
+    }
+  };
+  for (int t = 0; t < NCH; t += 2) {
+    step(t, std::integral_constant<int, 0>());
+    step(t + 1, std::integral_constant<int, 1>());
+  }
+
+  // ---- epilogue: y[pixel][n] = acc * inv2 + b2 + x[pixel][n]; lane = pixel l31 of the row tile, float4 per (channel tile, group g)
+  const int ip = rt2 * 32 + l31;
+  const int ipy = ip / TX, ipx = ip - ipy * TX;
+  const int oy = y0 + ipy, ox = x0 + ipx;
+  if (oy >= Hs || ox >= Ws) return;
+  const size_t o = ((size_t)b * Hs * Ws + (size_t)oy * Ws + ox) * C;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = 32 * (q0 + j) + 8 * g + 4 * hi;
+      const float4 iv = *reinterpret_cast<const float4*>(tab2 + n), bb = *reinterpret_cast<const float4*>(tab2 + C + n);
+      const float4 r = *reinterpret_cast<const float4*>(x + o + n);
+      float4 v;
+      v.x = fmaf(acc2[j][4 * g], iv.x, bb.x) + r.x; v.y = fmaf(acc2[j][4 * g + 1], iv.y, bb.y) + r.y;
+      v.z = fmaf(acc2[j][4 * g + 2], iv.z, bb.z) + r.z; v.w = fmaf(acc2[j][4 * g + 3], iv.w, bb.w) + r.w;
+      *reinterpret_cast<float4*>(y + o + n) = v;
+    }
+}
+
+bool mit_mlp_supported(int C) { return C == 64 || C == 128; }
+// the engine uses it at stage 1 (C = 64: 162 us vs ~260 us as three kernels); the C = 128 instantiation (one block per CU: 96 KB of LDS, 240 VGPRs) measured
+// 175 us vs ~165 us and is left off (PF_MIT_MLP_128=1), profiles/r02_mit_mlp.md
+bool mit_mlp_preferred(int C) {
+  static const int with128 = [] { const char* e = getenv("PF_MIT_MLP_128"); return e ? atoi(e) : 0; }();
+  return C == 64 || (C == 128 && with128);
+}
+int mit_mlp_chunk_bytes(int C) { return C == 64 ? MitMlpCfg<64>::CHUNK_BYTES : MitMlpCfg<128>::CHUNK_BYTES; }
+
+void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const float* tab2, int B, int Hs, int Ws, int C, float eps, hipStream_t s) {
+  if (C == 64) {
+    const dim3 grid((unsigned)(B * ((Hs + 7) / 8) * ((Ws + 15) / 16)));
+    hipLaunchKernelGGL((mit_mlp_kernel<64, 8, 16>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps);
+  } else if (C == 128) {
+    const dim3 grid((unsigned)(B * ((Hs + 7) / 8) * ((Ws + 7) / 8)));
+    hipLaunchKernelGGL((mit_mlp_kernel<128, 8, 8>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps);
+  }
+}
+
+}  // namespace pf

@@ -201,6 +201,12 @@ void launch_nearest_nhwc4(const float* x, float* y, int B, int H, int W, int Ho,
 bool cnx_mlp_supported(int C);
 bool cnx_mlp_preferred(int C);  // the stages where the engine uses it
 void launch_cnx_mlp(const float* d, float* y, const unsigned short* wpk, const float* tab, long M, int C, float eps, hipStream_t s);
+// Fused MiT block Mlp (mit_mlp.hip): y = x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))) for C = 64 / 128; x and y are different buffers.
+// wpk / tab2: packed by mit_mlp_pack (engine.hip), one chunk of mit_mlp_chunk_bytes(C) per 32 hidden units
+bool mit_mlp_supported(int C);
+bool mit_mlp_preferred(int C);  // the stages where the engine uses it
+int mit_mlp_chunk_bytes(int C);
+void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const float* tab2, int B, int Hs, int Ws, int C, float eps, hipStream_t s);
 void launch_gap_ln_head(const float* x, const float* g, const float* b, const float* w, const float* hb, float* out, int B, int HW, int C, int nout, float eps, hipStream_t s);
 
 // camera parameters {roll, elevation (rad), focal_rel, cx_rel, cy_rel} (device) -> up [2][H][W], latitude [H][W] degrees

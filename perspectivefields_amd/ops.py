@@ -124,6 +124,22 @@ def linear_ln(x, weight, bias, gamma, beta, eps, act=0, res1=None, tile=-1, prec
     return y
 
 
+def mit_mlp(x, fc1_w, fc1_b, ln_gamma, ln_beta, eps, dw_w, dw_b, fc2_w, fc2_b, iters=0):
+    """One MiT block Mlp in one kernel: x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))).  x: (B, Hs, Ws, C) on the GPU, C = 64 or 128.
+    iters > 0: returns the average ms per launch instead."""
+    import torch
+
+    lib = load_library()
+    x = x.contiguous()
+    B, Hs, Ws, C = x.shape
+    y = torch.empty_like(x)
+    ms = ctypes.c_float()
+    a = [_np(v) for v in (fc1_w, fc1_b, ln_gamma, ln_beta, dw_w, dw_b, fc2_w, fc2_b)]
+    _check(lib.pf_op_mit_mlp(x.device.index, x.data_ptr(), y.data_ptr(), B, Hs, Ws, C, _hp(a[0]), _hp(a[1]), _hp(a[2]), _hp(a[3]), float(eps), _hp(a[4]), _hp(a[5]), _hp(a[6]), _hp(a[7]),
+                             iters, ctypes.byref(ms), _stream_ptr()), None, "pf_op_mit_mlp")
+    return ms.value if iters > 0 else y
+
+
 def cnx_mlp(d, y, w1, b1, ln_gamma, ln_beta, eps, w2, b2, layer_scale, iters=0):
     """One ConvNeXt block MLP in one kernel: returns y + layer_scale * pwconv2(GELU(pwconv1(LayerNorm(d)))) (y is not modified: a copy is
     updated).  d, y: (rows, C) on the GPU, C = 96 or 192.  iters > 0: returns (result of the first launch is lost) the average ms per launch."""

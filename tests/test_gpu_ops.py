@@ -353,6 +353,27 @@ def test_convnext_block_mlp_fused(ops, C, rows):
     _close(got, two.double().cpu(), 2e-5, f"fused ConvNeXt MLP vs two GEMMs C={C}")
 
 
+@pytest.mark.parametrize("C,B,Hs,Ws", [(64, 2, 80, 80), (64, 1, 13, 21), (64, 3, 8, 16), (128, 2, 40, 40), (128, 1, 11, 9), (128, 2, 8, 8)])
+def test_mit_block_mlp_fused(ops, C, B, Hs, Ws):
+    """mit_mlp.hip: x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))) in one kernel (hidden map in LDS / registers) vs torch fp64
+    (mix_transformers.py:49-56,200,497-508).  Full-size and ragged maps (patches cut by the border, maps smaller than a patch + halo)."""
+    x = _rand((B, Hs, Ws, C), 51, 1.5) + 20.0 * _rand((B, Hs, Ws, 1), 52)
+    w1 = _rand((4 * C, C), 53, 1.0 / math.sqrt(C))
+    b1 = _rand((4 * C,), 54, 0.1)
+    g = 1 + _rand((C,), 55, 0.3)
+    be = _rand((C,), 56, 0.2)
+    wd = _rand((4 * C, 1, 3, 3), 57, 0.4)
+    bd = _rand((4 * C,), 58, 0.1)
+    w2 = _rand((C, 4 * C), 59, 1.0 / math.sqrt(4 * C))
+    b2 = _rand((C,), 60, 0.1)
+    xn = F.layer_norm(x.double(), (C,), g.double(), be.double(), 1e-6)
+    h = F.linear(xn, w1.double(), b1.double())                                   # (B, Hs, Ws, 4C)
+    h = F.conv2d(h.permute(0, 3, 1, 2), wd.double(), bd.double(), padding=1, groups=4 * C).permute(0, 2, 3, 1)
+    ref = x.double() + F.linear(pf_oracle.gelu(h), w2.double(), b2.double())
+    got = ops.mit_mlp(x.cuda(), w1, b1, g, be, 1e-6, wd, bd, w2, b2)
+    _close(got, ref, 5e-5, f"fused MiT Mlp C={C} {Hs}x{Ws}")
+
+
 def test_mfma_operand_orientation(ops):
     """A = I-like check with an ASYMMETRIC B: catches a row/col swap of the MFMA C layout."""
     K = N = 64
