@@ -48,9 +48,9 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
   constexpr int H = 4 * C, S1 = Cfg::S1, Q = Cfg::Q, NCH = H / 32;
   constexpr int HY = TY + 2, HX = TX + 2, NHALO = HY * HX, RT1 = (NHALO + 31) / 32, NINT = TY * TX, RT2 = NINT / 32;
   constexpr int T1 = (RT1 + 3) / 4;                 // GEMM-1 row tiles per wave (wave w: tiles w, w + 4)
-  constexpr int TPP = 256 / NINT, HPT = 32 / TPP;   // depthwise phase: threads per interior pixel, hidden units per thread
+  constexpr int SP = NINT / 32;                      // depthwise phase: a thread owns SP adjacent pixels of a patch row x 4 hidden units (32 strips x 8 groups)
   constexpr int HS = 36;                            // floats per hidden row in LDS (144 B: 16 consecutive rows hit distinct 16-byte bank groups)
-  static_assert(NINT % 32 == 0 && RT2 * Q == 8 && 256 % NINT == 0 && HPT % 8 == 0 && NCH % 2 == 0, "geometry");
+  static_assert(NINT % 32 == 0 && RT2 * Q == 8 && TX % SP == 0 && TY * (TX / SP) == 32 && NCH % 2 == 0, "geometry");
   constexpr int CHUNK = Cfg::CHUNK_BYTES;
   constexpr int HBUF_BYTES = RT1 * 32 * HS * 4, H2_BYTES = NINT * 64 * 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CHUNK + HBUF_BYTES + H2_BYTES];
@@ -128,10 +128,11 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
     for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
   const int rt2 = (2 * wave) / Q, q0 = (2 * wave) % Q;  // both sub-tiles share the row tile (Q is even)
 
-  // depthwise phase: thread -> (interior pixel dp, hidden units dh0 .. dh0 + HPT - 1 of the chunk)
-  const int dp = tid / TPP, dh0 = (tid % TPP) * HPT;
-  const int dpy = dp / TX, dpx = dp - dpy * TX;
-  const int hc = (dpy + 1) * HX + dpx + 1;  // halo index of the pixel itself
+  // depthwise phase: thread -> (strip of SP pixels of one patch row, hidden units 4 hg .. 4 hg + 3 of the chunk).  The nine taps of the four hidden
+  // units are read once per thread (9 float4) and the 3 x (SP + 2) neighbourhood of the strip once (instead of 9 + 9 float4 PER PIXEL with one pixel per
+  // thread): 27 instead of 72 LDS reads per thread and chunk at SP = 4
+  const int hg = tid & 7, strip = tid >> 3;
+  const int sy = strip / (TX / SP), sx0 = (strip % (TX / SP)) * SP;
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // chunk 0 in LDS
@@ -172,38 +173,36 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
     }
     __syncthreads();  // (A) hidden values of the whole halo tile in Hbuf; every wave is past GEMM 2 of the previous chunk
     if (t + 1 < NCH) dma_w(t + 1, 1 - BUF);  // that buffer was last read by chunk t - 1
-    // ---- depthwise 3x3 + bias + GELU for HPT hidden units of one interior pixel; fp16 split -> H2 (B operand of GEMM 2)
+    // ---- depthwise 3x3 + bias + GELU for SP pixels x 4 hidden units; fp16 split -> H2 (B operand of GEMM 2)
     {
       typedef float mm_f2 __attribute__((ext_vector_type(2)));
-      mm_f2 acc[HPT / 2];  // v_pk_fma_f32: two hidden units per instruction
+      float4 wt[9];
 #pragma unroll
-      for (int j = 0; j < HPT / 4; ++j) {
-        const float4 bv = *reinterpret_cast<const float4*>(tb + 96 + 9 * 32 + dh0 + 4 * j);
-        acc[2 * j] = mm_f2{bv.x, bv.y}; acc[2 * j + 1] = mm_f2{bv.z, bv.w};
-      }
+      for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const float4*>(tb + 96 + k * 32 + 4 * hg);
+      const float4 bv = *reinterpret_cast<const float4*>(tb + 96 + 9 * 32 + 4 * hg);
+      float4 hv[3][SP + 2];
 #pragma unroll
-      for (int c = 0; c < 3; ++c)    // tap order of the stand-alone kernel (elem.hip): (ky, kx) = (0, c), (1, c), (2, c)
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const float* hr = Hbuf + (hc + (ky - 1) * HX + (c - 1)) * HS + dh0;
-          const float* wt = tb + 96 + (ky * 3 + c) * 32 + dh0;
+        for (int xx = 0; xx < SP + 2; ++xx) hv[ky][xx] = *reinterpret_cast<const float4*>(Hbuf + ((sy + ky) * HX + sx0 + xx) * HS + 4 * hg);
 #pragma unroll
-          for (int j = 0; j < HPT / 4; ++j) {
-            const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * j), wv = *reinterpret_cast<const float4*>(wt + 4 * j);
-            acc[2 * j] = __builtin_elementwise_fma(mm_f2{hv.x, hv.y}, mm_f2{wv.x, wv.y}, acc[2 * j]);
-            acc[2 * j + 1] = __builtin_elementwise_fma(mm_f2{hv.z, hv.w}, mm_f2{wv.z, wv.w}, acc[2 * j + 1]);
+      for (int pp = 0; pp < SP; ++pp) {
+        mm_f2 a0 = {bv.x, bv.y}, a1 = {bv.z, bv.w};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)    // tap order of the stand-alone kernel (elem.hip): (ky, kx) = (0, c), (1, c), (2, c)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const float4 h4 = hv[ky][pp + c], w4 = wt[ky * 3 + c];
+            a0 = __builtin_elementwise_fma(mm_f2{h4.x, h4.y}, mm_f2{w4.x, w4.y}, a0);
+            a1 = __builtin_elementwise_fma(mm_f2{h4.z, h4.w}, mm_f2{w4.z, w4.w}, a1);
           }
-        }
-#pragma unroll
-      for (int j = 0; j < HPT / 8; ++j) {
-        const float4 g0 = make_float4(gelu_erf(acc[4 * j].x), gelu_erf(acc[4 * j].y), gelu_erf(acc[4 * j + 1].x), gelu_erf(acc[4 * j + 1].y));
-        const float4 g1 = make_float4(gelu_erf(acc[4 * j + 2].x), gelu_erf(acc[4 * j + 2].y), gelu_erf(acc[4 * j + 3].x), gelu_erf(acc[4 * j + 3].y));
-        uint2 h0, l0, h1, l1;
-        split4_f16(g0, h0, l0);
-        split4_f16(g1, h1, l1);
-        const int piece = ((dh0 >> 3) + j) ^ ((dp >> 2) & 3);
-        *reinterpret_cast<u32x4*>(H2 + dp * 32 + piece * 8) = u32x4{h0.x, h0.y, h1.x, h1.y};
-        *reinterpret_cast<u32x4*>(H2 + NINT * 32 + dp * 32 + piece * 8) = u32x4{l0.x, l0.y, l1.x, l1.y};
+        const float4 gv = make_float4(gelu_erf(a0.x), gelu_erf(a0.y), gelu_erf(a1.x), gelu_erf(a1.y));
+        uint2 h0, l0;
+        split4_f16(gv, h0, l0);
+        const int dp = sy * TX + sx0 + pp;
+        unsigned short* d = H2 + dp * 32 + ((hg >> 1) ^ ((dp >> 2) & 3)) * 8 + (hg & 1) * 4;
+        *reinterpret_cast<uint2*>(d) = h0;
+        *reinterpret_cast<uint2*>(d + NINT * 32) = l0;
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of chunk t + 1
