@@ -392,6 +392,22 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
+  int side_stream_mode = 1;  // 1 (default): the q projection of a MiT block runs on a second stream next to the sr conv + kv GEMM (both consume LayerNorm-1's
+                             // output, attention joins them) -- small launches that each fill a fraction of the chip: +0.6 % (3 x A/B on one box, profiles/
+                             // r02_negative_results.md); 2: also the low-level encoder conv next to MiT stage 3 (+0.1 %, noise); PF_SIDE_STREAM=0: one stream.
+                             // Never forked while tuning or profiling (per-launch events time one stream)
+  hipStream_t side = nullptr, side2 = nullptr;   // side: the q projections; side2: the low-level encoder conv, launched next to MiT stage 3
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_ll = nullptr;
+  bool ll_forked = false;
+  bool side_ready() {
+    if (side && side2) return true;
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+    if (hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess) { side2 = nullptr; return false; }
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_ll, hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+  }
+  bool can_fork(const Ctx& c) { return side_stream_mode && !c.dry && !c.tuning && !c.prof && side_ready(); }
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
   bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
@@ -823,7 +839,7 @@ struct pf_engine {
   // MiT-B3 forward_features (mix_transformers.py:449-485); feats[s] = NHWC stage outputs.
   // With `sba` every tensor that only feeds GEMMs (LayerNorm outputs, attention output, the GELU'd hidden map) is
   // written as split planes by its producer and never exists in fp32.
-  void mit(Ctx& c, int B, const float* x0, Ten feats[4]) {
+  void mit(Ctx& c, int B, const float* x0, Ten feats[4], const Ten* llf = nullptr) {
     const bool S = sba;
     Ten cur(const_cast<float*>(x0));
     int H = NET, W = NET;
@@ -837,6 +853,15 @@ struct pf_engine {
       const bool fused_mlp = !st.blocks.empty() && st.blocks[0].mlp_w && nterms == NT_F16X3;
       float* xalt = fused_mlp ? c.alloc(M * C) : nullptr;
       const SbT xs = S ? c.alloc_sb(M * C) : SbT();  // split copy of the stage output (next patch embed + decoder)
+      if (s == 2 && llf && side_stream_mode >= 2 && can_fork(c)) {  // PF_SIDE_STREAM=2 (measured: no gain)  // the low-level encoder conv (a full-chip launch of its own) next to the small launches of stages 3 / 4
+        (void)hipEventRecord(ev_ll, c.s);  // x0 is long since ready; the event only orders the side stream behind this forward's beginning
+        (void)hipStreamWaitEvent(side2, ev_ll, 0);
+        Ctx c2 = c;
+        c2.s = side2;
+        conv(c2, ll, Ten(const_cast<float*>(x0)), B, NET, NET, *llf, ACT_RELU);
+        (void)hipEventRecord(ev_ll, side2);
+        ll_forked = true;
+      }
       conv(c, st.pe, cur, B, H, W, Ten(x));
       ln(c, st.pen, x, Ten(x), M);
       const size_t mk = c.mark();
@@ -854,7 +879,17 @@ struct pf_engine {
         // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
         if (sr > 1) {
           ln(c, mb.n1, x, xn, M);
-          gemm(c, mb.q, xn, M, Ten(qb));
+          const bool fork = can_fork(c);
+          if (fork) {  // q projection next to sr conv + kv GEMM: both read xn, attention needs both
+            (void)hipEventRecord(ev_fork, c.s);
+            (void)hipStreamWaitEvent(side, ev_fork, 0);
+            Ctx c2 = c;
+            c2.s = side;
+            gemm(c2, mb.q, xn, M, Ten(qb));
+            (void)hipEventRecord(ev_join, side);
+          } else {
+            gemm(c, mb.q, xn, M, Ten(qb));
+          }
           conv(c, mb.sr, xn, B, Ho, Wo, Ten(srb));
           if (mb.kv.ln_s) {
             gemm(c, mb.kv, Ten(srb), Mkv, Ten(kvb));  // LayerNorm(sr conv) inside the kv GEMM
@@ -863,13 +898,23 @@ struct pf_engine {
             gemm(c, mb.kv, srn, Mkv, Ten(kvb));
           }
         } else if (mb.q.ln_s && mb.kv.ln_s) {
-          gemm(c, mb.q, Ten(x), M, Ten(qb));          // norm1 inside both of its consumers
+          if (can_fork(c)) {                          // norm1 inside both of its consumers; q next to kv
+            (void)hipEventRecord(ev_fork, c.s);
+            (void)hipStreamWaitEvent(side, ev_fork, 0);
+            Ctx c2 = c;
+            c2.s = side;
+            gemm(c2, mb.q, Ten(x), M, Ten(qb));
+            (void)hipEventRecord(ev_join, side);
+          } else {
+            gemm(c, mb.q, Ten(x), M, Ten(qb));
+          }
           gemm(c, mb.kv, Ten(x), M, Ten(kvb));
         } else {
           ln(c, mb.n1, x, xn, M);
           gemm(c, mb.q, xn, M, Ten(qb));
           gemm(c, mb.kv, xn, M, Ten(kvb));
         }
+        if ((sr > 1 || (mb.q.ln_s && mb.kv.ln_s)) && can_fork(c)) (void)hipStreamWaitEvent(c.s, ev_join, 0);
         if (!c.dry) {
           ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
           launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
@@ -1063,11 +1108,13 @@ struct pf_engine {
       else launch_prep_f32_nchw(static_cast<const float*>(in), x0, B, NET * NET, mean3, std3, c.s);
     }
     Ten feats[4];
-    mit(c, B, x0, feats);
     // low-level encoder output: conv0's second (concatenated) input only
     const bool Sh = sba && nterms != NT_F16X3;  // as in heads_fwd: the decoder's halo kernels read fp32
     const Ten llf = c.ten((size_t)B * (NET / 2) * (NET / 2) * LL_CH, !Sh, Sh);
-    conv(c, ll, Ten(x0), B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
+    ll_forked = false;
+    mit(c, B, x0, feats, &llf);
+    if (ll_forked) (void)hipStreamWaitEvent(c.s, ev_ll, 0);
+    else conv(c, ll, Ten(x0), B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
     const bool pf = pred_fused();
     float* tg = pf ? nullptr : c.alloc((size_t)2 * B * NET * NET * 32);
     float* tl = pf ? nullptr : tg + (size_t)B * NET * NET * 32;
@@ -1193,6 +1240,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_LN")) e->fuse_ln = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
+  if (const char* v = getenv("PF_SIDE_STREAM")) e->side_stream_mode = atoi(v);
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;
@@ -1220,6 +1268,11 @@ int pf_destroy(pf_handle h) {
   (void)hipSetDevice(h->device);
   for (void* d : h->dev_allocs) (void)hipFree(d);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_ll) (void)hipEventDestroy(h->ev_ll);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->side2) (void)hipStreamDestroy(h->side2);
   delete h;
   return PF_OK;
 }
