@@ -853,7 +853,7 @@ struct pf_engine {
       const bool fused_mlp = !st.blocks.empty() && st.blocks[0].mlp_w && nterms == NT_F16X3;
       float* xalt = fused_mlp ? c.alloc(M * C) : nullptr;
       const SbT xs = S ? c.alloc_sb(M * C) : SbT();  // split copy of the stage output (next patch embed + decoder)
-      if (s == 2 && llf && side_stream_mode >= 2 && can_fork(c)) {  // PF_SIDE_STREAM=2 (measured: no gain)  // the low-level encoder conv (a full-chip launch of its own) next to the small launches of stages 3 / 4
+      if (s == 2 && llf && B >= 4 && side_stream_mode >= 2 && can_fork(c)) {  // PF_SIDE_STREAM=2 (measured: no gain)  // the low-level encoder conv (a full-chip launch of its own) next to the small launches of stages 3 / 4
         (void)hipEventRecord(ev_ll, c.s);  // x0 is long since ready; the event only orders the side stream behind this forward's beginning
         (void)hipStreamWaitEvent(side2, ev_ll, 0);
         Ctx c2 = c;
@@ -879,7 +879,7 @@ struct pf_engine {
         // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
         if (sr > 1) {
           ln(c, mb.n1, x, xn, M);
-          const bool fork = can_fork(c);
+          const bool fork = B >= 4 && can_fork(c);  // batch 1-3: a launch already under-fills the chip; the event pair would only add latency
           if (fork) {  // q projection next to sr conv + kv GEMM: both read xn, attention needs both
             (void)hipEventRecord(ev_fork, c.s);
             (void)hipStreamWaitEvent(side, ev_fork, 0);
@@ -898,7 +898,7 @@ struct pf_engine {
             gemm(c, mb.kv, srn, Mkv, Ten(kvb));
           }
         } else if (mb.q.ln_s && mb.kv.ln_s) {
-          if (can_fork(c)) {                          // norm1 inside both of its consumers; q next to kv
+          if (B >= 4 && can_fork(c)) {                // norm1 inside both of its consumers; q next to kv
             (void)hipEventRecord(ev_fork, c.s);
             (void)hipStreamWaitEvent(side, ev_fork, 0);
             Ctx c2 = c;
@@ -914,7 +914,7 @@ struct pf_engine {
           gemm(c, mb.q, xn, M, Ten(qb));
           gemm(c, mb.kv, xn, M, Ten(kvb));
         }
-        if ((sr > 1 || (mb.q.ln_s && mb.kv.ln_s)) && can_fork(c)) (void)hipStreamWaitEvent(c.s, ev_join, 0);
+        if (B >= 4 && (sr > 1 || (mb.q.ln_s && mb.kv.ln_s)) && can_fork(c)) (void)hipStreamWaitEvent(c.s, ev_join, 0);
         if (!c.dry) {
           ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
           launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
