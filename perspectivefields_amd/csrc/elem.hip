@@ -366,8 +366,8 @@ static bool launch_dw3_mc(const float* x, const float* w9c, const float* bias, f
   return true;
 }
 // code = 100 shape + 10 strip + np.  shape (quads x x-threads per block): 0 = 32 x 8, 1 = 64 x 4, 2 = 64 x 2, 3 = 64 x 5; strip: 8 / 16 / 40 rows;
-// np (columns per thread, rows loaded ahead): 0 (1, 1), 1 (2, 0), 2 (2, 1), 3 (2, 2), 4 (1, 2).  The product build carries the three forms the
-// sweep picked (profiles/r02_tune_dw3_mc.txt); everything else is a tuning build (PF_TUNING_BUILD=1) -- unknown codes return false (-> default).
+// np (columns per thread, rows loaded ahead): 0 (1, 1), 1 (2, 0), 2 (2, 1), 3 (2, 2), 4 (1, 2).  The product build carries the four forms the
+// sweeps picked (profiles/r02_tune_dw3_mc.txt); everything else is a tuning build (PF_TUNING_BUILD=1) -- unknown codes return false (-> default).
 #define PF_DW3_ARGS x, w9c, bias, y, B, H, W, C, s, y_sb, sb_plane
 #ifdef PF_TUNING_BUILD
 template <int CQB, int XB, int TH>
@@ -404,7 +404,8 @@ static bool launch_dw3_mc_variant(int code, const float* x, const float* w9c, co
 #else
   switch (code) {
     case 223: return launch_dw3_mc<64, 2, 40, 2, 2>(PF_DW3_ARGS);  // 80^2 maps: 4 columns x 64 quads per 128-thread block, two rows ahead
-    case 100: return launch_dw3_mc<64, 4, 8, 1, 1>(PF_DW3_ARGS);   // 40^2 / 20^2
+    case 100: return launch_dw3_mc<64, 4, 8, 1, 1>(PF_DW3_ARGS);   // 20^2
+    case 102: return launch_dw3_mc<64, 4, 8, 2, 1>(PF_DW3_ARGS);   // 40^2 (in the pipeline 46.6 vs 51.5 us for the one-column form, profiles/r02_tune_dw3_mc.txt)
     case 314: return launch_dw3_mc<64, 5, 16, 1, 2>(PF_DW3_ARGS);  // 10^2
     default: return false;
   }
@@ -465,6 +466,7 @@ void launch_dwconv3x3_gelu(const float* x, const float* w9c, const float* bias, 
   int v = g_dw3_variant >= 0 ? g_dw3_variant : (H >= 16 ? 4 : 2);
   if (g_dw3_variant < 0 && (C / 4) % 64 == 0) {
     if (W >= 64 && W % 4 == 0) v = 1223;
+    else if (W >= 32 && W % 8 == 0) v = 1102;
     else if (W >= 16 && W % 4 == 0) v = 1100;
     else if (W % 5 == 0) v = 1314;
   }

@@ -427,7 +427,7 @@ def test_kernel_resources_static():
         "pf::sr_attention_kernel", "pf::dwconv7x7_lane_kernel<1, 3, 256, 0>", "pf::upsample2x_cell_kernel",
         "pf::dwconv3x3_gelu_direct_kernel<32, 8, 8, 0>", "pf::layernorm_kernel<64, 2>",
         # r02: multi-column depthwise 3x3 (the three shipped forms) and the fused-LayerNorm GEMM forms of the 4-wave tiles
-        "pf::dwconv3x3_gelu_mc_kernel<64, 2, 40, 2, 2, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 4, 8, 1, 1, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 5, 16, 1, 2, false>",
+        "pf::dwconv3x3_gelu_mc_kernel<64, 2, 40, 2, 2, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 4, 8, 1, 1, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 4, 8, 2, 1, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 5, 16, 1, 2, false>",
         "pf::cnx_mlp_kernel<96, 0>", "pf::mit_mlp_kernel<64, 8, 16>",  # fused block MLPs (hidden map on chip)
         "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23, true>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 2, 23, true>", "pf::igemm_sb_kernel<128, 256, 2, 4, 0, false, 1, 23, true>",
     ]
