@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256, C <= 96 ? 3 : 1) void cnx_mlp_kernel(const flo
 // measured slower than the two GEMMs it would replace (327 vs ~195 us at 51 200 rows, profiles/r02_negative_results.md)
 bool cnx_mlp_supported(int C) { return C == 96 || C == 192; }
 bool cnx_mlp_preferred(int C) {
-  static const int with192 = [] { const char* e = getenv("PF_CNX_MLP_192"); return e ? atoi(e) : 0; }();
+  const char* e = getenv("PF_CNX_MLP_192");  // read per call (weight build time only): a process may create engines of both kinds
+  const int with192 = e ? atoi(e) : 0;
   return C == 96 || (C == 192 && with192);
 }
 

@@ -253,7 +253,8 @@ bool mit_mlp_supported(int C) { return C == 64 || C == 128; }
 // the engine uses it at stage 1 (C = 64: 162 us vs ~260 us as three kernels); the C = 128 instantiation (one block per CU: 96 KB of LDS, 240 VGPRs) measured
 // 175 us vs ~165 us and is left off (PF_MIT_MLP_128=1), profiles/r02_mit_mlp.md
 bool mit_mlp_preferred(int C) {
-  static const int with128 = [] { const char* e = getenv("PF_MIT_MLP_128"); return e ? atoi(e) : 0; }();
+  const char* e = getenv("PF_MIT_MLP_128");  // read per call (weight build time only)
+  const int with128 = e ? atoi(e) : 0;
   return C == 64 || (C == 128 && with128);
 }
 int mit_mlp_chunk_bytes(int C) { return C == 64 ? MitMlpCfg<64>::CHUNK_BYTES : MitMlpCfg<128>::CHUNK_BYTES; }

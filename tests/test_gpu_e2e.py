@@ -193,6 +193,27 @@ def test_fused_layernorm_agrees_with_layernorm_kernels(monkeypatch, case):
         assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
 
 
+@pytest.mark.parametrize("env", ["PF_FUSE_CNX_MLP=0", "PF_FUSE_MIT_MLP=0", "PF_SIDE_STREAM=0", "PF_SIDE_STREAM=2", "PF_CNX_MLP_192=1", "PF_MIT_MLP_128=1"])
+def test_fused_block_mlps_and_stream_modes_agree(monkeypatch, env):
+    """The one-kernel block MLPs (cnx_mlp.hip / mit_mlp.hip: hidden map on the chip), their second-stage instantiations, the side-stream modes against the default engine on a batch of 6 (so that the batch >= 4 side-stream fork is active): same mathematics, other roundings / launch
+    structure -- far inside the parity tolerances."""
+    from perspectivefields_amd import PerspectiveFields
+
+    imgs = [synthetic_image(72, 96, seed=120 + i) for i in range(6)]
+    base = model("centered").inference_batch(imgs)
+    k, v = env.split("=")
+    monkeypatch.setenv(k, v)
+    alt_model = PerspectiveFields(CASES["centered"], weights="synthetic:0").eval().cuda()
+    alt = alt_model.inference_batch(imgs)
+    for i, (a, b) in enumerate(zip(base, alt)):
+        c = one_minus_cos(a["pred_gravity"].cpu().numpy(), b["pred_gravity"].cpu().numpy()).max()
+        e = l1(a["pred_latitude"].cpu().numpy(), b["pred_latitude"].cpu().numpy())
+        d = max(abs(float(a[k2]) - float(b[k2])) for k2 in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
+        if i == 0:
+            print(f"[{env} vs default img{i}] 1-cos {c:.2e} latL1 {e:.2e} param {d:.2e}")
+        assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
+
+
 def test_split_plane_activations_agree_with_fp32_activations(monkeypatch):
     """PF_SBA=1 stores GEMM-only tensors as split-bf16 planes written by their producers; the default keeps every GEMM
     input in fp32 and splits inside the GEMM.  The planes are lossless, so the two engines differ only through the
