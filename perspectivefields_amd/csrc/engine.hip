@@ -408,6 +408,9 @@ struct pf_engine {
     return true;
   }
   bool can_fork(const Ctx& c) { return side_stream_mode && !c.dry && !c.tuning && !c.prof && side_ready(); }
+  bool sba_heads = false;    // PF_SBA_HEADS=1: the tensors between the 3x3 convs of the decoders' ResidualConvUnits are written as split-f16 planes by the producing
+                             // conv's epilogue (plus fp32 where a residual add reads them) and the halo kernel copies them (igemm_sbh ASB) instead of splitting
+                             // every element once per n-tile and halo overlap; split-f16 scheme only
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
   bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
@@ -960,6 +963,7 @@ struct pf_engine {
   bool pred_fused() const { return fuse_pred && arch != PF_ARCH_PERSNET_CLS && nterms == NT_F16X3 && split_bf16; }
   void heads_fwd(Ctx& c, int B, Ten feats[4], Ten llf, float* t32 /*[2][B][320][320][32], unused when the heads are fused*/, float* pg, float* pl, float* pn) {
     const bool S = sba && nterms != NT_F16X3;  // the 3x3 halo kernels of the decoder stage fp32 inputs: split-f16 planes only in MiT / ConvNeXt
+    const bool SR = S || (sba_heads && !sba && nterms == NT_F16X3 && split_bf16);  // ResidualConvUnit chain in split planes (PF_SBA_HEADS: fp16 planes, halo kernel ASB)
     Head& hg = heads[0];
     Head& hl = heads[1];
     // a pair of per-head tensors, contiguous as [2][...] in fp32 and in every split plane
@@ -984,7 +988,7 @@ struct pf_engine {
       const size_t M = (size_t)B * h * h;
       const size_t mk = c.mark();
       Ten p0, p1;
-      pair(M * DEC_FEAT, true, S, p0, p1);
+      pair(M * DEC_FEAT, true, SR, p0, p1);
       if (fold_mlp) {
         ConvCall cc[2] = {{&hg.fold[k], feats[k], p0}, {&hl.fold[k], feats[k], p1}};
         conv_g(c, 2, cc, B, h, h, ACT_NONE, 1);                               // relu(_ck), Linear folded into the conv
@@ -999,15 +1003,15 @@ struct pf_engine {
       Ten o0 = p0, o1 = p1;
       if (k < 3) {                                                            // o = relu(up(prev) + RCU1(_ck))
         Ten t0, t1;
-        pair(M * DEC_FEAT, !S, S, t0, t1);
+        pair(M * DEC_FEAT, !SR, SR, t0, t1);
         ConvCall a[2] = {{&hg.r1c1[k], p0, t0}, {&hl.r1c1[k], p1, t1}};
         conv_g(c, 2, a, B, h, h, ACT_RELU);
-        pair(M * DEC_FEAT, true, S, o0, o1);
+        pair(M * DEC_FEAT, true, SR, o0, o1);
         ConvCall b2[2] = {{&hg.r1c2[k], t0, o0, p0.f, up[k + 1][0].f}, {&hl.r1c2[k], t1, o1, p1.f, up[k + 1][1].f}};
         conv_g(c, 2, b2, B, h, h, ACT_NONE, 1);
       }
       Ten t0, t1, q0, q1;
-      pair(M * DEC_FEAT, !S, S, t0, t1);
+      pair(M * DEC_FEAT, !SR, SR, t0, t1);
       ConvCall a[2] = {{&hg.r2c1[k], o0, t0}, {&hl.r2c1[k], o1, t1}};
       conv_g(c, 2, a, B, h, h, ACT_RELU);
       if (k == 0 && fuse_up) { q0 = qfin[0]; q1 = qfin[1]; }
@@ -1241,6 +1245,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_SIDE_STREAM")) e->side_stream_mode = atoi(v);
+  if (const char* v = getenv("PF_SBA_HEADS")) e->sba_heads = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;
   if (const char* v = getenv("PF_SBA")) e->sba = atoi(v) != 0;

@@ -34,7 +34,10 @@ __device__ __forceinline__ int sbh_piece(int row, int piece) { return piece ^ ((
 template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE, int TPG /*taps whose weights are staged together: 1 or 3 (one kernel row)*/, int SCH,
           bool DB = false /*two LDS buffers for the weights: the next tap's weights are stored while this tap is still being read -> one barrier per tap instead of two*/,
           bool UPS = false /*the first input x is stored at HALF resolution: the conv runs on its bilinear x2 up-sampling (decode_head.py:284-286,
-                             gravity_head.py:172), interpolated while the halo tile is staged -- the up-sampled tensor never exists in HBM*/>
+                             gravity_head.py:172), interpolated while the halo tile is staged -- the up-sampled tensor never exists in HBM*/,
+          bool ASB = false /*the input comes as the two fp16 planes of the split-f16 scheme (ConvPtrs::x_sb, written by the producing conv's epilogue): the halo
+                             staging is a plain 16-byte copy per plane -- no split arithmetic in this kernel (VALU instructions are paid in MFMA issue time,
+                             DESIGN.md 4.7), and an element is split once by its producer instead of once per n-tile and halo overlap here.  MODE 0, no UPS.*/>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
@@ -97,6 +100,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
   // (bit 9), lx (bits 10-11), ly (bits 12-13) with 0 -> 0, 1 -> 0.25, 2 -> 0.75, valid (bit 14).  src = (dst + 0.5) / 2 - 0.5
   // clamped at 0, neighbour clamped at the last row / column: exactly the stand-alone upsample2x kernels of elem.hip.
   static_assert(!UPS || (TPG == 1 && !DB && (H_TY % 2) == 0 && (H_TX % 2) == 0), "fused up-sampling: plain tap loop, even patch");
+  static_assert(!ASB || (SCH == NT_F16X3 && MODE == 0 && !UPS), "split-plane input: split-f16 scheme, one input, no fused up-sampling");
+  // ASB: element e -> (halo row e / 8, piece e % 8): pieces 0-3 = the four 16-byte pieces (8 channels each) of the hi plane's 32-channel chunk, 4-7 = the lo plane's
+  const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(ASB ? P.x_sb : nullptr), 0,
+                                                                       ASB ? (unsigned)(((p.x_sb_plane & ~(size_t)1) + (size_t)p.x_bytes / 4) * 2) : 0u, 0x00020000);
   unsigned a_off1[A_F4], a_off2[MODE == 2 ? A_F4 : 1], a_ups[UPS ? A_F4 : 1], s_off[S_F4];
   const int hs = p.H >> 1, ws = p.W >> 1;
 #pragma unroll
@@ -114,6 +121,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
       const int slot = (y0 - (oy0 / 2 - 1)) * S_TX + (x0 - (ox0 / 2 - 1));  // source tile origin (oy0/2 - 1, ox0/2 - 1)
       a_ups[UPS ? i : 0] = (unsigned)(ok ? slot : 0) | (x0 < ws - 1 ? 0x100u : 0u) | (y0 < hs - 1 ? 0x200u : 0u) | (lx << 10) | (ly << 12) | (ok ? 0x4000u : 0u);
       a_off1[i] = OOB;
+    } else if (ASB) {  // byte offset inside the plane pair: plane (c4 >> 2) + pixel + 16-byte piece (c4 & 3); the chunk offset (2 bytes per channel) is added per chunk
+      a_off1[i] = ok ? (unsigned)((size_t)(c4 >> 2) * (p.x_sb_plane & ~(size_t)1) * 2 + (size_t)pix * p.C1 * 2 + (c4 & 3) * 16) : OOB;
     } else {
       a_off1[i] = ok ? (unsigned)(pix * p.C1 * 4 + c4 * 16) : OOB;
     }
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
     const bool live = c < nC;
     const int ci0 = c * BK;
     const bool first = MODE != 2 || ci0 < p.C1;
-    const unsigned coff = (unsigned)((first ? ci0 : ci0 - p.C1) * 4);
+    const unsigned coff = (unsigned)((first ? ci0 : ci0 - p.C1) * (ASB ? 2 : 4));
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       if (UPS) {
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
         const float4 v2 = buf_load16(rx2, first ? OOB : off);
         ra[i] = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);
       } else {
-        ra[i] = buf_load16(rx, off);
+        ra[i] = buf_load16(ASB ? rxs : rx, off);
       }
     }
   };
@@ -207,6 +216,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       const int e = tid + NT * i, hrow = e >> 3, c4 = e & 7;  // recomputed (cheaper than six more live registers)
+      if (ASB) {
+        if (hrow < H_ROWS)  // the planes hold what split4_f16 would compute: copy piece (c4 & 3) of plane (c4 >> 2)
+          *reinterpret_cast<float4*>(As + (c4 >> 2) * PLANE_A + hrow * H_ROW + sbh_piece(hrow, c4 & 3) * 8) = ra[i];
+        continue;
+      }
       if (hrow < H_ROWS) {
         uint2 h, m, l;
         if (F16) split4_f16(ra[i], h, m);
@@ -360,6 +374,10 @@ static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
     }
     return;
   }
+  if (p.g[0].x_sb) {  // conv_sbh_tile_ok: split-f16 planes, one input, plain tap loop
+    if constexpr (TPG == 1 && !DB) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, 1, NT_F16X3, false, false, true>), grid, block, 0, s, p);
+    return;
+  }
   if (p.nterms == NT_F16X3) {
     if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, TPG, NT_F16X3, DB>), grid, block, 0, s, p);
     else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, TPG, NT_F16X3, DB>), grid, block, 0, s, p);
@@ -375,8 +393,10 @@ static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
 bool conv_sbh_ok(const ConvParams& p) {
   if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || (p.nterms != 6 && p.nterms != NT_F16X3) || p.nchw_out) return false;
   if ((p.C1 % BK) != 0 || (p.C2 % BK) != 0 || p.KWCp != p.KWC) return false;
+  const bool planes = p.g[0].x_sb != nullptr;  // split-plane input: the fp16 planes of the split-f16 scheme, one input, no fused up-sampling
+  if (planes && (p.nterms != NT_F16X3 || !(p.x_sb_plane & SB_FMT_F16) || p.C2 > 0 || p.ups)) return false;
   for (int g = 0; g < p.groups; ++g) {
-    if (!p.g[g].x || (p.C2 > 0 && !p.g[g].x2)) return false;
+    if (planes ? !p.g[g].x_sb : (!p.g[g].x || (p.C2 > 0 && !p.g[g].x2))) return false;
     if (p.nterms == NT_F16X3 ? (!p.g[g].w_h16 || !p.g[g].w_h16_inv_scale) : !p.g[g].w_sb) return false;
   }
   return true;
@@ -391,6 +411,7 @@ bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
 #else
   constexpr int kWide32 = 4;
 #endif
+  if (p.g[0].x_sb) return h_tile < 4 || h_tile == kWide32;  // plane input: the plain-tap-loop tiles
   if (p.ups) return (h_tile < 3 || h_tile == kWide32) && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
   if (h_tile >= kWide32) return p.nterms == NT_F16X3;  // sbh256x32 (and, in tuning builds, the whole-N tiles sbh256x256w8 / sbhd256x256w8)
 #ifdef PF_TUNING_BUILD
