@@ -26,7 +26,9 @@
  * by the caller; `h_` pointers are host memory.  All work is enqueued on the given
  * hipStream_t (passed as void*) and never synchronises.  Return value 0 = success,
  * negative = pf_status; pf_last_error() gives the message.  A handle is bound to one
- * device and is not thread-safe.  There is no CPU fallback: every entry point fails with
+ * device and is not thread-safe.  A workspace (`d_ws`) belongs to the calls in flight on it: two calls that
+ * share one workspace must be ordered by the caller (same stream, or an event between the streams) -- the
+ * Python host side does this for its own workspace (Engine._order_scratch).  There is no CPU fallback: every entry point fails with
  * PF_ERR_DEVICE when no gfx950 device is usable.
  */
 #ifndef PF_HIP_H

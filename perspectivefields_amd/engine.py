@@ -173,6 +173,7 @@ class Engine:
         self._h = ctypes.c_void_p()
         _check(self.lib.pf_create(ctypes.byref(self._h), self.device.index, arch_id), None, "pf_create")
         self._ws = None
+        self._scratch_stream = {}  # scratch name -> the torch stream of its last user (_order_scratch)
         self._finalized = False
         self.precision = "fp32"
         self.max_batch = int(self.lib.pf_max_batch())
@@ -244,13 +245,29 @@ class Engine:
     def workspace_bytes(self, batch: int) -> int:
         return int(self.lib.pf_workspace_bytes(self._h, batch))
 
+    def _order_scratch(self, name: str, buf):
+        """Engine-owned scratch (forward workspace, resize / post-process tables) is reused call after call.  Calls on ONE
+        stream are ordered by the stream; when the caller's current stream changes (inference_batch on the default stream,
+        then inference_stream's compute stream), the new stream is put behind the last user first -- otherwise two forwards
+        on two streams would run in the same workspace at once."""
+        import torch
+
+        cur = torch.cuda.current_stream(self.device)
+        last = self._scratch_stream.get(name)
+        if last is not None and last != cur:
+            cur.wait_stream(last)
+            if buf is not None:
+                buf.record_stream(cur)  # allocated on another stream: keep the allocator from recycling it under this one
+        self._scratch_stream[name] = cur
+        return buf
+
     def _workspace(self, nbytes: int):
         import torch
 
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws
+        return self._order_scratch("ws", self._ws)
 
     def forward(self, images) -> Tuple[object, object, Optional[object]]:
         """images: uint8 (B,320,320,3) BGR or float32 (B,3,320,320) BGR 0..255, on self.device.
@@ -335,6 +352,7 @@ class Engine:
         need = int(self.lib.pf_resize_workspace_bytes(H, W))
         if getattr(self, "_rs_ws", None) is None or self._rs_ws.numel() < need:
             self._rs_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._order_scratch("rs", self._rs_ws)
         with torch.cuda.device(self.device):
             rc = self.lib.pf_resize_bilinear_u8(self._h, img_u8.data_ptr(), H, W, out_u8_320.data_ptr(),
                                                 self._rs_ws.data_ptr(), self._rs_ws.numel(), _stream_ptr())
@@ -349,6 +367,7 @@ class Engine:
         need = 256 + sum((h * NET * 3 + 255) // 256 * 256 for h, _ in hw)
         if getattr(self, "_rs_ws", None) is None or self._rs_ws.numel() < need:
             self._rs_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._order_scratch("rs", self._rs_ws)
         ptrs = (ctypes.c_void_p * B)(*[t.data_ptr() for t in imgs_u8])
         hw_c = (ctypes.c_int32 * (2 * B))(*[v for s in hw for v in s])
         with torch.cuda.device(self.device):
@@ -404,6 +423,7 @@ class Engine:
                 need = B * 3 * NET * NET * 4 + 256
                 if getattr(self, "_pp_ws", None) is None or self._pp_ws.numel() < need:
                     self._pp_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self._order_scratch("pp", self._pp_ws)
                 ws_ptr, ws_n = self._pp_ws.data_ptr(), self._pp_ws.numel()
             rc = self.lib.pf_postprocess_batch(self._h, B, pg.data_ptr(), pl.data_ptr(), hw, ups, lats, ws_ptr, ws_n, _stream_ptr())
         _check(rc, self._h, "pf_postprocess_batch")

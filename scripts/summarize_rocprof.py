@@ -10,9 +10,9 @@ def short(name):
         t = re.search(r"igemm(?:_sb)?_kernel<(\d+), (\d+), (\d+), (\d+)", name)
         if t:
             return f"pf::{m.group(1)}<{t.group(1)}x{t.group(2)},w{int(t.group(3))*int(t.group(4))}>"
-        h = re.search(r"igemm_sbh_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>", name)
+        h = re.search(r"igemm_sbh_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+)(?:, (\w+))?>", name)  # trailing ASB (split-plane input) flag since r02
         if h:  # patch, BN, waves, mode (2 = concat), fused up-sampling
-            return f"pf::igemm_sbh_kernel<{h.group(1)}x{h.group(2)},n{h.group(3)},w{int(h.group(4))*int(h.group(5))}" + (",cat" if h.group(6) == "2" else "") + (",ups" if h.group(10) == "true" else "") + ">"
+            return f"pf::igemm_sbh_kernel<{h.group(1)}x{h.group(2)},n{h.group(3)},w{int(h.group(4))*int(h.group(5))}" + (",cat" if h.group(6) == "2" else "") + (",ups" if h.group(10) == "true" else "") + (",planes" if h.group(11) == "true" else "") + ">"
         return f"pf::{m.group(1)}"
     return name[:60]
 

@@ -303,6 +303,28 @@ def test_inference_stream_matches_inference_batch():
     assert on_dev[0][0]["pred_gravity_original"].is_cuda
 
 
+def test_engine_workspace_is_ordered_across_streams():
+    """The engine reuses one workspace: a forward issued on another stream right behind one still running on the default
+    stream must wait for it (Engine._order_scratch) -- both results equal the ones of synchronised calls, bit for bit."""
+    m = model("centered")
+    eng = m._get_engine()
+    xs = [torch.from_numpy(np.stack([m.aug.apply_image(synthetic_image(80, 100, seed=700 + 20 * j + i)) for i in range(16)])).cuda() for j in range(2)]
+    ref = []
+    for x in xs:
+        ref.append(eng.forward(x))
+        torch.cuda.synchronize()
+    for trial in range(3):
+        side = torch.cuda.Stream()
+        a = eng.forward(xs[0])                      # default stream, ~10 ms of GPU work; the inputs were complete long ago
+        with torch.cuda.stream(side):
+            b = eng.forward(xs[1])
+        c = eng.forward(xs[0])                      # and back on the default stream while `side` is busy
+        torch.cuda.synchronize()
+        for got, want in ((a, ref[0]), (b, ref[1]), (c, ref[0])):
+            for g, w in zip(got, want):
+                assert torch.equal(g, w), trial
+
+
 @pytest.mark.parametrize("tag", ["centered", "persnet"])
 def test_postprocess_batch_equals_per_image(tag):
     """pf_postprocess_batch (one launch for the batch) == pf_postprocess per image, bit for bit, mixed output sizes,

@@ -418,12 +418,12 @@ def test_kernel_resources_static():
         "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23, false>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 23, false>",
         "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 23, false>", "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 23, false>",
         "pf::igemm_sb_kernel<256, 256, 2, 4, 0, false, 1, 23, false>", "pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 23, false>",
-        "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1, 23, false, false>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 23, false, false>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 23, false, false>",
-        "pf::igemm_sbh_kernel<16, 16, 64, 4, 2, 0, 1, 23, false, false>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 2, 1, 23, false, true>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 23, false, true>", "pf::sr_attention_f16_kernel", "pf::dwconv7x7_cb_kernel<4, 3, 0>", "pf::dwconv7x7_cb_kernel<2, 3, 0>",
+        "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1, 23, false, false, false>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 23, false, false, false>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 23, false, false, false>",
+        "pf::igemm_sbh_kernel<16, 16, 64, 4, 2, 0, 1, 23, false, false, false>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 2, 1, 23, false, true, false>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 23, false, true, false>", "pf::sr_attention_f16_kernel", "pf::dwconv7x7_cb_kernel<4, 3, 0>", "pf::dwconv7x7_cb_kernel<2, 3, 0>",
         "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 6, false>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 6, false>",
         "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 6, false>", "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 6, false>",
         "pf::igemm_sb_kernel<256, 256, 2, 4, 0, false, 1, 6, false>",
-        "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1, 6, false, false>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 6, false, false>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 6, false, false>",
+        "pf::igemm_sbh_kernel<8, 16, 128, 2, 2, 0, 1, 6, false, false, false>", "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 6, false, false, false>", "pf::igemm_sbh_kernel<8, 16, 32, 4, 1, 0, 1, 6, false, false, false>",
         "pf::sr_attention_kernel", "pf::dwconv7x7_lane_kernel<1, 3, 256, 0>", "pf::upsample2x_cell_kernel",
         "pf::dwconv3x3_gelu_direct_kernel<32, 8, 8, 0>", "pf::layernorm_kernel<64, 2>",
         # r02: multi-column depthwise 3x3 (the three shipped forms) and the fused-LayerNorm GEMM forms of the 4-wave tiles
