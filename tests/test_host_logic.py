@@ -83,12 +83,13 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"pf_engine"}
     assert declared, "no declarations parsed"
+    checked = load_library()  # first: rebuilds a stale library (a raw dlopen before that would pin the old mapping in this process)
     assert os.path.exists(LIB_PATH), "libpf_hip.so not built (python -m perspectivefields_amd.build)"
     lib = ctypes.CDLL(LIB_PATH)
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f"library lacks {missing}"
     assert declared == set(declared_symbols()), (declared ^ set(declared_symbols()))
-    assert load_library().pf_version().startswith(b"pf_hip")
+    assert checked.pf_version().startswith(b"pf_hip")
 
 
 def test_no_gpu_means_loud_failure():
