@@ -27,6 +27,18 @@ __device__ __forceinline__ f32x16 mfma16h(const u32x4 a, const u32x4 b, const f3
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 static constexpr int H_ROW = BK;  // ushorts per LDS row (64 bytes)
+
+// Ablation forms of the halo kernel (tuning builds only; scripts/tune_conv.py tiles "sbhA<mask>", results are WRONG by construction -- they time the
+// kernel with one cost removed): 1 = no split arithmetic while staging the halo (raw bits stored), 2 = no wh 2^-11 scaling of the weight fragment,
+// 4 = no barriers in the K loop, 8 = half the LDS fragment reads (the second 16-deep chunk of a step reuses the first one's fragments),
+// 16 / 32 = no global loads of the halo / of the weights in the K loop (opaque register values instead), 0x100 / 0x200 = the next halo chunk's loads are
+// issued in tap step 0 / 2 instead of 4 (a real variant, right results).  The product build has no such parameter: ABL is the constant 0.
+#ifdef PF_TUNING_BUILD
+#define SBH_ABL_PARAM , int ABL = 0
+#else
+#define SBH_ABL_PARAM
+static constexpr int ABL = 0;
+#endif
 __device__ __forceinline__ int sbh_piece(int row, int piece) { return piece ^ ((row >> 2) & 3); }
 
 // SCH = 6: exact 3-way bf16 split, 6 MFMAs per product; SCH = NT_F16X3: 2-way fp16 split of the activations (2 LDS planes),
@@ -37,7 +49,8 @@ template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE,
                              gravity_head.py:172), interpolated while the halo tile is staged -- the up-sampled tensor never exists in HBM*/,
           bool ASB = false /*the input comes as the two fp16 planes of the split-f16 scheme (ConvPtrs::x_sb, written by the producing conv's epilogue): the halo
                              staging is a plain 16-byte copy per plane -- no split arithmetic in this kernel (VALU instructions are paid in MFMA issue time,
-                             DESIGN.md 4.7), and an element is split once by its producer instead of once per n-tile and halo overlap here.  MODE 0, no UPS.*/>
+                             DESIGN.md 4.7), and an element is split once by its producer instead of once per n-tile and halo overlap here.  MODE 0, no UPS.*/
+          SBH_ABL_PARAM>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
@@ -63,12 +76,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
   constexpr int S_TY = H_TY / 2 + 2, S_TX = H_TX / 2 + 2, S_PIX = S_TY * S_TX;  // 6 x 10 for an 8 x 16 patch
   constexpr int SRC_USHORTS = UPS ? S_PIX * BK * 2 : 0;
   constexpr int S_F4 = UPS ? (S_PIX * 8 + NT - 1) / NT : 1;  // float4 loads per thread per source chunk (2)
-  constexpr int OPER_USHORTS = NPA * PLANE_A + (DB ? 2 : 1) * BBUF + SRC_USHORTS;
+  // DMAW: the weights of a tap go from global memory straight into LDS (global_load_lds_dwordx4, no staging registers, no
+  // ds_write) into a ring of three buffers, two taps ahead of their use, one barrier per tap.  Motivation (profiles/r02_sbh_ablation.md): hipcc sinks the
+  // register-staged weight loads of the plain loop to the END of the tap's MFMA phase (it reuses the fragment registers for them under the 128-VGPR cap), so
+  // their L2 latency is exposed in every tap: 18 % of the kernel's time on 256 -> 256 @80^2.
+  // Default for the 16 x 16 patch / 8-wave tile (the 256 -> 256 decoder convs): its two resident blocks per CU fit the 66 KB; on the 4-wave tiles the ring would
+  // cost a resident block.  Measured (profiles/r02_sbh_ablation.md): 256 -> 256 @80^2 0.790 -> 0.762 ms, @40^2 0.253 -> 0.244, 64 -> 256 @80^2 0.210 -> 0.200,
+  // bit-identical results (same products, same order).  Tuning builds: ABL bit 0x1000 forces the ring, 0x2000 the register-staged loop.
+  constexpr bool DMAW = (ABL & 0x2000) == 0 && ((ABL & 0x1000) != 0 || (H_TY == 16 && BN == 64 && WM * WN == 8 && SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0));
+  static_assert(!DMAW || (SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0), "DMA weights: split-f16 scheme, plain tap loop, one fp32 input");
+  constexpr int NBUF = DMAW ? 3 : (DB ? 2 : 1);
+  constexpr int OPER_USHORTS = NPA * PLANE_A + NBUF * BBUF + SRC_USHORTS;
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
   unsigned short* As = smem_u;                  // [NPA][H_ROWS][H_ROW]
   unsigned short* Bs0 = smem_u + NPA * PLANE_A;  // [DB ? 2 : 1][TPG][NPB][BN][H_ROW]
-  float* Ss = reinterpret_cast<float*>(smem_u + NPA * PLANE_A + (DB ? 2 : 1) * BBUF);  // UPS: [S_PIX][BK] fp32 source tile
+  float* Ss = reinterpret_cast<float*>(smem_u + NPA * PLANE_A + NBUF * BBUF);  // UPS: [S_PIX][BK] fp32 source tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -174,7 +197,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
         const float4 v2 = buf_load16(rx2, first ? OOB : off);
         ra[i] = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);
       } else {
-        ra[i] = buf_load16(ASB ? rxs : rx, off);
+        if constexpr ((ABL & 16) != 0) {
+          float o = __builtin_bit_cast(float, off | 0x3f000000u);
+          asm volatile("" : "+v"(o));  // opaque: the split below stays
+          ra[i] = make_float4(o, o, o, o);
+        } else {
+          ra[i] = buf_load16(ASB ? rxs : rx, off);
+        }
       }
     }
   };
@@ -223,7 +252,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
       }
       if (hrow < H_ROWS) {
         uint2 h, m, l;
-        if (F16) split4_f16(ra[i], h, m);
+        if constexpr (F16 && (ABL & 1) != 0) {
+          h = make_uint2(__builtin_bit_cast(unsigned, ra[i].x), __builtin_bit_cast(unsigned, ra[i].y));
+          m = make_uint2(__builtin_bit_cast(unsigned, ra[i].z), __builtin_bit_cast(unsigned, ra[i].w));
+        } else if (F16) split4_f16(ra[i], h, m);
         else split4(ra[i], h, m, l);
         unsigned short* d = As + hrow * H_ROW + sbh_piece(hrow, c4 >> 1) * 8 + (c4 & 1) * 4;
         *reinterpret_cast<uint2*>(d) = h;
@@ -243,7 +275,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
       for (int i = 0; i < B_ROWS; ++i)
 #pragma unroll
         for (int pl = 0; pl < NPG; ++pl)
-          rb[u][i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes : OOB);
+          if constexpr ((ABL & 32) != 0) {
+            float o = __builtin_bit_cast(float, (b_off[i] + woff) | 0x3c003c00u);
+            asm volatile("" : "+v"(o));
+            rb[u][i][pl] = make_float4(o, o, o, o);
+          } else {
+            rb[u][i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)pl * p.w_sb_plane_bytes : OOB);
+          }
     }
   };
   auto store_b = [&](int buf = 0) {
@@ -257,6 +295,34 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
           for (int pl = 0; pl < NPG; ++pl)
             *reinterpret_cast<float4*>(Bs + (u * NPB + pl) * PLANE_B + (rb0 + RPB * i) * H_ROW + sbh_piece(rb0 + RPB * i, pc) * 8) = rb[u][i][pl];
         }
+  };
+
+  // ---- DMAW: 16-byte piece e = tid + NT j of a tap's weights, e -> (plane, row, LDS slot); the XOR piece swizzle is applied on the GLOBAL side
+  // (slot s of row r holds piece s ^ ((r >> 2) & 3)), the LDS side of the DMA is linear: wave w writes the 1 KB at piece index 64 w + NT j
+  constexpr int DMA_PIECES = NPB * BN * 4;
+  static_assert(!DMAW || DMA_PIECES % NT == 0, "DMA weights: whole rounds");
+  constexpr int DMA_R = DMAW ? DMA_PIECES / NT : 1;
+  const char* wsrc[DMA_R];
+#pragma unroll
+  for (int j = 0; j < DMA_R; ++j) {
+    const int e = tid + NT * j;
+    const int plane = e / (BN * 4), rem = e % (BN * 4), row = rem >> 2, slot = rem & 3;
+    const int piece = slot ^ ((row >> 2) & 3);
+    const int n = min(n0 + row, p.Cout - 1);  // columns past Cout are never stored: any finite weights do
+    wsrc[j] = reinterpret_cast<const char*>(P.w_h16) + (size_t)plane * p.w_sb_plane_bytes + ((size_t)n * 3 * p.KWCp + piece * 8) * 2;
+  }
+  const unsigned bs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Bs0;
+  auto dma_b = [&](int c, int tap, int buf) {
+    const int cc = c < nC ? c : nC - 1;  // past the end: a harmless reload (keeps the vmcnt bookkeeping static)
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const unsigned woff = (unsigned)(ky * p.KWCp + kx * p.Cin + cc * BK) * 2u;
+#pragma unroll
+    for (int j = 0; j < DMA_R; ++j) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(bs_lds + (unsigned)(buf * BBUF * 2 + (wave * 64 + NT * j) * 16));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(wsrc[j] + woff), "s"(dst) : "memory");
+    }
   };
 
   f32x16 acc[SM][SN];
@@ -286,12 +352,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
   const int swz_b = (l31 >> 2) & 3;
 
   auto compute = [&](int tap, int slot /*position of this tap's weights in the staged group*/, int buf = 0) {
-    const unsigned short* Bb = Bb0 + (DB ? buf * BBUF : 0);
+    const unsigned short* Bb = Bb0 + ((DB || DMAW) ? buf * BBUF : 0);
     const int ky = tap / 3, kx = tap - 3 * ky;
     const int toff = ky * H_HX + kx;
+    u32x4 af[SM][NPA], bf[SN][3];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per K step; this lane's 8 k-values = piece 2c + hi
-      u32x4 af[SM][NPA], bf[SN][3];
+      if ((ABL & 8) == 0 || c == 0) {
 #pragma unroll
       for (int i = 0; i < SM; ++i) {
         const int row = hb[i] + toff;
@@ -304,7 +371,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
       for (int j = 0; j < SN; ++j) {
 #pragma unroll
         for (int pl = 0; pl < NPB; ++pl) bf[j][pl] = *reinterpret_cast<const u32x4*>(Bb + (slot * NPB + pl) * PLANE_B + j * 32 * H_ROW + pob);
-        if (F16) bf[j][2] = __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, bf[j][0])));
+        if (F16) bf[j][2] = (ABL & 2) ? bf[j][0] : __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, bf[j][0])));
+      }
       }
       constexpr int TA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};  // plane of A: l h m m h h | split-f16: al ah ah
       constexpr int TB[6] = {F16 ? 2 : 0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};  // plane of B: h l m h m h | split-f16: wh2 wl wh
@@ -319,13 +387,43 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
   };
 
   // prologue: halo chunk 0 and the weights of the first tap group -> LDS
+  constexpr int NG = 9 / TPG;  // tap groups per chunk
+  if constexpr (DMAW) {
+    load_a(0);
+    dma_b(0, 0, 0);
+    dma_b(0, 1, 1);
+    store_a();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // step q = 9 c + g reads weight buffer q % 3 = g % 3; the DMA of step q + 2 goes into buffer (g + 2) % 3, last read in step q - 1 (every wave is past
+    // the barrier that ended it).  End of step q: every wave waits for ITS part of step q + 1's weights (issued one step ago: the younger VMEM
+    // instructions -- this step's DMA and the halo loads of this / the previous step -- stay in flight), then one barrier.
+    constexpr int LA = NG / 2;
+    for (int c = 0; c < nC; ++c) {
+#pragma unroll
+      for (int g = 0; g < 9; ++g) {
+        dma_b(g + 2 < 9 ? c : c + 1, (g + 2) % 9, (g + 2) % 3);
+        if (g == LA) load_a(c + 1);
+        compute(g, 0, g % 3);
+        constexpr int younger = DMA_R;  // this step's DMA
+        if (g == LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger + A_F4) : "memory");
+        else if (g == LA + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger + A_F4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger) : "memory");
+        if (g == 8 && c + 1 < nC) { __syncthreads(); store_a(); }  // every wave has read this chunk's halo
+        __syncthreads();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two look-ahead DMAs past the end: the epilogue reuses the LDS
+    __syncthreads();
+  } else {
   load_a(0);
   load_b(0, 0);
   if (UPS && 0 < p.C1) store_a_ups(); else store_a();
   store_b();
   __syncthreads();
-  constexpr int NG = 9 / TPG;  // tap groups per chunk
-  if constexpr (DB) {
+  }
+  if constexpr (DMAW) {
+  } else if constexpr (DB) {
     // weights of step q = 9 c + g live in LDS buffer q & 1: while the waves read buffer q & 1, the weights of step q + 1 (loaded
     // at the start of this step) are stored into the other buffer -- nobody reads it since the barrier that ended step q - 1
     int par = 0;
@@ -345,22 +443,37 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
   for (int c = 0; c < nC; ++c) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {  // unrolled: no branch around any load, the s_waitcnt counts stay exact
-      if (g == NG / 2) load_a(c + 1);  // next halo chunk: in flight during the second half of this one
-      if (g + 1 < NG) load_b(c, (g + 1) * TPG); else load_b(c + 1, 0);
+      if constexpr ((ABL & 0x800) != 0) {  // weights first: the wait in front of store_b then leaves the (younger) halo loads in flight
+        if (g + 1 < NG) load_b(c, (g + 1) * TPG); else load_b(c + 1, 0);
+      }
+      if (g == ((ABL & 0x100) ? 0 : (ABL & 0x200) ? 2 : NG / 2)) load_a(c + 1);  // next halo chunk: in flight during the second half of this one
+      if constexpr ((ABL & 0x800) == 0) {
+        if (g + 1 < NG) load_b(c, (g + 1) * TPG); else load_b(c + 1, 0);
+      }
 #pragma unroll
       for (int u = 0; u < TPG; ++u) compute(g * TPG + u, u);
-      __syncthreads();  // every wave has read this group's weights (and, in the last group, this chunk's halo)
+      if constexpr ((ABL & 4) == 0) __syncthreads();  // every wave has read this group's weights (and, in the last group, this chunk's halo)
       store_b();
       if (g == NG - 1 && c + 1 < nC) {
         if (UPS && (c + 1) * BK < p.C1) store_a_ups(); else store_a();  // block-uniform
       }
-      __syncthreads();
+      if constexpr ((ABL & 4) == 0) __syncthreads();
     }
   }
 
   const Tile2D t2{bimg, oy0, ox0, H_TX, ODD_SHIFT};
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2, F16 ? P.w_h16_inv_scale : nullptr);
 }
+
+#ifdef PF_TUNING_BUILD
+template <int MASK>
+static void launch_sbh_abl(const ConvParams& p, hipStream_t s) {  // sbh256x64w8 (the tile of the dominant 256 -> 256 @80^2 launches) with one cost removed
+  const int tilesN = (p.Cout + 63) / 64, tilesX = (p.Wo + 15) / 16, tilesY = (p.Ho + 15) / 16;
+  const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(512);
+  if (p.nterms != NT_F16X3 || p.C2 > 0 || p.ups || p.g[0].x_sb) return;
+  hipLaunchKernelGGL((igemm_sbh_kernel<16, 16, 64, 4, 2, 0, 1, NT_F16X3, false, false, false, MASK>), grid, block, 0, s, p);
+}
+#endif
 
 template <int H_TY, int H_TX, int BN, int WM, int WN, int TPG = 1, bool DB = false>
 static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
@@ -413,6 +526,9 @@ bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
 #endif
   if (p.g[0].x_sb) return h_tile < 4 || h_tile == kWide32;  // plane input: the plain-tap-loop tiles
   if (p.ups) return (h_tile < 3 || h_tile == kWide32) && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
+#ifdef PF_TUNING_BUILD
+  if (h_tile >= 13) return p.nterms == NT_F16X3 && p.C2 == 0;  // ablation forms: one plain fp32 input
+#endif
   if (h_tile >= kWide32) return p.nterms == NT_F16X3;  // sbh256x32 (and, in tuning builds, the whole-N tiles sbh256x256w8 / sbhd256x256w8)
 #ifdef PF_TUNING_BUILD
   return h_tile < 4 || p.nterms == NT_F16X3;
@@ -444,6 +560,25 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
     case 7: launch_sbh_cfg<16, 16, 64, 4, 2, 1, true>(p, s); break;
     case 8: launch_sbh_cfg<16, 16, 64, 4, 2, 3>(p, s); break;
     case 9: launch_sbh_cfg<8, 16, 64, 2, 2, 3>(p, s); break;
+    // ablation forms of sbh256x64w8 (wrong results by construction; timing only): "sbhA<mask>"
+    case 13: launch_sbh_abl<1>(p, s); break;
+    case 14: launch_sbh_abl<2>(p, s); break;
+    case 15: launch_sbh_abl<3>(p, s); break;
+    case 16: launch_sbh_abl<4>(p, s); break;
+    case 17: launch_sbh_abl<8>(p, s); break;
+    case 18: launch_sbh_abl<48>(p, s); break;
+    case 19: launch_sbh_abl<12>(p, s); break;
+    case 20: launch_sbh_abl<11>(p, s); break;
+    case 21: launch_sbh_abl<15>(p, s); break;
+    case 22: launch_sbh_abl<63>(p, s); break;
+    case 23: launch_sbh_abl<16>(p, s); break;
+    case 24: launch_sbh_abl<32>(p, s); break;
+    case 25: launch_sbh_abl<0x100>(p, s); break;
+    case 26: launch_sbh_abl<0x200>(p, s); break;
+    case 27: launch_sbh_abl<0x800>(p, s); break;
+    case 28: launch_sbh_abl<0x900>(p, s); break;
+    case 29: launch_sbh_abl<0x1000>(p, s); break;
+    case 30: launch_sbh_abl<0x2000>(p, s); break;
 #endif
     default: launch_sbh_cfg<16, 16, 64, 4, 2>(p, s); break;  // 16 x 16 patch, 8 waves, two blocks per CU: weights staged once per 256 rows
   }
