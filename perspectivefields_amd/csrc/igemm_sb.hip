@@ -30,6 +30,9 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {256, 64, 0, "sbhA1"}, {256, 64, 0, "sbhA2"}, {256, 64, 0, "sbhA3"}, {256, 64, 0, "sbhA4"}, {256, 64, 0, "sbhA8"}, {256, 64, 0, "sbhA48"},
                              {256, 64, 0, "sbhA12"}, {256, 64, 0, "sbhA11"}, {256, 64, 0, "sbhA15"}, {256, 64, 0, "sbhA63"},
                              {256, 64, 0, "sbhAa"}, {256, 64, 0, "sbhAb"}, {256, 64, 0, "sbhLA0"}, {256, 64, 0, "sbhLA2"}, {256, 64, 0, "sbhLAbf"}, {256, 64, 0, "sbhLAbf0"}, {256, 64, 0, "sbhDMA"}, {256, 64, 0, "sbhREG"},
+                             // DMA weight ring on the other tiles (two / three LDS buffers): right results
+                             {128, 64, 0, "sbhV2_128x64"}, {128, 32, 0, "sbhV2_128x32"}, {256, 32, 0, "sbhV2_256x32"}, {128, 64, 0, "sbhV3_128x64"},
+                             {128, 128, 0, "sbhV2_128x128"}, {256, 64, 0, "sbhV2_256x64w8"},
 #endif
 };
 static constexpr int kFirstH = 12;  // index of the first "sbh" tile

@@ -51,7 +51,7 @@ template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE,
                              staging is a plain 16-byte copy per plane -- no split arithmetic in this kernel (VALU instructions are paid in MFMA issue time,
                              DESIGN.md 4.7), and an element is split once by its producer instead of once per n-tile and halo overlap here.  MODE 0, no UPS.*/
           SBH_ABL_PARAM>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD
+__global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL & 0x5000) != 0 && (ABL & 0x8000) == 0 && BN <= 64)) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD (tuning builds: the DMA-ring variants of the 4-wave tiles keep the 128-VGPR / four-block residency of the shipped forms; 0x8000 lifts that)
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
   constexpr int BM = H_TY * H_TX;
@@ -83,9 +83,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
   // Default for the 16 x 16 patch / 8-wave tile (the 256 -> 256 decoder convs): its two resident blocks per CU fit the 66 KB; on the 4-wave tiles the ring would
   // cost a resident block.  Measured (profiles/r02_sbh_ablation.md): 256 -> 256 @80^2 0.790 -> 0.762 ms, @40^2 0.253 -> 0.244, 64 -> 256 @80^2 0.210 -> 0.200,
   // bit-identical results (same products, same order).  Tuning builds: ABL bit 0x1000 forces the ring, 0x2000 the register-staged loop.
+#ifdef PF_TUNING_BUILD
+  // 0x4000 the ring with TWO buffers (one tap ahead, issued at the start of the step: for the 4-wave tiles, where a third buffer costs a resident block).
+  constexpr bool DMAW = (ABL & 0x2000) == 0 && ((ABL & 0x5000) != 0 || (H_TY == 16 && BN == 64 && WM * WN == 8 && SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0));
+  static_assert(!DMAW || (SCH == NT_F16X3 && TPG == 1 && !DB && !ASB), "DMA weights: split-f16 scheme, plain tap loop, fp32 input(s)");
+  constexpr int NBUF = DMAW ? ((ABL & 0x4000) ? 2 : 3) : (DB ? 2 : 1);
+#else
   constexpr bool DMAW = (ABL & 0x2000) == 0 && ((ABL & 0x1000) != 0 || (H_TY == 16 && BN == 64 && WM * WN == 8 && SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0));
   static_assert(!DMAW || (SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0), "DMA weights: split-f16 scheme, plain tap loop, one fp32 input");
   constexpr int NBUF = DMAW ? 3 : (DB ? 2 : 1);
+#endif
   constexpr int OPER_USHORTS = NPA * PLANE_A + NBUF * BBUF + SRC_USHORTS;
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
@@ -388,6 +395,43 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
 
   // prologue: halo chunk 0 and the weights of the first tap group -> LDS
   constexpr int NG = 9 / TPG;  // tap groups per chunk
+#ifdef PF_TUNING_BUILD  // generalised ring (two or three buffers, concat / fused up-sampling inputs): measured in tuning builds first
+  if constexpr (DMAW) {
+    constexpr int AHEAD = NBUF - 1;  // taps of look-ahead
+    // VMEM instructions one load_a() issues (out-of-range offsets still issue): the static vmcnt bookkeeping below depends on it
+    constexpr int A_LOADS = UPS ? S_F4 + (MODE == 2 ? A_F4 : 0) : (MODE == 2 ? 2 : 1) * A_F4;
+    load_a(0);
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) dma_b(0, u, u);
+    if (UPS && 0 < p.C1) store_a_ups(); else store_a();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // step q = 9 c + g reads weight buffer q % 3 = g % 3; the DMA of step q + 2 goes into buffer (g + 2) % 3, last read in step q - 1 (every wave is past
+    // the barrier that ended it).  End of step q: every wave waits for ITS part of step q + 1's weights (issued one step ago: the younger VMEM
+    // instructions -- this step's DMA and the halo loads of this / the previous step -- stay in flight), then one barrier.
+    // Two buffers: step q reads buffer q % 2 (`par`: nine taps per chunk, the parity alternates from chunk to chunk), its DMA (tap q + 1) goes into the other one,
+    // last read in step q - 1; the wait at the end of the step then covers THIS step's DMA (younger: only this step's halo loads).
+    constexpr int LA = NG / 2;
+    int par = 0;
+    for (int c = 0; c < nC; ++c) {
+#pragma unroll
+      for (int g = 0; g < 9; ++g) {
+        dma_b(g + AHEAD < 9 ? c : c + 1, (g + AHEAD) % 9, NBUF == 3 ? (g + 2) % 3 : (par ^ 1));
+        if (g == LA) load_a(c + 1);
+        compute(g, 0, NBUF == 3 ? g % 3 : par);
+        constexpr int younger = NBUF == 3 ? DMA_R : 0;  // three buffers: this step's DMA is the NEXT step's business
+        if (g == LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger + A_LOADS) : "memory");
+        else if (g == LA + 1 && NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger + A_LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger) : "memory");
+        if (g == 8 && c + 1 < nC) {  // every wave has read this chunk's halo
+          __syncthreads();
+          if (UPS && (c + 1) * BK < p.C1) store_a_ups(); else store_a();  // block-uniform
+        }
+        __syncthreads();
+        par ^= 1;
+      }
+    }
+#else  // the validated form of the shipped tile (three buffers, one fp32 input)
   if constexpr (DMAW) {
     load_a(0);
     dma_b(0, 0, 0);
@@ -413,6 +457,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 && BN < 256) ? 4 : 2) v
         __syncthreads();
       }
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two look-ahead DMAs past the end: the epilogue reuses the LDS
     __syncthreads();
   } else {
@@ -475,6 +520,25 @@ static void launch_sbh_abl(const ConvParams& p, hipStream_t s) {  // sbh256x64w8
 }
 #endif
 
+#ifdef PF_TUNING_BUILD
+// DMA weight ring (MASK 0x4000: two buffers, 0x1000: three) on any tile geometry, every input form of the split-f16 scheme: right results, candidates for the product
+template <int H_TY, int H_TX, int BN, int WM, int WN, int MASK>
+static void launch_sbh_var(const ConvParams& p, hipStream_t s) {
+  const int tilesN = (p.Cout + BN - 1) / BN, tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
+  const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(WM * WN * 64);
+  if (p.nterms != NT_F16X3 || p.g[0].x_sb) return;
+  if (p.ups) {
+    if constexpr (WM * WN == 4) {
+      if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, 1, NT_F16X3, false, true, false, MASK>), grid, block, 0, s, p);
+      else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, 1, NT_F16X3, false, true, false, MASK>), grid, block, 0, s, p);
+    }
+    return;
+  }
+  if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, 1, NT_F16X3, false, false, false, MASK>), grid, block, 0, s, p);
+  else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, 1, NT_F16X3, false, false, false, MASK>), grid, block, 0, s, p);
+}
+#endif
+
 template <int H_TY, int H_TX, int BN, int WM, int WN, int TPG = 1, bool DB = false>
 static void launch_sbh_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesN = (p.Cout + BN - 1) / BN;
@@ -525,6 +589,13 @@ bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
   constexpr int kWide32 = 4;
 #endif
   if (p.g[0].x_sb) return h_tile < 4 || h_tile == kWide32;  // plane input: the plain-tap-loop tiles
+#ifdef PF_TUNING_BUILD
+  if (h_tile >= 31) {  // DMA-ring variants of the shipped tiles: every fp32 input form of the split-f16 scheme (fused up-sampling: the 4-wave tiles)
+    if (p.nterms != NT_F16X3) return false;
+    if (p.ups) return h_tile != 36 && (p.H % 2) == 0 && (p.W % 2) == 0;
+    return true;
+  }
+#endif
   if (p.ups) return (h_tile < 3 || h_tile == kWide32) && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
 #ifdef PF_TUNING_BUILD
   if (h_tile >= 13) return p.nterms == NT_F16X3 && p.C2 == 0;  // ablation forms: one plain fp32 input
@@ -579,6 +650,12 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
     case 28: launch_sbh_abl<0x900>(p, s); break;
     case 29: launch_sbh_abl<0x1000>(p, s); break;
     case 30: launch_sbh_abl<0x2000>(p, s); break;
+    case 31: launch_sbh_var<8, 16, 64, 2, 2, 0x4000>(p, s); break;    // "sbhV2_128x64"
+    case 32: launch_sbh_var<8, 16, 32, 4, 1, 0x4000>(p, s); break;    // "sbhV2_128x32"
+    case 33: launch_sbh_var<16, 16, 32, 4, 1, 0x4000>(p, s); break;   // "sbhV2_256x32"
+    case 34: launch_sbh_var<8, 16, 64, 2, 2, 0x1000>(p, s); break;    // "sbhV3_128x64"
+    case 35: launch_sbh_var<8, 16, 128, 2, 2, 0x4000>(p, s); break;   // "sbhV2_128x128"
+    case 36: launch_sbh_var<16, 16, 64, 4, 2, 0x4000>(p, s); break;   // "sbhV2_256x64w8"
 #endif
     default: launch_sbh_cfg<16, 16, 64, 4, 2>(p, s); break;  // 16 x 16 patch, 8 waves, two blocks per CU: weights staged once per 256 rows
   }
