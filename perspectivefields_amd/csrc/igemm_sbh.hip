@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL 
 #ifdef PF_TUNING_BUILD
   // 0x4000 the ring with TWO buffers (one tap ahead, issued at the start of the step: for the 4-wave tiles, where a third buffer costs a resident block).
   constexpr bool DMAW = (ABL & 0x2000) == 0 && ((ABL & 0x5000) != 0 || (H_TY == 16 && BN == 64 && WM * WN == 8 && SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0));
-  static_assert(!DMAW || (SCH == NT_F16X3 && TPG == 1 && !DB && !ASB), "DMA weights: split-f16 scheme, plain tap loop, fp32 input(s)");
+  static_assert(!DMAW || (SCH == NT_F16X3 && TPG == 1 && !DB), "DMA weights: split-f16 scheme, plain tap loop");
   constexpr int NBUF = DMAW ? ((ABL & 0x4000) ? 2 : 3) : (DB ? 2 : 1);
 #else
   constexpr bool DMAW = (ABL & 0x2000) == 0 && ((ABL & 0x1000) != 0 || (H_TY == 16 && BN == 64 && WM * WN == 8 && SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0));
@@ -526,7 +526,11 @@ template <int H_TY, int H_TX, int BN, int WM, int WN, int MASK>
 static void launch_sbh_var(const ConvParams& p, hipStream_t s) {
   const int tilesN = (p.Cout + BN - 1) / BN, tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(WM * WN * 64);
-  if (p.nterms != NT_F16X3 || p.g[0].x_sb) return;
+  if (p.nterms != NT_F16X3) return;
+  if (p.g[0].x_sb) {  // split-f16 planes from the producer (PF_SBA_HEADS=1): register copy of the halo, DMA ring for the weights
+    if (p.C2 == 0 && !p.ups) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, 1, NT_F16X3, false, false, true, MASK>), grid, block, 0, s, p);
+    return;
+  }
   if (p.ups) {
     if constexpr (WM * WN == 4) {
       if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, 1, NT_F16X3, false, true, false, MASK>), grid, block, 0, s, p);
@@ -587,6 +591,9 @@ bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
   constexpr int kWide32 = 10;  // "sbh256x32": after the tuning-only tiles
 #else
   constexpr int kWide32 = 4;
+#endif
+#ifdef PF_TUNING_BUILD
+  if (p.g[0].x_sb && h_tile >= 31) return true;  // DMA-ring variants take plane input too (conv_sbh_ok: one input, no fused up-sampling)
 #endif
   if (p.g[0].x_sb) return h_tile < 4 || h_tile == kWide32;  // plane input: the plain-tap-loop tiles
 #ifdef PF_TUNING_BUILD
