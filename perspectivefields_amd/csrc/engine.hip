@@ -804,7 +804,7 @@ struct pf_engine {
     float best_ms = 1e30f;
     for (int t = 0; t < conv_num_tiles(); ++t) {
       if (!conv_tile_usable(p, t)) continue;
-      if (strncmp(conv_tile_name(t), "sbhA", 4) == 0 || strncmp(conv_tile_name(t), "sbhLA", 5) == 0 || strncmp(conv_tile_name(t), "sbhDMA", 6) == 0 || strncmp(conv_tile_name(t), "sbhREG", 6) == 0 || strncmp(conv_tile_name(t), "sbhV", 4) == 0) continue;  // tuning builds: ablation forms (wrong results by construction) are for scripts/tune_conv.py only
+      if (strncmp(conv_tile_name(t), "sbhA", 4) == 0 || strncmp(conv_tile_name(t), "sbhLA", 5) == 0 || strncmp(conv_tile_name(t), "sbhDMA", 6) == 0 || strncmp(conv_tile_name(t), "sbhREG", 6) == 0 || strncmp(conv_tile_name(t), "sbhV", 4) == 0 || strncmp(conv_tile_name(t), "sbA", 3) == 0 || strncmp(conv_tile_name(t), "sbPI_", 5) == 0 || strncmp(conv_tile_name(t), "sbI_", 4) == 0) continue;  // tuning builds: ablation forms (wrong results by construction) are for scripts/tune_conv.py only
       if (conv_tile_bn(t) > 32 && p.Cout <= 32) continue;
       if ((long)conv_tile_bm(t) * conv_tile_bn(t) > 16L * p.M * p.Cout) continue;  // tile far larger than the problem
       launch_conv_tile(p, t, c.s);  // warm-up (instruction cache, L2 state)

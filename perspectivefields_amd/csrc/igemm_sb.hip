@@ -16,6 +16,13 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {128, 256, 1, "sb128x256w8"}, {128, 32, 1, "sb128x32"}, {256, 256, 1, "sb256x256w8"},
                              {64, 64, 2, "sb64x64f2"}, {64, 64, 3, "sb64x64f3"}, {128, 64, 2, "sb128x64f2"}, {128, 32, 2, "sb128x32f2"},
                              {128, 128, 2, "sb128x128f2"},
+#ifdef PF_TUNING_BUILD
+                             // ablation / scheduling forms of four linear tiles (igemm_sb_impl.h SB_ABL_PARAM): "sbA<mask>_*" wrong results by construction, "sbP_*" right
+                             {64, 64, 1, "sbA16_64x64"}, {64, 64, 1, "sbA32_64x64"}, {64, 64, 1, "sbA48_64x64"}, {64, 64, 1, "sbA1_64x64"}, {64, 64, 1, "sbI_64x64"}, {64, 64, 1, "sbPI_64x64"},
+                             {64, 64, 3, "sbA16_64x64f3"}, {64, 64, 3, "sbA32_64x64f3"}, {64, 64, 3, "sbA48_64x64f3"}, {64, 64, 3, "sbA1_64x64f3"}, {64, 64, 3, "sbI_64x64f3"}, {64, 64, 3, "sbPI_64x64f3"},
+                             {128, 128, 1, "sbA16_128x128"}, {128, 128, 1, "sbA32_128x128"}, {128, 128, 1, "sbA48_128x128"}, {128, 128, 1, "sbA1_128x128"}, {128, 128, 1, "sbI_128x128"}, {128, 128, 1, "sbPI_128x128"},
+                             {256, 128, 1, "sbA16_256x128w8"}, {256, 128, 1, "sbA32_256x128w8"}, {256, 128, 1, "sbA48_256x128w8"}, {256, 128, 1, "sbA1_256x128w8"}, {256, 128, 1, "sbI_256x128w8"}, {256, 128, 1, "sbPI_256x128w8"},
+#endif
                              // "sbh": 3x3 / stride 1 convs with an LDS-staged input halo tile, 8 x 16 output patch per block (igemm_sbh.hip)
                              {128, 128, 0, "sbh128x128"}, {128, 64, 0, "sbh128x64"}, {128, 32, 0, "sbh128x32"}, {256, 64, 0, "sbh256x64w8"},
 #ifdef PF_TUNING_BUILD
@@ -35,7 +42,11 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {128, 128, 0, "sbhV2_128x128"}, {256, 64, 0, "sbhV2_256x64w8"},
 #endif
 };
+#ifdef PF_TUNING_BUILD
+static constexpr int kFirstH = 12 + 24;  // index of the first "sbh" tile (behind the linear tiles' tuning forms)
+#else
 static constexpr int kFirstH = 12;  // index of the first "sbh" tile
+#endif
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }
 const char* conv_sb_tile_name(int id) { return kSb[id].name; }
 int conv_sb_tile_bm(int id) { return kSb[id].bm; }
@@ -90,6 +101,10 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile);                  // igemm_sbh.hip
 bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
+#ifdef PF_TUNING_BUILD
+  if (sb_tile >= 12 && sb_tile < kFirstH)  // tuning forms of the linear tiles: split-f16 scheme, one fp32 input, plain epilogue
+    return p.nterms == NT_F16X3 && !p.ln && p.C2 == 0 && !p.g[0].x_sb && p.Cin != 4 && (p.Cin % BK) == 0 && !p.ups && !p.g[0].head_kind;
+#endif
   if (p.g[0].head_kind && (kSb[sb_tile].bn != 32 || p.Cout != 32)) return false;  // the fused prediction head lives in the BN = 32 epilogue
   if (p.ln) {  // fused input LayerNorm: linear tiles, 1x1, fp32 rows, the whole row inside one block's K loop
     if (sb_tile >= kFirstH || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.C2 > 0 || (p.Cin % BK) != 0 || (p.Cout & 3) || p.splitk > 1 || p.ups) return false;
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
 void launch_conv_sb(const ConvParams& p0, int sb_tile, hipStream_t s) {
   ConvParams p = p0;
   // split-K only on the linear tiles, with scratch from the caller and 16-byte rows
-  if (p.splitk > 1 && (sb_tile >= kFirstH || p.ln || !p.g[0].partial || (p.groups > 1 && !p.g[1].partial) || (p.Cout & 3) || p.ldy != p.Cout)) p.splitk = 1;
+  if (p.splitk > 1 && (sb_tile >= 12 /* halo tiles and, in tuning builds, the linear tiles' tuning forms */ || p.ln || !p.g[0].partial || (p.groups > 1 && !p.g[1].partial) || (p.Cout & 3) || p.ldy != p.Cout)) p.splitk = 1;
   struct Reduce { const ConvParams& p; hipStream_t s; ~Reduce() {
     if (p.splitk <= 1) return;
     const long mn4 = (long)p.M * p.Cout / 4;

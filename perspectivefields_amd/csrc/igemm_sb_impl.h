@@ -71,7 +71,17 @@ __device__ __forceinline__ void split4_hm(const float4 v, uint2& h, uint2& m) {
 // row's first element: LayerNorm is shift invariant, and the shifted row has no large common offset left to cancel), accumulate
 // sum / sum of squares of what they stage, and the epilogue applies  y = rstd (acc - mean colsum) + bias  -- the normalised tensor
 // is never written or read (mix_transformers.py:200, :123-126; convnext.py:50-51).
-template <int BM, int BN, int WM, int WN, int MODE, bool ASB, int PFD, int NTERM, bool LNF = false>
+// Ablation / scheduling forms of the linear tiles (tuning builds only; scripts/tune_sb_ablate.py, tiles "sbA<mask>_*" -- WRONG results by construction, timing only:
+// 1 = no split arithmetic while staging A, 2 = no wh 2^-11 scaling, 4 = no barriers in the K loop, 8 = half the fragment reads, 16 / 32 = no global loads of A / B --
+// "sbI_*" (0x200, right results): K-step position carried instead of divided out; "sbPI_*" (0x300, right results): that plus scheduling barriers that keep the
+// loads of the next tile in front of this tile's MFMAs and the split arithmetic behind them (hipcc sinks the loads otherwise).
+#ifdef PF_TUNING_BUILD
+#define SB_ABL_PARAM , int SABL = 0
+#else
+#define SB_ABL_PARAM
+static constexpr int SABL = 0;
+#endif
+template <int BM, int BN, int WM, int WN, int MODE, bool ASB, int PFD, int NTERM, bool LNF = false SB_ABL_PARAM>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128) ? (PFD == 1 ? 3 : 2) : ((WM * WN == 8 && BM * BN == 256 * 128 && (NTERM == 6 || NTERM == NT_F16X3)) ? SB_W8_WAVES : 1)) void igemm_sb_kernel(const ConvParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int RPP = NT / 8;    // fp32 A rows staged per pass (8 threads x float4 = 32 floats)
@@ -192,6 +202,25 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   const int nK_all = p.KH * nJ;
   const int it0 = (int)((long)sidx * nK_all / S), nK = (int)((long)(sidx + 1) * nK_all / S);  // this block's K steps [it0, nK)
 
+#ifdef PF_TUNING_BUILD
+  // SABL 0x200 (tuning builds, right results): the (ky, kx, channel) position of a K step is carried from call to call (load_tiles sees consecutive steps)
+  // instead of two integer divisions by run-time values per step -- ~40 dependent SALU instructions in front of every tile's loads (hipcc -S), which is as
+  // long as the six MFMAs of a 64 x 64 tile's step.  Not for the stem form (MODE 1: its chunk is a kernel row of 8 taps).
+  constexpr bool INCR = (SABL & 0x200) != 0 && MODE != 1;
+  int q_ky = it0 / nJ, q_j0 = (it0 - q_ky * nJ) * BK, q_kx = q_j0 / p.Cin, q_ci0 = q_j0 - q_kx * p.Cin;
+  // branch-free: a step at or past nK loads from the out-of-range offset (zeros, never stored)
+  auto load_tiles = [&](int it, Raw& R) {
+    const bool live = it < nK;
+    const int ky = INCR ? q_ky : it / nJ;
+    const int j0 = INCR ? q_j0 : (it - ky * nJ) * BK;
+    const int kx = INCR ? q_kx : j0 / p.Cin;
+    const int ci0 = INCR ? q_ci0 : j0 - kx * p.Cin;
+    if constexpr (INCR) {  // advance to step it + 1
+      q_j0 += BK; q_ci0 += BK;
+      if (q_ci0 >= p.Cin) { q_ci0 = 0; ++q_kx; }
+      if (q_j0 >= p.KWCp) { q_j0 = 0; q_ci0 = 0; q_kx = 0; ++q_ky; }
+    }
+#else
   // branch-free: a step at or past nK loads from the out-of-range offset (zeros, never stored)
   auto load_tiles = [&](int it, Raw& R) {
     const bool live = it < nK;
@@ -199,6 +228,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     const int j0 = (it - ky * nJ) * BK;
     const int kx = j0 / p.Cin;
     const int ci0 = j0 - kx * p.Cin;
+#endif
     const int bit = (ky * p.KW + kx) & 63;
     const bool first = MODE != 2 || ci0 < p.C1;
     const int toff = ((ky * p.W + kx) * (first ? p.C1 : p.C2) + (first ? ci0 : ci0 - p.C1)) * ESZ;
@@ -225,6 +255,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
         const float4 v1 = buf_load16(rx[0], first ? off : OOB);
         const float4 v2 = buf_load16(rx2[0], first ? OOB : off);
         R.a[i] = make_float4(v1.x + v2.x, v1.y + v2.y, v1.z + v2.z, v1.w + v2.w);
+      } else if constexpr ((SABL & 16) != 0) {
+        float o = __builtin_bit_cast(float, off | 0x3f000000u);
+        asm volatile("" : "+v"(o));  // opaque: the split in store_tiles stays
+        R.a[i] = make_float4(o, o, o, o);
       } else {
         R.a[i] = buf_load16(rx[0], off);
       }
@@ -234,7 +268,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     for (int i = 0; i < B_ROWS; ++i)
 #pragma unroll
       for (int pl = 0; pl < NPG; ++pl)
-        R.b[i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)BPL[pl] * p.w_sb_plane_bytes : OOB);
+        if constexpr ((SABL & 32) != 0) {
+          float o = __builtin_bit_cast(float, (b_off[i] + woff) | 0x3c003c00u);
+          asm volatile("" : "+v"(o));
+          R.b[i][pl] = make_float4(o, o, o, o);
+        } else {
+          R.b[i][pl] = buf_load16(rw, (live && b_off[i] != OOB) ? b_off[i] + woff + (unsigned)BPL[pl] * p.w_sb_plane_bytes : OOB);
+        }
   };
   // statistics in packed fp32 (v_pk_add_f32 / v_pk_fma_f32: two lanes of the sum per instruction -- VALU instructions are paid in MFMA issue time,
   // profiles/r02_cnx_mlp.md): 6 instead of 12 VALU instructions per staged float4
@@ -263,7 +303,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
           ln_s1[LNF ? i : 0] = (ln_s1[LNF ? i : 0] + a0) + a1;
           ln_s2[LNF ? i : 0] = __builtin_elementwise_fma(a1, a1, __builtin_elementwise_fma(a0, a0, ln_s2[LNF ? i : 0]));
         }
-        if (F16) split4_f16(av, h, m);
+        if constexpr (F16 && (SABL & 1) != 0) {
+          h = make_uint2(__builtin_bit_cast(unsigned, av.x), __builtin_bit_cast(unsigned, av.y));
+          m = make_uint2(__builtin_bit_cast(unsigned, av.z), __builtin_bit_cast(unsigned, av.w));
+        } else if (F16) split4_f16(av, h, m);
         else if (NTERM == 6) split4(av, h, m, l);
         else if (NTERM == 3) split4_hm(av, h, m);
         else h = round4_bf16(av);
@@ -298,10 +341,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   const int swz = (l31 >> 2) & 3;  // wm0, wn0 and i*32 are multiples of 32: the swizzle depends on the lane only
 
   auto compute = [&]() {
+    u32x4 af[SM][NPL], bf[SN][F16 ? 3 : NPB];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {  // two 16-deep chunks per K step; this lane's 8 k-values = piece 2c + hi
       const int po = ((2 * c + hi) ^ swz) * 8;
-      u32x4 af[SM][NPL], bf[SN][F16 ? 3 : NPB];
+      if ((SABL & 8) == 0 || c == 0) {
 #pragma unroll
       for (int i = 0; i < SM; ++i)
 #pragma unroll
@@ -312,7 +356,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
         for (int pl = 0; pl < NPB; ++pl) bf[j][pl] = *reinterpret_cast<const u32x4*>(Bb + pl * PLANE_B + j * 32 * SB_ROW + po);
       if constexpr (F16) {
 #pragma unroll
-        for (int j = 0; j < SN; ++j) bf[j][2] = __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, bf[j][0])));
+        for (int j = 0; j < SN; ++j) bf[j][2] = (SABL & 2) ? bf[j][0] : __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, bf[j][0])));
+      }
       }
       // six partial products, smallest first; the (i, j) loop is innermost so that consecutive MFMAs never
       // depend on each other's accumulator
@@ -347,10 +392,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
 #pragma unroll
     for (int d = 0; d < PFD; ++d) {
       load_tiles(it + d + PFD, raw[d]);  // refill the set whose tile (it + d) is in LDS now
+      if constexpr ((SABL & 0x100) != 0) __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of this tile's MFMAs ...
       compute();                         // tile it + d
-      __syncthreads();                   // every wave has read this step's planes
+      if constexpr ((SABL & 0x100) != 0) __builtin_amdgcn_sched_barrier(0);  // ... and the split arithmetic of the next store behind them
+      if constexpr ((SABL & 4) == 0) __syncthreads();  // every wave has read this step's planes
       store_tiles(raw[(d + 1) % PFD]);   // tile it + d + 1 (the oldest loads in flight)
-      __syncthreads();
+      if constexpr ((SABL & 4) == 0) __syncthreads();
     }
   }
 #pragma unroll
@@ -411,9 +458,42 @@ static void launch_sb_cfg(const ConvParams& p, hipStream_t s) {
   }
 }
 
+#ifdef PF_TUNING_BUILD
+template <int BM, int BN, int WM, int WN, int PFD, int MASK>
+static void launch_sb_abl(const ConvParams& p, hipStream_t s) {  // split-f16 scheme, one fp32 input, no LayerNorm fusion, no split-K
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
+  const dim3 grid(tilesM * tilesN * p.groups), block(WM * WN * 64);
+  if (p.nterms != NT_F16X3 || p.g[0].x_sb || p.Cin == 4 || p.C2 > 0 || p.ln || p.splitk > 1) return;
+  hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, false, PFD, NT_F16X3, false, MASK>), grid, block, 0, s, p);
+}
+template <int BM, int BN, int WM, int WN, int PFD>
+static void launch_sb_abl_set(const ConvParams& p, int k, hipStream_t s) {  // k: 0..5 -> masks 16, 32, 48, 1, 0x200, 0x300
+  switch (k) {
+    case 0: launch_sb_abl<BM, BN, WM, WN, PFD, 16>(p, s); break;
+    case 1: launch_sb_abl<BM, BN, WM, WN, PFD, 32>(p, s); break;
+    case 2: launch_sb_abl<BM, BN, WM, WN, PFD, 48>(p, s); break;
+    case 3: launch_sb_abl<BM, BN, WM, WN, PFD, 1>(p, s); break;
+    case 4: launch_sb_abl<BM, BN, WM, WN, PFD, 0x200>(p, s); break;
+    default: launch_sb_abl<BM, BN, WM, WN, PFD, 0x300>(p, s); break;
+  }
+}
+#endif
+
 // tile ids: kSb[] in igemm_sb.hip
 template <int NT>
 static void launch_conv_sb_nt(const ConvParams& p, int sb_tile, hipStream_t s) {
+#ifdef PF_TUNING_BUILD
+  if constexpr (NT == NT_F16X3) {
+    if (sb_tile >= 12 && sb_tile < 12 + 24) {  // kSb[]: four base tiles x six forms
+      const int base = (sb_tile - 12) / 6, k = (sb_tile - 12) % 6;
+      if (base == 0) launch_sb_abl_set<64, 64, 2, 2, 1>(p, k, s);
+      else if (base == 1) launch_sb_abl_set<64, 64, 2, 2, 3>(p, k, s);
+      else if (base == 2) launch_sb_abl_set<128, 128, 2, 2, 1>(p, k, s);
+      else launch_sb_abl_set<256, 128, 4, 2, 1>(p, k, s);
+      return;
+    }
+  }
+#endif
   switch (sb_tile) {
     case 0: launch_sb_cfg<128, 128, 2, 2, 1, NT>(p, s); break;
     case 1: launch_sb_cfg<64, 64, 2, 2, 1, NT>(p, s); break;
