@@ -437,3 +437,22 @@ def test_kernel_resources_static():
         assert by[k]["spill"] == 0 and by[k]["scratch"] == 0, by[k]
     # the two-blocks-per-CU 8-wave tiles trade a handful of spilled registers for the second resident block
     assert by["pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 6, false>"]["vgpr"] <= 128
+
+
+def test_subpixel_form_of_upsample_conv_algebra():
+    """Planned next kernel form: conv3x3(bilinear_up2(x)) as four phase convs on the half-resolution map with host-combined weights plus closed-form
+    border corrections (scripts/proto/subpixel_conv.py) -- the algebra against torch's interpolate + conv2d in float64, incl. 1-pixel-wide maps."""
+    import importlib.util
+
+    import torch
+    import torch.nn.functional as F
+
+    spec = importlib.util.spec_from_file_location("subpixel_conv", os.path.join(ROOT, "scripts", "proto", "subpixel_conv.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    rng = np.random.default_rng(1)
+    for cin, cout, h, w_ in [(6, 5, 5, 8), (3, 3, 1, 1), (2, 4, 3, 1)]:
+        x = rng.standard_normal((cin, h, w_))
+        w = rng.standard_normal((cout, cin, 3, 3))
+        ref = F.conv2d(F.interpolate(torch.from_numpy(x)[None], scale_factor=2, mode="bilinear", align_corners=False), torch.from_numpy(w), padding=1)[0].numpy()
+        assert np.abs(sp.subpixel_conv(x, w) - ref).max() < 1e-9
