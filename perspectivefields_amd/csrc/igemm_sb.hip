@@ -78,6 +78,7 @@ bool conv_sbh_ok(const ConvParams& p);                                   // igem
 // that still gives every CU about two blocks, with a register prefetch ring (f2 / f3) when the K loop is deep.
 int conv_sb_default_tile(const ConvParams& p) {
   const long K = (long)p.KH * p.KWCp;
+  if (p.subpx) return kFirstH;  // sub-pixel form: the four phases (128 virtual channels) in one block -> "sbh128x128"
   if (p.ups) return kFirstH + (p.Cout <= 32 ? 2 : (p.Cout <= 64 ? 1 : 0));  // the only tiles that interpolate while staging
   if (conv_sbh_ok(p) && p.Ho >= 40 && p.Wo >= 40) {
     if (p.Cout <= 32) return kFirstH + 2;
@@ -105,7 +106,7 @@ bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
   if (sb_tile >= 12 && sb_tile < kFirstH)  // tuning forms of the linear tiles: split-f16 scheme, one fp32 input, plain epilogue
     return p.nterms == NT_F16X3 && !p.ln && p.C2 == 0 && !p.g[0].x_sb && p.Cin != 4 && (p.Cin % BK) == 0 && !p.ups && !p.g[0].head_kind;
 #endif
-  if (p.g[0].head_kind && (kSb[sb_tile].bn != 32 || p.Cout != 32)) return false;  // the fused prediction head lives in the BN = 32 epilogue
+  if (p.g[0].head_kind && !p.subpx && (kSb[sb_tile].bn != 32 || p.Cout != 32)) return false;  // the fused prediction head lives in the BN = 32 epilogue (sub-pixel form: per 32-channel phase slice)
   if (p.ln) {  // fused input LayerNorm: linear tiles, 1x1, fp32 rows, the whole row inside one block's K loop
     if (sb_tile >= kFirstH || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.C2 > 0 || (p.Cin % BK) != 0 || (p.Cout & 3) || p.splitk > 1 || p.ups) return false;
     for (int g = 0; g < p.groups; ++g)
@@ -113,6 +114,7 @@ bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
     return true;
   }
   if (sb_tile >= kFirstH) return conv_sbh_tile_ok(p, sb_tile - kFirstH);
+  if (p.subpx) return false;  // sub-pixel form: halo tiles only
   if (p.Cin == 4) return kSb[sb_tile].bm <= 128 && kSb[sb_tile].bn <= 128;  // stem form: built for the 4-wave tiles
   return !p.ups;
 }

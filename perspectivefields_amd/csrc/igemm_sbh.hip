@@ -141,7 +141,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL 
     const int e = tid + NT * i;
     const int hrow = e >> 3, c4 = e & 7;
     const int hy = hrow / H_HX, hx = hrow - hy * H_HX;
+#ifdef PF_TUNING_BUILD
+    int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    if (p.subpx) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }  // sub-pixel form: replicate padding (the interpolation's clamping)
+#else
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+#endif
     const bool in_tile = hrow < H_ROWS;
     const bool ok = in_tile && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     const int pix = (bimg * p.H + iy) * p.W + ix;
@@ -507,6 +512,14 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL 
   }
 
   const Tile2D t2{bimg, oy0, ox0, H_TX, ODD_SHIFT};
+#ifdef PF_TUNING_BUILD
+  if constexpr (BN == 128 && F16 && MODE == 0 && !UPS && !ASB) {
+    if (p.subpx) {  // launch-uniform
+      epilogue_subpx<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, p.subpx_corr[g1 ? 1 : 0], acc, reinterpret_cast<float*>(smem_u), n0, t2, P.w_h16_inv_scale);
+      return;
+    }
+  }
+#endif
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2, F16 ? P.w_h16_inv_scale : nullptr);
 }
 
@@ -587,6 +600,11 @@ bool conv_sbh_ok(const ConvParams& p) {
 // fused up-sampling (p.ups): split-f16 scheme, tiles 0-2 (8 x 16 patch, 4 waves, plain tap loop)
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
   if (!conv_sbh_ok(p)) return false;
+#ifdef PF_TUNING_BUILD
+  if (p.subpx) return (h_tile == 0 || h_tile == 35) && p.nterms == NT_F16X3 && p.Cout == 128 && p.C2 == 0 && !p.ups && !p.g[0].x_sb;  // sbh128x128 / sbhV2_128x128: the four phases in one block
+#else
+  if (p.subpx) return false;
+#endif
 #ifdef PF_TUNING_BUILD
   constexpr int kWide32 = 10;  // "sbh256x32": after the tuning-only tiles
 #else

@@ -15,3 +15,10 @@ done
 # linear tiles: ablation + the two scheduling fixes (K-step position carried, loads pinned in front of the MFMAs)
 unset PF_TILE_TABLE
 timeout 120 python scripts/tune_sb_ablate.py 2>&1 | tail -90
+# sub-pixel form of conv_fuse_conv1 (tuning build): op test against the fp64 formula, then the whole forward with PF_SUBPX_CONV1=1 (golden / oracle tests + bench)
+timeout 120 python -m pytest tests/test_gpu_ops.py -q -m gpu -p no:cacheprovider -k subpixel -s 2>&1 | tail -8
+export PF_SUBPX_CONV1=1
+timeout 200 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_fullsize.py -q -m gpu -p no:cacheprovider -x -k "golden or oracle or batch32" 2>&1 | tail -2
+for i in 1 2; do timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | cut -c1-140; done
+timeout 120 python scripts/profile_layers.py --out gpurun_out/layers_subpx.txt 2>&1 | head -16
+unset PF_SUBPX_CONV1

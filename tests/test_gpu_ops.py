@@ -514,3 +514,25 @@ def test_upsample2x(ops, B, H, W, C):
     x = _rand((B, H, W, C), 30)
     ref = F.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1).contiguous()
     _close(ops.upsample2x(x.cuda()), ref, 2e-6, "upsample2x")
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 40, 64), (1, 8, 16, 32), (1, 11, 19, 64), (1, 1, 1, 32), (1, 3, 1, 32)])
+def test_subpixel_upsample_conv_tuning_build(ops, shape):
+    """Sub-pixel form of conv3x3(bilinear x2 (x)) (tuning builds only -- skipped on the product library): four phase convs on the half-resolution map
+    with host-combined weights, replicate padding, closed-form border terms, pixel-shuffled store, against the fp64 formula (reference: decode_head.py:284-286,
+    gravity_head.py:170-172).  Partial patches, 1-pixel-wide maps (every pixel is a corner)."""
+    import torch.nn.functional as F
+
+    B, H, W, Cin = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(32, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(32, generator=g)
+    y = ops.subpx_conv(x.cuda(), w, b, act=1)
+    if y is None:
+        pytest.skip("product build: pf_tuning_subpx_conv not compiled in")
+    up = F.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    ref = F.relu(F.conv2d(up, w.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    err = (y.cpu().double() - ref).abs().max().item()
+    print(f"[subpx {shape}] max |err| {err:.2e}")
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item())
