@@ -19,6 +19,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # the scripts under scripts/ can select; the product build carries the default path and its parity alternatives only
 if os.environ.get("PF_TUNING_BUILD", "0") == "1":
     FLAGS.append("-DPF_TUNING_BUILD")
+# PF_LO_UNSCALED=1: the split-f16 scheme with the low activation plane unscaled (sb_split.h; candidate, needs a full GPU test run before it becomes the default)
+if os.environ.get("PF_LO_UNSCALED", "0") == "1":
+    FLAGS.append("-DPF_LO_UNSCALED")
 
 
 def _hipcc() -> str:

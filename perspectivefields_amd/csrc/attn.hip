@@ -184,12 +184,15 @@ __device__ __forceinline__ void at_split8(const float (&a)[8], at_u32x4& h, at_u
   for (int e = 0; e < 8; ++e) {
     const float c = __builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);
     hi[e] = (float)(_Float16)c;
-    lo[e] = SCALED_LO ? (c - hi[e]) * 2048.f : (c - hi[e]);
+    lo[e] = SCALED_LO ? (c - hi[e]) * SB_LO_SCALE : (c - hi[e]);
   }
   h = at_u32x4{at_pack(hi[0], hi[1]), at_pack(hi[2], hi[3]), at_pack(hi[4], hi[5]), at_pack(hi[6], hi[7])};
   l = at_u32x4{at_pack(lo[0], lo[1]), at_pack(lo[2], lo[3]), at_pack(lo[4], lo[5]), at_pack(lo[6], lo[7])};
 }
 __device__ __forceinline__ at_u32x4 at_scale_2m11(const at_u32x4 v) {
+#ifdef PF_LO_UNSCALED
+  return v;
+#endif
   const at_h2 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
   auto mul = [&](unsigned u) { return __builtin_bit_cast(unsigned, (at_h2)(__builtin_bit_cast(at_h2, u) * k)); };
   return at_u32x4{mul(v.x), mul(v.y), mul(v.z), mul(v.w)};

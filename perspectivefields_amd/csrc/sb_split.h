@@ -48,6 +48,17 @@ __device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2
 // ---- split-f16 scheme (NT_F16X3): x ~ hi + lo * 2^-11 with hi = fp16_rn(x), lo = fp16_rn((x - hi) * 2^11): 22-23 significant
 // bits in two fp16 values (representation error <= 2^-22 |x|).  |x| is clamped to the fp16 range (65504) first, so an
 // out-of-range activation saturates instead of turning into inf - inf; the scaled remainder is at most |x| / 2.
+// PF_LO_UNSCALED (build switch, python -m perspectivefields_amd.build with PF_LO_UNSCALED=1; candidate for the next round, profiles/r02_mfma_f16_subnormals.md): the low
+// plane is carried UNSCALED, lo = fp16_rn(x - hi).  The matrix cores of gfx950 keep fp16 subnormal inputs (measured), so nothing is lost below 2^-14 either: same
+// accuracy over the whole network in the CPU emulation (scripts/emulate_split.py f16x3u) -- and the third weight operand wh 2^-11 (4 v_pk_mul_f16 per weight
+// fragment in every split kernel) and one multiply per split element disappear.  SB_LO_SCALE / SB_LO_UNSCALE are the factors on the stored low part / on its use.
+#ifdef PF_LO_UNSCALED
+#define SB_LO_SCALE 1.0f
+#define SB_LO_UNSCALE 1.0f
+#else
+#define SB_LO_SCALE 2048.f
+#define SB_LO_UNSCALE 0.00048828125f
+#endif
 typedef _Float16 sb_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4_f16(const float4 v, uint2& h, uint2& l) {
   const float a[4] = {v.x, v.y, v.z, v.w};
@@ -56,7 +67,7 @@ __device__ __forceinline__ void split4_f16(const float4 v, uint2& h, uint2& l) {
   for (int e = 0; e < 4; ++e) {
     const float c = __builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);
     hh[e] = (_Float16)c;
-    ll[e] = (_Float16)((c - (float)hh[e]) * 2048.f);
+    ll[e] = (_Float16)((c - (float)hh[e]) * SB_LO_SCALE);
   }
   const sb_h2 h0 = {hh[0], hh[1]}, h1 = {hh[2], hh[3]}, l0 = {ll[0], ll[1]}, l1 = {ll[2], ll[3]};
   h = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
@@ -64,6 +75,9 @@ __device__ __forceinline__ void split4_f16(const float4 v, uint2& h, uint2& l) {
 }
 // 8 fp16 values (one 16-byte piece) times 2^-11 (exact unless the result is subnormal): the third weight plane wh2 = wh * 2^-11
 __device__ __forceinline__ float4 scale8_f16_2m11(const float4 v) {
+#ifdef PF_LO_UNSCALED
+  return v;  // the low activation plane is unscaled: the product al * wh needs no 2^-11
+#endif
   const sb_h2 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
   auto mul = [&](float f) { return __builtin_bit_cast(float, (sb_h2)(__builtin_bit_cast(sb_h2, f) * k)); };
   return make_float4(mul(v.x), mul(v.y), mul(v.z), mul(v.w));
@@ -98,7 +112,7 @@ __device__ __forceinline__ float4 load_sb4(const unsigned short* base, size_t pl
     const uint2 h = *reinterpret_cast<const uint2*>(base + idx);
     const uint2 l = *reinterpret_cast<const uint2*>(base + plane_elems + idx);
     auto f = [](unsigned w, int hi) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(hi ? (w >> 16) : (w & 0xffffu))); };
-    const float s = 0.00048828125f;
+    const float s = SB_LO_UNSCALE;
     return make_float4(fmaf(f(l.x, 0), s, f(h.x, 0)), fmaf(f(l.x, 1), s, f(h.x, 1)), fmaf(f(l.y, 0), s, f(h.y, 0)), fmaf(f(l.y, 1), s, f(h.y, 1)));
   }
   const uint2 h = *reinterpret_cast<const uint2*>(base + idx);

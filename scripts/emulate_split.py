@@ -45,6 +45,17 @@ def split_f16(x64):
     return hi.double(), lo.double() / 2048.0
 
 
+def split_f16_unscaled(x64, flush):
+    """lo kept UNSCALED: lo = fp16_rn(x - hi) -- fp16 subnormals below 2^-14 (|x| < ~0.25), preserved or flushed to zero.  Would save the wh 2^-11 operand
+    (4 v_pk_mul_f16 per weight fragment in every split kernel) if the matrix cores keep fp16 subnormal inputs."""
+    x32 = x64.to(torch.float32)
+    hi = x32.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
+    lo = (x32 - hi).to(torch.float16).to(torch.float32)
+    if flush:
+        lo = torch.where(lo.abs() < 2.0 ** -14, torch.zeros_like(lo), lo)
+    return hi.double(), lo.double()
+
+
 def split_bf16_hm(x64):
     x32 = x64.to(torch.float32)
     h = (x32.view(torch.int32) & -65536).view(torch.float32)
@@ -61,10 +72,10 @@ def weight_scale(w):
 
 def contract(op, x, w, **kw):
     xd, wd = x.double(), w.double()
-    if SCHEME == "f16x3":
+    if SCHEME in ("f16x3", "f16x3u", "f16x3uf"):
         s = weight_scale(w)
         sh = [-1] + [1] * (w.dim() - 1)
-        xh, xl = split_f16(xd)
+        xh, xl = split_f16(xd) if SCHEME == "f16x3" else split_f16_unscaled(xd, SCHEME == "f16x3uf")
         wh, wl = split_f16(wd * s.view(sh))
         y = op(xh, wh, **kw) + op(xh, wl, **kw) + op(xl, wh, **kw)
         shape = [1, -1, 1, 1] if op is _conv2d else [-1]
@@ -127,7 +138,7 @@ def run(sd, arch, imgs, mode):
         F.conv2d, F.linear = _conv2d, _linear
         dtype = torch.float64 if mode == "fp64" else torch.float32
     else:
-        SCHEME = "f16x3" if mode.startswith("f16x3") else mode
+        SCHEME = mode if mode in ("f16x3u", "f16x3uf") else ("f16x3" if mode.startswith("f16x3") else mode)
         F.conv2d, F.linear = conv2d_q, linear_q
         if mode == "f16x3+attn":
             pf_oracle.mit_attention = attention_q
@@ -148,7 +159,7 @@ def main():
     imgs = [synthetic_image(640, 640, seed=1000 + i) for i in range(int(os.environ.get("N_IMG", "3")))]
     keys = ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal")
     truth = run(sd, arch, imgs, "fp64")
-    for mode in ("fp32", "f16x3", "f16x3+attn", "bf16x3"):
+    for mode in os.environ.get("MODES", "fp32,f16x3,f16x3+attn,bf16x3").split(","):
         res = run(sd, arch, imgs, mode)
         dpar, dcos, dlat = 0.0, 0.0, 0.0
         for r, t in zip(res, truth):
