@@ -119,7 +119,7 @@ def attention_q(w, x, H, W, heads, sr):
     v = kv[:, :, 1].transpose(1, 2)
 
     def mm(a, b_scaled64):  # a: activations split hi + lo/2048; b: (64 b) split hi + lo_true; the lo*lo term is dropped
-        ah, al = split_f16(a.double())
+        ah, al = split_f16(a.double()) if SCHEME == "f16x3" else split_f16_unscaled(a.double(), SCHEME == "f16x3uf")
         bh, bl = split_f16(b_scaled64.double() * 64.0)
         return ((ah @ bh + ah @ bl + al @ bh) / 64.0).to(torch.float32)
 
@@ -138,9 +138,9 @@ def run(sd, arch, imgs, mode):
         F.conv2d, F.linear = _conv2d, _linear
         dtype = torch.float64 if mode == "fp64" else torch.float32
     else:
-        SCHEME = mode if mode in ("f16x3u", "f16x3uf") else ("f16x3" if mode.startswith("f16x3") else mode)
+        SCHEME = "f16x3uf" if mode.startswith("f16x3uf") else ("f16x3u" if mode.startswith("f16x3u") else ("f16x3" if mode.startswith("f16x3") else mode))
         F.conv2d, F.linear = conv2d_q, linear_q
-        if mode == "f16x3+attn":
+        if mode.endswith("+attn"):
             pf_oracle.mit_attention = attention_q
         dtype = torch.float32
     try:

@@ -456,3 +456,30 @@ def test_subpixel_form_of_upsample_conv_algebra():
         w = rng.standard_normal((cout, cin, 3, 3))
         ref = F.conv2d(F.interpolate(torch.from_numpy(x)[None], scale_factor=2, mode="bilinear", align_corners=False), torch.from_numpy(w), padding=1)[0].numpy()
         assert np.abs(sp.subpixel_conv(x, w) - ref).max() < 1e-9
+
+
+def test_unscaled_low_plane_representation():
+    """Candidate form of the split-f16 scheme (build switch PF_LO_UNSCALED, profiles/r02_mfma_f16_subnormals.md): lo = fp16_rn(x - hi) WITHOUT the 2^11 scale, relying
+    on the matrix cores keeping fp16 subnormals (measured on gfx950).  Representation error: <= 2^-22 |x| while lo is a normal fp16 (|x| >= 2^-2 is sufficient),
+    an ABSOLUTE 2^-25 below that (subnormal spacing 2^-24) -- i.e. what differs from the scaled form is the error of SMALL elements (2^-25 instead of 2^-36), which is
+    harmless next to O(1) terms of the same dot product and a relative loss only for an all-tiny tensor."""
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-12, 8, 200000))).astype(np.float32)
+    x = x[np.abs(x) <= 65504]
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)  # numpy keeps fp16 subnormals, like v_cvt_f16_f32 in the default float mode and like the MFMA inputs
+    err = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - x.astype(np.float64))
+    big = np.abs(x) >= 0.25
+    assert np.max(err[big] / np.abs(x[big])) <= 2.0 ** -22
+    assert np.max(err[~big]) <= 2.0 ** -25
+    # a dot product of O(1) data: same error level as the scaled form
+    a = rng.standard_normal((32, 2304)).astype(np.float32)
+    w = (rng.standard_normal((24, 2304)) / 48).astype(np.float32)
+    ah = a.astype(np.float16); al = (a - ah.astype(np.float32)).astype(np.float16)
+    mx = np.abs(w).max(axis=1, keepdims=True); S = np.ldexp(np.float32(1), 14 - np.frexp(mx)[1]).astype(np.float32)
+    ws = w * S; wh = ws.astype(np.float16); wl = (ws - wh.astype(np.float32)).astype(np.float16)
+    f = lambda t: t.astype(np.float64)
+    got = (f(ah) @ f(wh).T + f(ah) @ f(wl).T + f(al) @ f(wh).T) / f(S).T
+    ref = f(a) @ f(w).T
+    scale = np.abs(f(a)) @ np.abs(f(w)).T
+    assert np.max(np.abs(got - ref) / scale) <= 3 * 2.0 ** -22
