@@ -483,3 +483,29 @@ def test_unscaled_low_plane_representation():
     ref = f(a) @ f(w).T
     scale = np.abs(f(a)) @ np.abs(f(w)).T
     assert np.max(np.abs(got - ref) / scale) <= 3 * 2.0 ** -22
+
+
+def test_carried_k_step_position_equals_divided():
+    """Candidate change of the linear split-GEMM tiles (igemm_sb_impl.h, tuning form "sbI_*"): the (ky, kx, channel) position of a K step is CARRIED from one
+    load_tiles call to the next instead of being divided out of the step index (two integer divisions by run-time values = ~40 SALU instructions per step).
+    Emulation of both index computations over the shapes of the forward, incl. split-K start offsets and the steps past the end that the branch-free prefetch issues."""
+    BK = 32
+    for KH, KW, Cin in [(1, 1, 64), (1, 1, 320), (3, 3, 64), (3, 3, 320), (2, 2, 320), (8, 8, 64), (4, 4, 128), (7, 7, 32), (1, 1, 3072)]:
+        KWCp = KW * Cin  # Cin % 32 == 0: no row padding (the stem form keeps the divisions)
+        nJ = KWCp // BK
+        nK_all = KH * nJ
+        for S in (1, 3, 8):
+            for sidx in range(S):
+                it0 = sidx * nK_all // S
+                ky, j0 = it0 // nJ, (it0 - (it0 // nJ) * nJ) * BK
+                kx = j0 // Cin
+                ci0 = j0 - kx * Cin
+                for it in range(it0, min(nK_all, (sidx + 1) * nK_all // S) + 3):  # + PFD steps past the end
+                    rky = it // nJ
+                    rj0 = (it - rky * nJ) * BK
+                    rkx = rj0 // Cin
+                    rci0 = rj0 - rkx * Cin
+                    assert (ky, j0, kx, ci0) == (rky, rj0, rkx, rci0), (KH, KW, Cin, S, sidx, it)
+                    j0 += BK; ci0 += BK
+                    if ci0 >= Cin: ci0 = 0; kx += 1
+                    if j0 >= KWCp: j0 = 0; ci0 = 0; kx = 0; ky += 1
