@@ -14,7 +14,9 @@ Reported next to `value` (never as `value`):
   * `parity`: one image of the LAST timed step checked against the CPU oracle after the timed loop.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...          (no WORLD_SIZE in the environment: re-launches itself as N ranks, one per GPU, under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --workload mixed ...  (BASELINE configs[4]: mixed-resolution stream, bucketed resize-in / post-process-out, per-bucket images/sec)
     (--dry-run-cpu: the same control flow on CPU with a stub engine and the gloo backend -- tests/test_bench_dist_gloo.py)
 """
 from __future__ import annotations
@@ -56,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the device-resize figure, the latency numbers and the parity check")
     ap.add_argument("--events-in-timed", type=int, default=1, help="bracket the kernels with HIP events inside the timed region")
     ap.add_argument("--event-steps", type=int, default=1, help="how many of the timed steps carry the per-launch HIP events (0 = all); a profiled step is ~15 % slower (two event records per launch, one stream)")
+    ap.add_argument("--workload", default="fixed", choices=("fixed", "mixed"),
+                    help="fixed: BASELINE configs[2] (the headline: --batch images of --size x --size per GPU); mixed: configs[4], a stream of 384x512 / 640x640 / 1024x1365 "
+                         "originals (1:2:1) resident in HBM, sharded round-robin within each (H, W) bucket, device resize + forward + post-process per step, per-bucket images/sec")
     ap.add_argument("--dry-run-cpu", action="store_true", help="control-flow test: stub engine on CPU, gloo backend (no GPU, no numbers)")
     return ap.parse_args(argv)
 
@@ -101,12 +106,14 @@ def cpu_baseline(version, size, budget_s=12.0, max_images=12):
             n += 2
         dt = time.perf_counter() - t0
     return {
-        "value": round(n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+        "value": round(n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "host_logical_cpus": ncpu,
+        "cores_note": f"`cores` = torch intra-op threads actually used (the fastest of 16 / 32 / 64 on one image each); the box has {ncpu} logical CPUs",
+        "kind": "port",
         "sample": f"{n} synthetic {size}x{size} images through oracle/pf_oracle.py inference_batch (PIL resize + fp32 forward + post-process), batches of 2, {dt:.1f} s",
     }
 
 
-def parity_check(version, resized_u8, size, out, index):
+def parity_check(version, resized_u8, hw, out, index):
     """One image of the last timed step against the CPU oracle (same 320x320 uint8 input, same synthetic checkpoint)."""
     from oracle import pf_oracle
     from perspectivefields_amd.config import arch_of, get_cfg
@@ -116,7 +123,7 @@ def parity_check(version, resized_u8, size, out, index):
     sd = to_torch(synthetic_state_dict(version, 0))
     arch = arch_of(get_cfg(version))
     with torch.no_grad():
-        ref = pf_oracle.forward(sd, arch, resized_u8[index:index + 1], [(size, size)])[0]
+        ref = pf_oracle.forward(sd, arch, resized_u8[index:index + 1], [tuple(hw)])[0]
     up, lat = outs[index]
     g, go = up.double().cpu(), ref["pred_gravity_original"].double()
     cosv = float((1.0 - (g * go).sum(0) / torch.sqrt((g * g).sum(0) * (go * go).sum(0))).max())
@@ -148,10 +155,43 @@ class _StubEngine:
     def postprocess_batch(self, pg, pl, sizes):
         return [(torch.zeros((2, 2, 2)), torch.zeros((2, 2))) for _ in sizes]
 
+    def resize_batch_into(self, imgs, out):
+        return out
+
+
+MIXED_PATTERN = [(384, 512), (640, 640), (640, 640), (1024, 1365)]  # BASELINE configs[4]: short edge 384 / 640 / 1024, mix 1:2:1
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` started as a plain process (no WORLD_SIZE): run the N ranks ourselves, one per GPU, under
+    torch.distributed.run on 127.0.0.1 -- the JSON line then really describes N ranks.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    if not args.dry_run_cpu:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s); refusing to report a {args.gpus}-GPU number from fewer devices", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *(sys.argv[1:] if argv is None else list(argv))]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
 
 def main(argv=None):
     args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # one rank per GPU is the contract: a line that says n_gpus = WORLD_SIZE while the caller asked for --gpus N would be a false curve
+        print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world}; launch with --nproc-per-node {args.gpus} (or without torchrun: bench.py launches the ranks itself)", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dry = args.dry_run_cpu
@@ -164,23 +204,36 @@ def main(argv=None):
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     if not dry:
         torch.cuda.set_device(dev)
 
-    from perspectivefields_amd.dist import gather_params
+    from perspectivefields_amd.dist import gather_params, shard_round_robin_by_bucket
     from perspectivefields_amd.synth import synthetic_image
 
     precision = args.precision
     B, S = args.batch, args.size
-    # per-rank shard of the global batch: synthetic images, host resize (outside the timed region)
-    imgs = [synthetic_image(S, S, seed=1000 + rank * B + i) for i in range(min(B, 4))]
+    mixed = args.workload == "mixed"
+    counts = None
+    if mixed:
+        # configs[4]: a global stream of B x world images over three (H, W) buckets; round-robin WITHIN each bucket gives every rank the same mix of
+        # resize-in / post-process-out work (the network batch itself is resolution independent: everything becomes 320x320)
+        sizes_global = [MIXED_PATTERN[i % len(MIXED_PATTERN)] for i in range(B * world)]
+        shards = [shard_round_robin_by_bucket(sizes_global, r, world) for r in range(world)]
+        counts = [len(sh) for sh in shards]
+        sizes = [sizes_global[i] for i in shards[rank]]
+        imgs = [synthetic_image(h, w, seed=7 + k) for k, (h, w) in enumerate(sorted(set(MIXED_PATTERN)))]
+        by_size = dict(zip(sorted(set(MIXED_PATTERN)), imgs))
+    else:
+        # per-rank shard of the global batch: synthetic images (4 distinct ones tiled over the batch: the network is data independent), host resize outside the timed region
+        imgs = [synthetic_image(S, S, seed=1000 + rank * B + i) for i in range(min(B, 4))]
+        sizes = [(S, S)] * B
+    Bl = len(sizes)  # images of this rank per step
+    orig = None
     if dry:
         model, eng = None, _StubEngine(rank)
         t_resize = 0.0
-        resized = np.stack([np.full((8, 8, 3), (rank * B + i) % 251, dtype=np.uint8) for i in range(B)])
+        resized = np.stack([np.full((8, 8, 3), (rank * B + i) % 251, dtype=np.uint8) for i in range(Bl)])
     else:
         from perspectivefields_amd import PerspectiveFields
 
@@ -188,12 +241,17 @@ def main(argv=None):
         t_resize = time.perf_counter()
         resized4 = [model.aug.apply_image(im) for im in imgs]
         t_resize = (time.perf_counter() - t_resize) / len(imgs)
-        resized = np.stack([resized4[i % len(resized4)] for i in range(B)])
+        if mixed:
+            rs = dict(zip(sorted(set(MIXED_PATTERN)), resized4))
+            resized = np.stack([rs[hw] for hw in sizes])
+            dev_img = {hw: torch.from_numpy(im).to(dev) for hw, im in by_size.items()}
+            orig = [dev_img[hw] for hw in sizes]  # the ORIGINAL uint8 images, resident in HBM
+        else:
+            resized = np.stack([resized4[i % len(resized4)] for i in range(B)])
         eng = model._get_engine()
         if args.autotune:
-            eng.autotune(B)
+            eng.autotune(Bl)
     batch = torch.from_numpy(resized).to(dev)
-    sizes = [(S, S)] * B
 
     def sync():
         if not dry:
@@ -207,9 +265,11 @@ def main(argv=None):
         sync()
 
     def step():
+        if orig is not None:
+            eng.resize_batch_into(orig, batch)  # bucketed bit-exact PIL resize on the device (inside the timed region for the mixed stream)
         pg, pl, params = eng.forward(batch)
         outs = eng.postprocess_batch(pg, pl, sizes)
-        allp = gather_params(params) if (params is not None and world > 1) else params
+        allp = gather_params(params, counts) if (params is not None and world > 1) else params
         return pg, pl, outs, allp
 
     for _ in range(args.warmup):
@@ -236,9 +296,53 @@ def main(argv=None):
 
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    total_images = B * world * args.steps
+    total_images = (sum(counts) if mixed else B * world) * args.steps
     value = total_images / dt
     gathered_rows = int(out[3].shape[0]) if out[3] is not None else 0
+
+    per_bucket = None
+    if mixed:
+        # per-bucket throughput: the forward is shared by all buckets (cost per image = forward / images of the rank); resize-in and post-process-out are timed
+        # per (H, W) bucket on every rank, MAX over ranks
+        def timed(fn, n=5):
+            fn(); sync()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            sync()
+            return (time.perf_counter() - t1) / n
+
+        keys = sorted(set(MIXED_PATTERN))
+        tv = [timed(lambda: eng.forward(batch))]
+        nloc = []
+        for hw in keys:
+            idx = [i for i, t in enumerate(sizes) if t == hw]
+            nloc.append(len(idx))
+            if not idx:
+                tv.append(0.0)
+                continue
+            ii = torch.tensor(idx, device=dev)
+            pgb, plb, szb = out[0].index_select(0, ii), out[1].index_select(0, ii), [hw] * len(idx)
+            if orig is not None:
+                ob, u8b = [orig[i] for i in idx], torch.empty((len(idx),) + tuple(batch.shape[1:]), dtype=torch.uint8, device=dev)
+                tv.append(timed(lambda: (eng.resize_batch_into(ob, u8b), eng.postprocess_batch(pgb, plb, szb))))
+            else:
+                tv.append(timed(lambda: eng.postprocess_batch(pgb, plb, szb)))
+        tt = torch.tensor(tv, dtype=torch.float64, device=dev)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        fwd_img = float(tt[0]) / max(Bl, 1)
+        per_bucket = {}
+        for j, hw in enumerate(keys):
+            n_glob = sum(1 for t in sizes_global if t == hw)
+            io_img = float(tt[1 + j]) / max(nloc[j], 1)
+            per_bucket[f"{hw[0]}x{hw[1]}"] = {
+                "images_per_step_all_ranks": n_glob, "images_per_step_this_rank": nloc[j],
+                "resize_plus_postprocess_us_per_image": round(io_img * 1e6, 1), "forward_us_per_image": round(fwd_img * 1e6, 1),
+                "images_per_sec_all_ranks": round(world / (fwd_img + io_img), 1),
+            }
 
     if rank != 0:
         if world > 1:
@@ -264,13 +368,19 @@ def main(argv=None):
                   "fp32_bf16x6": "f32 (exact 3-way bf16 split on the MFMA, fp32 accumulate)"}.get(precision, precision),
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[2]: batch {B}/GPU {S}x{S} {args.version}, fields + ParamNet, 320x320 network inputs resident in HBM, post-process to {S}x{S}",
-            "global_batch": B * world, "image_size": [S, S], "parallelism": f"dp{world} (images sharded, all-gather of ParamNet scalars)",
+            "workload": (f"BASELINE configs[4]: mixed-resolution stream, {B} images/GPU per step (384x512 : 640x640 : 1024x1365 = 1:2:1, one synthetic image per bucket), {args.version}; ORIGINAL "
+                         "uint8 images resident in HBM -> bucketed bit-exact device resize -> forward at 320x320 -> post-process to each original size; sharded round-robin within each bucket"
+                         ) if mixed else (
+                         f"BASELINE configs[2]: batch {B}/GPU {S}x{S} {args.version}, fields + ParamNet, 320x320 network inputs resident in HBM (4 distinct synthetic images tiled over the batch; "
+                         f"the network is data independent), post-process to {S}x{S}"),
+            "global_batch": sum(counts) if mixed else B * world, "image_size": "mixed" if mixed else [S, S], "parallelism": f"dp{world} (images sharded, all-gather of ParamNet scalars)",
             "weights": "seeded synthetic checkpoint (no network for the trained .pth)", "precision": precision,
             "tiles": "autotuned on this device before the warm-up" if args.autotune else "shipped tile table + static heuristic (no tuning)",
             "gathered_param_rows": gathered_rows,
         },
     }
+    if per_bucket is not None:
+        line["per_bucket"] = per_bucket
     if dry:
         line["data"] = "dry run (stub engine on CPU, gloo): control flow only, numbers are meaningless"
     if prof is not None:
@@ -317,8 +427,11 @@ def main(argv=None):
                 ach = work_ / (ms_ * 1e-3) / 1e12
                 line["roofline"] = {
                     "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": traffic, "traffic_unit": "HBM bytes per launch of this shape (rocprofv3 PMC: (2*FETCH_SIZE + WRITE_SIZE)*1024)", "traffic_source": traffic_src,
-                    "kernel": f"pf::igemm_sbh_kernel (3x3 halo-tile implicit GEMM, split-f16) on the dominant launch shape: GEMM M={M_} (both decoder heads, batch {B}) N={N_} K={K_}",
+                    "traffic": traffic if KH_ == 3 else None,
+                    "traffic_unit": "HBM bytes per launch of the 3x3 256->256 @80x80 two-head shape (rocprofv3 PMC: (2*FETCH_SIZE + WRITE_SIZE)*1024); NOT measured in this run: read from the committed PMC pass",
+                    "traffic_source": traffic_src,
+                    "kernel": (f"pf::igemm_sbh_kernel (3x3 halo-tile implicit GEMM, split scheme of --precision {precision}) on the dominant launch shape: GEMM M={M_} N={N_} K={K_} (KH={KH_})" if KH_ == 3 else
+                               f"pf::igemm_sb_kernel / fused block MLP (linear tile, split scheme of --precision {precision}) on the dominant launch shape: GEMM M={M_} N={N_} K={K_} (KH={KH_})"),
                     "peak_basis": f"achieved = algorithmic FLOPs of the launch (2*M*N*K = {2.0 * M_ * N_ * K_ / 1e9:.1f} GFLOP) / its average HIP-event duration, priced against the DENSE 16-bit MFMA peak; "
                                   f"the kernel executes {nt} MFMA FLOPs per algorithmic FLOP (executed_mfma_tflops): its ceiling is 2500/{nt} = {2500.0 / nt:.1f} TFLOP/s",
                     "executed_mfma_tflops": round(ach * nt, 1), "frac_of_scheme_ceiling": round(ach * nt / BF16_MFMA_PEAK_TFLOPS, 4),
@@ -360,18 +473,21 @@ def main(argv=None):
     if not dry and not args.no_extras:
         # ---- (1) parity of the timed configuration: one image of the LAST timed step against the CPU oracle
         try:
-            line["parity"] = parity_check(args.version, resized, S, out, index=min(B - 1, 3))
+            pi = min(Bl - 1, 3)
+            line["parity"] = parity_check(args.version, resized, sizes[pi], out, index=pi)
             line["parity_checked"] = bool(line["parity"]["ok"])
         except Exception as e:  # the checker failing must not hide the measurement
             line["parity"] = {"error": repr(e)}
             line["parity_checked"] = False
         # ---- (2) the same step starting from the original 640x640 uint8 images in HBM (device PIL resize inside the timed region)
         try:
-            orig = [torch.from_numpy(imgs[i % len(imgs)]).to(dev) for i in range(B)]
+            if mixed:
+                raise RuntimeError("not applicable: the mixed stream already starts from the original images")
+            orig640 = [torch.from_numpy(imgs[i % len(imgs)]).to(dev) for i in range(B)]
             u8 = torch.empty((B, 320, 320, 3), dtype=torch.uint8, device=dev)
 
             def step_resize():
-                eng.resize_batch_into(orig, u8)
+                eng.resize_batch_into(orig640, u8)
                 pg, pl, params = eng.forward(u8)
                 return eng.postprocess_batch(pg, pl, sizes)
 

@@ -9,7 +9,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+# The product library lives in lib/.  Build variants (tuning kernels, candidate schemes) get their own directory next to it so that several variants can be
+# prebuilt in the tree and travel to the GPU box together: lib_tune/ (PF_TUNING_BUILD=1), lib_lo/ (PF_LO_UNSCALED=1), lib_tune_lo/ (both).
+_VARIANT = ("_tune" if os.environ.get("PF_TUNING_BUILD", "0") == "1" else "") + ("_lo" if os.environ.get("PF_LO_UNSCALED", "0") == "1" else "")
+LIBDIR = os.path.join(HERE, "lib" + _VARIANT)
 LIB = os.path.join(LIBDIR, "libpf_hip.so")
 SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sb3.hip", "igemm_sb1.hip", "igemm_sbf.hip", "igemm_sbh.hip", "attn.hip", "elem.hip", "dw7.hip", "cnx_mlp.hip", "mit_mlp.hip", "engine.hip"]
 # dw7.hip: the scalar one-channel-per-lane kernel must not be SLP-vectorised (see the file header)

@@ -89,7 +89,12 @@ __global__ __launch_bounds__(256, C <= 96 ? 3 : 1) void cnx_mlp_kernel(const flo
     float4 v[2 * S1];
 #pragma unroll
     for (int j = 0; j < 2 * S1; ++j) v[j] = src[j];
-    const float piv = __shfl(v[0].x, l31);  // channel 0 of the row (held by the hi = 0 lane)
+    // pivot = the row's mean (first pass over the registers; an approximate mean is enough, the statistics below are taken of the shifted row): a single
+    // channel as pivot would turn an outlier channel into a common offset of the whole shifted row
+    float piv = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * S1; ++j) piv += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    piv = (piv + __shfl_xor(piv, 32)) * (1.0f / C);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 2 * S1; ++j) {

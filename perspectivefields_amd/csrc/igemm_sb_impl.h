@@ -377,9 +377,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   // prologue: tiles 0 .. PFD-1 in flight, tile 0 -> LDS (tile k lives in register set k % PFD)
 #pragma unroll
   for (int d = 0; d < PFD; ++d) load_tiles(it0 + d, raw[d]);
-  if constexpr (LNF) {  // pivot = channel 0 of the row, held by the thread with c4 == 0 of the row's 8 staging lanes
+  if constexpr (LNF) {
+    // pivot = MEAN of the row's first 32 channels (the chunk its 8 staging lanes hold now; xor butterfly: the same bits in all 8 lanes).  A single channel as pivot
+    // (r02: channel 0) turns an outlier channel -- trained transformers have channels tens of sigma off -- into a large common offset of the shifted row; the chunk
+    // mean moves by 1/32 of an outlier at most.
 #pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) ln_piv[i] = __shfl(raw[0].a[i].x, lane & ~7);
+    for (int i = 0; i < A_ROWS; ++i) {
+      float sp = (raw[0].a[i].x + raw[0].a[i].y) + (raw[0].a[i].z + raw[0].a[i].w);
+      sp += __shfl_xor(sp, 1); sp += __shfl_xor(sp, 2); sp += __shfl_xor(sp, 4);
+      ln_piv[i] = sp * (1.0f / 32.0f);
+    }
   }
   store_tiles(raw[0]);
   __syncthreads();

@@ -12,8 +12,9 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 
+from .build import LIB as LIB_PATH  # lib/libpf_hip.so (lib_tune/, lib_lo/ for the build variants, see build.py)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpf_hip.so")
 TILE_TABLE = os.path.join(_HERE, "tuned", "gfx950_tiles.txt")  # per-shape tile choices measured on MI355X (scripts/gen_tile_table.py)
 NET = 320
 PARAMS_STRIDE = 8
@@ -240,6 +241,7 @@ class Engine:
             raise PfError(f"unknown precision '{mode}' (expected one of {sorted(self.PRECISIONS)})")
         _check(self.lib.pf_set_precision(self._h, self.PRECISIONS[mode]), self._h, "pf_set_precision")
         self.precision = mode
+        self._graph_bufs = {}  # captured graphs and their workspace were sized for the previous mode (the workspace differs between the schemes)
 
     # ---------------------------------------------------------------- forward
     def workspace_bytes(self, batch: int) -> int:

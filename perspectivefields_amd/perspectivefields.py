@@ -68,7 +68,7 @@ def _resolve_weights(version: str, weights) -> Dict[str, np.ndarray]:
                 f"Download {model_zoo[version]['weights']} elsewhere and point PF_WEIGHTS_DIR at it, pass weights=<path|state_dict>, "
                 "or weights='synthetic' for the seeded random checkpoint used by tests and benchmarks."
             )
-    ckpt = torch.load(path, map_location="cpu")
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)  # a checkpoint is tensors in dicts: never unpickle arbitrary objects from a downloaded file
     return OrderedDict(ckpt["model"] if "model" in ckpt else ckpt)
 
 

@@ -87,9 +87,47 @@ def contract(op, x, w, **kw):
     return y.to(torch.float32)
 
 
+WINOGRAD = False
+_BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+_G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
+_AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+
+
+def conv3x3_winograd(x, w, b):
+    """Winograd F(2x2, 3x3) as a kernel would run it: input transform B^T d B in fp32 (adds only), weight transform G g G^T in fp64 at
+    finalize, the 16 position GEMMs on the split-f16 scheme (weights scaled per (position, output channel) by a power of two; fp64 accumulation stands for the fp32 MFMA
+    accumulator as elsewhere in this file), output transform A^T m A in fp32."""
+    B, C, H, W = x.shape
+    O = w.shape[0]
+    He, We = H + (H & 1), W + (W & 1)
+    xp = F.pad(x, (1, 1 + We - W, 1, 1 + He - H))                                      # zero padding of the conv + round up to whole 2x2 output tiles
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                              # (B, C, ty, tx, 4, 4) fp32
+    bt = _BT.to(torch.float32)
+    v = torch.einsum("ij,bcyxjk->bcyxik", bt, d)                                        # fp32 adds (entries of B are 0, +-1)
+    v = torch.einsum("bcyxik,lk->bcyxil", v, bt)
+    u = torch.einsum("ij,ocjk,lk->ocil", _G, w.double(), _G)                            # (O, C, 4, 4) fp64
+    ty, tx = v.shape[2], v.shape[3]
+    m = torch.empty((B, O, ty, tx, 4, 4), dtype=torch.float32)
+    for i in range(4):
+        for j in range(4):
+            uw = u[:, :, i, j]                                                          # (O, C)
+            s = weight_scale(uw)
+            wh, wl = split_f16(uw * s.view(-1, 1))
+            ah, al = split_f16(v[..., i, j].double()) if SCHEME == "f16x3" else split_f16_unscaled(v[..., i, j].double(), False)
+            y = torch.einsum("bcyx,oc->boyx", ah, wh) + torch.einsum("bcyx,oc->boyx", ah, wl) + torch.einsum("bcyx,oc->boyx", al, wh)
+            m[..., i, j] = (y / s.view(1, -1, 1, 1)).to(torch.float32)
+    at = _AT.to(torch.float32)
+    o = torch.einsum("ij,boyxjk->boyxik", at, m)
+    o = torch.einsum("boyxik,lk->boyxil", o, at)                                        # (B, O, ty, tx, 2, 2) fp32
+    o = o.permute(0, 1, 2, 4, 3, 5).reshape(B, O, 2 * ty, 2 * tx)[:, :, :H, :W]
+    return o if b is None else o + b.view(1, -1, 1, 1)
+
+
 def conv2d_q(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     if groups != 1 or x.shape[1] % 32 != 0 or x.dtype != torch.float32:
         return _conv2d(x, w, b, stride, padding, dilation, groups)
+    if WINOGRAD and tuple(w.shape) == (256, 256, 3, 3) and stride in (1, (1, 1)) and padding in (1, (1, 1)):
+        return conv3x3_winograd(x, w, b)
     y = contract(_conv2d, x, w, stride=stride, padding=padding)
     return y if b is None else y + b.view(1, -1, 1, 1)
 
@@ -133,7 +171,10 @@ _attention = pf_oracle.mit_attention
 
 
 def run(sd, arch, imgs, mode):
-    global SCHEME
+    global SCHEME, WINOGRAD
+    WINOGRAD = mode.endswith("+wino")
+    if WINOGRAD:
+        mode = mode[:-5]
     if mode in ("fp32", "fp64"):
         F.conv2d, F.linear = _conv2d, _linear
         dtype = torch.float64 if mode == "fp64" else torch.float32

@@ -46,3 +46,40 @@ def test_bench_single_process_dry_run():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 4 and d["config"]["gathered_param_rows"] == 4
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun must run two ranks (the driver's SCALE command is `bench.py --gpus N`): the line says n_gpus == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "2", "--warmup", "1", "--batch", "4"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["gathered_param_rows"] == 8
+
+
+def test_bench_refuses_mismatched_world():
+    """--gpus 8 inside a 1-rank environment (WORLD_SIZE=1 set by a launcher) must not print an n_gpus = 1 line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-cpu", "--steps", "1", "--warmup", "0", "--batch", "2"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "does not match WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_bench_mixed_workload_shards_by_bucket(world):
+    """configs[4]: the mixed-resolution stream is sharded round-robin within each (H, W) bucket; ragged shards gather to the full stream; per-bucket figures are reported."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-run-cpu", "--workload", "mixed", "--steps", "2", "--warmup", "1", "--batch", "6"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    n = 6 * world
+    assert d["n_gpus"] == world and d["config"]["global_batch"] == n and d["config"]["gathered_param_rows"] == n
+    pb = d["per_bucket"]
+    assert set(pb) == {"384x512", "640x640", "1024x1365"}
+    assert sum(v["images_per_step_all_ranks"] for v in pb.values()) == n
+    assert pb["640x640"]["images_per_step_all_ranks"] == sum(1 for i in range(n) if i % 4 in (1, 2))
+    assert abs(d["value"] - n * 2 / (d["ms_per_step"] * 2e-3)) <= 0.02 * d["value"]

@@ -329,6 +329,67 @@ def test_linear_with_fused_layernorm(ops, K, N, rows):
     assert ran >= 20
 
 
+def _with_outlier_channels(x, seed, sigma=100.0):
+    """Rows as trained transformers produce them (VERDICT r02 / ADVICE): a third of the rows get a `sigma`-sized outlier in channel 0, a third in a random
+    channel, a third both with opposite signs -- a pivot taken from one channel would turn that into a common offset of the whole shifted row."""
+    x = x.clone()
+    flat = x.reshape(-1, x.shape[-1])
+    g = torch.Generator().manual_seed(seed)
+    ch = torch.randint(0, flat.shape[1], (flat.shape[0],), generator=g)
+    sgn = torch.where(torch.rand(flat.shape[0], generator=g) < 0.5, -1.0, 1.0) * sigma * float(flat.std())
+    r = torch.arange(flat.shape[0])
+    a, b = r % 3 == 0, r % 3 == 1
+    flat[a | ~(a | b), 0] += sgn[a | ~(a | b)]
+    sel = b | ~(a | b)
+    flat[r[sel], ch[sel]] -= sgn[sel]
+    return x
+
+
+@pytest.mark.parametrize("K,N,rows", [(64, 256, 300), (320, 1280, 257), (512, 1024, 129), (96, 384, 200), (768, 3072, 33)])
+def test_linear_with_fused_layernorm_outlier_channels(ops, K, N, rows):
+    """The fused LayerNorm with 100-sigma outlier channels (in channel 0, in a random channel, in both): the per-row pivot is the mean of the first staged
+    32-channel chunk, not one channel, so neither the one-pass variance nor `acc - mean * colsum` cancels.  Every linear split tile; oracle torch fp64."""
+    x = _with_outlier_channels(_rand((rows, K), 131, 1.5) + 10.0 * _rand((rows, 1), 132), 133)
+    w = _rand((N, K), 134, 1.0 / math.sqrt(K))
+    b = _rand((N,), 135, 0.1)
+    g = 1 + _rand((K,), 136, 0.3)
+    be = _rand((K,), 137, 0.2)
+    ref = F.linear(F.layer_norm(x.double(), (K,), g.double(), be.double(), 1e-6), w.double(), b.double())
+    tiles = ops.conv_tiles()
+    ran = 0
+    for t, name in enumerate(tiles):
+        if not name.startswith("sb") or name.startswith("sbh") or name.startswith(("sbA", "sbI_", "sbPI_")):
+            continue
+        _close(ops.linear_ln(x.cuda(), w, b, g, be, 1e-6, tile=t), ref, 5e-5, f"linear_ln with outlier channels, tile {name}")
+        ran += 1
+    assert ran >= 8
+
+
+@pytest.mark.parametrize("C,rows", [(96, 1000), (192, 300)])
+def test_convnext_block_mlp_fused_outlier_channels(ops, C, rows):
+    d = _with_outlier_channels(_rand((rows, C), 141, 1.5) + 10.0 * _rand((rows, 1), 142), 143)
+    y = _rand((rows, C), 43)
+    w1, b1 = _rand((4 * C, C), 44, 1.0 / math.sqrt(C)), _rand((4 * C,), 45, 0.1)
+    g, be = 1 + _rand((C,), 46, 0.3), _rand((C,), 47, 0.2)
+    w2, b2, ls = _rand((C, 4 * C), 48, 1.0 / math.sqrt(4 * C)), _rand((C,), 49, 0.1), _rand((C,), 50, 0.5)
+    h = pf_oracle.gelu(F.linear(F.layer_norm(d.double(), (C,), g.double(), be.double(), 1e-6), w1.double(), b1.double()))
+    ref = y.double() + ls.double() * F.linear(h, w2.double(), b2.double())
+    _close(ops.cnx_mlp(d.cuda(), y.cuda(), w1, b1, g, be, 1e-6, w2, b2, ls), ref, 5e-5, f"fused ConvNeXt MLP with outlier channels C={C}")
+
+
+@pytest.mark.parametrize("C,B,Hs,Ws", [(64, 1, 24, 40), (128, 1, 16, 16)])
+def test_mit_block_mlp_fused_outlier_channels(ops, C, B, Hs, Ws):
+    x = _with_outlier_channels(_rand((B, Hs, Ws, C), 151, 1.5) + 10.0 * _rand((B, Hs, Ws, 1), 152), 153)
+    w1, b1 = _rand((4 * C, C), 53, 1.0 / math.sqrt(C)), _rand((4 * C,), 54, 0.1)
+    g, be = 1 + _rand((C,), 55, 0.3), _rand((C,), 56, 0.2)
+    wd, bd = _rand((4 * C, 1, 3, 3), 57, 0.4), _rand((4 * C,), 58, 0.1)
+    w2, b2 = _rand((C, 4 * C), 59, 1.0 / math.sqrt(4 * C)), _rand((C,), 60, 0.1)
+    h = F.linear(F.layer_norm(x.double(), (C,), g.double(), be.double(), 1e-6), w1.double(), b1.double())
+    h = F.conv2d(h.permute(0, 3, 1, 2), wd.double(), bd.double(), padding=1, groups=4 * C).permute(0, 2, 3, 1)
+    ref = x.double() + F.linear(pf_oracle.gelu(h), w2.double(), b2.double())
+    _close(ops.mit_mlp(x.cuda(), w1, b1, g, be, 1e-6, wd, bd, w2, b2), ref, 5e-5, f"fused MiT Mlp with outlier channels C={C}")
+
+
 @pytest.mark.parametrize("C,rows", [(96, 128), (96, 1000), (96, 6400), (192, 300), (192, 1600)])
 def test_convnext_block_mlp_fused(ops, C, rows):
     """cnx_mlp.hip: y + ls * pwconv2(GELU(pwconv1(LayerNorm(d)))) in one kernel (hidden map in registers) vs torch fp64 (convnext.py:49-58).
