@@ -9,12 +9,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-# The product library lives in lib/.  Build variants (tuning kernels, candidate schemes) get their own directory next to it so that several variants can be
-# prebuilt in the tree and travel to the GPU box together: lib_tune/ (PF_TUNING_BUILD=1), lib_lo/ (PF_LO_UNSCALED=1), lib_tune_lo/ (both).
-_VARIANT = ("_tune" if os.environ.get("PF_TUNING_BUILD", "0") == "1" else "") + ("_lo" if os.environ.get("PF_LO_UNSCALED", "0") == "1" else "")
+# The product library lives in lib/.  The tuning build (PF_TUNING_BUILD=1: ablation kernels, rejected variants) gets its own directory, lib_tune/, so that both can
+# be prebuilt in the tree and travel to the GPU box together.
+_VARIANT = "_tune" if os.environ.get("PF_TUNING_BUILD", "0") == "1" else ""
 LIBDIR = os.path.join(HERE, "lib" + _VARIANT)
 LIB = os.path.join(LIBDIR, "libpf_hip.so")
-SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sb3.hip", "igemm_sb1.hip", "igemm_sbf.hip", "igemm_sbh.hip", "attn.hip", "elem.hip", "dw7.hip", "cnx_mlp.hip", "mit_mlp.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sb3.hip", "igemm_sb1.hip", "igemm_sbf.hip", "igemm_sbh.hip", "rr_gemm.hip", "attn.hip", "elem.hip", "dw7.hip", "cnx_mlp.hip", "mit_mlp.hip", "engine.hip"]
 # dw7.hip: the scalar one-channel-per-lane kernel must not be SLP-vectorised (see the file header)
 EXTRA_FLAGS = {"dw7.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
@@ -22,9 +22,6 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # the scripts under scripts/ can select; the product build carries the default path and its parity alternatives only
 if os.environ.get("PF_TUNING_BUILD", "0") == "1":
     FLAGS.append("-DPF_TUNING_BUILD")
-# PF_LO_UNSCALED=1: the split-f16 scheme with the low activation plane unscaled (sb_split.h; candidate, needs a full GPU test run before it becomes the default)
-if os.environ.get("PF_LO_UNSCALED", "0") == "1":
-    FLAGS.append("-DPF_LO_UNSCALED")
 
 
 def _hipcc() -> str:

@@ -176,26 +176,13 @@ __device__ __forceinline__ unsigned at_pack(float a, float b) {
   const at_h2 v = {(_Float16)a, (_Float16)b};
   return __builtin_bit_cast(unsigned, v);
 }
-// 8 floats -> hi / lo fragments; SCALED_LO: lo = fp16((x - hi) 2^11) (activation side), else lo = fp16(x - hi) (pre-scaled "weight" side)
-template <bool SCALED_LO>
+// 8 floats -> hi / lo fragments of the split-f16 scheme (sb_split.h: lo = fp16(x - hi), unscaled, on both the activation and the "weight" side)
 __device__ __forceinline__ void at_split8(const float (&a)[8], at_u32x4& h, at_u32x4& l) {
-  float hi[8], lo[8];
+  unsigned hh[4], ll[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float c = __builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);
-    hi[e] = (float)(_Float16)c;
-    lo[e] = SCALED_LO ? (c - hi[e]) * SB_LO_SCALE : (c - hi[e]);
-  }
-  h = at_u32x4{at_pack(hi[0], hi[1]), at_pack(hi[2], hi[3]), at_pack(hi[4], hi[5]), at_pack(hi[6], hi[7])};
-  l = at_u32x4{at_pack(lo[0], lo[1]), at_pack(lo[2], lo[3]), at_pack(lo[4], lo[5]), at_pack(lo[6], lo[7])};
-}
-__device__ __forceinline__ at_u32x4 at_scale_2m11(const at_u32x4 v) {
-#ifdef PF_LO_UNSCALED
-  return v;
-#endif
-  const at_h2 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
-  auto mul = [&](unsigned u) { return __builtin_bit_cast(unsigned, (at_h2)(__builtin_bit_cast(at_h2, u) * k)); };
-  return at_u32x4{mul(v.x), mul(v.y), mul(v.z), mul(v.w)};
+  for (int e = 0; e < 4; ++e) split2_f16(a[2 * e], a[2 * e + 1], hh[e], ll[e]);
+  h = at_u32x4{hh[0], hh[1], hh[2], hh[3]};
+  l = at_u32x4{ll[0], ll[1], ll[2], ll[3]};
 }
 __device__ __forceinline__ f32x16 at_mfma(const at_u32x4 a, const at_u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(at_f16x8, a), __builtin_bit_cast(at_f16x8, b), c, 0, 0, 0);
@@ -262,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
   for (int t = 0; t < 4; ++t) {
     const float4 v0 = *reinterpret_cast<const float4*>(qp + 16 * t), v1 = *reinterpret_cast<const float4*>(qp + 16 * t + 4);
     const float a[8] = {v0.x * 0.125f, v0.y * 0.125f, v0.z * 0.125f, v0.w * 0.125f, v1.x * 0.125f, v1.y * 0.125f, v1.z * 0.125f, v1.w * 0.125f};  // d^-0.5, exact
-    at_split8<true>(a, qh[t], ql[t]);
+    at_split8(a, qh[t], ql[t]);
   }
 
   // ---- S^T[kv][q] * 16: kv blocks of 32 rows (rows past M read a clamped row and are masked below)
@@ -279,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
       for (int t = 0; t < 4; ++t) {
         const at_u32x4 kh = *reinterpret_cast<const at_u32x4*>(Kh + krow * AT_KS + 16 * t + 8 * hi);
         const at_u32x4 kl = *reinterpret_cast<const at_u32x4*>(Kl + krow * AT_KS + 16 * t + 8 * hi);
-        sacc[c] = at_mfma(at_scale_2m11(kh), ql[t], sacc[c]);
+        sacc[c] = at_mfma(kh, ql[t], sacc[c]);
         sacc[c] = at_mfma(kl, qh[t], sacc[c]);
         sacc[c] = at_mfma(kh, qh[t], sacc[c]);
       }
@@ -341,12 +328,12 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
 #pragma unroll
       for (int e = 0; e < 8; ++e) pe[e] = sacc[cc >> 1][8 * (cc & 1) + e];
       at_u32x4 ph, pl;
-      at_split8<true>(pe, ph, pl);
+      at_split8(pe, ph, pl);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const at_u32x4 vh = *reinterpret_cast<const at_u32x4*>(VTh + (32 * j + l31) * AT_VS + 16 * cc + 8 * hi);
         const at_u32x4 vl = *reinterpret_cast<const at_u32x4*>(VTl + (32 * j + l31) * AT_VS + 16 * cc + 8 * hi);
-        oacc[j] = at_mfma(at_scale_2m11(vh), pl, oacc[j]);
+        oacc[j] = at_mfma(vh, pl, oacc[j]);
         oacc[j] = at_mfma(vl, ph, oacc[j]);
         oacc[j] = at_mfma(vh, ph, oacc[j]);
       }

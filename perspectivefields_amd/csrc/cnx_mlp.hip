@@ -28,7 +28,6 @@ typedef _Float16 cm_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 cm_mfma(const u32x4 a, const u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cm_f16x8, a), __builtin_bit_cast(cm_f16x8, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ u32x4 cm_scale(const u32x4 w) { return __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, w))); }
 
 // Packed weights (cnx_mlp_pack in engine.hip), per 32-hidden-unit chunk t, all fp16 in MFMA fragment order (lane-major, 8 values per lane):
 //   W1 part: [s = C/16 steps][plane hi / lo][lane][8]   value = W1s[32 t + (lane & 31)][ (lane >> 5) C/2 + 8 s + e ]
@@ -146,8 +145,8 @@ __global__ __launch_bounds__(256, C <= 96 ? 3 : 1) void cnx_mlp_kernel(const flo
       const u32x4 wh1 = *reinterpret_cast<const u32x4*>(wb + (s * 2 + 2) * 512);
       const u32x4 wl1 = *reinterpret_cast<const u32x4*>(wb + (s * 2 + 3) * 512);
       if (DIAG == 3) { acc1[0] += __uint_as_float(wh0.x ^ wl0.y ^ xl[s].x ^ wh1.x ^ wl1.y ^ xl[s + 1].x); continue; }
-      acc1 = cm_mfma(cm_scale(wh0), xl[s], acc1);
-      acc1b = cm_mfma(cm_scale(wh1), xl[s + 1], acc1b);
+      acc1 = cm_mfma(wh0, xl[s], acc1);
+      acc1b = cm_mfma(wh1, xl[s + 1], acc1b);
       acc1 = cm_mfma(wl0, xh[s], acc1);
       acc1b = cm_mfma(wl1, xh[s + 1], acc1b);
       acc1 = cm_mfma(wh0, xh[s], acc1);
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(256, C <= 96 ? 3 : 1) void cnx_mlp_kernel(const flo
         continue;
       }
 #pragma unroll
-      for (int q = 0; q < Q; ++q) acc2[q] = cm_mfma(cm_scale(wh[q]), hl[u], acc2[q]);
+      for (int q = 0; q < Q; ++q) acc2[q] = cm_mfma(wh[q], hl[u], acc2[q]);
 #pragma unroll
       for (int q = 0; q < Q; ++q) acc2[q] = cm_mfma(wl[q], hh[u], acc2[q]);
 #pragma unroll

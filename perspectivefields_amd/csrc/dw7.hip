@@ -32,6 +32,7 @@ template <> struct LaneVec<1> {
 };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 template <> struct LaneVec<2> {
   typedef f32x2 T;
   static __device__ __forceinline__ T zero() { return f32x2{0.f, 0.f}; }
@@ -238,6 +239,140 @@ __global__ __launch_bounds__(256) void dwconv7x7_cb_kernel(const float* __restri
     if (t0 + r >= nrows) break;
     do_row(t0 + r, r);
   }
+}
+
+// ---- LDS-tile form for the SMALL maps (20^2 x 384 and 10^2 x 768: 12 of the 18 launches of a ConvNeXt-T forward, convnext.py:30-32,48).  On a map that is only 10-20
+// rows tall the streaming kernel above is a chain of 10-20 dependent row steps, each waiting for its loads (r02: 21.4 us for a 39 MB launch whose bandwidth time is
+// 8 us; no sweep setting moved it below 16.9 us).  Here a block = (image, strip of TH rows, 32-channel slab) first pulls its WHOLE input tile -- (TH + 6) x (W + 6)
+// pixels x 128 B, out-of-image pixels as hardware zeros -- into LDS with every load of the block in flight at once, and then runs the same compile-time accumulator
+// ring from LDS: a row step now costs NC + 6 ds_read_b32 (lane = channel: 32 consecutive banks, conflict-free) instead of a round trip to L2 / HBM.  Same
+// accumulation order as the streaming kernel: bit-identical results.
+template <int NC /*adjacent output columns per thread*/, int NF4 /*float4 pieces of the tile per thread*/>
+__global__ __launch_bounds__(NC == 2 ? 320 : 256) void dwconv7x7_lds_kernel(const float* __restrict__ x, const float* __restrict__ w49c, const float* __restrict__ bias,
+                                                                             float* __restrict__ y, int B, int H, int W, int C, int TH) {
+  constexpr int NI = NC + 6;
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [TH + 6][W + 6][32]
+  const int groups = (W + NC - 1) / NC;
+  const int slabs = C / 32, strips = (H + TH - 1) / TH;
+  const int nblk = B * strips * slabs;
+  int t;
+  {  // XCD-aware order: the slabs of one image strip share an L2 (each 128-byte line of a pixel is one slab's)
+    const int b = blockIdx.x, qd = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    t = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+  }
+  const int slab = t % slabs; t /= slabs;
+  const int st = t % strips; t /= strips;
+  const int b = t;
+  const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+  const int y0 = st * TH, y1 = min(y0 + TH, H);
+  const int TW = W + 6, nrows = (y1 - y0) + 6;
+  float* const xb = const_cast<float*>(x + (long)b * H * W * C);
+  float* const yb = y + (long)b * H * W * C;
+  const unsigned img_bytes = (unsigned)((long)H * W * C * 4);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(xb, 0, img_bytes, 0x00020000);
+  // ---- stage: piece e = tid + nthr i -> (tile pixel e / 8, float4 e % 8 of the slab); all NF4 loads of a thread are in flight before its first LDS write
+  {
+    const int npieces = nrows * TW * 8;
+    float4 v[NF4];
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const int e = tid + nthr * i;
+      const int pix = e >> 3, c4 = e & 7;
+      const int ty = pix / TW, tx = pix - ty * TW;
+      const int iy = y0 - 3 + ty, ix = tx - 3;
+      const bool ok = e < npieces && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const unsigned off = ok ? (unsigned)(((iy * W + ix) * C + slab * 32 + c4 * 4) * 4) : 0x80000000u;
+      const u32x4v q = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      v[i] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+    }
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const int e = tid + nthr * i;
+      if (e < npieces) *reinterpret_cast<float4*>(tile + (size_t)e * 4) = v[i];
+    }
+  }
+  const int g = tid >> 5, cl = tid & 31;
+  const int c = slab * 32 + cl;
+  const int x0 = g * NC;
+  const bool g_ok = g < groups;
+  float wk[49];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) wk[k] = w49c[(long)k * C + c];
+  const float bv = bias[c];
+  unsigned voff_out[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) voff_out[j] = (g_ok && x0 + j < W) ? (unsigned)((x0 + j) * C + c) * 4u : 0x80000000u;
+  const unsigned row_bytes = (unsigned)(W * C) * 4u;
+  float acc[7][NC];
+#pragma unroll
+  for (int s = 0; s < 7; ++s)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) acc[s][j] = bv;
+  __syncthreads();
+  // a thread's window stays inside its tile row whenever x0 + NC <= W; the ragged last group of an odd-width map reads up to NC - 1 pixels past the row end for the
+  // columns it never stores (the launcher allocates NC - 1 spare pixels behind the tile)
+  const float* trow = tile + x0 * 32 + cl;
+  // relative row tt: input row iy = y0 - 3 + tt feeds output rows oy = iy - ky + 3 (accumulator slot (tt - ky + 3) mod 7); after row tt the output row iy - 3
+  // (slot (tt + 4) mod 7) is complete.  r = tt mod 7 is a compile-time constant.
+  auto do_row = [&](int tt, int r) {
+    const int iy = y0 - 3 + tt;
+    float in[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) in[j] = trow[(tt * TW + j) * 32];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      const int oy = iy - ky + 3;
+      if (oy >= y0 && oy < y1) {  // block-uniform
+        const int s = (r - ky + 3 + 7) % 7;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          float a = acc[s][j];
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) a = fmaf(in[j + kx], wk[ky * 7 + kx], a);
+          acc[s][j] = a;
+        }
+      }
+    }
+    const int oy = iy - 3;
+    const bool st_ok = oy >= y0;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yb, 0, st_ok ? img_bytes : 0u, 0x00020000);
+    const unsigned soff = st_ok ? (unsigned)oy * row_bytes : 0u;
+    const int so = (r + 4) % 7;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[so][j]), ry, voff_out[j], soff, 0);
+      acc[so][j] = bv;
+    }
+  };
+  int t0 = 0;
+  for (; t0 + 7 <= nrows; t0 += 7) {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) do_row(t0 + r, r);
+  }
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    if (t0 + r >= nrows) break;
+    do_row(t0 + r, r);
+  }
+}
+
+// maps of at most 20 columns (threads = 32 x column groups <= 320); th <= 0: automatic strip height
+bool dwconv7x7_lds_ok(int H, int W, int C) { return W <= 20 && W >= 2 && (C % 32) == 0 && H >= 1; }
+void launch_dwconv7x7_lds(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int th, hipStream_t s) {
+  constexpr int NC = 2;
+  const int groups = (W + NC - 1) / NC;
+  const int threads = 32 * groups;
+  // strip height: the tallest tile whose pieces fit 13 float4 per thread (20^2: TH = 10 -> 16 x 26 x 8 = 3328 pieces / 320 threads = 11; 10^2: the whole map, 2048 / 160 = 13)
+  int TH = th > 0 ? std::min(th, H) : H;
+  auto pieces = [&](int t) { return (long)(std::min(t, H) + 6) * (W + 6) * 8; };
+  while (TH > 1 && (pieces(TH) + threads - 1) / threads > 13) --TH;
+  if (th <= 0) {  // prefer equal strips
+    const int strips = (H + TH - 1) / TH;
+    TH = (H + strips - 1) / strips;
+  }
+  const long blocks = (long)B * ((H + TH - 1) / TH) * (C / 32);
+  const size_t lds = ((size_t)(TH + 6) * (W + 6) + (NC - 1)) * 32 * 4;
+  hipLaunchKernelGGL((dwconv7x7_lds_kernel<NC, 13>), dim3((unsigned)blocks), dim3(threads), lds, s, x, w49c, bias, y, B, H, W, C, TH);
 }
 
 template <int NC, int NB>

@@ -614,19 +614,23 @@ void launch_dwconv7x7_lane(const float* x, const float* w49c, const float* bias,
 void launch_dwconv7x7_cb(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s);
 
 void launch_dwconv7x7_cb_cfg(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int nc, int nb, int th, hipStream_t s);
+bool dwconv7x7_lds_ok(int H, int W, int C);
+void launch_dwconv7x7_lds(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int th, hipStream_t s);
 static int g_dw7_variant = -1;
 // explicit variant / column-blocked configuration (tests, tuning); variant < 0: the default path
 void launch_dwconv7x7_cfg(int variant, int nc, int nb, int th, const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
-  if (variant == 3) { launch_dwconv7x7_cb_cfg(x, w49c, bias, y, B, H, W, C, nc, nb, th, s); return; }
+  if (variant == 4 && dwconv7x7_lds_ok(H, W, C)) { launch_dwconv7x7_lds(x, w49c, bias, y, B, H, W, C, th, s); return; }
+  if (variant == 3 || variant == 4) { launch_dwconv7x7_cb_cfg(x, w49c, bias, y, B, H, W, C, nc, nb, th, s); return; }
   if (variant == 2) { launch_dwconv7x7_lane(x, w49c, bias, y, B, H, W, C, s); return; }
   launch_dwconv7x7(x, w49c, bias, y, B, H, W, C, s);
 }
 void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
   if (g_dw7_variant == -1) {
     const char* e = getenv("PF_DW7_VARIANT");
-    g_dw7_variant = e ? atoi(e) : 3;  // 3: column-blocked streaming kernel (dw7.hip), 2: one column per lane, 1: ring, 0: LDS halo tile
+    g_dw7_variant = e ? atoi(e) : 4;  // 4: LDS-tile kernel on maps of <= 20 columns, column-blocked streaming kernel otherwise (dw7.hip); 3: column-blocked everywhere; 2: one column per lane; 1: ring, 0: LDS halo tile (tuning builds)
   }
-  if (g_dw7_variant == 3) { launch_dwconv7x7_cb(x, w49c, bias, y, B, H, W, C, s); return; }
+  if (g_dw7_variant == 4 && dwconv7x7_lds_ok(H, W, C)) { launch_dwconv7x7_lds(x, w49c, bias, y, B, H, W, C, 0, s); return; }
+  if (g_dw7_variant == 3 || g_dw7_variant == 4) { launch_dwconv7x7_cb(x, w49c, bias, y, B, H, W, C, s); return; }
   if (g_dw7_variant == 2) { launch_dwconv7x7_lane(x, w49c, bias, y, B, H, W, C, s); return; }
 #ifdef PF_TUNING_BUILD
   const int CQ = C / 4;
@@ -1160,52 +1164,5 @@ void launch_paramnet_scalars(const float* raw, int nraw, float* out8, int B, int
   hipLaunchKernelGGL(paramnet_scalars_kernel, dim3((B + 63) / 64), dim3(64), 0, s, raw, nraw, out8, B, mode);
 }
 
-#ifdef PF_TUNING_BUILD
-// ---------------------------------------------------------------------------------------------------------------------------------------------
-// Sub-pixel form of conv3x3(bilinear x2 (x)) (scripts/proto/subpixel_conv.py): the phase conv on the replicate-padded half-resolution map is exact
-// except for the taps that land on the ZERO padding of the up-sampled map -- output rows 0 / 2H - 1 (phase py 0 of half-res row 0, py 1 of row H - 1) and columns
-// likewise.  Those taps read u_hat[-1, X] = the interpolation of x[0, :] along x, so their sum is a 1 x 3 half-resolution conv with host-combined weights (top /
-// bottom / left / right tables); a corner pixel subtracts its corner tap twice and gets it back once (it reads x[corner] with coefficient 1).  One block per border
-// pixel, one thread per virtual channel (py, px, c); plain fp32 FMAs (the main contraction is fp32-class as well).  Pixels that are listed twice (corners appear in
-// the row lists AND the column lists of the perimeter index) are used from the row lists only (igemm_common.h epilogue_subpx).
-__global__ void subpx_corr_kernel(const float* __restrict__ x, const float* __restrict__ tab, float* __restrict__ corr, int H, int W, int Cin, int Cr) {
-  const int PER = 2 * W + 2 * H;
-  const int b = blockIdx.x / PER, pi = blockIdx.x - b * PER;
-  int oy, ox;
-  if (pi < W) { oy = 0; ox = pi; }
-  else if (pi < 2 * W) { oy = H - 1; ox = pi - W; }
-  else if (pi < 2 * W + H) { oy = pi - 2 * W; ox = 0; }
-  else { oy = pi - 2 * W - H; ox = W - 1; }
-  const int n = threadIdx.x, phase = n / Cr, c = n - phase * Cr, py = phase >> 1, px = phase & 1;
-  const bool t = oy == 0 && py == 0, bt = oy == H - 1 && py == 1, l = ox == 0 && px == 0, r = ox == W - 1 && px == 1;
-  const size_t S = (size_t)Cin * Cr;
-  const float *top = tab, *bot = tab + 6 * S, *lef = tab + 12 * S, *rig = tab + 18 * S, *cor = tab + 24 * S;
-  auto X = [&](int iy, int ix) { return x + (((size_t)b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * Cin; };
-  float acc = 0.f;
-  if (t || bt) {
-    const float* w = (t ? top : bot) + (size_t)px * 3 * S + c;
-    for (int dx = 0; dx < 3; ++dx) {
-      const float* xr = X(t ? 0 : H - 1, ox + dx - 1);
-      for (int ci = 0; ci < Cin; ++ci) acc = fmaf(-w[((size_t)dx * Cin + ci) * Cr], xr[ci], acc);
-    }
-  }
-  if (l || r) {
-    const float* w = (l ? lef : rig) + (size_t)py * 3 * S + c;
-    for (int dy = 0; dy < 3; ++dy) {
-      const float* xr = X(oy + dy - 1, l ? 0 : W - 1);
-      for (int ci = 0; ci < Cin; ++ci) acc = fmaf(-w[((size_t)dy * Cin + ci) * Cr], xr[ci], acc);
-    }
-  }
-  if ((t || bt) && (l || r)) {
-    const float* w = cor + (size_t)(py * 2 + px) * S + c;
-    const float* xr = X(oy, ox);
-    for (int ci = 0; ci < Cin; ++ci) acc = fmaf(w[(size_t)ci * Cr], xr[ci], acc);
-  }
-  corr[((size_t)b * PER + pi) * (4 * Cr) + n] = acc;
-}
-void launch_subpx_corr(const float* x, const float* tab, float* corr, int B, int H, int W, int Cin, int Cr, hipStream_t s) {
-  hipLaunchKernelGGL(subpx_corr_kernel, dim3(B * (2 * W + 2 * H)), dim3(4 * Cr), 0, s, x, tab, corr, H, W, Cin, Cr);
-}
-#endif
 
 }  // namespace pf

@@ -52,46 +52,6 @@ struct HostTensor {
   bool used = false;
 };
 
-// Sub-pixel form of conv3x3(bilinear x2 (x)) (scripts/proto/subpixel_conv.py): w [Cr][Cin][3][3] ->
-//   weff [4 Cr][Cin][3][3], virtual channel n = (2 py + px) Cr + c:  weff[n][ci][dy][dx] = sum_{ky,kx} A[py][dy][ky] A[px][dx][kx] w[c][ci][ky][kx]
-//   tab: top / bottom [2 px][3 dx][Cin][Cr] = sum_kx A[px][dx][kx] w[c][ci][0 / 2][kx], left / right [2 py][3 dy][Cin][Cr] = sum_ky A[py][dy][ky] w[c][ci][ky][0 / 2],
-//        corner [2 py][2 px][Cin][Cr] = w[c][ci][py ? 2 : 0][px ? 2 : 0]        (subpx_corr_kernel, elem.hip)
-// A[p][d][k]: coefficient of half-resolution neighbour d - 1 in tap k of output phase p (bilinear x2, align_corners = False).  Combined in double.
-static void subpx_combine(const float* w, int Cr, int Cin, std::vector<float>* weff, std::vector<float>* tab) {
-  static const double A[2][3][3] = {{{0.75, 0.25, 0.0}, {0.25, 0.75, 0.75}, {0.0, 0.0, 0.25}}, {{0.25, 0.0, 0.0}, {0.75, 0.75, 0.25}, {0.0, 0.25, 0.75}}};
-  const size_t S = (size_t)Cin * Cr;
-  weff->assign((size_t)4 * Cr * Cin * 9, 0.f);
-  tab->assign(28 * S, 0.f);
-  for (int c = 0; c < Cr; ++c)
-    for (int ci = 0; ci < Cin; ++ci) {
-      const float* k = w + ((size_t)c * Cin + ci) * 9;
-      for (int py = 0; py < 2; ++py)
-        for (int px = 0; px < 2; ++px) {
-          const size_t n = (size_t)(2 * py + px) * Cr + c;
-          for (int dy = 0; dy < 3; ++dy)
-            for (int dx = 0; dx < 3; ++dx) {
-              double a = 0.0;
-              for (int ky = 0; ky < 3; ++ky)
-                for (int kx = 0; kx < 3; ++kx) a += A[py][dy][ky] * A[px][dx][kx] * (double)k[ky * 3 + kx];
-              (*weff)[(n * Cin + ci) * 9 + dy * 3 + dx] = (float)a;
-            }
-          (*tab)[24 * S + ((size_t)(py * 2 + px) * Cin + ci) * Cr + c] = k[(py ? 2 : 0) * 3 + (px ? 2 : 0)];
-        }
-      for (int q = 0; q < 2; ++q)      // q = px for the row tables, py for the column tables
-        for (int d = 0; d < 3; ++d) {
-          double tp = 0.0, bt = 0.0, lf = 0.0, rg = 0.0;
-          for (int kk = 0; kk < 3; ++kk) {
-            tp += A[q][d][kk] * (double)k[0 * 3 + kk];
-            bt += A[q][d][kk] * (double)k[2 * 3 + kk];
-            lf += A[q][d][kk] * (double)k[kk * 3 + 0];
-            rg += A[q][d][kk] * (double)k[kk * 3 + 2];
-          }
-          const size_t o = ((size_t)(q * 3 + d) * Cin + ci) * Cr + c;
-          (*tab)[o] = (float)tp; (*tab)[6 * S + o] = (float)bt; (*tab)[12 * S + o] = (float)lf; (*tab)[18 * S + o] = (float)rg;
-        }
-    }
-}
-
 struct ConvW {
   float* w = nullptr;
   float* b = nullptr;
@@ -111,7 +71,6 @@ struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
 struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
   float* predw = nullptr; float* predb = nullptr; int nout = 0;
-  ConvW conv1sp; float* sp_tab = nullptr;  // sub-pixel form of conv_fuse_conv1 (tuning builds, PF_SUBPX_CONV1=1): 64 -> 4 x 32 phase weights + border tables
 };
 struct CnxBlock { DwW dw; LNW n; ConvW pw1, pw2; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused MLP (cnx_mlp.hip), when built */ };
 struct Cnx { ConvW stem, ds[3]; LNW stemn, dsn[3], norm; std::vector<CnxBlock> blocks[4]; float* headw = nullptr; float* headb = nullptr; int nout = 0; };
@@ -452,7 +411,6 @@ struct pf_engine {
   bool sba_heads = false;    // PF_SBA_HEADS=1: the tensors between the 3x3 convs of the decoders' ResidualConvUnits are written as split-f16 planes by the producing
                              // conv's epilogue (plus fp32 where a residual add reads them) and the halo kernel copies them (igemm_sbh ASB) instead of splitting
                              // every element once per n-tile and halo overlap; split-f16 scheme only
-  bool subpx_conv1 = false;  // PF_SUBPX_CONV1=1 (tuning builds): conv_fuse_conv1 in its sub-pixel form -- a 64 -> 4 x 32 conv on the 160^2 map, no interpolation arithmetic
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
   bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
@@ -647,20 +605,6 @@ struct pf_engine {
     }
     hd.conv0 = make_conv(p + "conv_fuse_conv0.conv.weight", p + "conv_fuse_conv0.conv.bias", 64, DEC_FEAT + LL_CH, 3, 1, 1);
     hd.conv1 = make_conv(p + "conv_fuse_conv1.conv.weight", p + "conv_fuse_conv1.conv.bias", 32, 64, 3, 1, 1);
-#ifdef PF_TUNING_BUILD
-    if (subpx_conv1) {
-      std::vector<float> weff, tab;
-      subpx_combine(get(p + "conv_fuse_conv1.conv.weight", {32, 64, 3, 3}).data.data(), 32, 64, &weff, &tab);
-      const std::vector<float>& b1 = get(p + "conv_fuse_conv1.conv.bias", {32}).data;
-      std::vector<float> b4(128);
-      for (int n = 0; n < 128; ++n) b4[n] = b1[n & 31];
-      ConvW& cw = hd.conv1sp;
-      upload_conv_weights(cw, pack_conv(weff.data(), 128, 64, 3, 3, 64, nullptr, &cw.KWC, &cw.KWCp), 64, 128);
-      cw.b = upload(b4);
-      cw.Cout = 128; cw.Cin = 64; cw.CinReal = 64; cw.KH = cw.KW = 3; cw.stride = 1; cw.pad = 1;
-      hd.sp_tab = upload(tab);
-    }
-#endif
     hd.nout = nout;
     const std::string pk = p + "linear_pred_" + name;
     if (cls) {
@@ -784,15 +728,14 @@ struct pf_engine {
     int head_kind = 0; const float* head_w = nullptr; const float* head_b = nullptr; float* head_out = nullptr; float* head_pn = nullptr;
   };
   // ups: calls[].x is stored at half resolution (H/2 x W/2); the conv runs on its bilinear x2 up-sampling (ConvParams::ups)
-  void conv_g(Ctx& c, int ngroups, const ConvCall* calls, int B, int H, int W, int act = ACT_NONE, int post_relu = 0, int C1 = -1, int nchw = 0, int ups = 0,
-              const float* const* subpx_corr = nullptr /*sub-pixel form (ConvParams::subpx): per group, the border terms*/) {
+  void conv_g(Ctx& c, int ngroups, const ConvCall* calls, int B, int H, int W, int act = ACT_NONE, int post_relu = 0, int C1 = -1, int nchw = 0, int ups = 0) {
     const ConvW& w = *calls[0].w;
     const size_t Ho_ = (H + 2 * w.pad - w.KH) / w.stride + 1, Wo_ = (W + 2 * w.pad - w.KW) / w.stride + 1;
     // split-K scratch (conv_splitk_factor: deep-K launches with too few tiles for 256 CUs -- the MiT spatial-reduction convs); decided
     // from the shape and the call's operand set, so that the workspace dry run takes the same decision
     int splitk = 1;
     {
-      bool plain = !nchw && !ups && !subpx_corr && !w.ln_s && w.Cin % 32 == 0 && w.KWCp > 0;
+      bool plain = !nchw && !ups && !w.ln_s && w.Cin % 32 == 0 && w.KWCp > 0;
       for (int g = 0; g < ngroups; ++g)
         if (calls[g].head_kind || calls[g].w->btab || calls[g].res2 || calls[g].y.s.p || !calls[g].y.f || calls[g].x.s.p) plain = false;
       if (plain && split_bf16) splitk = conv_splitk_shape((long)B * Ho_ * Wo_, w.Cout, w.KH, w.KWCp, ngroups);
@@ -824,7 +767,6 @@ struct pf_engine {
     p.nterms = nterms;
     p.ups = ups;
     p.ln = w.ln_s ? 1 : 0; p.ln_eps = w.ln_eps;
-    if (subpx_corr) { p.subpx = 1; for (int g = 0; g < ngroups; ++g) p.subpx_corr[g] = subpx_corr[g]; }
     p.finish();
     if (part) {
       p.splitk = splitk;
@@ -834,7 +776,7 @@ struct pf_engine {
     {
       // operand formats are part of the key: a split-plane input changes which tile is fastest
       const int prec_code = nterms == NT_F16X3 ? 0 : (nterms == 6 ? 3 : (nterms == 3 ? 1 : 2));  // = PF_PRECISION_*
-      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * prec_code + 128 * ups + 256 * (calls[0].head_kind ? 1 : 0) + 1024 * (subpx_corr ? 1 : 0);
+      const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * prec_code + 128 * ups + 256 * (calls[0].head_kind ? 1 : 0);
       std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out, fmt_bits + 512 * p.ln, p.act};
       auto it = tile_cache.find(key);
       if (it == tile_cache.end() && p.ln && !(c.tuning && c.tune_scratch)) { key[10] = fmt_bits; it = tile_cache.find(key); }  // table without the fused form: same shape's tile
@@ -1101,20 +1043,6 @@ struct pf_engine {
       b2[0].head_kind = 1; b2[0].head_w = hg.predw; b2[0].head_b = hg.predb; b2[0].head_out = pg; b2[0].head_pn = pn;
       b2[1].head_kind = 2; b2[1].head_w = hl.predw; b2[1].head_b = hl.predb; b2[1].head_out = pl; b2[1].head_pn = pn;
     }
-#ifdef PF_TUNING_BUILD
-    if (subpx_conv1 && fuse_up && hg.conv1sp.wh16 && hl.conv1sp.wh16) {  // 64 -> 4 x 32 on the 160^2 map (replicate padding) + closed-form border terms, pixel-shuffled store / heads
-      const int hh = NET / 2, PER = 4 * hh;
-      float* corr = c.alloc((size_t)2 * B * PER * 128);
-      if (!c.dry) {
-        launch_subpx_corr(z0.f, hg.sp_tab, corr, B, hh, hh, 64, 32, c.s);
-        launch_subpx_corr(z1.f, hl.sp_tab, corr + (size_t)B * PER * 128, B, hh, hh, 64, 32, c.s);
-      }
-      b2[0].w = &hg.conv1sp; b2[1].w = &hl.conv1sp;
-      const float* cp[2] = {corr, corr + (size_t)B * PER * 128};
-      conv_g(c, 2, b2, B, hh, hh, ACT_RELU, 0, -1, 0, 0, cp);
-      return;
-    }
-#endif
     conv_g(c, 2, b2, B, NET, NET, ACT_RELU, 0, -1, 0, fuse_up ? 1 : 0);
   }
 
@@ -1318,7 +1246,6 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
 #ifdef PF_TUNING_BUILD
-  if (const char* v = getenv("PF_SUBPX_CONV1")) e->subpx_conv1 = atoi(v) != 0;
 #endif
   if (const char* v = getenv("PF_SIDE_STREAM")) e->side_stream_mode = atoi(v);
   if (const char* v = getenv("PF_SBA_HEADS")) e->sba_heads = atoi(v) != 0;
@@ -1717,53 +1644,6 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   tmp.sync_free(s);
   return rc;
 }
-
-#ifdef PF_TUNING_BUILD
-// Test entry of the sub-pixel form (tuning builds; not part of include/pf_hip.h): y [B][2H][2W][Cr] = act(conv3x3_pad1(bilinear_x2(x)) + b), x [B][H][W][Cin] (Cin % 32 == 0),
-// hw [Cr][Cin][3][3], Cr == 32.  tile_id < 0: "sbh128x128".
-// host-only: the combined weights and border tables (scripts/proto/check_subpx_host.py mirrors the kernels' indexing in numpy, no GPU needed)
-int pf_tuning_subpx_combine(const float* hw, int Cr, int Cin, float* weff /*[4 Cr][Cin][3][3]*/, float* tab /*[28][Cin][Cr]*/) {
-  std::vector<float> a, b;
-  subpx_combine(hw, Cr, Cin, &a, &b);
-  std::copy(a.begin(), a.end(), weff);
-  std::copy(b.begin(), b.end(), tab);
-  return PF_OK;
-}
-int pf_tuning_subpx_conv(int device, const float* x, int B, int H, int W, int Cin, const float* hw, const float* hb, int Cr, int act, int tile_id, float* y, void* stream) {
-  std::string err;
-  int rc = check_device(device, &err);
-  if (rc != PF_OK) { g_create_error = err; return rc; }
-  if (Cr != 32 || Cin % 32 != 0 || !x || !y || !hw) { g_create_error = "pf_tuning_subpx_conv: Cr must be 32, Cin a multiple of 32"; return PF_ERR_ARG; }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  TmpDev tmp;
-  std::vector<float> weff, tab;
-  subpx_combine(hw, Cr, Cin, &weff, &tab);
-  ConvParams p;
-  std::vector<float> packed = pack_conv(weff.data(), 4 * Cr, Cin, 3, 3, Cin, nullptr, &p.KWC, &p.KWCp);
-  p.g[0].w = tmp.up(packed);
-  const F16Planes f = split_f16x2(packed, 4 * Cr);
-  p.g[0].w_h16 = tmp.up_u16(f.planes); p.g[0].w_h16_inv_scale = tmp.up(f.inv_scale);
-  std::vector<float> b4(4 * Cr, 0.f);
-  if (hb) for (int n = 0; n < 4 * Cr; ++n) b4[n] = hb[n % Cr];
-  p.g[0].bias = tmp.up(b4);
-  const float* dtab = tmp.up(tab);
-  void* dcorr = nullptr;
-  const size_t PER = (size_t)2 * W + 2 * H;
-  if (hipMalloc(&dcorr, (size_t)B * PER * 4 * Cr * 4) != hipSuccess) { g_create_error = "pf_tuning_subpx_conv: hipMalloc failed"; return PF_ERR_DEVICE; }
-  tmp.p.push_back(dcorr);
-  launch_subpx_corr(x, dtab, static_cast<float*>(dcorr), B, H, W, Cin, Cr, s);
-  p.g[0].x = x; p.g[0].y = y;
-  p.B = B; p.H = H; p.W = W; p.C1 = Cin; p.C2 = 0; p.KH = p.KW = 3; p.stride = 1; p.pad = 1;
-  p.Cout = 4 * Cr; p.act = act; p.post_relu = 0; p.nchw_out = 0; p.nterms = NT_F16X3;
-  p.subpx = 1; p.subpx_corr[0] = static_cast<const float*>(dcorr);
-  p.finish();
-  if (tile_id >= 0 && !conv_tile_usable(p, tile_id)) { g_create_error = "pf_tuning_subpx_conv: tile config cannot run the sub-pixel form"; return PF_ERR_ARG; }
-  launch_conv_tile(p, tile_id, s);
-  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
-  tmp.sync_free(s);
-  return rc;
-}
-#endif
 
 int pf_op_linear_ln(int device, const float* x, long rows, int K, const float* hw, const float* hb, const float* hgamma, const float* hbeta, float eps, int N,
                     int act, const float* res1, int tile_id, float* y, int precision, void* stream) {

@@ -290,7 +290,7 @@ bool conv_tile_is_sb(int id) { return id >= kNumF32 && id < conv_num_tiles(); }
 bool conv_tile_usable(const ConvParams& p, int id) {
   if (id < 0 || id >= conv_num_tiles()) return false;
   if (id >= kNumF32) return conv_sb_eligible(p) && conv_sb_tile_ok(p, id - kNumF32);
-  if (p.ups || p.g[0].head_kind || p.ln || p.subpx) return false;  // fused up-sampling / prediction head / input LayerNorm / sub-pixel form: split tiles only
+  if (p.ups || p.g[0].head_kind || p.ln) return false;  // fused up-sampling / prediction head / input LayerNorm: split tiles only
   for (int g = 0; g < p.groups; ++g)  // the exact-fp32 kernel reads fp32 inputs; split-plane output only through the NHWC epilogue
     if (!p.g[g].x || (p.C2 > 0 && !p.g[g].x2) || (p.nchw_out && (!p.g[g].y || p.g[g].y_sb))) return false;
   return true;

@@ -145,76 +145,6 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
   }
 }
 
-#ifdef PF_TUNING_BUILD
-// Epilogue of the sub-pixel form (ConvParams::subpx): block tile = half-resolution patch x 128 virtual channels = 4 phases x 32 real channels (Cout = 128).  Same LDS
-// staging as epilogue_nhwc; a staged row is one half-resolution pixel, its float4 cq belongs to phase cq / 8 (py = phase / 2, px = phase % 2), channels 4 (cq % 8) ...
-// Order of operations per value: scale, border correction, bias, activation -- then the fused prediction head (8 lanes = the 32 channels of one OUTPUT pixel) or the store.
-template <int BM, int BN, int WM, int WN, int SM, int SN, int NT, int SMEM_FLOATS>
-__device__ __forceinline__ void epilogue_subpx(const ConvParams& p, const ConvPtrs& P, const float* corr, f32x16 (&acc)[SM][SN], float* Cs, int n0, const Tile2D& t2, const float* oscale) {
-  static_assert(BN == 128, "sub-pixel epilogue: four phases of 32 channels per block");
-  constexpr int CROW = BN + 4, CH_ROWS = WM * 32, F4_PER_ROW = BN / 4;
-  static_assert(CH_ROWS * CROW <= SMEM_FLOATS, "epilogue chunk must fit the operand buffers");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int wave_m = wave / WN;
-  const int wn0 = (wave % WN) * (SN * 32);
-  const int HW4 = 4 * p.Ho * p.Wo, W2 = 2 * p.Wo, PER = 2 * p.Wo + 2 * p.Ho;
-#pragma unroll
-  for (int i = 0; i < SM; ++i) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < SN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        Cs[(wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CROW + wn0 + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
-    for (int idx = tid; idx < CH_ROWS * F4_PER_ROW; idx += NT) {
-      const int row_l = idx / F4_PER_ROW, cq = idx - row_l * F4_PER_ROW;
-      const int lm = (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
-      const int ry = lm / t2.tx, rx = lm - ry * t2.tx;
-      const int oy = t2.oy0 + ry, ox = t2.ox0 + ((ry & 1) ? (rx + t2.odd_shift) % t2.tx : rx);
-      if (oy >= p.Ho || ox >= p.Wo) continue;  // whole 8-lane groups (one row_l) take the same branch
-      const int n = n0 + cq * 4;  // virtual channel (n0 = 0: the block holds all four phases)
-      const int phase = cq >> 3, sub = cq & 7, py = phase >> 1, px = phase & 1;
-      float4 v = *reinterpret_cast<const float4*>(Cs + row_l * CROW + cq * 4);
-      if (oscale) { const float4 sc = *reinterpret_cast<const float4*>(oscale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
-      if (corr && (oy == 0 || oy == p.Ho - 1 || ox == 0 || ox == p.Wo - 1)) {
-        const int pi = oy == 0 ? ox : (oy == p.Ho - 1 ? p.Wo + ox : (ox == 0 ? 2 * p.Wo + oy : 2 * p.Wo + p.Ho + oy));
-        const float4 q = *reinterpret_cast<const float4*>(corr + ((size_t)t2.b * PER + pi) * BN + n);
-        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-      }
-      if (P.bias) { const float4 bb = *reinterpret_cast<const float4*>(P.bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-      if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      else if (p.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-      const int r = (2 * oy + py) * W2 + 2 * ox + px;      // output pixel inside the image
-      const long mo = (long)t2.b * HW4 + r;
-      if (P.head_kind) {  // block-uniform; the 8 lanes sub = 0..7 hold the 32 channels of output pixel mo
-        const float4 w0 = reinterpret_cast<const float4*>(P.head_w)[sub];
-        float d0 = head_dot4(v, w0), d1 = 0.f;
-        if (P.head_kind == 1) d1 = head_dot4(v, reinterpret_cast<const float4*>(P.head_w)[8 + sub]);
-#pragma unroll
-        for (int sh = 4; sh > 0; sh >>= 1) { d0 += __shfl_xor(d0, sh, 8); d1 += __shfl_xor(d1, sh, 8); }
-        if (sub == 0) {
-          if (P.head_kind == 1) {
-            d0 += P.head_b[0]; d1 += P.head_b[1];
-            const float nrm = fmaxf(sqrtf(fmaf(d1, d1, __fmul_rn(d0, d0))), 1e-12f);
-            d0 /= nrm; d1 /= nrm;
-            P.head_out[((long)t2.b * 2) * HW4 + r] = d0;
-            P.head_out[((long)t2.b * 2 + 1) * HW4 + r] = d1;
-            if (P.head_pn) *reinterpret_cast<float2*>(P.head_pn + mo * 4) = make_float2(d0, d1);
-          } else {
-            d0 = fminf(fmaxf(d0 + P.head_b[0], -1.f), 1.f);
-            P.head_out[mo] = d0;
-            if (P.head_pn) *reinterpret_cast<float2*>(P.head_pn + mo * 4 + 2) = make_float2(d0, 0.f);
-          }
-        }
-        continue;
-      }
-      if (P.y) *reinterpret_cast<float4*>(P.y + mo * 32 + sub * 4) = v;
-    }
-  }
-}
-#endif
-
 // Direct epilogue for TRANSPOSED accumulators.  With the MFMA operands swapped (weights as the instruction's A operand, pixels as B)
 // the 32x32 C/D layout puts GEMM row m = lane & 31 and, per register group g = r >> 2, the four CONSECUTIVE output channels
 // n = 8 g + 4 (lane >> 5) + (r & 3) into one lane: every lane owns float4s of its own output row and can apply scale / LayerNorm

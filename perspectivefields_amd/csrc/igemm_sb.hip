@@ -17,11 +17,11 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {64, 64, 2, "sb64x64f2"}, {64, 64, 3, "sb64x64f3"}, {128, 64, 2, "sb128x64f2"}, {128, 32, 2, "sb128x32f2"},
                              {128, 128, 2, "sb128x128f2"},
 #ifdef PF_TUNING_BUILD
-                             // ablation / scheduling forms of four linear tiles (igemm_sb_impl.h SB_ABL_PARAM): "sbA<mask>_*" wrong results by construction, "sbP_*" right
-                             {64, 64, 1, "sbA16_64x64"}, {64, 64, 1, "sbA32_64x64"}, {64, 64, 1, "sbA48_64x64"}, {64, 64, 1, "sbA1_64x64"}, {64, 64, 1, "sbI_64x64"}, {64, 64, 1, "sbPI_64x64"},
-                             {64, 64, 3, "sbA16_64x64f3"}, {64, 64, 3, "sbA32_64x64f3"}, {64, 64, 3, "sbA48_64x64f3"}, {64, 64, 3, "sbA1_64x64f3"}, {64, 64, 3, "sbI_64x64f3"}, {64, 64, 3, "sbPI_64x64f3"},
-                             {128, 128, 1, "sbA16_128x128"}, {128, 128, 1, "sbA32_128x128"}, {128, 128, 1, "sbA48_128x128"}, {128, 128, 1, "sbA1_128x128"}, {128, 128, 1, "sbI_128x128"}, {128, 128, 1, "sbPI_128x128"},
-                             {256, 128, 1, "sbA16_256x128w8"}, {256, 128, 1, "sbA32_256x128w8"}, {256, 128, 1, "sbA48_256x128w8"}, {256, 128, 1, "sbA1_256x128w8"}, {256, 128, 1, "sbI_256x128w8"}, {256, 128, 1, "sbPI_256x128w8"},
+                             // ablation / scheduling forms of four linear tiles (igemm_sb_impl.h SB_ABL_PARAM): "sbA<mask>_*" wrong results by construction, timing only
+                             {64, 64, 1, "sbA16_64x64"}, {64, 64, 1, "sbA32_64x64"}, {64, 64, 1, "sbA48_64x64"}, {64, 64, 1, "sbA1_64x64"},
+                             {64, 64, 3, "sbA16_64x64f3"}, {64, 64, 3, "sbA32_64x64f3"}, {64, 64, 3, "sbA48_64x64f3"}, {64, 64, 3, "sbA1_64x64f3"},
+                             {128, 128, 1, "sbA16_128x128"}, {128, 128, 1, "sbA32_128x128"}, {128, 128, 1, "sbA48_128x128"}, {128, 128, 1, "sbA1_128x128"},
+                             {256, 128, 1, "sbA16_256x128w8"}, {256, 128, 1, "sbA32_256x128w8"}, {256, 128, 1, "sbA48_256x128w8"}, {256, 128, 1, "sbA1_256x128w8"},
 #endif
                              // "sbh": 3x3 / stride 1 convs with an LDS-staged input halo tile, 8 x 16 output patch per block (igemm_sbh.hip)
                              {128, 128, 0, "sbh128x128"}, {128, 64, 0, "sbh128x64"}, {128, 32, 0, "sbh128x32"}, {256, 64, 0, "sbh256x64w8"},
@@ -37,17 +37,17 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {256, 64, 0, "sbhA1"}, {256, 64, 0, "sbhA2"}, {256, 64, 0, "sbhA3"}, {256, 64, 0, "sbhA4"}, {256, 64, 0, "sbhA8"}, {256, 64, 0, "sbhA48"},
                              {256, 64, 0, "sbhA12"}, {256, 64, 0, "sbhA11"}, {256, 64, 0, "sbhA15"}, {256, 64, 0, "sbhA63"},
                              {256, 64, 0, "sbhAa"}, {256, 64, 0, "sbhAb"}, {256, 64, 0, "sbhLA0"}, {256, 64, 0, "sbhLA2"}, {256, 64, 0, "sbhLAbf"}, {256, 64, 0, "sbhLAbf0"}, {256, 64, 0, "sbhDMA"}, {256, 64, 0, "sbhREG"},
-                             // DMA weight ring on the other tiles (two / three LDS buffers): right results
-                             {128, 64, 0, "sbhV2_128x64"}, {128, 32, 0, "sbhV2_128x32"}, {256, 32, 0, "sbhV2_256x32"}, {128, 64, 0, "sbhV3_128x64"},
-                             {128, 128, 0, "sbhV2_128x128"}, {256, 64, 0, "sbhV2_256x64w8"},
 #endif
+                             // "sbr": row-resident GEMM for the small-M linear layers and the kernel == stride convs (rr_gemm.hip); always the LAST two entries
+                             {128, 160, 0, "sbr128x160"}, {128, 128, 0, "sbr128x128"},
 };
 #ifdef PF_TUNING_BUILD
-static constexpr int kFirstH = 12 + 24;  // index of the first "sbh" tile (behind the linear tiles' tuning forms)
+static constexpr int kFirstH = 12 + 16;  // index of the first "sbh" tile (behind the linear tiles' tuning forms)
 #else
 static constexpr int kFirstH = 12;  // index of the first "sbh" tile
 #endif
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }
+static constexpr int kFirstR = (int)(sizeof(kSb) / sizeof(kSb[0])) - 2;  // index of the first "sbr" tile
 const char* conv_sb_tile_name(int id) { return kSb[id].name; }
 int conv_sb_tile_bm(int id) { return kSb[id].bm; }
 int conv_sb_tile_bn(int id) { return kSb[id].bn; }
@@ -72,13 +72,14 @@ bool conv_sb_eligible(const ConvParams& p) {
 }
 
 bool conv_sbh_ok(const ConvParams& p);                                   // igemm_sbh.hip
+bool conv_rr_ok(const ConvParams& p, int variant);                       // rr_gemm.hip
+void launch_conv_rr(const ConvParams& p, int variant, hipStream_t s);
 
 // Static choice for shapes the tile table (tuned/gfx950_tiles.txt) does not hold; follows what the per-shape tuning picks
 // (profiles/r01_tune_conv_*.txt): halo tiles for 3x3 / stride-1 convs on maps of 40^2 and more; otherwise the largest tile
 // that still gives every CU about two blocks, with a register prefetch ring (f2 / f3) when the K loop is deep.
 int conv_sb_default_tile(const ConvParams& p) {
   const long K = (long)p.KH * p.KWCp;
-  if (p.subpx) return kFirstH;  // sub-pixel form: the four phases (128 virtual channels) in one block -> "sbh128x128"
   if (p.ups) return kFirstH + (p.Cout <= 32 ? 2 : (p.Cout <= 64 ? 1 : 0));  // the only tiles that interpolate while staging
   if (conv_sbh_ok(p) && p.Ho >= 40 && p.Wo >= 40) {
     if (p.Cout <= 32) return kFirstH + 2;
@@ -102,11 +103,12 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile);                  // igemm_sbh.hip
 bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
+  if (sb_tile >= kFirstR) return conv_rr_ok(p, sb_tile - kFirstR);
 #ifdef PF_TUNING_BUILD
   if (sb_tile >= 12 && sb_tile < kFirstH)  // tuning forms of the linear tiles: split-f16 scheme, one fp32 input, plain epilogue
     return p.nterms == NT_F16X3 && !p.ln && p.C2 == 0 && !p.g[0].x_sb && p.Cin != 4 && (p.Cin % BK) == 0 && !p.ups && !p.g[0].head_kind;
 #endif
-  if (p.g[0].head_kind && !p.subpx && (kSb[sb_tile].bn != 32 || p.Cout != 32)) return false;  // the fused prediction head lives in the BN = 32 epilogue (sub-pixel form: per 32-channel phase slice)
+  if (p.g[0].head_kind && (kSb[sb_tile].bn != 32 || p.Cout != 32)) return false;  // the fused prediction head lives in the BN = 32 epilogue
   if (p.ln) {  // fused input LayerNorm: linear tiles, 1x1, fp32 rows, the whole row inside one block's K loop
     if (sb_tile >= kFirstH || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.C2 > 0 || (p.Cin % BK) != 0 || (p.Cout & 3) || p.splitk > 1 || p.ups) return false;
     for (int g = 0; g < p.groups; ++g)
@@ -114,7 +116,6 @@ bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
     return true;
   }
   if (sb_tile >= kFirstH) return conv_sbh_tile_ok(p, sb_tile - kFirstH);
-  if (p.subpx) return false;  // sub-pixel form: halo tiles only
   if (p.Cin == 4) return kSb[sb_tile].bm <= 128 && kSb[sb_tile].bn <= 128;  // stem form: built for the 4-wave tiles
   return !p.ups;
 }
@@ -171,6 +172,10 @@ void launch_conv_sb(const ConvParams& p0, int sb_tile, hipStream_t s) {
                          reinterpret_cast<const float4*>(q.res1), p.post_relu, reinterpret_cast<float4*>(q.y));
     }
   } } reduce_after{p, s};
+  if (sb_tile >= kFirstR) {
+    if (conv_rr_ok(p, sb_tile - kFirstR)) { launch_conv_rr(p, sb_tile - kFirstR, s); return; }
+    sb_tile = conv_sb_default_tile(p);
+  }
   if (sb_tile >= kFirstH) {
     if (conv_sbh_tile_ok(p, sb_tile - kFirstH)) { launch_conv_sbh(p, sb_tile - kFirstH, s); return; }
     sb_tile = conv_sb_default_tile(p);

@@ -67,14 +67,14 @@ __device__ __forceinline__ void split4_hm(const float4 v, uint2& h, uint2& m) {
 #ifndef SB_W8_WAVES
 #define SB_W8_WAVES 4  // min waves per SIMD of the 256x128 / 128x256 8-wave tiles: 4 = two blocks per CU (<= 128 VGPRs)
 #endif
-// LNF: LayerNorm of the input rows fused into a 1x1 layer (ConvParams::ln).  The staging threads subtract a per-row pivot (the
-// row's first element: LayerNorm is shift invariant, and the shifted row has no large common offset left to cancel), accumulate
+// LNF: LayerNorm of the input rows fused into a 1x1 layer (ConvParams::ln).  The staging threads subtract a per-row pivot (the mean of the
+// row's first 32 channels: LayerNorm is shift invariant, and the shifted row has no large common offset left to cancel), accumulate
 // sum / sum of squares of what they stage, and the epilogue applies  y = rstd (acc - mean colsum) + bias  -- the normalised tensor
 // is never written or read (mix_transformers.py:200, :123-126; convnext.py:50-51).
 // Ablation / scheduling forms of the linear tiles (tuning builds only; scripts/tune_sb_ablate.py, tiles "sbA<mask>_*" -- WRONG results by construction, timing only:
-// 1 = no split arithmetic while staging A, 2 = no wh 2^-11 scaling, 4 = no barriers in the K loop, 8 = half the fragment reads, 16 / 32 = no global loads of A / B --
-// "sbI_*" (0x200, right results): K-step position carried instead of divided out; "sbPI_*" (0x300, right results): that plus scheduling barriers that keep the
-// loads of the next tile in front of this tile's MFMAs and the split arithmetic behind them (hipcc sinks the loads otherwise).
+// 1 = no split arithmetic while staging A, 4 = no barriers in the K loop, 8 = half the fragment reads, 16 / 32 = no global loads of A / B.
+// Measured and deleted in r03 (profiles/r03_sb_ablate.txt): the K-step position carried instead of two integer divisions per step ("sbI_*": 64x64 -3 %, 128x128 / 256x128 +3...+20 %)
+// and that plus scheduling barriers pinning the loads in front of the MFMAs ("sbPI_*": no better).
 #ifdef PF_TUNING_BUILD
 #define SB_ABL_PARAM , int SABL = 0
 #else
@@ -202,25 +202,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   const int nK_all = p.KH * nJ;
   const int it0 = (int)((long)sidx * nK_all / S), nK = (int)((long)(sidx + 1) * nK_all / S);  // this block's K steps [it0, nK)
 
-#ifdef PF_TUNING_BUILD
-  // SABL 0x200 (tuning builds, right results): the (ky, kx, channel) position of a K step is carried from call to call (load_tiles sees consecutive steps)
-  // instead of two integer divisions by run-time values per step -- ~40 dependent SALU instructions in front of every tile's loads (hipcc -S), which is as
-  // long as the six MFMAs of a 64 x 64 tile's step.  Not for the stem form (MODE 1: its chunk is a kernel row of 8 taps).
-  constexpr bool INCR = (SABL & 0x200) != 0 && MODE != 1;
-  int q_ky = it0 / nJ, q_j0 = (it0 - q_ky * nJ) * BK, q_kx = q_j0 / p.Cin, q_ci0 = q_j0 - q_kx * p.Cin;
-  // branch-free: a step at or past nK loads from the out-of-range offset (zeros, never stored)
-  auto load_tiles = [&](int it, Raw& R) {
-    const bool live = it < nK;
-    const int ky = INCR ? q_ky : it / nJ;
-    const int j0 = INCR ? q_j0 : (it - ky * nJ) * BK;
-    const int kx = INCR ? q_kx : j0 / p.Cin;
-    const int ci0 = INCR ? q_ci0 : j0 - kx * p.Cin;
-    if constexpr (INCR) {  // advance to step it + 1
-      q_j0 += BK; q_ci0 += BK;
-      if (q_ci0 >= p.Cin) { q_ci0 = 0; ++q_kx; }
-      if (q_j0 >= p.KWCp) { q_j0 = 0; q_ci0 = 0; q_kx = 0; ++q_ky; }
-    }
-#else
   // branch-free: a step at or past nK loads from the out-of-range offset (zeros, never stored)
   auto load_tiles = [&](int it, Raw& R) {
     const bool live = it < nK;
@@ -228,7 +209,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     const int j0 = (it - ky * nJ) * BK;
     const int kx = j0 / p.Cin;
     const int ci0 = j0 - kx * p.Cin;
-#endif
     const int bit = (ky * p.KW + kx) & 63;
     const bool first = MODE != 2 || ci0 < p.C1;
     const int toff = ((ky * p.W + kx) * (first ? p.C1 : p.C2) + (first ? ci0 : ci0 - p.C1)) * ESZ;
@@ -354,16 +334,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
       for (int j = 0; j < SN; ++j)
 #pragma unroll
         for (int pl = 0; pl < NPB; ++pl) bf[j][pl] = *reinterpret_cast<const u32x4*>(Bb + pl * PLANE_B + j * 32 * SB_ROW + po);
-      if constexpr (F16) {
-#pragma unroll
-        for (int j = 0; j < SN; ++j) bf[j][2] = (SABL & 2) ? bf[j][0] : __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, bf[j][0])));
-      }
       }
       // six partial products, smallest first; the (i, j) loop is innermost so that consecutive MFMAs never
       // depend on each other's accumulator
       //                                                                                                  split-f16: al ah ah
       constexpr int TA[6] = {F16 ? 1 : (NTERM == 6 ? 2 : (NTERM == 3 ? 1 : 0)), 0, NTERM == 6 ? 1 : 0, 1, 0, 0};  // plane of A: l h m m h h | m h h | h
-      constexpr int TB[6] = {F16 ? 2 : 0, F16 ? 1 : (NTERM == 6 ? 2 : (NTERM == 3 ? 1 : 0)), NTERM == 6 ? 1 : 0, 0, 1, 0};  // plane of B: h l m h m h | h m h | h | wh2 wl wh
+      constexpr int TB[6] = {0, F16 ? 1 : (NTERM == 6 ? 2 : (NTERM == 3 ? 1 : 0)), NTERM == 6 ? 1 : 0, 0, 1, 0};  // plane of B: h l m h m h | h m h | h | wh2 wl wh
 #pragma unroll
       for (int t6 = 0; t6 < NMF; ++t6)
 #pragma unroll
@@ -399,9 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
 #pragma unroll
     for (int d = 0; d < PFD; ++d) {
       load_tiles(it + d + PFD, raw[d]);  // refill the set whose tile (it + d) is in LDS now
-      if constexpr ((SABL & 0x100) != 0) __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of this tile's MFMAs ...
       compute();                         // tile it + d
-      if constexpr ((SABL & 0x100) != 0) __builtin_amdgcn_sched_barrier(0);  // ... and the split arithmetic of the next store behind them
       if constexpr ((SABL & 4) == 0) __syncthreads();  // every wave has read this step's planes
       store_tiles(raw[(d + 1) % PFD]);   // tile it + d + 1 (the oldest loads in flight)
       if constexpr ((SABL & 4) == 0) __syncthreads();
@@ -474,14 +448,12 @@ static void launch_sb_abl(const ConvParams& p, hipStream_t s) {  // split-f16 sc
   hipLaunchKernelGGL((igemm_sb_kernel<BM, BN, WM, WN, 0, false, PFD, NT_F16X3, false, MASK>), grid, block, 0, s, p);
 }
 template <int BM, int BN, int WM, int WN, int PFD>
-static void launch_sb_abl_set(const ConvParams& p, int k, hipStream_t s) {  // k: 0..5 -> masks 16, 32, 48, 1, 0x200, 0x300
+static void launch_sb_abl_set(const ConvParams& p, int k, hipStream_t s) {  // k: 0..3 -> masks 16, 32, 48, 1
   switch (k) {
     case 0: launch_sb_abl<BM, BN, WM, WN, PFD, 16>(p, s); break;
     case 1: launch_sb_abl<BM, BN, WM, WN, PFD, 32>(p, s); break;
     case 2: launch_sb_abl<BM, BN, WM, WN, PFD, 48>(p, s); break;
-    case 3: launch_sb_abl<BM, BN, WM, WN, PFD, 1>(p, s); break;
-    case 4: launch_sb_abl<BM, BN, WM, WN, PFD, 0x200>(p, s); break;
-    default: launch_sb_abl<BM, BN, WM, WN, PFD, 0x300>(p, s); break;
+    default: launch_sb_abl<BM, BN, WM, WN, PFD, 1>(p, s); break;
   }
 }
 #endif
@@ -491,8 +463,8 @@ template <int NT>
 static void launch_conv_sb_nt(const ConvParams& p, int sb_tile, hipStream_t s) {
 #ifdef PF_TUNING_BUILD
   if constexpr (NT == NT_F16X3) {
-    if (sb_tile >= 12 && sb_tile < 12 + 24) {  // kSb[]: four base tiles x six forms
-      const int base = (sb_tile - 12) / 6, k = (sb_tile - 12) % 6;
+    if (sb_tile >= 12 && sb_tile < 12 + 16) {  // kSb[]: four base tiles x four forms
+      const int base = (sb_tile - 12) / 4, k = (sb_tile - 12) % 4;
       if (base == 0) launch_sb_abl_set<64, 64, 2, 2, 1>(p, k, s);
       else if (base == 1) launch_sb_abl_set<64, 64, 2, 2, 3>(p, k, s);
       else if (base == 2) launch_sb_abl_set<128, 128, 2, 2, 1>(p, k, s);

@@ -51,7 +51,7 @@ template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE,
                              staging is a plain 16-byte copy per plane -- no split arithmetic in this kernel (VALU instructions are paid in MFMA issue time,
                              DESIGN.md 4.7), and an element is split once by its producer instead of once per n-tile and halo overlap here.  MODE 0, no UPS.*/
           SBH_ABL_PARAM>
-__global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL & 0x5000) != 0 && (ABL & 0x8000) == 0 && BN <= 64)) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD (tuning builds: the DMA-ring variants of the 4-wave tiles keep the 128-VGPR / four-block residency of the shipped forms; 0x8000 lifts that)
+__global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || (SCH == NT_F16X3 && TPG == 1 && !DB && (ABL & 0xa000) == 0 && BN <= 64)) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD (the DMA-ring forms of the 4-wave tiles with BN <= 64 stay inside 128 VGPRs: four resident blocks; tuning builds: 0x8000 lifts that)
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
   constexpr int BM = H_TY * H_TX;
@@ -76,23 +76,16 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL 
   constexpr int S_TY = H_TY / 2 + 2, S_TX = H_TX / 2 + 2, S_PIX = S_TY * S_TX;  // 6 x 10 for an 8 x 16 patch
   constexpr int SRC_USHORTS = UPS ? S_PIX * BK * 2 : 0;
   constexpr int S_F4 = UPS ? (S_PIX * 8 + NT - 1) / NT : 1;  // float4 loads per thread per source chunk (2)
-  // DMAW: the weights of a tap go from global memory straight into LDS (global_load_lds_dwordx4, no staging registers, no
-  // ds_write) into a ring of three buffers, two taps ahead of their use, one barrier per tap.  Motivation (profiles/r02_sbh_ablation.md): hipcc sinks the
-  // register-staged weight loads of the plain loop to the END of the tap's MFMA phase (it reuses the fragment registers for them under the 128-VGPR cap), so
-  // their L2 latency is exposed in every tap: 18 % of the kernel's time on 256 -> 256 @80^2.
-  // Default for the 16 x 16 patch / 8-wave tile (the 256 -> 256 decoder convs): its two resident blocks per CU fit the 66 KB; on the 4-wave tiles the ring would
-  // cost a resident block.  Measured (profiles/r02_sbh_ablation.md): 256 -> 256 @80^2 0.790 -> 0.762 ms, @40^2 0.253 -> 0.244, 64 -> 256 @80^2 0.210 -> 0.200,
-  // bit-identical results (same products, same order).  Tuning builds: ABL bit 0x1000 forces the ring, 0x2000 the register-staged loop.
-#ifdef PF_TUNING_BUILD
-  // 0x4000 the ring with TWO buffers (one tap ahead, issued at the start of the step: for the 4-wave tiles, where a third buffer costs a resident block).
-  constexpr bool DMAW = (ABL & 0x2000) == 0 && ((ABL & 0x5000) != 0 || (H_TY == 16 && BN == 64 && WM * WN == 8 && SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0));
-  static_assert(!DMAW || (SCH == NT_F16X3 && TPG == 1 && !DB), "DMA weights: split-f16 scheme, plain tap loop");
-  constexpr int NBUF = DMAW ? ((ABL & 0x4000) ? 2 : 3) : (DB ? 2 : 1);
-#else
-  constexpr bool DMAW = (ABL & 0x2000) == 0 && ((ABL & 0x1000) != 0 || (H_TY == 16 && BN == 64 && WM * WN == 8 && SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0));
-  static_assert(!DMAW || (SCH == NT_F16X3 && TPG == 1 && !DB && !UPS && !ASB && MODE == 0), "DMA weights: split-f16 scheme, plain tap loop, one fp32 input");
-  constexpr int NBUF = DMAW ? 3 : (DB ? 2 : 1);
-#endif
+  // DMAW: the weights of a tap go from global memory straight into LDS (global_load_lds_dwordx4, no staging registers, no ds_write) into a ring of buffers ahead of
+  // their use, one barrier per tap.  Motivation (profiles/r02_sbh_ablation.md): hipcc sinks the register-staged weight loads of the plain loop to the END of the tap's
+  // MFMA phase (it reuses the fragment registers for them under the 128-VGPR cap), so their L2 latency is exposed in every tap: 18 % of the kernel's time on
+  // 256 -> 256 @80^2.  Every split-f16 tile with the plain tap loop uses it (r03): THREE buffers (two taps ahead) on the 16 x 16 patch / 8-wave tile of the
+  // 256 -> 256 decoder convs, whose two resident blocks per CU fit the 66 KB (0.790 -> 0.762 ms at 256 -> 256 @80^2); TWO buffers (one tap ahead, issued at the
+  // start of the step) on the 4-wave tiles, where a third buffer would cost a resident block (profiles/r03_sbh_variants.txt: 128x32 0.563 -> 0.507 ms, 256x32
+  // 0.503 -> 0.465, 128x128 0.220 -> 0.204, 128x64 0.214 -> 0.209; +0.8 % end to end once the unscaled low plane had halved the K loop's VALU work).  Results are
+  // bit-identical to the register-staged loop (same products, same order).  Tuning builds: ABL bit 0x2000 forces the register-staged loop, 0x1000 / 0x4000 three / two buffers.
+  constexpr bool DMAW = SCH == NT_F16X3 && TPG == 1 && !DB && (ABL & 0x2000) == 0;
+  constexpr int NBUF = DMAW ? (((ABL & 0x1000) != 0 || ((ABL & 0x4000) == 0 && H_TY == 16 && BN == 64 && WM * WN == 8)) ? 3 : 2) : (DB ? 2 : 1);
   constexpr int OPER_USHORTS = NPA * PLANE_A + NBUF * BBUF + SRC_USHORTS;
   constexpr int SMEM_USHORTS = OPER_USHORTS > EPI_USHORTS ? OPER_USHORTS : EPI_USHORTS;
   __shared__ __attribute__((aligned(16))) unsigned short smem_u[SMEM_USHORTS];
@@ -141,12 +134,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL 
     const int e = tid + NT * i;
     const int hrow = e >> 3, c4 = e & 7;
     const int hy = hrow / H_HX, hx = hrow - hy * H_HX;
-#ifdef PF_TUNING_BUILD
-    int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-    if (p.subpx) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }  // sub-pixel form: replicate padding (the interpolation's clamping)
-#else
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-#endif
     const bool in_tile = hrow < H_ROWS;
     const bool ok = in_tile && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     const int pix = (bimg * p.H + iy) * p.W + ix;
@@ -383,11 +371,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL 
       for (int j = 0; j < SN; ++j) {
 #pragma unroll
         for (int pl = 0; pl < NPB; ++pl) bf[j][pl] = *reinterpret_cast<const u32x4*>(Bb + (slot * NPB + pl) * PLANE_B + j * 32 * H_ROW + pob);
-        if (F16) bf[j][2] = (ABL & 2) ? bf[j][0] : __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, bf[j][0])));
       }
       }
       constexpr int TA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};  // plane of A: l h m m h h | split-f16: al ah ah
-      constexpr int TB[6] = {F16 ? 2 : 0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};  // plane of B: h l m h m h | split-f16: wh2 wl wh
+      constexpr int TB[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};  // plane of B: h l m h m h | split-f16: wh wl wh (al is unscaled: no wh 2^-11 operand)
 #pragma unroll
       for (int t6 = 0; t6 < (F16 ? 3 : 6); ++t6)
 #pragma unroll
@@ -400,7 +387,6 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL 
 
   // prologue: halo chunk 0 and the weights of the first tap group -> LDS
   constexpr int NG = 9 / TPG;  // tap groups per chunk
-#ifdef PF_TUNING_BUILD  // generalised ring (two or three buffers, concat / fused up-sampling inputs): measured in tuning builds first
   if constexpr (DMAW) {
     constexpr int AHEAD = NBUF - 1;  // taps of look-ahead
     // VMEM instructions one load_a() issues (out-of-range offsets still issue): the static vmcnt bookkeeping below depends on it
@@ -436,33 +422,6 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL 
         par ^= 1;
       }
     }
-#else  // the validated form of the shipped tile (three buffers, one fp32 input)
-  if constexpr (DMAW) {
-    load_a(0);
-    dma_b(0, 0, 0);
-    dma_b(0, 1, 1);
-    store_a();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // step q = 9 c + g reads weight buffer q % 3 = g % 3; the DMA of step q + 2 goes into buffer (g + 2) % 3, last read in step q - 1 (every wave is past
-    // the barrier that ended it).  End of step q: every wave waits for ITS part of step q + 1's weights (issued one step ago: the younger VMEM
-    // instructions -- this step's DMA and the halo loads of this / the previous step -- stay in flight), then one barrier.
-    constexpr int LA = NG / 2;
-    for (int c = 0; c < nC; ++c) {
-#pragma unroll
-      for (int g = 0; g < 9; ++g) {
-        dma_b(g + 2 < 9 ? c : c + 1, (g + 2) % 9, (g + 2) % 3);
-        if (g == LA) load_a(c + 1);
-        compute(g, 0, g % 3);
-        constexpr int younger = DMA_R;  // this step's DMA
-        if (g == LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger + A_F4) : "memory");
-        else if (g == LA + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger + A_F4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger) : "memory");
-        if (g == 8 && c + 1 < nC) { __syncthreads(); store_a(); }  // every wave has read this chunk's halo
-        __syncthreads();
-      }
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two look-ahead DMAs past the end: the epilogue reuses the LDS
     __syncthreads();
   } else {
@@ -512,14 +471,6 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || ((ABL 
   }
 
   const Tile2D t2{bimg, oy0, ox0, H_TX, ODD_SHIFT};
-#ifdef PF_TUNING_BUILD
-  if constexpr (BN == 128 && F16 && MODE == 0 && !UPS && !ASB) {
-    if (p.subpx) {  // launch-uniform
-      epilogue_subpx<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, p.subpx_corr[g1 ? 1 : 0], acc, reinterpret_cast<float*>(smem_u), n0, t2, P.w_h16_inv_scale);
-      return;
-    }
-  }
-#endif
   epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), 0, n0, &t2, F16 ? P.w_h16_inv_scale : nullptr);
 }
 
@@ -530,29 +481,6 @@ static void launch_sbh_abl(const ConvParams& p, hipStream_t s) {  // sbh256x64w8
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(512);
   if (p.nterms != NT_F16X3 || p.C2 > 0 || p.ups || p.g[0].x_sb) return;
   hipLaunchKernelGGL((igemm_sbh_kernel<16, 16, 64, 4, 2, 0, 1, NT_F16X3, false, false, false, MASK>), grid, block, 0, s, p);
-}
-#endif
-
-#ifdef PF_TUNING_BUILD
-// DMA weight ring (MASK 0x4000: two buffers, 0x1000: three) on any tile geometry, every input form of the split-f16 scheme: right results, candidates for the product
-template <int H_TY, int H_TX, int BN, int WM, int WN, int MASK>
-static void launch_sbh_var(const ConvParams& p, hipStream_t s) {
-  const int tilesN = (p.Cout + BN - 1) / BN, tilesX = (p.Wo + H_TX - 1) / H_TX, tilesY = (p.Ho + H_TY - 1) / H_TY;
-  const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(WM * WN * 64);
-  if (p.nterms != NT_F16X3) return;
-  if (p.g[0].x_sb) {  // split-f16 planes from the producer (PF_SBA_HEADS=1): register copy of the halo, DMA ring for the weights
-    if (p.C2 == 0 && !p.ups) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, 1, NT_F16X3, false, false, true, MASK>), grid, block, 0, s, p);
-    return;
-  }
-  if (p.ups) {
-    if constexpr (WM * WN == 4) {
-      if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, 1, NT_F16X3, false, true, false, MASK>), grid, block, 0, s, p);
-      else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, 1, NT_F16X3, false, true, false, MASK>), grid, block, 0, s, p);
-    }
-    return;
-  }
-  if (p.C2 > 0) hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 2, 1, NT_F16X3, false, false, false, MASK>), grid, block, 0, s, p);
-  else          hipLaunchKernelGGL((igemm_sbh_kernel<H_TY, H_TX, BN, WM, WN, 0, 1, NT_F16X3, false, false, false, MASK>), grid, block, 0, s, p);
 }
 #endif
 
@@ -601,26 +529,11 @@ bool conv_sbh_ok(const ConvParams& p) {
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
   if (!conv_sbh_ok(p)) return false;
 #ifdef PF_TUNING_BUILD
-  if (p.subpx) return (h_tile == 0 || h_tile == 35) && p.nterms == NT_F16X3 && p.Cout == 128 && p.C2 == 0 && !p.ups && !p.g[0].x_sb;  // sbh128x128 / sbhV2_128x128: the four phases in one block
-#else
-  if (p.subpx) return false;
-#endif
-#ifdef PF_TUNING_BUILD
   constexpr int kWide32 = 10;  // "sbh256x32": after the tuning-only tiles
 #else
   constexpr int kWide32 = 4;
 #endif
-#ifdef PF_TUNING_BUILD
-  if (p.g[0].x_sb && h_tile >= 31) return true;  // DMA-ring variants take plane input too (conv_sbh_ok: one input, no fused up-sampling)
-#endif
   if (p.g[0].x_sb) return h_tile < 4 || h_tile == kWide32;  // plane input: the plain-tap-loop tiles
-#ifdef PF_TUNING_BUILD
-  if (h_tile >= 31) {  // DMA-ring variants of the shipped tiles: every fp32 input form of the split-f16 scheme (fused up-sampling: the 4-wave tiles)
-    if (p.nterms != NT_F16X3) return false;
-    if (p.ups) return h_tile != 36 && (p.H % 2) == 0 && (p.W % 2) == 0;
-    return true;
-  }
-#endif
   if (p.ups) return (h_tile < 3 || h_tile == kWide32) && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
 #ifdef PF_TUNING_BUILD
   if (h_tile >= 13) return p.nterms == NT_F16X3 && p.C2 == 0;  // ablation forms: one plain fp32 input
@@ -675,12 +588,6 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
     case 28: launch_sbh_abl<0x900>(p, s); break;
     case 29: launch_sbh_abl<0x1000>(p, s); break;
     case 30: launch_sbh_abl<0x2000>(p, s); break;
-    case 31: launch_sbh_var<8, 16, 64, 2, 2, 0x4000>(p, s); break;    // "sbhV2_128x64"
-    case 32: launch_sbh_var<8, 16, 32, 4, 1, 0x4000>(p, s); break;    // "sbhV2_128x32"
-    case 33: launch_sbh_var<16, 16, 32, 4, 1, 0x4000>(p, s); break;   // "sbhV2_256x32"
-    case 34: launch_sbh_var<8, 16, 64, 2, 2, 0x1000>(p, s); break;    // "sbhV3_128x64"
-    case 35: launch_sbh_var<8, 16, 128, 2, 2, 0x4000>(p, s); break;   // "sbhV2_128x128"
-    case 36: launch_sbh_var<16, 16, 64, 4, 2, 0x4000>(p, s); break;   // "sbhV2_256x64w8"
 #endif
     default: launch_sbh_cfg<16, 16, 64, 4, 2>(p, s); break;  // 16 x 16 patch, 8 waves, two blocks per CU: weights staged once per 256 rows
   }

@@ -27,7 +27,6 @@ typedef _Float16 mm_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mm_mfma(const u32x4 a, const u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mm_f16x8, a), __builtin_bit_cast(mm_f16x8, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ u32x4 mm_scale(const u32x4 w) { return __builtin_bit_cast(u32x4, scale8_f16_2m11(__builtin_bit_cast(float4, w))); }
 
 // Chunk layout (mit_mlp_pack in engine.hip), CHUNK_BYTES per 32 hidden units, fp16 fragments lane-major (64 lanes x 8 values = 1 KB each):
 //   [0, S1 * 2 KB)                      W1: [s][plane hi / lo][lane][8] = W1s[32 t + (lane & 31)][(lane >> 5) C/2 + 8 s + e]      (S1 = C / 16)
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
         for (int s = 0; s < S1; ++s) {
           const u32x4 wh = *reinterpret_cast<const u32x4*>(w1f + (s * 2) * 512);
           const u32x4 wl = *reinterpret_cast<const u32x4*>(w1f + (s * 2 + 1) * 512);
-          a1 = mm_mfma(mm_scale(wh), xl[k][s], a1);
+          a1 = mm_mfma(wh, xl[k][s], a1);
           a1 = mm_mfma(wl, xh[k][s], a1);
           a1 = mm_mfma(wh, xh[k][s], a1);
         }
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
       for (int j = 0; j < 2; ++j) {
         const u32x4 wh = *reinterpret_cast<const u32x4*>(w2f + (((q0 + j) * 2 + u) * 2) * 512);
         const u32x4 wl = *reinterpret_cast<const u32x4*>(w2f + (((q0 + j) * 2 + u) * 2 + 1) * 512);
-        acc2[j] = mm_mfma(mm_scale(wh), hl, acc2[j]);
+        acc2[j] = mm_mfma(wh, hl, acc2[j]);
         acc2[j] = mm_mfma(wl, hh, acc2[j]);
         acc2[j] = mm_mfma(wh, hh, acc2[j]);
       }

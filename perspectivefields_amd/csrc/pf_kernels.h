@@ -78,13 +78,6 @@ struct ConvParams {
   unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)
   unsigned w_sb_plane_bytes;            // bytes of one bf16 weight plane
   size_t x_sb_plane = 0, x2_sb_plane = 0, y_sb_plane = 0;  // elements between consecutive planes of x_sb / x2_sb / y_sb
-  // Sub-pixel form of conv3x3(bilinear x2 (x)) (scripts/proto/subpixel_conv.py; used by tuning builds only so far): the launch is the 3x3 conv on the
-  // HALF-resolution map with Cout = 4 x (real channels) phase-major virtual channels (weights combined on the host), replicate instead of zero padding (clamped halo
-  // coordinates); the epilogue stores virtual channel (py, px, c) of pixel (oy, ox) as channel c of pixel (2 oy + py, 2 ox + px) -- or feeds it to the fused prediction
-  // head -- and adds subpx_corr[group] ([B][2 Wo + 2 Ho][Cout]: the closed-form terms of the taps that land on the zero padding of the up-sampled map, border pixels
-  // only) in front of the bias.  Trailing members: the offsets of everything above are those of the shipped kernels.
-  int subpx = 0;
-  const float* subpx_corr[2] = {nullptr, nullptr};
   // fills the derived fields (Ho, Wo, M, Cin, *_bytes) from the primary ones
   void finish() {
     Cin = C1 + C2;
@@ -99,11 +92,6 @@ struct ConvParams {
   }
 };
 
-#ifdef PF_TUNING_BUILD
-// Border terms of the sub-pixel form (ConvParams::subpx_corr): x [B][H][W][Cin] half-resolution input, tab = the host-combined tables
-// top / bottom [2 px][3 dx][Cin][Cr], left / right [2 py][3 dy][Cin][Cr], corner [2 py][2 px][Cin][Cr]; corr [B][2 W + 2 H][4 Cr]
-void launch_subpx_corr(const float* x, const float* tab, float* corr, int B, int H, int W, int Cin, int Cr, hipStream_t s);
-#endif
 void launch_conv(const ConvParams& p, hipStream_t s);
 // tile choice is exposed for tests / tuning: -1 = auto
 void launch_conv_tile(const ConvParams& p, int tile_id, hipStream_t s);

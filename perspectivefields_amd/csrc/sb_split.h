@@ -45,47 +45,31 @@ __device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2
   l = make_uint2(sb_pack_hi16(lb[0], lb[1]), sb_pack_hi16(lb[2], lb[3]));
 }
 
-// ---- split-f16 scheme (NT_F16X3): x ~ hi + lo * 2^-11 with hi = fp16_rn(x), lo = fp16_rn((x - hi) * 2^11): 22-23 significant
-// bits in two fp16 values (representation error <= 2^-22 |x|).  |x| is clamped to the fp16 range (65504) first, so an
-// out-of-range activation saturates instead of turning into inf - inf; the scaled remainder is at most |x| / 2.
-// PF_LO_UNSCALED (build switch, python -m perspectivefields_amd.build with PF_LO_UNSCALED=1; candidate for the next round, profiles/r02_mfma_f16_subnormals.md): the low
-// plane is carried UNSCALED, lo = fp16_rn(x - hi).  The matrix cores of gfx950 keep fp16 subnormal inputs (measured), so nothing is lost below 2^-14 either: same
-// accuracy over the whole network in the CPU emulation (scripts/emulate_split.py f16x3u) -- and the third weight operand wh 2^-11 (4 v_pk_mul_f16 per weight
-// fragment in every split kernel) and one multiply per split element disappear.  SB_LO_SCALE / SB_LO_UNSCALE are the factors on the stored low part / on its use.
-#ifdef PF_LO_UNSCALED
-#define SB_LO_SCALE 1.0f
-#define SB_LO_UNSCALE 1.0f
-#else
-#define SB_LO_SCALE 2048.f
-#define SB_LO_UNSCALE 0.00048828125f
-#endif
+// ---- split-f16 scheme (NT_F16X3): x ~ hi + lo with hi = fp16_rn(x), lo = fp16_rn(x - hi), the low part UNSCALED (r03; r02 carried lo 2^11 and paid for it with a
+// third weight operand wh 2^-11 made per fragment in registers: 72 of the 242 VALU instructions of a halo-kernel chunk).  The matrix cores of gfx950 keep fp16
+// subnormal inputs (measured, profiles/r02_mfma_f16_subnormals.md), so lo stays usable below 2^-14.  Representation error: <= 2^-22 |x| for |x| >= 2^-3 (lo is a
+// normal fp16 number there), <= 2^-25 ABSOLUTE below (lo is a subnormal: quantum 2^-24) -- an error of 3e-8 per element, i.e. fp32 rounding at unit scale; it is a
+// RELATIVE loss only for a tensor whose every element is << 0.1 (pf_check_range reports such tensors; precision "fp32_bf16x6" has no such window).  |x| is clamped to
+// the fp16 range (65504) first, so an out-of-range activation saturates instead of turning into inf - inf.
+// Instruction count: v_med3 + (half a) v_cvt_pk_f16_f32 + one v_fma_mix{lo,hi}_f16 per element -- the mixed-precision fma takes the fp32 value and the fp16 hi part
+// (fp16 source operand, negated) and rounds x - hi straight to fp16: 2.5 VALU instructions per element where the C expression compiles to 4.25 (cvt back to fp32,
+// subtract, convert, pack).  x - hi is exact in fp32, so the fma rounds once, like the C expression it replaces (bit check: tests/test_gpu_ops.py::test_split_planes_bits).
 typedef _Float16 sb_h2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split4_f16(const float4 v, uint2& h, uint2& l) {
-  const float a[4] = {v.x, v.y, v.z, v.w};
-  _Float16 hh[4], ll[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float c = __builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);
-    hh[e] = (_Float16)c;
-    ll[e] = (_Float16)((c - (float)hh[e]) * SB_LO_SCALE);
-  }
-  const sb_h2 h0 = {hh[0], hh[1]}, h1 = {hh[2], hh[3]}, l0 = {ll[0], ll[1]}, l1 = {ll[2], ll[3]};
-  h = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-  l = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+__device__ __forceinline__ void split2_f16(const float a0, const float a1, unsigned& h, unsigned& l) {
+  const float c0 = __builtin_amdgcn_fmed3f(a0, -65504.f, 65504.f), c1 = __builtin_amdgcn_fmed3f(a1, -65504.f, 65504.f);
+  const sb_h2 hv = {(_Float16)c0, (_Float16)c1};
+  h = __builtin_bit_cast(unsigned, hv);
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(c0), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(c1), "v"(h));
 }
-// 8 fp16 values (one 16-byte piece) times 2^-11 (exact unless the result is subnormal): the third weight plane wh2 = wh * 2^-11
-__device__ __forceinline__ float4 scale8_f16_2m11(const float4 v) {
-#ifdef PF_LO_UNSCALED
-  return v;  // the low activation plane is unscaled: the product al * wh needs no 2^-11
-#endif
-  const sb_h2 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
-  auto mul = [&](float f) { return __builtin_bit_cast(float, (sb_h2)(__builtin_bit_cast(sb_h2, f) * k)); };
-  return make_float4(mul(v.x), mul(v.y), mul(v.z), mul(v.w));
+__device__ __forceinline__ void split4_f16(const float4 v, uint2& h, uint2& l) {
+  split2_f16(v.x, v.y, h.x, l.x);
+  split2_f16(v.z, v.w, h.y, l.y);
 }
 
 // ---- plane formats.  Every `plane` argument of the producers / consumers below is (elements between consecutive planes,
 // always even) | format bit:  0 = three exact bf16 planes (x == h + m + l),  SB_FMT_F16 = two fp16 planes of the split-f16
-// scheme (x ~ hi + lo 2^-11: the same two values the split-f16 GEMM would compute from the fp32 tensor while staging it,
+// scheme (x ~ hi + lo: the same two values the split-f16 GEMM would compute from the fp32 tensor while staging it,
 // 4 bytes per element like the fp32 tensor itself -- the consuming GEMM's A staging becomes a plain copy).
 // (SB_FMT_F16 is declared in pf_kernels.h)
 
@@ -108,12 +92,11 @@ __device__ __forceinline__ void store_sb4(unsigned short* base, size_t plane_fmt
 
 __device__ __forceinline__ float4 load_sb4(const unsigned short* base, size_t plane_fmt, size_t idx) {
   const size_t plane_elems = plane_fmt & ~(size_t)1;
-  if (plane_fmt & SB_FMT_F16) {  // hi + lo 2^-11 (the value the split-f16 GEMM works with; not the original fp32 bits)
+  if (plane_fmt & SB_FMT_F16) {  // hi + lo (the value the split-f16 GEMM works with; not the original fp32 bits)
     const uint2 h = *reinterpret_cast<const uint2*>(base + idx);
     const uint2 l = *reinterpret_cast<const uint2*>(base + plane_elems + idx);
     auto f = [](unsigned w, int hi) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(hi ? (w >> 16) : (w & 0xffffu))); };
-    const float s = SB_LO_UNSCALE;
-    return make_float4(fmaf(f(l.x, 0), s, f(h.x, 0)), fmaf(f(l.x, 1), s, f(h.x, 1)), fmaf(f(l.y, 0), s, f(h.y, 0)), fmaf(f(l.y, 1), s, f(h.y, 1)));
+    return make_float4(f(l.x, 0) + f(h.x, 0), f(l.x, 1) + f(h.x, 1), f(l.y, 0) + f(h.y, 0), f(l.y, 1) + f(h.y, 1));
   }
   const uint2 h = *reinterpret_cast<const uint2*>(base + idx);
   const uint2 m = *reinterpret_cast<const uint2*>(base + plane_elems + idx);

@@ -269,27 +269,3 @@ def dwconv3x3_bench(variant, B, H, W, C, iters=10, device=0):
     ms = ctypes.c_float()
     _check(lib.pf_op_dwconv3x3_bench(device, variant, B, H, W, C, iters, ctypes.byref(ms)), None, "pf_op_dwconv3x3_bench")
     return ms.value
-
-
-def subpx_conv(x, weight, bias=None, act=0, tile=-1):
-    """TUNING BUILDS ONLY (pf_tuning_subpx_conv): act(conv3x3_pad1(bilinear_x2(x)) + bias) in its sub-pixel form -- four phase convs on the half-resolution map with
-    host-combined weights + closed-form border terms.  x: (B,H,W,Cin) cuda fp32, Cin % 32 == 0; weight (32,Cin,3,3) -> (B,2H,2W,32).
-    Returns None when the library is a product build."""
-    import torch
-
-    lib = load_library()
-    fn = getattr(lib, "pf_tuning_subpx_conv", None)
-    if fn is None:
-        return None
-    fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                   ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    x = x.contiguous()
-    B, H, W, Cin = x.shape
-    w = _np(weight)
-    b = _np(bias)
-    Cr = w.shape[0]
-    y = torch.empty((B, 2 * H, 2 * W, Cr), dtype=torch.float32, device=x.device)
-    rc = fn(x.device.index, x.data_ptr(), B, H, W, Cin, _hp(w), _hp(b), Cr, act, tile, y.data_ptr(), _stream_ptr())
-    _check(rc, None, "pf_tuning_subpx_conv")
-    return y

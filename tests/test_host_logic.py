@@ -197,17 +197,17 @@ def test_split_bf16_scheme_is_fp32_accurate():
 
 
 def test_split_f16_scheme_is_fp32_class():
-    """The default parity scheme of the split kernels (csrc/igemm_sb_impl.h, NT_F16X3): a ~ ah + al 2^-11 with two fp16
-    values, weights scaled per output channel by a power of two and split as wh + wl, three partial products
-    ah wh + ah wl + al (wh 2^-11) in ONE fp32 accumulator.  Emulated in numpy (fp16 rounding by numpy, products and sums
-    exact in float64): the per-product error is <= 3 * 2^-22 and the dot-product error stays at the level of a plain fp32
-    dot product -- for O(1) data, for per-channel weight magnitudes over 2^+-20 and for activations down to 1e-6."""
+    """The default parity scheme of the split kernels (csrc/sb_split.h, NT_F16X3): a ~ ah + al with ah = fp16_rn(a), al = fp16_rn(a - ah) UNSCALED (the matrix
+    cores keep fp16 subnormals), weights scaled per output channel by a power of two and split as wh + wl, three partial products ah wh + ah wl + al wh in ONE fp32
+    accumulator.  Emulated in numpy (fp16 rounding by numpy, which keeps subnormals; products and sums exact in float64): the per-product error is
+    <= 3 * 2^-22 relative for |a| >= 2^-3 plus 2^-25 ABSOLUTE per element below (al is an fp16 subnormal there), and the dot-product error of O(1) data stays at the
+    level of a plain fp32 dot product -- also with per-channel weight magnitudes over 2^+-20."""
     rng = np.random.default_rng(1)
 
     def split_a(a):
         a = np.clip(a.astype(np.float32), -65504, 65504)
         hi = a.astype(np.float16)
-        lo = ((a - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+        lo = (a - hi.astype(np.float32)).astype(np.float16)
         return hi.astype(np.float64), lo.astype(np.float64)
 
     def split_w(w):  # rows = output channels
@@ -218,38 +218,31 @@ def test_split_f16_scheme_is_fp32_class():
         assert np.array_equal(ws.astype(np.float64), w.astype(np.float64) * S.astype(np.float64)), "power-of-two scale must be exact"
         hi = ws.astype(np.float16)
         lo = (ws - hi.astype(np.float32)).astype(np.float16)
-        h2 = (hi * np.float16(2.0 ** -11)).astype(np.float16)
-        return hi.astype(np.float64), lo.astype(np.float64), h2.astype(np.float64), 1.0 / S.astype(np.float64)
+        return hi.astype(np.float64), lo.astype(np.float64), 1.0 / S.astype(np.float64)
 
-    for a_scale, w_spread in ((1.0, 0), (1.0, 20), (1e-3, 0), (300.0, 8)):
+    for a_scale, w_spread in ((1.0, 0), (1.0, 20), (1e-3, 0), (1e-6, 0), (300.0, 8)):
         a = (rng.standard_normal((48, 2304)) * a_scale).astype(np.float32)
         w = (rng.standard_normal((40, 2304)) / 48).astype(np.float32) * np.exp2(rng.integers(-w_spread, w_spread + 1, (40, 1))).astype(np.float32)
         ah, al = split_a(a)
-        wh, wl, wh2, inv = split_w(w)
-        got = ((ah @ wh.T) + (ah @ wl.T) + (al @ wh2.T)) * inv.T
+        wh, wl, inv = split_w(w)
+        got = ((ah @ wh.T) + (ah @ wl.T) + (al @ wh.T)) * inv.T
         ref = a.astype(np.float64) @ w.astype(np.float64).T
         scale = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T
-        err = np.max(np.abs(got - ref) / scale)
-        assert err <= 3 * 2.0 ** -22, (a_scale, w_spread, err)
-        f32 = (a @ w.T).astype(np.float64)
-        assert np.max(np.abs(got - ref) / scale) <= 4 * np.max(np.abs(f32 - ref) / scale) + 2.0 ** -24, (a_scale, w_spread)
-    # below the fp16 normal range (|a| < ~1.2e-4) the representation error becomes ABSOLUTE, 2^-36 per element (fp16 subnormal
-    # spacing of the scaled low part): harmless next to O(1) terms, a relative loss only for an all-tiny tensor
-    a = (rng.standard_normal((48, 2304)) * 1e-6).astype(np.float32)
-    w = (rng.standard_normal((40, 2304)) / 48).astype(np.float32)
-    ah, al = split_a(a)
-    wh, wl, wh2, inv = split_w(w)
-    got = ((ah @ wh.T) + (ah @ wl.T) + (al @ wh2.T)) * inv.T
-    ref = a.astype(np.float64) @ w.astype(np.float64).T
-    bound = 2.0 ** -35 * np.abs(w).astype(np.float64).sum(axis=1)[None, :] + 3 * 2.0 ** -22 * (np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T)
-    assert np.all(np.abs(got - ref) <= bound)
-    # representation: 22+ significant bits per operand, saturation at the fp16 range
+        bound = 3 * 2.0 ** -22 * scale + 2.0 ** -25 * np.abs(w).astype(np.float64).sum(axis=1)[None, :]
+        assert np.all(np.abs(got - ref) <= bound), (a_scale, w_spread)
+        if a_scale >= 1.0:  # O(1) data: the level of a plain fp32 dot product
+            f32 = (a @ w.T).astype(np.float64)
+            assert np.max(np.abs(got - ref) / scale) <= 4 * np.max(np.abs(f32 - ref) / scale) + 2.0 ** -24, (a_scale, w_spread)
+            assert np.max(np.abs(got - ref) / scale) <= 3 * 2.0 ** -22
+    # representation: 22+ significant bits per operand from 2^-3 up, 2^-25 absolute below, saturation at the fp16 range
     x = (rng.standard_normal(100000) * np.exp(rng.uniform(-8, 8, 100000))).astype(np.float32)
-    x = x[(np.abs(x) >= 1.3e-4) & (np.abs(x) <= 65504)]
+    x = x[np.abs(x) <= 65504]
     hi, lo = split_a(x)
-    assert np.max(np.abs(hi + lo / 2048 - x) / np.abs(x)) <= 2.0 ** -22
+    big = np.abs(x) >= 0.125
+    assert np.max(np.abs(hi + lo - x)[big] / np.abs(x[big])) <= 2.0 ** -22
+    assert np.max(np.abs(hi + lo - x)[~big]) <= 2.0 ** -25
     hi, lo = split_a(np.array([1e9, -1e9], dtype=np.float32))
-    assert np.array_equal(hi + lo / 2048, [65504.0, -65504.0])
+    assert np.array_equal(hi + lo, [65504.0, -65504.0])
 
 
 def test_load_state_dict_strictness():
@@ -432,34 +425,20 @@ def test_kernel_resources_static():
         "pf::cnx_mlp_kernel<96, 0>", "pf::mit_mlp_kernel<64, 8, 16>",  # fused block MLPs (hidden map on chip)
         "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23, true>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 2, 23, true>", "pf::igemm_sb_kernel<128, 256, 2, 4, 0, false, 1, 23, true>",
     ]
+    # r03: the 128 x 64 halo tile with the two-buffer DMA weight ring keeps the 128-VGPR cap (four resident blocks) at the price of 8 registers spilled around the
+    # once-per-chunk halo store (4 reloads per 32-channel chunk, none in the tap loop): measured faster than the uncapped form (profiles/r03_sbh_variants.txt)
+    # ... and the LayerNorm-fused 128 x 256 / 8-wave tile spills 3 registers in its prologue since the pivot became a chunk mean
+    few_spills = {"pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 23, false, false, false>": 8, "pf::igemm_sb_kernel<128, 256, 2, 4, 0, false, 1, 23, true>": 3}
+    hot += ["pf::rr_gemm_kernel<160, 5, false>", "pf::rr_gemm_kernel<160, 5, true>", "pf::rr_gemm_kernel<128, 4, false>", "pf::rr_gemm_kernel<128, 4, true>", "pf::dwconv7x7_lds_kernel<2, 13>"]
     for k in hot:
         assert k in by, (k, [n for n in by if n.startswith(k.split("<")[0])][:4])
-        assert by[k]["spill"] == 0 and by[k]["scratch"] == 0, by[k]
+        assert by[k]["spill"] <= few_spills.get(k, 0) and by[k]["scratch"] <= 6 * few_spills.get(k, 0), by[k]
     # the two-blocks-per-CU 8-wave tiles trade a handful of spilled registers for the second resident block
     assert by["pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 6, false>"]["vgpr"] <= 128
 
 
-def test_subpixel_form_of_upsample_conv_algebra():
-    """Planned next kernel form: conv3x3(bilinear_up2(x)) as four phase convs on the half-resolution map with host-combined weights plus closed-form
-    border corrections (scripts/proto/subpixel_conv.py) -- the algebra against torch's interpolate + conv2d in float64, incl. 1-pixel-wide maps."""
-    import importlib.util
-
-    import torch
-    import torch.nn.functional as F
-
-    spec = importlib.util.spec_from_file_location("subpixel_conv", os.path.join(ROOT, "scripts", "proto", "subpixel_conv.py"))
-    sp = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(sp)
-    rng = np.random.default_rng(1)
-    for cin, cout, h, w_ in [(6, 5, 5, 8), (3, 3, 1, 1), (2, 4, 3, 1)]:
-        x = rng.standard_normal((cin, h, w_))
-        w = rng.standard_normal((cout, cin, 3, 3))
-        ref = F.conv2d(F.interpolate(torch.from_numpy(x)[None], scale_factor=2, mode="bilinear", align_corners=False), torch.from_numpy(w), padding=1)[0].numpy()
-        assert np.abs(sp.subpixel_conv(x, w) - ref).max() < 1e-9
-
-
 def test_unscaled_low_plane_representation():
-    """Candidate form of the split-f16 scheme (build switch PF_LO_UNSCALED, profiles/r02_mfma_f16_subnormals.md): lo = fp16_rn(x - hi) WITHOUT the 2^11 scale, relying
+    """The split-f16 scheme's low plane (sb_split.h; adopted in r03, profiles/r03_candidates.md): lo = fp16_rn(x - hi) WITHOUT a 2^11 scale, relying
     on the matrix cores keeping fp16 subnormals (measured on gfx950).  Representation error: <= 2^-22 |x| while lo is a normal fp16 (|x| >= 2^-2 is sufficient),
     an ABSOLUTE 2^-25 below that (subnormal spacing 2^-24) -- i.e. what differs from the scaled form is the error of SMALL elements (2^-25 instead of 2^-36), which is
     harmless next to O(1) terms of the same dot product and a relative loss only for an all-tiny tensor."""
@@ -485,27 +464,3 @@ def test_unscaled_low_plane_representation():
     assert np.max(np.abs(got - ref) / scale) <= 3 * 2.0 ** -22
 
 
-def test_carried_k_step_position_equals_divided():
-    """Candidate change of the linear split-GEMM tiles (igemm_sb_impl.h, tuning form "sbI_*"): the (ky, kx, channel) position of a K step is CARRIED from one
-    load_tiles call to the next instead of being divided out of the step index (two integer divisions by run-time values = ~40 SALU instructions per step).
-    Emulation of both index computations over the shapes of the forward, incl. split-K start offsets and the steps past the end that the branch-free prefetch issues."""
-    BK = 32
-    for KH, KW, Cin in [(1, 1, 64), (1, 1, 320), (3, 3, 64), (3, 3, 320), (2, 2, 320), (8, 8, 64), (4, 4, 128), (7, 7, 32), (1, 1, 3072)]:
-        KWCp = KW * Cin  # Cin % 32 == 0: no row padding (the stem form keeps the divisions)
-        nJ = KWCp // BK
-        nK_all = KH * nJ
-        for S in (1, 3, 8):
-            for sidx in range(S):
-                it0 = sidx * nK_all // S
-                ky, j0 = it0 // nJ, (it0 - (it0 // nJ) * nJ) * BK
-                kx = j0 // Cin
-                ci0 = j0 - kx * Cin
-                for it in range(it0, min(nK_all, (sidx + 1) * nK_all // S) + 3):  # + PFD steps past the end
-                    rky = it // nJ
-                    rj0 = (it - rky * nJ) * BK
-                    rkx = rj0 // Cin
-                    rci0 = rj0 - rkx * Cin
-                    assert (ky, j0, kx, ci0) == (rky, rj0, rkx, rci0), (KH, KW, Cin, S, sidx, it)
-                    j0 += BK; ci0 += BK
-                    if ci0 >= Cin: ci0 = 0; kx += 1
-                    if j0 >= KWCp: j0 = 0; ci0 = 0; kx = 0; ky += 1
