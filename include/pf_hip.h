@@ -177,6 +177,23 @@ int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n)
  * total number of records, fills at most max_records entries; mnk = GEMM view [M, N, K, KH] for class 0 */
 int pf_profile_records(pf_handle h, int max_records, int* cat, double* work, float* ms, int* mnk);
 
+/* ---- Debug forward: localise a numerical problem layer by layer, and check a checkpoint's activations against the split-f16 scheme's window.
+ * The reference has no such mode; it replaces "print the tensor after every module" in a PyTorch session (perspectivefields.py:223-272 run by hand).
+ *   flags & 1  SHADOW taps: the boundary tensors of the path -- every MiT block output "mit.s<stage>.b<block>" (mix_transformers.py:198-202), the four stage
+ *              outputs "c1".."c4" (:457-485), the low-level encoder output "ll" (perspectivefields.py:70-83), both decoders' "dec.<head>.conv0" maps
+ *              (gravity_head.py:170-171), the ParamNet input "pn.in", stem "pn.stem" and every ConvNeXt block output "pn.s<stage>.b<block>" (convnext.py:46-59,
+ *              140-152) -- are copied, NHWC fp32, into d_tap_buf (pf_debug_tap_bytes(batch) bytes); pf_debug_taps returns names, byte offsets and shapes.
+ *   flags & 2  RANGE records: for every tensor that enters a dense contraction (all conv / linear layers incl. the fused block MLPs, attention q / kv) max |x|, sum x^2,
+ *              the number of elements beyond the fp16 range (the default precision SATURATES them at 65504) and of non-finite elements; pf_debug_ranges returns them.
+ *              A tensor whose rms is below ~2^-5 loses relative accuracy in the default precision (the low part of the split turns subnormal below |x| = 2^-3):
+ *              run such a checkpoint with PF_PRECISION_FP32_BF16X6.
+ * Same results as pf_forward_u8; synchronises the stream before returning.  The record functions return the total number of records and fill at most max_records. */
+size_t pf_debug_tap_bytes(pf_handle h, int batch);
+int pf_debug_forward_u8(pf_handle h, int batch, const uint8_t* d_in_u8, float* d_pred_gravity, float* d_pred_latitude, float* d_params, void* d_workspace,
+                        size_t workspace_bytes, int flags, void* d_tap_buf, size_t tap_bytes, void* stream);
+int pf_debug_taps(pf_handle h, int max_records, char* names /*[max][64]*/, long long* byte_offsets, int* shapes /*[max][4]: B, H, W, C*/);
+int pf_debug_ranges(pf_handle h, int max_records, char* names /*[max][96]*/, long long* elems, float* stats /*[max][4]*/);
+
 /* The same for a whole batch in one launch per 32 images (the reference's per-image Python loop,
  * gravity_head.py:244-260 / latitude_head.py:201-218): h_hw = HOST array [B][2] of (H, W); h_up_out / h_lat_out = HOST
  * arrays of B DEVICE pointers ([2][H][W] and [H][W] each).  Classification arch: workspace of B*3*320*320 floats. */

@@ -112,8 +112,9 @@ def mit_block(w, x, H, W, heads, sr):
     return x
 
 
-def mit_b3(w, x):
-    """forward_features, mix_transformers.py:449-485.  Returns 4 NCHW maps."""
+def mit_b3(w, x, taps=None):
+    """forward_features, mix_transformers.py:449-485.  Returns 4 NCHW maps.  taps: optional dict that receives every block output "mit.s<stage>.b<block>" as
+    (B, H, W, C) -- the names and layout of the engine's shadow taps (include/pf_hip.h pf_debug_forward_u8)."""
     outs = []
     B = x.shape[0]
     for s in range(4):
@@ -125,6 +126,8 @@ def mit_b3(w, x):
         x = layer_norm(x, pe("norm.weight"), pe("norm.bias"), 1e-5)  # OverlapPatchEmbed.norm :224
         for i in range(MIT_DEPTHS[s]):
             x = mit_block(w.sub(f"block{s + 1}.{i}."), x, H, W, MIT_HEADS[s], MIT_SR[s])
+            if taps is not None:
+                taps[f"mit.s{s + 1}.b{i}"] = x.reshape(B, H, W, -1)
         x = layer_norm(x, w(f"norm{s + 1}.weight"), w(f"norm{s + 1}.bias"), 1e-6)
         x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
         outs.append(x)
@@ -156,7 +159,7 @@ def feature_fusion(w, top, skip=None):
     return bilinear(o, scale=2)
 
 
-def decoder_layers(w, feats, ll, pred_name):
+def decoder_layers(w, feats, ll, pred_name, taps=None):
     """GravityDecoder.layers / LatitudeDecoder.layers (gravity_head.py:139-176,
     latitude_head.py:138-175).  `feats` = [c1..c4] NCHW, `ll` = (B,64,160,160)."""
     fused = None
@@ -169,20 +172,22 @@ def decoder_layers(w, feats, ll, pred_name):
         fused = feature_fusion(w.sub(f"fusion{k}."), e) if fused is None else feature_fusion(w.sub(f"fusion{k}."), fused, e)
     x = torch.cat([fused, ll], dim=1)  # gravity_head.py:170
     x = F.relu(F.conv2d(x, w("conv_fuse_conv0.conv.weight"), w("conv_fuse_conv0.conv.bias"), padding=1))
+    if taps is not None:
+        taps[f"dec.{pred_name}.conv0"] = x.permute(0, 2, 3, 1)
     x = bilinear(x, scale=2)
     x = F.relu(F.conv2d(x, w("conv_fuse_conv1.conv.weight"), w("conv_fuse_conv1.conv.bias"), padding=1))
     return F.conv2d(x, w(f"linear_pred_{pred_name}.weight"), w(f"linear_pred_{pred_name}.bias"))
 
 
-def gravity_inference(w, feats, ll, classification):
+def gravity_inference(w, feats, ll, classification, taps=None):
     """gravity_head.py:190-197 (the scale_factor=1 interpolate is an identity)."""
-    x = decoder_layers(w, feats, ll, "gravity")
+    x = decoder_layers(w, feats, ll, "gravity", taps)
     return x if classification else F.normalize(x, dim=1)
 
 
-def latitude_inference(w, feats, ll, classification):
+def latitude_inference(w, feats, ll, classification, taps=None):
     """latitude_head.py:189-193: regression output is sin(latitude) clamped to [-1,1]."""
-    x = decoder_layers(w, feats, ll, "latitude")
+    x = decoder_layers(w, feats, ll, "latitude", taps)
     return x if classification else torch.clamp(x, -1, 1)
 
 
@@ -242,18 +247,25 @@ def convnext_block(w, x):
     return x + y.permute(0, 3, 1, 2)
 
 
-def convnext_tiny(w, x):
-    """ConvNeXt.forward, convnext.py:140-152 (depths 3,3,9,3; dims 96..768)."""
+def convnext_tiny(w, x, taps=None):
+    """ConvNeXt.forward, convnext.py:140-152 (depths 3,3,9,3; dims 96..768).  taps: optional dict receiving "pn.in" (padded to 4 channels like the engine's
+    NHWC4 input), "pn.stem" and every block output "pn.s<stage>.b<block>" as (B, H, W, C)."""
+    if taps is not None:
+        taps["pn.in"] = F.pad(x.permute(0, 2, 3, 1), (0, 1))
     for s in range(4):
         ds = w.sub(f"downsample_layers.{s}.")
         if s == 0:
             x = F.conv2d(x, ds("0.weight"), ds("0.bias"), stride=4)
             x = convnext_ln_cf(x, ds("1.weight"), ds("1.bias"))
+            if taps is not None:
+                taps["pn.stem"] = x.permute(0, 2, 3, 1)
         else:
             x = convnext_ln_cf(x, ds("0.weight"), ds("0.bias"))
             x = F.conv2d(x, ds("1.weight"), ds("1.bias"), stride=2)
         for j in range(CNX_DEPTHS[s]):
             x = convnext_block(w.sub(f"stages.{s}.{j}."), x)
+            if taps is not None:
+                taps[f"pn.s{s + 1}.b{j}"] = x.permute(0, 2, 3, 1)
     x = layer_norm(x.mean([-2, -1]), w("norm.weight"), w("norm.bias"), 1e-6)
     return F.linear(x, w("head.weight"), w("head.bias"))
 
@@ -313,13 +325,13 @@ def fields_from_params(roll, pitch, vfov, rel_cx, rel_cy, im_h, im_w, mode="deg"
     return up, lat.reshape(im_h, im_w), focal_rel
 
 
-def param_net(w, pred_gravity, pred_latitude, arch):
+def param_net(w, pred_gravity, pred_latitude, arch, taps=None):
     """ParamNet.forward (param_network.py:46-69) and ParamNetConvNextRegress.forward
     (param_network.py:193-221).  Input is the *normalised 320x320* up-vector and the
     clamped sin-latitude, not the post-processed fields."""
     x = torch.cat((pred_gravity, pred_latitude), dim=1)
     if arch["param_net"] == "ParamNet":
-        y = convnext_tiny(w.sub("backbone."), x)
+        y = convnext_tiny(w.sub("backbone."), x, taps)
         return {
             "raw": y,
             "pred_roll": y[:, 0] * 90.0,
@@ -329,7 +341,7 @@ def param_net(w, pred_gravity, pred_latitude, arch):
         }
     size = arch["param_input_size"]
     x = F.interpolate(x, (size, size))  # nearest, param_network.py:197
-    y = convnext_tiny(w.sub("backbone."), x)
+    y = convnext_tiny(w.sub("backbone."), x, taps)
     factors = {"roll": 90.0, "pitch": 90.0, "vfov": 90.0, "rel_focal": 1.0, "rel_cx": 1.0, "rel_cy": 1.0, "general_vfov": 90.0}
     out = {"raw": y}
     for i, key in enumerate(arch["predict_params"]):
@@ -355,18 +367,24 @@ def resize_to_net(img_bgr_u8):
     return np.asarray(Image.fromarray(img_bgr_u8).resize((NET, NET), Image.BILINEAR))
 
 
-def forward(sd, arch, images_u8_320, sizes, dtype=torch.float32, stages=False):
+def forward(sd, arch, images_u8_320, sizes, dtype=torch.float32, stages=False, taps=None):
     """PerspectiveFields.forward (perspectivefields.py:223-272) restated.
 
     images_u8_320: (B,320,320,3) uint8 BGR (post-resize), sizes: list of (H,W).
-    Returns a list of dicts with the reference's keys (tensors float32)."""
+    Returns a list of dicts with the reference's keys (tensors float32).
+    taps: optional dict that receives the boundary tensors the engine's debug forward exposes (same names, NHWC): every MiT block output, c1..c4, ll,
+    dec.<head>.conv0, pn.in / pn.stem / every ConvNeXt block output."""
     w = Weights(sd, "", dtype)
     x = torch.from_numpy(np.ascontiguousarray(images_u8_320)).permute(0, 3, 1, 2).to(torch.float32)
     x = normalise_input(x, dtype)
-    feats = mit_b3(w.sub("backbone."), x)
+    feats = mit_b3(w.sub("backbone."), x, taps)
     ll = low_level_encoder(w.sub("ll_enc."), x)
-    g = gravity_inference(w.sub("persformer_heads.gravity_head."), feats, ll, arch["gravity_cls"])
-    l = latitude_inference(w.sub("persformer_heads.latitude_head."), feats, ll, arch["latitude_cls"])
+    if taps is not None:
+        for k, f in enumerate(feats):
+            taps[f"c{k + 1}"] = f.permute(0, 2, 3, 1)
+        taps["ll"] = ll.permute(0, 2, 3, 1)
+    g = gravity_inference(w.sub("persformer_heads.gravity_head."), feats, ll, arch["gravity_cls"], taps)
+    l = latitude_inference(w.sub("persformer_heads.latitude_head."), feats, ll, arch["latitude_cls"], taps)
     results = []
     for i, (H, W) in enumerate(sizes):
         gi, li = g[i].to(torch.float32), l[i].to(torch.float32)
@@ -380,7 +398,7 @@ def forward(sd, arch, images_u8_320, sizes, dtype=torch.float32, stages=False):
             }
         )
     if arch["param_net"] is not None:
-        p = param_net(w.sub("param_net."), g, l, arch)
+        p = param_net(w.sub("param_net."), g, l, arch, taps)
         raw = p.pop("raw")
         if "pred_general_vfov" not in p:
             p["pred_general_vfov"] = p["pred_vfov"]

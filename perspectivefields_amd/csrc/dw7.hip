@@ -357,7 +357,10 @@ __global__ __launch_bounds__(NC == 2 ? 320 : 256) void dwconv7x7_lds_kernel(cons
 }
 
 // maps of at most 20 columns (threads = 32 x column groups <= 320); th <= 0: automatic strip height
-bool dwconv7x7_lds_ok(int H, int W, int C) { return W <= 20 && W >= 2 && (C % 32) == 0 && H >= 1; }
+bool dwconv7x7_lds_ok(int H, int W, int C) {
+  if (W > 20 || W < 2 || (C % 32) != 0 || H < 1) return false;
+  return (long)7 * (W + 6) * 8 <= (long)13 * 32 * ((W + 1) / 2);  // a one-row strip must fit the 13 float4 pieces per thread (fails for W = 2: the streaming kernel takes those)
+}
 void launch_dwconv7x7_lds(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int th, hipStream_t s) {
   constexpr int NC = 2;
   const int groups = (W + NC - 1) / NC;

@@ -697,6 +697,36 @@ __global__ __launch_bounds__(256) void fill_random_kernel(float* __restrict__ p,
     p[i] = ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
   }
 }
+// Range record of one tensor (debug forward, DebugSink in engine.hip): out[0] = max |x| (atomicMax on the bit pattern of a non-negative float), out[1] = sum x^2,
+// out[2] = elements with |x| > 65504 (saturate in the split-f16 scheme), out[3] = non-finite elements.  `out` must be zeroed before the launch.
+__global__ __launch_bounds__(256) void range_stats_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  float mx = 0.f, ss = 0.f, sat = 0.f, bad = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i], a = fabsf(v);
+    if (!(a <= 3.4e38f)) { bad += 1.f; continue; }
+    mx = fmaxf(mx, a);
+    ss = fmaf(v, v, ss);
+    if (a > 65504.f) sat += 1.f;
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, sh));
+    ss += __shfl_xor(ss, sh);
+    sat += __shfl_xor(sat, sh);
+    bad += __shfl_xor(bad, sh);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(mx));
+    atomicAdd(out + 1, ss);
+    if (sat > 0.f) atomicAdd(out + 2, sat);
+    if (bad > 0.f) atomicAdd(out + 3, bad);
+  }
+}
+void launch_range_stats(const float* x, long n, float* out4, hipStream_t s) {
+  const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(range_stats_kernel, dim3(blocks), dim3(256), 0, s, x, n, out4);
+}
+
 void launch_fill_random(float* p, long n, unsigned seed, float scale, hipStream_t s) {
   hipLaunchKernelGGL(fill_random_kernel, dim3(256 * 16), dim3(256), 0, s, p, n, seed, scale);
 }

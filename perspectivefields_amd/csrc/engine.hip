@@ -90,12 +90,26 @@ struct Ten {
 };
 
 struct Profiler;
+// Debug forward (pf_debug_forward_u8): SHADOW taps -- named stage / block boundary tensors copied out for a layer-by-layer comparison with the oracle -- and RANGE
+// records -- max |x|, sum x^2, saturated (|x| > 65504) and non-finite counts of every tensor that enters a dense contraction (the split-f16 scheme's window, sb_split.h).
+struct DebugSink {
+  bool shadow = false, range = false;
+  char* buf = nullptr; size_t cap = 0, used = 0; bool overflow = false;  // shadow: caller's device buffer
+  struct Tap { std::string name; size_t off; int shape[4]; };          // NHWC
+  std::vector<Tap> taps;
+  float* stats = nullptr; int max_ranges = 0;                          // range: device [max_ranges][4], zeroed before the forward
+  struct Rng { std::string name; long long elems; };
+  std::vector<Rng> ranges;
+  int seq = 0;  // running number of dense launches
+};
+
 struct Ctx {
   hipStream_t s;
   uintptr_t base;
   size_t off = 0, peak = 0;
   bool dry;
   Profiler* prof = nullptr;
+  DebugSink* dbg = nullptr;
   bool tuning = false;      // autotune pass: time every tile config per conv shape
   float* tune_scratch = nullptr;  // [max_conv_out] floats, followed by 3 bf16 planes of max_conv_out elements
   size_t tune_scratch_elems = 0;
@@ -418,6 +432,8 @@ struct pf_engine {
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
   int nterms = NT_F16X3;     // pf_set_precision: NT_F16X3 = 2-way fp16 split, 3 MFMAs per product (default parity mode); 6 = exact 3-way bf16 split
                              // (fp32-accurate, PF_PRECISION_FP32_BF16X6); 3 = "bf16x3", 1 = "bf16" (reduced precision, not parity modes)
+  DebugSink dbg;  // records of the last pf_debug_forward_u8
+  DebugSink* debug_sink = nullptr;  // non-null while pf_debug_forward_u8 runs
   // hipGraph replay of small-batch forwards (pf_forward_u8_graph): one graph per (batch, buffer set, precision)
   struct GraphEntry { std::vector<uintptr_t> key; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
@@ -720,6 +736,24 @@ struct pf_engine {
     host.clear();
   }
 
+  // ------------------------------------------------------------------ debug forward (shadow taps / range records)
+  void tap(Ctx& c, const std::string& name, const float* p, int B, int H, int W, int C) {
+    DebugSink* d = c.dbg;
+    if (!d || !d->shadow || !p) return;
+    const size_t bytes = (size_t)B * H * W * C * 4, off = (d->used + 255) & ~(size_t)255;
+    d->taps.push_back({name, off, {B, H, W, C}});
+    d->used = off + bytes;
+    if (c.dry) return;
+    if (d->used > d->cap) { d->overflow = true; return; }
+    (void)hipMemcpyAsync(d->buf + off, p, bytes, hipMemcpyDeviceToDevice, c.s);
+  }
+  void range_in(Ctx& c, const std::string& name, const float* p, size_t elems) {
+    DebugSink* d = c.dbg;
+    if (!d || !d->range || c.dry || !p || (int)d->ranges.size() >= d->max_ranges) return;
+    launch_range_stats(p, (long)elems, d->stats + 4 * d->ranges.size(), c.s);
+    d->ranges.push_back({name, (long long)elems});
+  }
+
   // ------------------------------------------------------------------ layer helpers
   struct ConvCall {  // one problem of a (possibly grouped) conv launch
     const ConvW* w; Ten x; Ten y;
@@ -768,6 +802,14 @@ struct pf_engine {
     p.ups = ups;
     p.ln = w.ln_s ? 1 : 0; p.ln_eps = w.ln_eps;
     p.finish();
+    if (c.dbg && c.dbg->range) {
+      const int q = c.dbg->seq++;
+      for (int g = 0; g < ngroups; ++g) {
+        const std::string nm = fmt("dense%03d%s %dx%d s%d %s M=%d N=%d K=%d", q, ngroups > 1 ? (g ? "[latitude]" : "[gravity]") : "", w.KH, w.KW, w.stride, w.ln_s ? "LN-fused " : "", p.M, p.Cout, w.KH * w.KW * w.CinReal);
+        range_in(c, nm + " x", calls[g].x.f, (size_t)B * (ups ? H / 2 : H) * (ups ? W / 2 : W) * p.C1);
+        if (p.C2 > 0) range_in(c, nm + " x2", calls[g].x2.f, (size_t)B * H * W * p.C2);
+      }
+    }
     if (part) {
       p.splitk = splitk;
       for (int g = 0; g < ngroups; ++g) p.g[g].partial = part + (size_t)g * splitk * p.M * p.Cout;
@@ -879,7 +921,10 @@ struct pf_engine {
       float* kvb = c.alloc(Mkv * 2 * C);
       float* hb = c.alloc(M * 4 * C);
       const Ten h2 = c.ten(M * 4 * C, !S, S);
+      int blk = -1;
       for (MitBlock& mb : st.blocks) {
+        if (blk >= 0) tap(c, fmt("mit.s%d.b%d", s + 1, blk), x, B, Ho, Wo, C);  // the previous block's output (token stream, pre stage norm)
+        ++blk;
         // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
         if (sr > 1) {
           ln(c, mb.n1, x, xn, M);
@@ -919,6 +964,10 @@ struct pf_engine {
           gemm(c, mb.kv, xn, M, Ten(kvb));
         }
         if (B >= 4 && (sr > 1 || (mb.q.ln_s && mb.kv.ln_s)) && can_fork(c)) (void)hipStreamWaitEvent(c.s, ev_join, 0);
+        if (c.dbg && c.dbg->range) {
+          range_in(c, fmt("attention s%d.b%d q", s + 1, blk), qb, (size_t)M * C);
+          range_in(c, fmt("attention s%d.b%d kv", s + 1, blk), kvb, (size_t)Mkv * 2 * C);
+        }
         if (!c.dry) {
           ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
           launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
@@ -926,6 +975,7 @@ struct pf_engine {
         gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
         // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
         if (fused_mlp && mb.mlp_w) {                  // norm2 + fc1 + depthwise 3x3 + GELU + fc2 + residual in one kernel, x -> xalt
+          range_in(c, fmt("mit_mlp s%d.b%d x (LN-fused)", s + 1, blk), x, (size_t)M * C);
           if (!c.dry) {
             ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * 2.0 * M * (double)C * 4 * C, (int)M, C, 8 * C, 9);
             launch_mit_mlp(x, xalt, mb.mlp_w, mb.mlp_tab, B, Ho, Wo, C, mb.n2.eps, c.s);
@@ -946,7 +996,9 @@ struct pf_engine {
         gemm(c, mb.fc2, h2, M, Ten(x), ACT_NONE, x);
       }
       c.release(mk);
+      if (blk >= 0) tap(c, fmt("mit.s%d.b%d", s + 1, blk), x, B, Ho, Wo, C);
       ln(c, st.norm, x, Ten(x, xs), M);  // stage norm; the normalised map is both the output and the next stage's input (:457-462)
+      tap(c, fmt("c%d", s + 1), x, B, Ho, Wo, C);
       feats[s] = Ten(x, xs);
       cur = feats[s];
       H = Ho; W = Wo;
@@ -1031,6 +1083,8 @@ struct pf_engine {
     pair((size_t)B * h * h * 64, true, false, z0, z1);
     ConvCall a[2] = {{&hg.conv0, fuse_up ? qfin[0] : up[0][0], z0, nullptr, nullptr, llf}, {&hl.conv0, fuse_up ? qfin[1] : up[0][1], z1, nullptr, nullptr, llf}};
     conv_g(c, 2, a, B, h, h, ACT_RELU, 0, DEC_FEAT, 0, fuse_up ? 1 : 0);     // cat (and the x2 up-sampling) fused into the A gather (:170-171)
+    tap(c, "dec.gravity.conv0", z0.f, B, h, h, 64);
+    tap(c, "dec.latitude.conv0", z1.f, B, h, h, 64);
     if (!fuse_up) {
       pair((size_t)B * NET * NET * 64, !S, S, zu0, zu1);
       if (!c.dry) {
@@ -1059,8 +1113,10 @@ struct pf_engine {
     }
     int h = H / 4;
     float* y = c.alloc((size_t)B * h * h * CNX_DIMS[0]);
+    tap(c, "pn.in", src, B, H, H, 4);
     conv(c, cnx.stem, Ten(const_cast<float*>(src)), B, H, H, Ten(y));
     ln(c, cnx.stemn, y, Ten(y), (long)B * h * h);
+    tap(c, "pn.stem", y, B, h, h, CNX_DIMS[0]);
     for (int s = 0; s < 4; ++s) {
       const int C = CNX_DIMS[s];
       if (s > 0) {
@@ -1077,12 +1133,16 @@ struct pf_engine {
       float* d = c.alloc(M * C);
       const Ten dn = S ? Ten(nullptr, c.alloc_sb(M * C)) : Ten(d);
       const Ten hb = c.ten(M * 4 * C, !S, S);
+      int blk = -1;
       for (CnxBlock& cb : cnx.blocks[s]) {
+        if (blk >= 0) tap(c, fmt("pn.s%d.b%d", s + 1, blk), y, B, h, h, C);
+        ++blk;
         if (!c.dry) {
           ProfScope ps(c.prof, c.s, PC_DW7, 8.0 * M * C);
           launch_dwconv7x7(y, cb.dw.w, cb.dw.b, d, B, h, h, C, c.s);
         }
         if (cb.mlp_w && nterms == NT_F16X3) {         // norm + pwconv1 + GELU + pwconv2 + layer scale + residual in one kernel
+          range_in(c, fmt("cnx_mlp s%d.b%d d (LN-fused)", s + 1, blk), d, (size_t)M * C);
           if (!c.dry) {
             ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * 2.0 * M * (double)C * 4 * C, (int)M, C, 8 * C, 1);
             launch_cnx_mlp(d, y, cb.mlp_w, cb.mlp_tab, M, C, cb.n.eps, c.s);
@@ -1097,6 +1157,7 @@ struct pf_engine {
         }
         gemm(c, cb.pw2, hb, M, Ten(y), ACT_NONE, y);  // y += gamma * pwconv2(...)  (gamma folded)
       }
+      if (blk >= 0) tap(c, fmt("pn.s%d.b%d", s + 1, blk), y, B, h, h, C);
       c.release(mk);
     }
     float* raw = c.alloc((size_t)B * 8);
@@ -1120,6 +1181,7 @@ struct pf_engine {
     mit(c, B, x0, feats, &llf);
     if (ll_forked) (void)hipStreamWaitEvent(c.s, ev_ll, 0);
     else conv(c, ll, Ten(x0), B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
+    tap(c, "ll", llf.f, B, NET / 2, NET / 2, LL_CH);
     const bool pf = pred_fused();
     float* tg = pf ? nullptr : c.alloc((size_t)2 * B * NET * NET * 32);
     float* tl = pf ? nullptr : tg + (size_t)B * NET * NET * 32;
@@ -1167,6 +1229,7 @@ struct pf_engine {
     Ctx c{s, base, 0, 0, false, nullptr};
     c.sb_planes = nterms == NT_F16X3 ? 2 : 3;
     c.prof = prof.on ? &prof : nullptr;
+    c.dbg = debug_sink;
     if (tune) {
       c.tuning = true;
       c.tune_scratch = reinterpret_cast<float*>(base + scratch_off[B]);
@@ -1275,6 +1338,7 @@ int pf_destroy(pf_handle h) {
   if (!h) return PF_ERR_ARG;
   (void)hipSetDevice(h->device);
   for (void* d : h->dev_allocs) (void)hipFree(d);
+  if (h->dbg.stats) (void)hipFree(h->dbg.stats);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1372,6 +1436,65 @@ int pf_forward_u8_graph(pf_handle h, int batch, const uint8_t* in, float* pg, fl
   }
   if (hipGraphLaunch(exec, s) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipGraphLaunch failed");
   return PF_OK;
+}
+
+// Debug forward: the ordinary forward plus SHADOW taps (flags & 1: stage / block boundary tensors copied into d_tap_buf, NHWC fp32) and / or RANGE records (flags & 2:
+// statistics of every tensor that enters a dense contraction).  Synchronises the stream before it returns; the records are read with pf_debug_taps / pf_debug_ranges.
+size_t pf_debug_tap_bytes(pf_handle h, int batch) {
+  if (!h || batch <= 0 || batch > PF_MAX_BATCH || !h->finalized) return 0;
+  DebugSink d;
+  d.shadow = true;
+  Ctx c{nullptr, 4096, 0, 0, true, nullptr};
+  c.sb_planes = h->nterms == NT_F16X3 ? 2 : 3;
+  c.dbg = &d;
+  h->run(c, batch, nullptr, true, nullptr, nullptr, nullptr);
+  return d.used + 256;
+}
+int pf_debug_forward_u8(pf_handle h, int batch, const uint8_t* in, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, int flags, void* d_tap_buf,
+                        size_t tap_bytes, void* stream) {
+  if (!h) return PF_ERR_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((flags & 1) && !d_tap_buf) return h->fail(PF_ERR_ARG, "pf_debug_forward_u8: shadow taps need a buffer of pf_debug_tap_bytes(batch) bytes");
+  if (h->prof.on || h->autotune) return h->fail(PF_ERR_ARG, "pf_debug_forward_u8: not inside a profiling window / with autotuning on");
+  DebugSink& d = h->dbg;
+  if (d.stats) { (void)hipFree(d.stats); }
+  d = DebugSink();
+  d.shadow = (flags & 1) != 0; d.range = (flags & 2) != 0;
+  d.buf = static_cast<char*>(d_tap_buf); d.cap = tap_bytes;
+  if (d.range) {
+    d.max_ranges = 1024;
+    if (hipMalloc(reinterpret_cast<void**>(&d.stats), (size_t)d.max_ranges * 16) != hipSuccess) { d.stats = nullptr; return h->fail(PF_ERR_DEVICE, "pf_debug_forward_u8: hipMalloc failed"); }
+    (void)hipMemsetAsync(d.stats, 0, (size_t)d.max_ranges * 16, s);
+  }
+  h->debug_sink = &d;
+  const int rc = h->forward(batch, in, true, pg, pl, params, ws, ws_bytes, s);
+  h->debug_sink = nullptr;
+  if (rc != PF_OK) return rc;
+  if (hipStreamSynchronize(s) != hipSuccess) return h->fail(PF_ERR_DEVICE, "pf_debug_forward_u8: stream synchronisation failed");
+  if (d.overflow) return h->fail(PF_ERR_WORKSPACE, fmt("pf_debug_forward_u8: tap buffer too small: %zu < %zu bytes", d.cap, d.used));
+  return PF_OK;
+}
+int pf_debug_taps(pf_handle h, int max_records, char* names /*[max][64]*/, long long* byte_offsets, int* shapes /*[max][4]: B, H, W, C (NHWC)*/) {
+  if (!h) return PF_ERR_ARG;
+  const DebugSink& d = h->dbg;
+  const int n = (int)std::min<size_t>(d.taps.size(), (size_t)(max_records < 0 ? 0 : max_records));
+  for (int i = 0; i < n; ++i) {
+    if (names) { std::strncpy(names + 64 * i, d.taps[i].name.c_str(), 63); names[64 * i + 63] = 0; }
+    if (byte_offsets) byte_offsets[i] = (long long)d.taps[i].off;
+    if (shapes) for (int k = 0; k < 4; ++k) shapes[4 * i + k] = d.taps[i].shape[k];
+  }
+  return (int)d.taps.size();
+}
+int pf_debug_ranges(pf_handle h, int max_records, char* names /*[max][96]*/, long long* elems, float* stats /*[max][4]: max |x|, sum x^2, saturated, non-finite*/) {
+  if (!h) return PF_ERR_ARG;
+  const DebugSink& d = h->dbg;
+  const int n = (int)std::min<size_t>(d.ranges.size(), (size_t)(max_records < 0 ? 0 : max_records));
+  if (n > 0 && stats && d.stats && hipMemcpy(stats, d.stats, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) return h->fail(PF_ERR_DEVICE, "pf_debug_ranges: hipMemcpy failed");
+  for (int i = 0; i < n; ++i) {
+    if (names) { std::strncpy(names + 96 * i, d.ranges[i].name.c_str(), 95); names[96 * i + 95] = 0; }
+    if (elems) elems[i] = d.ranges[i].elems;
+  }
+  return (int)d.ranges.size();
 }
 
 int pf_forward_f32(pf_handle h, int batch, const float* in, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, void* stream) {

@@ -147,6 +147,7 @@ void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hip
 void launch_split_planes(const float* x, unsigned short* y_sb, size_t sb_plane, long n, hipStream_t s);
 void launch_merge_planes(const unsigned short* x_sb, size_t sb_plane, float* y, long n, hipStream_t s);
 void launch_fill_random(float* p, long n, unsigned seed, float scale, hipStream_t s);
+void launch_range_stats(const float* x, long n, float* out4 /*zeroed: max |x|, sum x^2, saturated, non-finite*/, hipStream_t s);
 
 // input normalisation: uint8 NHWC BGR [B][320][320][3] or fp32 NCHW [B][3][320][320] -> fp32 NHWC4 (x-mean)/std, ch3=0
 void launch_prep_u8(const uint8_t* in, float* out, long npix, const float* mean3, const float* std3, hipStream_t s);

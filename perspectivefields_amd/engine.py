@@ -55,6 +55,10 @@ _SIGNATURES = {
     "pf_profile_pause": (_c.c_int, [_P]),
     "pf_profile_end": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.c_int]),
     "pf_profile_records": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double), _c.POINTER(_c.c_float), _c.POINTER(_c.c_int)]),
+    "pf_debug_tap_bytes": (_c.c_size_t, [_P, _c.c_int]),
+    "pf_debug_forward_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _c.c_int, _P, _c.c_size_t, _P]),
+    "pf_debug_taps": (_c.c_int, [_P, _c.c_int, _P, _c.POINTER(_c.c_longlong), _c.POINTER(_c.c_int)]),
+    "pf_debug_ranges": (_c.c_int, [_P, _c.c_int, _P, _c.POINTER(_c.c_longlong), _c.POINTER(_c.c_float)]),
     "pf_op_conv2d": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P,
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_int,
                                 _c.c_int, _c.c_int, _P, _P, _c.c_long, _P, _c.c_long, _P, _c.c_long, _c.c_int, _P]),
@@ -308,6 +312,52 @@ class Engine:
             )
         _check(rc, self._h, "pf_forward")
         return pg, pl, params
+
+    def forward_debug(self, images, shadow=True, ranges=True):
+        """pf_debug_forward_u8: the forward plus shadow taps and / or range records (include/pf_hip.h).  images: (B,320,320,3) uint8 on the device.
+        Returns (pred_gravity, pred_latitude, params, taps, ranges): taps = {name: NHWC fp32 tensor} in forward order (every MiT / ConvNeXt block output, the stage
+        outputs c1..c4, ll, the decoders' conv0 maps, the ParamNet input and stem); ranges = list of dicts (name, elems, max_abs, rms, saturated, non_finite) for every
+        tensor that enters a dense contraction."""
+        import collections
+
+        import torch
+
+        images = images.contiguous()
+        B = images.shape[0]
+        with torch.cuda.device(self.device):
+            pg = torch.empty((B, self.gravity_channels, NET, NET), dtype=torch.float32, device=self.device)
+            pl = torch.empty((B, self.latitude_channels, NET, NET), dtype=torch.float32, device=self.device)
+            params = torch.empty((B, PARAMS_STRIDE), dtype=torch.float32, device=self.device) if self.param_outputs else None
+            ws = self._workspace(self.workspace_bytes(B))
+            nb = int(self.lib.pf_debug_tap_bytes(self._h, B)) if shadow else 0
+            tapbuf = torch.empty(max(nb, 256), dtype=torch.uint8, device=self.device)
+            rc = self.lib.pf_debug_forward_u8(self._h, B, images.data_ptr(), pg.data_ptr(), pl.data_ptr(), params.data_ptr() if params is not None else None,
+                                              ws.data_ptr(), ws.numel(), (1 if shadow else 0) | (2 if ranges else 0), tapbuf.data_ptr(), tapbuf.numel(), _stream_ptr())
+        _check(rc, self._h, "pf_debug_forward_u8")
+        taps = collections.OrderedDict()
+        n = self.lib.pf_debug_taps(self._h, 0, None, None, None)
+        if n > 0:
+            names = ctypes.create_string_buffer(64 * n)
+            offs = (ctypes.c_longlong * n)()
+            shp = (ctypes.c_int * (4 * n))()
+            self.lib.pf_debug_taps(self._h, n, names, offs, shp)
+            for i in range(n):
+                nm = names.raw[64 * i:64 * i + 64].split(b"\0")[0].decode()
+                sh = tuple(shp[4 * i:4 * i + 4])
+                cnt = sh[0] * sh[1] * sh[2] * sh[3]
+                taps[nm] = tapbuf[offs[i]:offs[i] + 4 * cnt].view(torch.float32).view(sh)
+        out = []
+        n = self.lib.pf_debug_ranges(self._h, 0, None, None, None)
+        if n > 0:
+            names = ctypes.create_string_buffer(96 * n)
+            el = (ctypes.c_longlong * n)()
+            st = (ctypes.c_float * (4 * n))()
+            _check(min(0, self.lib.pf_debug_ranges(self._h, n, names, el, st)), self._h, "pf_debug_ranges")
+            for i in range(n):
+                nm = names.raw[96 * i:96 * i + 96].split(b"\0")[0].decode()
+                out.append({"name": nm, "elems": int(el[i]), "max_abs": float(st[4 * i]), "rms": float((st[4 * i + 1] / max(el[i], 1)) ** 0.5),
+                            "saturated": int(st[4 * i + 2]), "non_finite": int(st[4 * i + 3])})
+        return pg, pl, params, taps, out
 
     def _forward_graph(self, images):
         """Small batches: persistent input / output / workspace buffers + a hipGraph captured on first use

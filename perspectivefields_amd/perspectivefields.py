@@ -174,6 +174,34 @@ class PerspectiveFields(nn.Module):
             batch = torch.from_numpy(np.stack(resized)).to(self.device, non_blocking=False)  # uint8 (B,320,320,3)
         return self._run(batch, sizes)
 
+    # ------------------------------------------------------------------ debug forward (sanitizer / shadow-compare mode)
+    @torch.no_grad()
+    def debug_forward(self, img_bgr_list: List[np.ndarray], shadow: bool = True, ranges: bool = True):
+        """The forward of `inference_batch` with the engine's debug sink (pf_debug_forward_u8): returns (results, taps, ranges).
+        taps: {name: NHWC fp32 device tensor} of every block / stage boundary -- compare with `oracle.pf_oracle.forward(..., taps={})` to find the FIRST layer that
+        is off; ranges: per dense layer input max |x|, rms, saturated / non-finite counts -- the first thing to run on a real checkpoint (see `check_range`)."""
+        sizes = [tuple(int(v) for v in im.shape[:2]) for im in img_bgr_list]
+        resized = [self.aug.apply_image(np.ascontiguousarray(im[:, :, ::-1] if self.input_format == "RGB" else im)) for im in img_bgr_list]
+        batch = torch.from_numpy(np.stack(resized)).to(self.device)
+        eng = self._get_engine()
+        pg, pl, params, taps, rng = eng.forward_debug(batch, shadow=shadow, ranges=ranges)
+        return self._assemble(eng, pg, pl, params, sizes), taps, rng
+
+    def check_range(self, img_bgr_list: List[np.ndarray], verbose: bool = True) -> dict:
+        """Range report of a checkpoint on real images.  The default precision ("fp32": 2-way fp16 split) represents |x| in [2^-3, 65504] with 22+ bits, SATURATES
+        beyond 65504 and keeps only an absolute 2^-25 per element below 2^-3: a layer input with saturated elements, or whose rms is below 2^-5 (an all-tiny tensor), is
+        outside the window -- use precision="fp32_bf16x6" (exact bf16 split, no window) for such a checkpoint.  Returns {"ok", "saturated", "tiny", "non_finite", "layers"}."""
+        _, _, rng = self.debug_forward(img_bgr_list, shadow=False, ranges=True)
+        sat = [r for r in rng if r["saturated"] > 0]
+        bad = [r for r in rng if r["non_finite"] > 0]
+        tiny = [r for r in rng if 0.0 < r["rms"] < 2.0 ** -5]
+        if verbose:
+            print(f"{len(rng)} dense-layer inputs: max |x| {max(r['max_abs'] for r in rng):.4g}, smallest rms {min(r['rms'] for r in rng):.4g}; "
+                  f"{len(sat)} with saturated elements, {len(tiny)} with rms < 2^-5, {len(bad)} with non-finite elements")
+            for r in (sat + tiny + bad)[:20]:
+                print(f"  {r['name']}: max |x| {r['max_abs']:.4g} rms {r['rms']:.4g} saturated {r['saturated']} non-finite {r['non_finite']}")
+        return {"ok": not (sat or bad or tiny), "saturated": sat, "tiny": tiny, "non_finite": bad, "layers": rng}
+
     # ------------------------------------------------------------------ streaming (SURVEY row N3)
     _HOST_KEYS = ("pred_gravity", "pred_gravity_original", "pred_latitude", "pred_latitude_original")
 
@@ -289,6 +317,9 @@ class PerspectiveFields(nn.Module):
                 out.extend(self._run(batch[i0:i0 + chunk], sizes[i0:i0 + chunk]))
             return out
         pg, pl, params = eng.forward(batch)
+        return self._assemble(eng, pg, pl, params, sizes)
+
+    def _assemble(self, eng, pg, pl, params, sizes) -> List[dict]:
         results = []
         fields = eng.postprocess_batch(pg, pl, sizes)  # the reference's per-image post-process loop as one launch
         for i, (h, w) in enumerate(sizes):

@@ -1,0 +1,83 @@
+"""Debug forward (include/pf_hip.h pf_debug_forward_u8; SURVEY section 5: sanitizer / shadow-compare mode): every block / stage boundary tensor of the HIP path
+against the CPU oracle's tensor of the same name (a failure names the FIRST layer that is off instead of "e2e is off by 3e-4"), the stage outputs against the
+reference goldens, and the range records that tell whether a checkpoint's activations stay inside the split-f16 scheme's window."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pf_oracle
+from perspectivefields_amd.config import arch_of, get_cfg
+from perspectivefields_amd.synth import synthetic_image, synthetic_state_dict, to_torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _model(version, sd=None):
+    from perspectivefields_amd import PerspectiveFields
+
+    return PerspectiveFields(version, weights="synthetic:0" if sd is None else sd).eval().cuda()
+
+
+@pytest.mark.parametrize("version", ["Paramnet-360Cities-edina-centered", "Paramnet-360Cities-edina-uncentered", "PersNet-360Cities"])
+def test_shadow_taps_vs_oracle(version):
+    """Layer-by-layer: the relative error of every tap grows slowly along the network and stays below 2e-4 of the tensor's scale (the end-to-end gates are 1e-3 / 1e-4
+    on normalised outputs); the report prints the first tap over 1e-4 if any."""
+    m = _model(version)
+    imgs = [synthetic_image(96, 128, seed=7), synthetic_image(150, 100, seed=8)]
+    res, taps, _ = m.debug_forward(imgs, shadow=True, ranges=False)
+    ref_taps = {}
+    u8 = np.stack([pf_oracle.resize_to_net(im) for im in imgs])
+    with torch.no_grad():
+        ref = pf_oracle.forward(to_torch(synthetic_state_dict(version, 0)), arch_of(get_cfg(version)), u8, [im.shape[:2] for im in imgs], taps=ref_taps)
+    assert len(taps) >= 35 and set(taps) <= set(ref_taps), sorted(set(taps) - set(ref_taps))
+    worst, first_bad = 0.0, None
+    for name, t in taps.items():
+        r = ref_taps[name].to(torch.float64)
+        assert tuple(t.shape) == tuple(r.shape), (name, tuple(t.shape), tuple(r.shape))
+        err = float((t.double().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+        worst = max(worst, err)
+        if err > 1e-4 and first_bad is None:
+            first_bad = (name, err)
+    print(f"[shadow {version}] {len(taps)} taps, worst max|d| / max|ref| {worst:.2e}" + (f", first tap over 1e-4: {first_bad}" if first_bad else ""))
+    assert worst <= 2e-4, first_bad
+    # same results as the ordinary forward
+    plain = m.inference_batch(imgs)
+    for a, b in zip(res, plain):
+        assert torch.equal(a["pred_gravity"], b["pred_gravity"]) and torch.equal(a["pred_latitude_original"], b["pred_latitude_original"])
+
+
+def test_shadow_taps_vs_reference_goldens():
+    """The stage-boundary activations the goldens hold (written by the unmodified reference, oracle/gen_golden.py): c1..c4 and ll of image 0, sub-sampled."""
+    g = np.load(os.path.join(GOLD, "centered.npz"))
+    m = _model("Paramnet-360Cities-edina-centered")
+    eng = m._get_engine()
+    _, _, _, taps, _ = eng.forward_debug(torch.from_numpy(g["in_u8_0"][None]).cuda(), shadow=True, ranges=False)
+    for k, st in (("c1", 4), ("c2", 2), ("c3", 1), ("c4", 1)):
+        got = taps[k][0].permute(2, 0, 1)[:, ::st, ::st].cpu().numpy()
+        ref = g[k + "_s"]
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (k, float(np.abs(got - ref).max()))
+    got = taps["ll"][0].permute(2, 0, 1)[:, ::8, ::8].cpu().numpy()
+    assert np.abs(got - g["ll_s"]).max() <= 1e-4 * max(1.0, np.abs(g["ll_s"]).max())
+
+
+def test_range_records_and_check_range():
+    """Every dense layer of the forward reports its input range; the seeded synthetic checkpoint sits inside the window.  A checkpoint whose first patch embedding is
+    scaled up 3000x (activations beyond the fp16 range) and one scaled down to 1e-4 are reported as saturated / tiny, and the exact bf16-split precision handles both."""
+    version = "Paramnet-360Cities-edina-centered"
+    m = _model(version)
+    imgs = [synthetic_image(128, 160, seed=3)]
+    rep = m.check_range(imgs, verbose=True)
+    assert rep["ok"] and len(rep["layers"]) > 250, (rep["saturated"][:2], rep["tiny"][:2], len(rep["layers"]))
+    assert all(r["elems"] > 0 and np.isfinite(r["max_abs"]) for r in rep["layers"])
+    assert any("LN-fused" in r["name"] for r in rep["layers"]) and any(r["name"].startswith("attention") for r in rep["layers"])
+    # a checkpoint outside the window: the LayerNorm after patch_embed1 absorbs any scale of its conv, so scale that LayerNorm's output instead
+    sd = synthetic_state_dict(version, 0)
+    for factor, key in ((3.0e5, "saturated"), (1.0e-5, "tiny")):
+        sd2 = dict(sd)
+        sd2["backbone.patch_embed1.norm.weight"] = sd["backbone.patch_embed1.norm.weight"] * np.float32(factor)
+        sd2["backbone.patch_embed1.norm.bias"] = sd["backbone.patch_embed1.norm.bias"] * np.float32(factor)
+        rep2 = _model(version, sd2).check_range(imgs, verbose=False)
+        assert not rep2["ok"] and len(rep2[key]) > 0, (factor, key)
