@@ -5,7 +5,7 @@ set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 BENCH="timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0"
 echo "== full GPU suite"
-timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider -x 2>&1 | tail -25 | tee gpurun_out/test_gpu.log | tail -12
+timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | tail -40 | tee gpurun_out/test_gpu.log | tail -30
 echo "== sbr tiles vs LDS tiles"
 timeout 300 python scripts/tune_rr.py 2>&1 | tail -60
 echo "== depthwise 7x7: streaming (3) vs LDS tile (4)"
