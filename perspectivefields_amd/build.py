@@ -22,6 +22,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # the scripts under scripts/ can select; the product build carries the default path and its parity alternatives only
 if os.environ.get("PF_TUNING_BUILD", "0") == "1":
     FLAGS.append("-DPF_TUNING_BUILD")
+    if os.environ.get("PF_EXP_SETPRIO", "0") == "1":  # experiment of the moment, compiled into the tuning library only
+        FLAGS.append("-DPF_EXP_SETPRIO")
 
 
 def _hipcc() -> str:

@@ -375,6 +375,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || (SCH =
       }
       constexpr int TA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};  // plane of A: l h m m h h | split-f16: al ah ah
       constexpr int TB[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};  // plane of B: h l m h m h | split-f16: wh wl wh (al is unscaled: no wh 2^-11 operand)
+#ifdef PF_EXP_SETPRIO
+      __builtin_amdgcn_s_setprio(1);  // experiment (tuning builds): the wave that has MFMAs to issue wins the issue slot over co-resident waves in their staging phase
+#endif
 #pragma unroll
       for (int t6 = 0; t6 < (F16 ? 3 : 6); ++t6)
 #pragma unroll
@@ -382,6 +385,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || (SCH =
 #pragma unroll
           for (int j = 0; j < SN; ++j)
             acc[i][j] = mfma16h<F16>(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j]);
+#ifdef PF_EXP_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
   };
 

@@ -166,22 +166,30 @@ __global__ __launch_bounds__(256, 2) void rr_gemm_kernel(const ConvParams p) {
         const bool more = u + 2 < U;
         if (more) dma(u + 2, (u + 2) % NBUF);
         const unsigned short* wb = smem + (u % NBUF) * UNIT + lane * 8;
-        // two accumulators (even / odd k steps): consecutive MFMAs never wait for each other's result
+        // two accumulators (even / odd k steps): consecutive MFMAs never wait for each other's result.  The fragments of step pair s + 2 are read BEFORE the six
+        // MFMAs of pair s are issued (two register sets): with one or two waves per SIMD nothing else hides the LDS latency (hipcc otherwise reads a pair's
+        // fragments right in front of its MFMAs and waits -- 40 % of the unit's time on the launches that give a CU a single block).
         f32x16 accb;
 #pragma unroll
         for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+        u32x4 fr[2][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) fr[0][f] = *reinterpret_cast<const u32x4*>(wb + f * 512);
 #pragma unroll
         for (int s = 0; s < S; s += 2) {
-          const u32x4 wh0 = *reinterpret_cast<const u32x4*>(wb + (2 * s) * 512);
-          const u32x4 wl0 = *reinterpret_cast<const u32x4*>(wb + (2 * s + 1) * 512);
-          const u32x4 wh1 = *reinterpret_cast<const u32x4*>(wb + (2 * s + 2) * 512);
-          const u32x4 wl1 = *reinterpret_cast<const u32x4*>(wb + (2 * s + 3) * 512);
-          acc[jj] = rr_mfma(wh0, xl[s], acc[jj]);
-          accb = rr_mfma(wh1, xl[s + 1], accb);
-          acc[jj] = rr_mfma(wl0, xh[s], acc[jj]);
-          accb = rr_mfma(wl1, xh[s + 1], accb);
-          acc[jj] = rr_mfma(wh0, xh[s], acc[jj]);
-          accb = rr_mfma(wh1, xh[s + 1], accb);
+          constexpr int dummy = 0; (void)dummy;
+          const int cur = (s >> 1) & 1;
+          if (s + 2 < S) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) fr[cur ^ 1][f] = *reinterpret_cast<const u32x4*>(wb + (2 * (s + 2) + f) * 512);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads in front of the MFMAs
+          acc[jj] = rr_mfma(fr[cur][0], xl[s], acc[jj]);
+          accb = rr_mfma(fr[cur][2], xl[s + 1], accb);
+          acc[jj] = rr_mfma(fr[cur][1], xh[s], acc[jj]);
+          accb = rr_mfma(fr[cur][3], xh[s + 1], accb);
+          acc[jj] = rr_mfma(fr[cur][0], xh[s], acc[jj]);
+          accb = rr_mfma(fr[cur][2], xh[s + 1], accb);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[jj][e] += accb[e];

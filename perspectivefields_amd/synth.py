@@ -90,6 +90,36 @@ def synthetic_state_dict(version: str, seed: int = 0) -> "OrderedDict[str, np.nd
     return out
 
 
+def heavy_tailed_state_dict(version: str, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """The synthetic checkpoint made to LOOK like a trained one where it matters for the split-f16 contractions (trunc-normal weights never produce what
+    trained transformers do): per-output-channel weight magnitudes spread over two orders of magnitude (log-normal, sigma 1), 0.5 % of the entries of every dense
+    weight 8x larger (heavy tail), and OUTLIER CHANNELS in the token streams -- two channels per MiT block get a +-25 bias on `attn.proj` / `mlp.fc2`, the same two in every block of a stage (they pile up
+    along the residual stream to tens of sigma: what the fused LayerNorms then see as raw rows), two LayerNorm gains per norm layer are 20x.  Same schema, same generator streams."""
+    sd = synthetic_state_dict(version, seed)
+    for key in list(sd):
+        v = sd[key]
+        rng = _rng(seed + 7919, key)
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf == "weight" and v.ndim >= 2 and "dwconv" not in key and "linear_pred" not in key and not key.endswith("head.weight"):
+            ch = np.exp(rng.standard_normal(v.shape[0]) * 1.0).astype(np.float32)
+            ch /= np.sqrt(np.mean(ch.astype(np.float64) ** 2)).astype(np.float32)  # same overall gain
+            w = v * ch.reshape((-1,) + (1,) * (v.ndim - 1))
+            big = rng.random(v.shape) < 0.005
+            sd[key] = np.where(big, w * np.float32(8.0), w).astype(np.float32)
+        elif leaf == "bias" and key.startswith("backbone.block") and key.endswith(("attn.proj.bias", "mlp.fc2.bias")):
+            b = v.copy()
+            srng = _rng(seed + 7919, key.split(".")[1])  # the SAME two channels (and signs) in every block of a stage: they pile up along the residual stream
+            idx = srng.choice(b.shape[0], 2, replace=False)
+            b[idx] += np.float32(25.0) * np.where(srng.random(2) < 0.5, -1.0, 1.0).astype(np.float32)
+            sd[key] = b
+        elif leaf == "weight" and v.ndim == 1 and ("norm" in key) and "bn1" not in key:
+            g = v.copy()
+            idx = rng.choice(g.shape[0], 2, replace=False)
+            g[idx] *= np.float32(20.0)
+            sd[key] = g
+    return sd
+
+
 def to_torch(state_dict):
     import torch
 

@@ -19,6 +19,8 @@ for (B, H, W, C) in [(32, 20, 20, 384), (32, 10, 10, 768)]:
         print(f"dw7 {H}x{W}x{C} B={B} variant {v} th {th}: {ms * 1e3:6.1f} us  {mb / ms / 1e3:6.2f} TB/s")
 P
 echo "== bench, shipped tile table"; for i in 1 2; do $BENCH 2>&1 | tail -1 | cut -c1-150; done
+echo "== bench, tuning library (= product + the experiment of the moment: s_setprio around the halo kernel's MFMAs)"
+for i in 1 2; do PF_TUNING_BUILD=1 PF_EXP_SETPRIO=1 $BENCH 2>&1 | tail -1 | cut -c1-150; done
 echo "== bench, tiles autotuned for this library (B = 32)"
 export PF_TUNE_CACHE=$PWD/gpurun_out/tiles_b32.txt
 $BENCH --autotune 1 2>&1 | tail -1 | cut -c1-150
