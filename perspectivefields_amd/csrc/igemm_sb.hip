@@ -37,6 +37,7 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {256, 64, 0, "sbhA1"}, {256, 64, 0, "sbhA2"}, {256, 64, 0, "sbhA3"}, {256, 64, 0, "sbhA4"}, {256, 64, 0, "sbhA8"}, {256, 64, 0, "sbhA48"},
                              {256, 64, 0, "sbhA12"}, {256, 64, 0, "sbhA11"}, {256, 64, 0, "sbhA15"}, {256, 64, 0, "sbhA63"},
                              {256, 64, 0, "sbhAa"}, {256, 64, 0, "sbhAb"}, {256, 64, 0, "sbhLA0"}, {256, 64, 0, "sbhLA2"}, {256, 64, 0, "sbhLAbf"}, {256, 64, 0, "sbhLAbf0"}, {256, 64, 0, "sbhDMA"}, {256, 64, 0, "sbhREG"},
+                             {256, 128, 0, "sbh256x128w8"},  // 16 x 16 patch x 128 channels, 8 waves: wave tile 64 x 64 (683 B of LDS fragment reads per MFMA instead of 1024)
 #endif
                              // "sbr": row-resident GEMM for the small-M linear layers and the kernel == stride convs (rr_gemm.hip); always the LAST two entries
                              {128, 160, 0, "sbr128x160"}, {128, 128, 0, "sbr128x128"},

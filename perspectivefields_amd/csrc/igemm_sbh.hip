@@ -594,6 +594,7 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
     case 28: launch_sbh_abl<0x900>(p, s); break;
     case 29: launch_sbh_abl<0x1000>(p, s); break;
     case 30: launch_sbh_abl<0x2000>(p, s); break;
+    case 31: launch_sbh_cfg<16, 16, 128, 4, 2>(p, s); break;          // "sbh256x128w8"
 #endif
     default: launch_sbh_cfg<16, 16, 64, 4, 2>(p, s); break;  // 16 x 16 patch, 8 waves, two blocks per CU: weights staged once per 256 rows
   }
