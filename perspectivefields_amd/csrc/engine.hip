@@ -57,7 +57,6 @@ struct ConvW {
   float* b = nullptr;
   float* btab = nullptr;  // [9][Cout] border-case biases of a folded Linear->3x3 pair
   unsigned short* wsb = nullptr;  // weights split exactly into 3 bf16 planes (split-bf16 kernel), when Cin % 32 == 0
-  unsigned short* wrr = nullptr;  // the split-f16 planes in the DMA order of the row-resident GEMM (rr_gemm.hip), for linear layers / kernel == stride convs
   unsigned short* wh16 = nullptr; // split-f16 scheme: per-channel power-of-two scaled weights as two fp16 planes wh, wl
   float* wh16_inv = nullptr;      //   and the inverse scale per output channel
   float* ln_s = nullptr;          // fused input LayerNorm (ConvParams::ln): column sums of the gamma-folded weights; nullptr = no fusion
@@ -433,7 +432,6 @@ struct pf_engine {
   bool fold_mlp = true;      // PF_FOLD_MLP=0 keeps Linear(C->768) and conv3x3(768->256) as two kernels
   int nterms = NT_F16X3;     // pf_set_precision: NT_F16X3 = 2-way fp16 split, 3 MFMAs per product (default parity mode); 6 = exact 3-way bf16 split
                              // (fp32-accurate, PF_PRECISION_FP32_BF16X6); 3 = "bf16x3", 1 = "bf16" (reduced precision, not parity modes)
-  bool use_rr = true;  // PF_RR=0: no packed weights for the row-resident GEMM (its "sbr" tiles then are never eligible)
   DebugSink dbg;  // records of the last pf_debug_forward_u8
   DebugSink* debug_sink = nullptr;  // non-null while pf_debug_forward_u8 runs
   // hipGraph replay of small-batch forwards (pf_forward_u8_graph): one graph per (batch, buffer set, precision)
@@ -482,17 +480,13 @@ struct pf_engine {
     return static_cast<unsigned short*>(d);
   }
   // packed fp32 weights -> device, plus the split-bf16 planes when the layer is eligible for igemm_sb
-  // rr: the layer is a linear layer on (gathered) rows -- 1x1, or kernel == stride without padding -- and gets the packed copy of its fp16 planes that the
-  // row-resident GEMM streams (c.KWC / c.KWCp are set by the pack_conv call in the argument list)
-  void upload_conv_weights(ConvW& c, const std::vector<float>& packed, int CinP, int Cout, bool rr = false) {
+  void upload_conv_weights(ConvW& c, const std::vector<float>& packed, int CinP, int Cout) {
     c.w = upload(packed);
     if (split_bf16 && (CinP % 32 == 0 || CinP == 4)) {  // CinP == 4: the 3-channel stems (split-f16 "stem" form of igemm_sb_kernel)
       c.wsb = upload_u16(split_bf16x3(packed));
       const F16Planes f = split_f16x2(packed, Cout);
       c.wh16 = upload_u16(f.planes);
       c.wh16_inv = upload(f.inv_scale);
-      if (rr && use_rr && c.KWC == c.KWCp && (Cout % 32) == 0 && rr_chunk_of(c.KWC) > 0)
-        c.wrr = upload_u16(rr_pack_weights(f.planes, Cout, (int)(packed.size() / (size_t)Cout), rr_chunk_of(c.KWC)));
     }
   }
   const HostTensor& get(const std::string& key, std::initializer_list<int64_t> shape) {
@@ -513,7 +507,7 @@ struct pf_engine {
     ConvW c;
     const int CinP = roundup(Cin, 4);
     const HostTensor& w = get(wkey, {Cout, Cin, K, K});
-    upload_conv_weights(c, pack_conv(w.data.data(), Cout, Cin, K, K, CinP, out_scale, &c.KWC, &c.KWCp), CinP, Cout, stride == K && pad == 0);
+    upload_conv_weights(c, pack_conv(w.data.data(), Cout, Cin, K, K, CinP, out_scale, &c.KWC, &c.KWCp), CinP, Cout);
     if (bias_override) c.b = upload(*bias_override);
     else if (!bkey.empty()) {
       std::vector<float> b = get(bkey, {Cout}).data;
@@ -534,11 +528,11 @@ struct pf_engine {
       std::vector<float> wf, bf, cs;
       fold_ln_linear(w.data.data(), b.data(), g.data(), be.data(), N, K, &wf, &bf, &cs);
       b = bf;
-      upload_conv_weights(c, pack_conv(wf.data(), N, K, 1, 1, K, nullptr, &c.KWC, &c.KWCp), K, N, true);
+      upload_conv_weights(c, pack_conv(wf.data(), N, K, 1, 1, K, nullptr, &c.KWC, &c.KWCp), K, N);
       c.ln_s = upload(cs);
       c.ln_eps = ln_eps;
     } else {
-      upload_conv_weights(c, pack_conv(w.data.data(), N, K, 1, 1, K, out_scale, &c.KWC, &c.KWCp), K, N, true);
+      upload_conv_weights(c, pack_conv(w.data.data(), N, K, 1, 1, K, out_scale, &c.KWC, &c.KWCp), K, N);
       if (out_scale) for (int n = 0; n < N; ++n) b[n] = (float)(b[n] * out_scale[n]);
     }
     c.b = upload(b);
@@ -792,7 +786,7 @@ struct pf_engine {
     for (int g = 0; g < ngroups; ++g) {
       const ConvW& wg = *calls[g].w;
       ConvPtrs& q = p.g[g];
-      q.x = calls[g].x.f; q.x2 = calls[g].x2.f; q.w = wg.w; q.w_sb = wg.wsb; q.w_h16 = wg.wh16; q.w_h16_inv_scale = wg.wh16_inv; q.w_rr = wg.wrr; q.bias = wg.b; q.bias_tab = wg.btab;
+      q.x = calls[g].x.f; q.x2 = calls[g].x2.f; q.w = wg.w; q.w_sb = wg.wsb; q.w_h16 = wg.wh16; q.w_h16_inv_scale = wg.wh16_inv; q.bias = wg.b; q.bias_tab = wg.btab;
       q.res1 = calls[g].res1; q.res2 = calls[g].res2; q.y = calls[g].y.f;
       q.x_sb = calls[g].x.s.p; q.x2_sb = calls[g].x2.s.p; q.y_sb = calls[g].y.s.p;
       q.ln_colsum = wg.ln_s;
@@ -1312,7 +1306,6 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_UPSAMPLE")) e->fuse_upsample = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_PRED")) e->fuse_pred = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_LN")) e->fuse_ln = atoi(v) != 0;
-  if (const char* v = getenv("PF_RR")) e->use_rr = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
 #ifdef PF_TUNING_BUILD
@@ -1723,11 +1716,6 @@ int pf_profile_records(pf_handle h, int max_records, int* cat, double* work, flo
 }
 
 // ---- kernel-level entry points -------------------------------------------------------------
-// the packed weight copy of the row-resident GEMM for a hand-built ConvParams (finish()ed fields KH, KW, KWC, KWCp, C1, Cout must be set)
-static void attach_rr_weights(ConvParams& p, const F16Planes& f, TmpDev& tmp) {
-  if (p.KH == p.KW && p.stride == p.KH && p.pad == 0 && p.C2 == 0 && p.KWC == p.KWCp && (p.Cout % 32) == 0 && rr_chunk_of(p.KWC) > 0)
-    p.g[0].w_rr = tmp.up_u16(rr_pack_weights(f.planes, p.Cout, p.KH * p.KWCp, rr_chunk_of(p.KWC)));
-}
 
 int pf_op_num_conv_tiles(void) { return conv_num_tiles(); }
 const char* pf_op_conv_tile_name(int id) { return conv_tile_name(id); }
@@ -1753,8 +1741,6 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
     sb = split_bf16x3(packed); p.g[0].w_sb = tmp.up_u16(sb);
     const F16Planes f = split_f16x2(packed, Cout);
     p.g[0].w_h16 = tmp.up_u16(f.planes); p.g[0].w_h16_inv_scale = tmp.up(f.inv_scale);
-    p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.C1 = C1; p.C2 = C2; p.Cout = Cout;
-    attach_rr_weights(p, f, tmp);
   }
   p.g[0].bias = tmp.up(hb, Cout);
   p.g[0].x = x; p.g[0].x2 = x2; p.g[0].res1 = res1; p.g[0].res2 = res2; p.g[0].y = y;
@@ -1800,8 +1786,6 @@ int pf_op_linear_ln(int device, const float* x, long rows, int K, const float* h
   p.g[0].w_sb = tmp.up_u16(sb);
   const F16Planes f = split_f16x2(packed, N);
   p.g[0].w_h16 = tmp.up_u16(f.planes); p.g[0].w_h16_inv_scale = tmp.up(f.inv_scale);
-  p.KH = p.KW = 1; p.stride = 1; p.pad = 0; p.C1 = K; p.C2 = 0; p.Cout = N;
-  attach_rr_weights(p, f, tmp);
   p.g[0].bias = tmp.up(bf); p.g[0].ln_colsum = tmp.up(cs);
   p.g[0].x = x; p.g[0].res1 = res1; p.g[0].y = y;
   p.B = 1; p.H = (int)rows; p.W = 1; p.C1 = K; p.C2 = 0; p.KH = p.KW = 1; p.stride = 1; p.pad = 0;
@@ -1894,7 +1878,6 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   float *dx = nullptr, *dw = nullptr, *dy = nullptr, *db = nullptr;
   unsigned short *dsb = nullptr, *dxs = nullptr, *dys = nullptr, *dh16 = nullptr;
   float* dinv = nullptr;
-  TmpDev tmp_rr;  // packed weights of the row-resident GEMM, freed on return
   if (hipMalloc(&dx, nx * 4) != hipSuccess || hipMalloc(&dw, nw * 4) != hipSuccess || hipMalloc(&dy, ny * 4) != hipSuccess ||
       hipMalloc(&db, (size_t)Cout * 4) != hipSuccess || hipMalloc(&dsb, nw * 10) != hipSuccess || hipMalloc(&dh16, nw * 4) != hipSuccess ||
       hipMalloc(&dinv, (size_t)Cout * 4) != hipSuccess ||
@@ -1913,7 +1896,6 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
     const F16Planes f = split_f16x2(hw, Cout);
     (void)hipMemcpy(dh16, f.planes.data(), nw * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dinv, f.inv_scale.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
-    if (Cin % 32 == 0) attach_rr_weights(p, f, tmp_rr);
   }
   p.g[0].x = dx; p.g[0].w = dw; p.g[0].bias = db; p.g[0].y = dy;
   if (Cin % 32 == 0 || Cin == 4) { p.g[0].w_sb = dsb; p.g[0].w_h16 = dh16; p.g[0].w_h16_inv_scale = dinv; }

@@ -37,10 +37,8 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {256, 64, 0, "sbhA1"}, {256, 64, 0, "sbhA2"}, {256, 64, 0, "sbhA3"}, {256, 64, 0, "sbhA4"}, {256, 64, 0, "sbhA8"}, {256, 64, 0, "sbhA48"},
                              {256, 64, 0, "sbhA12"}, {256, 64, 0, "sbhA11"}, {256, 64, 0, "sbhA15"}, {256, 64, 0, "sbhA63"},
                              {256, 64, 0, "sbhAa"}, {256, 64, 0, "sbhAb"}, {256, 64, 0, "sbhLA0"}, {256, 64, 0, "sbhLA2"}, {256, 64, 0, "sbhLAbf"}, {256, 64, 0, "sbhLAbf0"}, {256, 64, 0, "sbhDMA"}, {256, 64, 0, "sbhREG"},
-                             {256, 128, 0, "sbh256x128w8"},  // 16 x 16 patch x 128 channels, 8 waves: wave tile 64 x 64 (683 B of LDS fragment reads per MFMA instead of 1024)
+                             {256, 128, 0, "sbh256x128w8"}, {256, 128, 0, "sbh256x128w8u"},  // 16 x 16 patch x 128 channels, 8 waves: wave tile 64 x 64 (683 B of LDS fragment reads per MFMA instead of 1024); "u" = no 128-VGPR cap
 #endif
-                             // "sbr": row-resident GEMM for the small-M linear layers and the kernel == stride convs (rr_gemm.hip); always the LAST two entries
-                             {128, 160, 0, "sbr128x160"}, {128, 128, 0, "sbr128x128"},
 };
 #ifdef PF_TUNING_BUILD
 static constexpr int kFirstH = 12 + 16;  // index of the first "sbh" tile (behind the linear tiles' tuning forms)
@@ -48,7 +46,6 @@ static constexpr int kFirstH = 12 + 16;  // index of the first "sbh" tile (behin
 static constexpr int kFirstH = 12;  // index of the first "sbh" tile
 #endif
 int conv_sb_num_tiles() { return (int)(sizeof(kSb) / sizeof(kSb[0])); }
-static constexpr int kFirstR = (int)(sizeof(kSb) / sizeof(kSb[0])) - 2;  // index of the first "sbr" tile
 const char* conv_sb_tile_name(int id) { return kSb[id].name; }
 int conv_sb_tile_bm(int id) { return kSb[id].bm; }
 int conv_sb_tile_bn(int id) { return kSb[id].bn; }
@@ -73,8 +70,6 @@ bool conv_sb_eligible(const ConvParams& p) {
 }
 
 bool conv_sbh_ok(const ConvParams& p);                                   // igemm_sbh.hip
-bool conv_rr_ok(const ConvParams& p, int variant);                       // rr_gemm.hip
-void launch_conv_rr(const ConvParams& p, int variant, hipStream_t s);
 
 // Static choice for shapes the tile table (tuned/gfx950_tiles.txt) does not hold; follows what the per-shape tuning picks
 // (profiles/r01_tune_conv_*.txt): halo tiles for 3x3 / stride-1 convs on maps of 40^2 and more; otherwise the largest tile
@@ -104,7 +99,6 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile);                  // igemm_sbh.hip
 bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
-  if (sb_tile >= kFirstR) return conv_rr_ok(p, sb_tile - kFirstR);
 #ifdef PF_TUNING_BUILD
   if (sb_tile >= 12 && sb_tile < kFirstH)  // tuning forms of the linear tiles: split-f16 scheme, one fp32 input, plain epilogue
     return p.nterms == NT_F16X3 && !p.ln && p.C2 == 0 && !p.g[0].x_sb && p.Cin != 4 && (p.Cin % BK) == 0 && !p.ups && !p.g[0].head_kind;
@@ -173,10 +167,6 @@ void launch_conv_sb(const ConvParams& p0, int sb_tile, hipStream_t s) {
                          reinterpret_cast<const float4*>(q.res1), p.post_relu, reinterpret_cast<float4*>(q.y));
     }
   } } reduce_after{p, s};
-  if (sb_tile >= kFirstR) {
-    if (conv_rr_ok(p, sb_tile - kFirstR)) { launch_conv_rr(p, sb_tile - kFirstR, s); return; }
-    sb_tile = conv_sb_default_tile(p);
-  }
   if (sb_tile >= kFirstH) {
     if (conv_sbh_tile_ok(p, sb_tile - kFirstH)) { launch_conv_sbh(p, sb_tile - kFirstH, s); return; }
     sb_tile = conv_sb_default_tile(p);

@@ -51,7 +51,7 @@ template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE,
                              staging is a plain 16-byte copy per plane -- no split arithmetic in this kernel (VALU instructions are paid in MFMA issue time,
                              DESIGN.md 4.7), and an element is split once by its producer instead of once per n-tile and halo overlap here.  MODE 0, no UPS.*/
           SBH_ABL_PARAM>
-__global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || (SCH == NT_F16X3 && TPG == 1 && !DB && (ABL & 0xa000) == 0 && BN <= 64)) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD (the DMA-ring forms of the 4-wave tiles with BN <= 64 stay inside 128 VGPRs: four resident blocks; tuning builds: 0x8000 lifts that)
+__global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256 && (ABL & 0x8000) == 0) || (SCH == NT_F16X3 && TPG == 1 && !DB && (ABL & 0xa000) == 0 && BN <= 64)) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD (the DMA-ring forms of the 4-wave tiles with BN <= 64 stay inside 128 VGPRs: four resident blocks; tuning builds: 0x8000 lifts that)
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
   constexpr int BM = H_TY * H_TX;
@@ -375,9 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || (SCH =
       }
       constexpr int TA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};  // plane of A: l h m m h h | split-f16: al ah ah
       constexpr int TB[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};  // plane of B: h l m h m h | split-f16: wh wl wh (al is unscaled: no wh 2^-11 operand)
-#ifdef PF_EXP_SETPRIO
-      __builtin_amdgcn_s_setprio(1);  // experiment (tuning builds): the wave that has MFMAs to issue wins the issue slot over co-resident waves in their staging phase
-#endif
+      // (s_setprio(1) around this MFMA cluster, as in cnx_mlp.hip: measured -3.5 % end to end, profiles/r03_validate_call4.log)
 #pragma unroll
       for (int t6 = 0; t6 < (F16 ? 3 : 6); ++t6)
 #pragma unroll
@@ -385,9 +383,6 @@ __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256) || (SCH =
 #pragma unroll
           for (int j = 0; j < SN; ++j)
             acc[i][j] = mfma16h<F16>(af[i][TA[t6]], bf[j][TB[t6]], acc[i][j]);
-#ifdef PF_EXP_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
   };
 
@@ -595,6 +590,12 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
     case 29: launch_sbh_abl<0x1000>(p, s); break;
     case 30: launch_sbh_abl<0x2000>(p, s); break;
     case 31: launch_sbh_cfg<16, 16, 128, 4, 2>(p, s); break;          // "sbh256x128w8"
+    case 32: {                                                        // "sbh256x128w8u": the same without the 128-VGPR cap (one block of 8 waves per CU, no spills)
+      const int tilesN = (p.Cout + 127) / 128, tilesX = (p.Wo + 15) / 16, tilesY = (p.Ho + 15) / 16;
+      if (p.nterms == NT_F16X3 && p.C2 == 0 && !p.ups && !p.g[0].x_sb)
+        hipLaunchKernelGGL((igemm_sbh_kernel<16, 16, 128, 4, 2, 0, 1, NT_F16X3, false, false, false, 0x8000>), dim3(p.B * tilesY * tilesX * tilesN * p.groups), dim3(512), 0, s, p);
+      break;
+    }
 #endif
     default: launch_sbh_cfg<16, 16, 64, 4, 2>(p, s); break;  // 16 x 16 patch, 8 waves, two blocks per CU: weights staged once per 256 rows
   }

@@ -30,7 +30,6 @@ struct ConvPtrs {
   // [2^13, 2^14)) as two fp16 planes [2][Cout][KH][KWCp]: wh = fp16(w S), wl = fp16(w S - wh); w_h16_inv_scale = 1 / S
   const unsigned short* w_h16 = nullptr;
   const float* w_h16_inv_scale = nullptr;  // [Cout]: applied to the accumulators before the bias
-  const unsigned short* w_rr = nullptr;    // the same two planes in the DMA order of the row-resident GEMM (rr_gemm.hip rr_pack_weights); nullptr: not packed
   const float* bias = nullptr;      // [Cout] or nullptr
   const float* bias_tab = nullptr;  // [9][Cout]: bias per 3x3 border case (folded Linear->conv), overrides bias
   const float* res1 = nullptr;      // [M][Cout] or nullptr (may alias y)
@@ -94,8 +93,6 @@ struct ConvParams {
   }
 };
 
-int rr_chunk_of(int kwc);  // rr_gemm.hip: K chunk of the row-resident GEMM for a kernel row of kwc contiguous floats (0: not eligible)
-std::vector<unsigned short> rr_pack_weights(const std::vector<unsigned short>& planes, int Cout, int K, int KC);
 void launch_conv(const ConvParams& p, hipStream_t s);
 // tile choice is exposed for tests / tuning: -1 = auto
 void launch_conv_tile(const ConvParams& p, int tile_id, hipStream_t s);

@@ -98,7 +98,7 @@ def test_conv2d_split_plane_operands(ops, case):
     b = _rand((Cout,), 4, 0.1)
     ref = _ref_conv(x.cpu(), w, b, stride, pad, None if x2 is None else x2.cpu())
     names = ops.conv_tiles()
-    sb = [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith(("sbh", "sbr"))]  # the halo and row-resident tiles take fp32 operands only
+    sb = [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbh")]  # the halo tiles take fp32 operands only
     assert sb
     for tile in sb:
         # (splitk=False: split-K, which only fp32-in / fp32-out launches use, changes the summation order)
@@ -178,7 +178,7 @@ def test_conv2d_split_f16_plane_operands(ops, case):
     b = _rand((Cout,), 4, 0.1)
     names = ops.conv_tiles()
     halo_ok = K == 3 and stride == 1 and pad == 1 and C2 == 0  # the halo kernel copies fp16 planes too (igemm_sbh ASB): one input, plain tap loop
-    for tile in [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbr") and (halo_ok or not n.startswith("sbh"))]:
+    for tile in [i for i, n in enumerate(names) if n.startswith("sb") and (halo_ok or not n.startswith("sbh"))]:
         base = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, precision=0, splitk=False)
         got_in = ops.conv2d(x, w, b, stride=stride, pad=pad, x2=x2, tile=tile, act=1, planes_in=True, planes_fmt="f16x2", splitk=False)
         assert torch.equal(got_in, base), f"{name} {names[tile]}: fp16-plane input differs from fp32 input"
@@ -210,44 +210,6 @@ def test_split_planes_bits(ops):
     assert not bool(bad.any()), f"lo plane differs in {int(bad.sum())} of {n} elements, first at {int(bad.nonzero()[0])}: x = {float(v.reshape(-1)[bad.nonzero()[0]])}"
 
 
-@pytest.mark.parametrize("K,N,rows", [(320, 320, 257), (320, 1280, 300), (1280, 320, 129), (384, 1536, 200), (1536, 384, 130), (128, 512, 1000), (512, 128, 260),
-                                      (64, 64, 500), (192, 768, 140), (768, 192, 33), (96, 384, 64), (2048, 512, 100), (640, 160, 7)])
-def test_row_resident_gemm(ops, K, N, rows):
-    """rr_gemm.hip ("sbr" tiles): every K chunk size (160 / 128 / 96 / 64), column parts with a short last part, ragged row blocks, bias / GELU / residual epilogues,
-    against torch fp64 -- and against the LDS-tiled kernel on the same operands (same scheme, other summation order: ~1e-6)."""
-    x = _rand((rows, K), 113, 1.3)
-    w = _rand((N, K), 114, 1.0 / math.sqrt(K))
-    b = _rand((N,), 115, 0.1)
-    r = _rand((rows, N), 116)
-    ref = F.linear(x.double(), w.double(), b.double())
-    names = ops.conv_tiles()
-    t64 = names.index("sb64x64")
-    ran = 0
-    for t, name in enumerate(names):
-        if not name.startswith("sbr"):
-            continue
-        _close(ops.linear(x.cuda(), w, b, tile=t), ref, 3e-5, f"{name} linear")
-        _close(ops.linear(x.cuda(), w, b, act=2, tile=t), pf_oracle.gelu(ref), 3e-5, f"{name} linear+gelu")
-        got = ops.linear(x.cuda(), w, b, res1=r.cuda(), tile=t)
-        _close(got, ref + r.double(), 3e-5, f"{name} linear+res")
-        _close(got, ops.linear(x.cuda(), w, b, res1=r.cuda(), tile=t64).double().cpu(), 1e-5, f"{name} vs sb64x64")
-        ran += 1
-    assert ran == 2
-
-
-@pytest.mark.parametrize("B,H,W,C,k,Cout", [(1, 20, 20, 320, 2, 320), (2, 40, 40, 128, 4, 128), (2, 16, 16, 64, 8, 64), (1, 20, 20, 96, 2, 192), (3, 10, 6, 384, 2, 768)])
-def test_row_resident_gemm_patch_convs(ops, B, H, W, C, k, Cout):
-    """The kernel == stride convs (MiT spatial reduction mix_transformers.py:84-88, ConvNeXt down-sampling convnext.py:95-101) as gathered-row GEMMs on the "sbr" tiles."""
-    x = _rand((B, H, W, C), 121)
-    w = _rand((Cout, C, k, k), 122, 1.0 / math.sqrt(C * k * k))
-    b = _rand((Cout,), 123, 0.1)
-    ref = _ref_conv(x, w, b, k, 0)
-    names = ops.conv_tiles()
-    for t, name in enumerate(names):
-        if name.startswith("sbr"):
-            _close(ops.conv2d(x.cuda(), w, b, stride=k, pad=0, tile=t, splitk=False), ref, 3e-5, f"{name} {k}x{k}s{k}")
-
-
 @pytest.mark.parametrize("precision,tol", [(1, 2e-4), (2, 3e-2)], ids=["bf16x3", "bf16"])
 def test_conv2d_reduced_precision_modes(ops, precision, tol):
     """The optional reduced-precision forms of the split-bf16 kernel (3 / 1 partial products instead of 6) on every
@@ -260,7 +222,7 @@ def test_conv2d_reduced_precision_modes(ops, precision, tol):
     ref = _ref_conv(x, w, b, 1, 1)
     xd = x.cuda()
     names = ops.conv_tiles()
-    for tile in [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith(("sbh", "sbr"))]:  # halo / row-resident tiles: fp32-accurate modes only
+    for tile in [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbh")]:  # halo tiles: fp32-accurate modes only
         got = ops.conv2d(xd, w, b, pad=1, tile=tile, precision=precision)
         _close(got, ref, tol, f"{names[tile]} precision {precision}")
         e_red = float((got.double().cpu() - ref).abs().max())
@@ -385,8 +347,6 @@ def test_linear_with_fused_layernorm(ops, K, N, rows):
                 ops.linear_ln(x.cuda(), w, b, g, be, 1e-6, tile=t)   # exact-fp32 and halo tiles do not carry the fused form: loud
             continue
         for prec, tol in ((0, 5e-5), (3, 5e-5)):
-            if prec != 0 and name.startswith("sbr"):
-                continue  # the row-resident GEMM exists for the split-f16 scheme only
             _close(ops.linear_ln(x.cuda(), w, b, g, be, 1e-6, tile=t, precision=prec), ref, tol, f"linear_ln tile {name} precision {prec}")
             ran += 1
     assert ran >= 20

@@ -429,7 +429,7 @@ def test_kernel_resources_static():
     # once-per-chunk halo store (4 reloads per 32-channel chunk, none in the tap loop): measured faster than the uncapped form (profiles/r03_sbh_variants.txt)
     # ... and the LayerNorm-fused 128 x 256 / 8-wave tile spills 3 registers in its prologue since the pivot became a chunk mean
     few_spills = {"pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 23, false, false, false>": 8, "pf::igemm_sb_kernel<128, 256, 2, 4, 0, false, 1, 23, true>": 3}
-    hot += ["pf::rr_gemm_kernel<160, 5, false>", "pf::rr_gemm_kernel<160, 5, true>", "pf::rr_gemm_kernel<128, 4, false>", "pf::rr_gemm_kernel<128, 4, true>", "pf::dwconv7x7_lds_kernel<2, 13>"]
+    hot += ["pf::dwconv7x7_lds_kernel<2, 13>"]
     for k in hot:
         assert k in by, (k, [n for n in by if n.startswith(k.split("<")[0])][:4])
         assert by[k]["spill"] <= few_spills.get(k, 0) and by[k]["scratch"] <= 6 * few_spills.get(k, 0), by[k]
