@@ -74,7 +74,7 @@ def pmc_traffic():
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT) + (f" (taken at commit {d['commit']})" if d.get("commit") else "")
 
 
 def cpu_baseline(version, size, budget_s=12.0, max_images=12):
@@ -435,10 +435,10 @@ def main(argv=None):
                     "peak_basis": f"achieved = algorithmic FLOPs of the launch (2*M*N*K = {2.0 * M_ * N_ * K_ / 1e9:.1f} GFLOP) / its average HIP-event duration, priced against the DENSE 16-bit MFMA peak; "
                                   f"the kernel executes {nt} MFMA FLOPs per algorithmic FLOP (executed_mfma_tflops): its ceiling is 2500/{nt} = {2500.0 / nt:.1f} TFLOP/s",
                     "executed_mfma_tflops": round(ach * nt, 1), "frac_of_scheme_ceiling": round(ach * nt / BF16_MFMA_PEAK_TFLOPS, 4),
-                    "measured_mfma_only_ceiling_tflops": 1790.0,
-                    "measured_mfma_only_ceiling_note": "scripts/microbench/valu_mfma_overlap.hip on MI355X: back-to-back v_mfma_f32_32x32x16_f16 with independent accumulators "
-                                                       "retire one per 42-45 nominal (2.4 GHz) cycles instead of 32 (clock under MFMA load ~1.7 GHz), and VALU instructions of "
-                                                       "co-resident waves do not run under them (profiles/r02_cnx_mlp.md); `peak` stays the guide's 2500",
+                    "mfma_only_ceiling_tflops": 1900.0,
+                    "mfma_only_ceiling_note": "NOT measured in this run: scripts/microbench/valu_mfma_interleave.hip on MI355X (profiles/r03_candidates.md): back-to-back "
+                                              "v_mfma_f32_32x32x16_f16 retire one per 42 nominal (2.4 GHz) cycles instead of 32 (the part clocks ~1.8 GHz under MFMA load), and a VALU "
+                                              "instruction next to them costs 55-75 % of its stand-alone issue time wherever it is placed; `peak` stays the guide's 2500",
                     "launches_per_step": n_ // ev_steps, "avg_launch_us": round(1000.0 * ms_ / n_, 2),
                     "algorithmic_gflop_per_launch": round(work_ / n_ / 1e9, 2),
                     "share_of_step_time": round(ms_ / ev_steps / (1000.0 * dt / args.steps), 4), "event_steps": ev_steps,

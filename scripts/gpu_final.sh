@@ -1,14 +1,14 @@
 #!/bin/bash
-# Round-end evidence run: full GPU test suite, smoke, tile table, bench (with cpu baseline + extras), other precisions / configs,
-# per-layer table, rocprofv3 kernel trace + PMC passes.  Everything lands in gpurun_out/; copy what is to be judged into profiles/.
+# Round-end evidence run on ONE box at the final HEAD: full GPU test suite, smoke, bench (default line with cpu baseline + extras; no-events; other precisions;
+# the mixed-resolution workload; other BASELINE configs), per-layer table, rocprofv3 kernel trace + PMC passes.  Everything lands in gpurun_out/; what is to be judged
+# is copied into profiles/ (r03_*).  The tile table is the shipped one (what the driver's run uses).
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
-echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider -s 2>&1 | grep -E "^\[|passed|failed|FAILED|Error" | tail -120 | tee gpurun_out/test_gpu.log | tail -5
+echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider -s 2>&1 | grep -E "^\[|passed|failed|FAILED|Error" | tail -150 | tee gpurun_out/test_gpu.log | tail -5
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
-echo "== tile table"; timeout 1500 python scripts/gen_tile_table.py --out gpurun_out/gfx950_tiles.txt --batches 1,8,32,64 2>&1 | tail -3
-export PF_TILE_TABLE=$PWD/gpurun_out/gfx950_tiles.txt
 echo "== bench"; timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -1 | tee gpurun_out/bench.json | cut -c1-300
 echo "== bench noevents"; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_noevents.json | cut -c1-160
+echo "== bench mixed (configs[4])"; timeout 300 python bench.py --workload mixed --batch 64 --steps 8 --warmup 2 --no-cpu-baseline --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_mixed.json | cut -c1-400
 for P in fp32_bf16x6 bf16x3 bf16; do
   echo "== bench $P"; timeout 300 python bench.py --precision $P --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_$P.json | cut -c1-160
 done
