@@ -167,8 +167,11 @@ int pf_postprocess(pf_handle h, const float* d_pred_gravity, const float* d_pred
  * 2 LayerNorm, 3 depthwise3x3+GELU, 4 depthwise7x7, 5 bilinear x2 (work = algorithmic bytes in+out), 6 other,
  * 7 implicit-GEMM launches served by the split-bf16 kernel (class 0 then counts only the exact-fp32 MFMA launches).
  * Between begin and end every launch of a class whose bit is set in class_mask is bracketed by an
- * event pair; pf_profile_end synchronises those events and sums elapsed ms / work / launches per class. */
+ * event pair; pf_profile_end synchronises those events and sums elapsed ms / work / launches per class.
+ * class_mask bit 31 (PF_PROFILE_LARGE_ONLY): only launches of >= 200 GFLOP are bracketed (a dozen per B = 32 step: the dominant
+ * decoder convs) -- cheap enough for every timed step of a benchmark, and the internal side stream stays on. */
 #define PF_PROFILE_CLASSES 8
+#define PF_PROFILE_LARGE_ONLY 0x80000000u
 int pf_profile_begin(pf_handle h, unsigned class_mask);
 /* stop bracketing further launches without synchronising (the window can cover the first steps of a timed loop only) */
 int pf_profile_pause(pf_handle h);

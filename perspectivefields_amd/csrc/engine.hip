@@ -152,6 +152,8 @@ struct Profiler {
   size_t used = 0;
   bool on = false;
   unsigned mask = 0xffffffffu;
+  double min_work = 0.0;  // > 0: only launches with at least this much algorithmic work are bracketed (class-mask bit 31: the few large launches of a step --
+                          // a dozen event records per step cost nothing, so EVERY timed step of bench.py can carry them, with the side stream left on)
   hipEvent_t get() {
     if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
     return pool[used++];
@@ -162,7 +164,7 @@ struct Profiler {
 struct ProfScope {
   Profiler* p; hipStream_t s; hipEvent_t b = nullptr;
   ProfScope(Profiler* pr, hipStream_t st, int cat, double work, int m = 0, int n = 0, int k = 0, int kh = 0) : p(pr), s(st) {
-    if (!p || !p->on || !((p->mask >> cat) & 1u)) { p = nullptr; return; }
+    if (!p || !p->on || !((p->mask >> cat) & 1u) || work < p->min_work) { p = nullptr; return; }
     hipEvent_t a = p->get(); b = p->get();
     if (!a || !b) { p = nullptr; return; }
     (void)hipEventRecord(a, s);
@@ -421,7 +423,7 @@ struct pf_engine {
         hipEventCreateWithFlags(&ev_ll, hipEventDisableTiming) != hipSuccess) return false;
     return true;
   }
-  bool can_fork(const Ctx& c) { return side_stream_mode && !c.dry && !c.tuning && !c.prof && side_ready(); }
+  bool can_fork(const Ctx& c) { return side_stream_mode && !c.dry && !c.tuning && (!c.prof || c.prof->min_work > 0.0) && side_ready(); }  // (a full per-launch profile keeps one stream: its event pairs must bracket what they name)
   bool sba_heads = false;    // PF_SBA_HEADS=1: the tensors between the 3x3 convs of the decoders' ResidualConvUnits are written as split-f16 planes by the producing
                              // conv's epilogue (plus fp32 where a residual add reads them) and the halo kernel copies them (igemm_sbh ASB) instead of splitting
                              // every element once per n-tile and halo overlap; split-f16 scheme only
@@ -1676,7 +1678,8 @@ int pf_fields_from_params(int device, const float* d_cam5, int H, int W, float* 
 int pf_profile_begin(pf_handle h, unsigned class_mask) {
   if (!h) return PF_ERR_ARG;
   h->prof.reset();
-  h->prof.mask = class_mask;
+  h->prof.mask = class_mask & 0x7fffffffu;
+  h->prof.min_work = (class_mask & 0x80000000u) ? 2.0e11 : 0.0;  // bit 31: launches of >= 200 GFLOP only (the 256 -> 256 @80^2 convs, conv_fuse_conv0 / conv1 at B = 32)
   h->prof.on = true;
   return PF_OK;
 }

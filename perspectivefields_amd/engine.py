@@ -428,8 +428,9 @@ class Engine:
 
     PROFILE_CLASSES = ("igemm", "attention", "layernorm", "dwconv3x3_gelu", "dwconv7x7", "upsample2x", "other", "igemm_sb")
 
-    def profile_begin(self, classes=None):
-        mask = 0
+    def profile_begin(self, classes=None, large_only=False):
+        """large_only: bracket only the launches of >= 200 GFLOP (PF_PROFILE_LARGE_ONLY): negligible overhead, side stream stays on."""
+        mask = 0x80000000 if large_only else 0
         for i, n in enumerate(self.PROFILE_CLASSES):
             if classes is None or n in classes:
                 mask |= 1 << i

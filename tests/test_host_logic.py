@@ -350,7 +350,7 @@ def test_bench_cli_contract_and_loud_failure_without_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert h.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--precision", "--event-steps"):
+    for flag in ("--gpus", "--steps", "--warmup", "--precision", "--events-in-timed", "--workload"):
         assert flag in h.stdout, flag
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
