@@ -227,12 +227,12 @@ __global__ __launch_bounds__(256, C <= 96 ? 3 : 1) void cnx_mlp_kernel(const flo
     }
 }
 
-// C = 192 (stage 2) runs, and is tested, but is not used by the engine: 96 + 96 fragment / accumulator registers leave one wave per SIMD and it
-// measured slower than the two GEMMs it would replace (327 vs ~195 us at 51 200 rows, profiles/r02_negative_results.md)
+// C = 192 (stage 2): 96 + 96 fragment / accumulator registers leave one wave per SIMD; r02 measured it slower than the two GEMMs it replaces (old operand split),
+// with the r03 split it is ahead end to end (1477-1481 vs 1471-1473 img/s, two runs each on one box, profiles/r03_candidates.md): on by default, PF_CNX_MLP_192=0 restores the GEMM pair
 bool cnx_mlp_supported(int C) { return C == 96 || C == 192; }
 bool cnx_mlp_preferred(int C) {
   const char* e = getenv("PF_CNX_MLP_192");  // read per call (weight build time only): a process may create engines of both kinds
-  const int with192 = e ? atoi(e) : 0;
+  const int with192 = e ? atoi(e) : 1;
   return C == 96 || (C == 192 && with192);
 }
 
