@@ -75,8 +75,11 @@ def _resolve_weights(version: str, weights) -> Dict[str, np.ndarray]:
 class PerspectiveFields(nn.Module):
     def __init__(self, version: str = "Paramnet-360Cities-edina-centered", weights=None, precision: str = "fp32"):
         super().__init__()
-        # 'fp32' (default) is the parity mode: fp32-accurate contractions.  'bf16x3' / 'bf16' are faster reduced-precision
-        # modes of the dense contractions (Engine.set_precision); their outputs are not held to the parity tolerances.
+        # 'fp32' (default) is the parity mode: fp32-class contractions on the 2-way fp16 split -- full accuracy for activations in [2^-3, 65504], saturation
+        # beyond, an absolute 2^-25 per element below (sb_split.h).  'fp32_bf16x6' is the exact bf16 split (no window, ~1.5x the MFMA work).  'auto' decides between
+        # the two ONCE, on the first batch the model sees: a range-recording forward (pf_debug_forward_u8) and 'fp32_bf16x6' if any dense-layer input saturates or is
+        # all-tiny, 'fp32' otherwise (`self.precision` then holds the decision).  'bf16x3' / 'bf16' are faster reduced-precision modes of the dense contractions
+        # (Engine.set_precision); their outputs are not held to the parity tolerances.
         self.precision = precision
         cfg = get_cfg(version)  # KeyError on an unknown version, as the reference (:127)
         self.version = version
@@ -141,7 +144,7 @@ class PerspectiveFields(nn.Module):
         if self._engine is None or self._engine.device != dev:
             eng = Engine(self.arch["arch_id"], dev)
             eng.load_state_dict(self._state)
-            eng.set_precision(self.precision)  # always: the model's precision wins over any PF_PRECISION default of the library
+            eng.set_precision("fp32" if self.precision == "auto" else self.precision)  # always: the model's precision wins over any default of the library
             self._engine = eng
         return self._engine
 
@@ -316,6 +319,14 @@ class PerspectiveFields(nn.Module):
             for i0 in range(0, len(sizes), chunk):
                 out.extend(self._run(batch[i0:i0 + chunk], sizes[i0:i0 + chunk]))
             return out
+        if self.precision == "auto":  # first batch: look at the activations this checkpoint produces, then settle on a precision for the model's lifetime
+            probe = batch if batch.dtype == torch.uint8 else batch.permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8)  # forward(): (B,3,320,320) float -> the u8 NHWC form of the debug entry
+            _, _, _, _, rng = eng.forward_debug(probe.contiguous(), shadow=False, ranges=True)
+            outside = [r for r in rng if r["saturated"] > 0 or r["non_finite"] > 0 or 0.0 < r["rms"] < 2.0 ** -5]
+            self.precision = "fp32_bf16x6" if outside else "fp32"
+            self.precision_reason = (f"{len(outside)} of {len(rng)} dense-layer inputs outside the split-f16 window, first: {outside[0]['name']} "
+                                     f"(max |x| {outside[0]['max_abs']:.4g}, rms {outside[0]['rms']:.4g})") if outside else f"all {len(rng)} dense-layer inputs inside the split-f16 window"
+            eng.set_precision(self.precision)
         pg, pl, params = eng.forward(batch)
         return self._assemble(eng, pg, pl, params, sizes)
 
