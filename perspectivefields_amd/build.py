@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # The product library lives in lib/.  The tuning build (PF_TUNING_BUILD=1: ablation kernels, rejected variants) gets its own directory, lib_tune/, so that both can
 # be prebuilt in the tree and travel to the GPU box together.
-_VARIANT = "_tune" if os.environ.get("PF_TUNING_BUILD", "0") == "1" else ""
+# PF_LIB_SUFFIX=<s> (with PF_SKIP_DIGEST_CHECK=1) selects lib<s>/: a library built from OTHER sources kept next to the product for a same-box A/B.
+_VARIANT = ("_tune" if os.environ.get("PF_TUNING_BUILD", "0") == "1" else "") + os.environ.get("PF_LIB_SUFFIX", "")
 LIBDIR = os.path.join(HERE, "lib" + _VARIANT)
 LIB = os.path.join(LIBDIR, "libpf_hip.so")
 SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sb3.hip", "igemm_sb1.hip", "igemm_sbf.hip", "igemm_sbh.hip", "attn.hip", "elem.hip", "dw7.hip", "cnx_mlp.hip", "mit_mlp.hip", "engine.hip"]
