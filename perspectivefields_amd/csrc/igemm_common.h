@@ -30,6 +30,11 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned 
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// Read-only operand of an epilogue as a buffer resource: a null pointer gives an EMPTY buffer (every load returns zeros), so the loads need no branch
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const float* ptr, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, ptr ? (int)(bytes < 0x7fffffffL ? bytes : 0x7fffffffL) : 0, 0x00020000);
+}
+
 // XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a contiguous run of tiles so that
 // neighbouring m-tiles (shared halo rows) and the n-tiles of one m-tile (same A rows) meet in one L2.
 __device__ __forceinline__ int xcd_tile_index(int nblk) {
@@ -53,11 +58,36 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
   constexpr int CH_ROWS = WM * 32;        // rows per chunk: subtile row i of every wave row
   constexpr int F4_PER_ROW = BN / 4;
   static_assert(CH_ROWS * CROW <= SMEM_FLOATS, "epilogue chunk must fit the operand buffers");
+  // A thread keeps ONE column group (cq) over all its items: NT is a multiple of the float4s per row.  Items per chunk and thread: ITERS = 4 SN, taken U at a time
+  constexpr int RSTEP = NT / F4_PER_ROW, ITERS = CH_ROWS * F4_PER_ROW / NT;
+  // U = 2 where the registers are there (the 8-wave halo tiles); elsewhere one item at a time: two items' operands cost the 4-wave linear tiles a resident block
+  constexpr int U = (NT == 512 && BM * BN < 128 * 256) ? 2 : 1;
+  static_assert(NT % F4_PER_ROW == 0 && (CH_ROWS * F4_PER_ROW) % NT == 0 && ITERS % U == 0, "epilogue item mapping");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wave_m = wave / WN;
   const int wn0 = (wave % WN) * (SN * 32);
   const int HoWo = p.Ho * p.Wo;
   const bool vec_ok = (p.Cout & 3) == 0 && (p.ldy & 3) == 0;
+  const int cq = tid % F4_PER_ROW, row0 = tid / F4_PER_ROW;
+  const int n = n0 + cq * 4;
+  const bool n_ok = n < p.Cout;
+  const int act = p.act, post_relu = p.post_relu;
+  const float *res1 = P.res1, *res2 = P.res2, *bias_tab = P.bias_tab;
+  float* const y = P.y;
+  unsigned short* const y_sb = P.y_sb;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Memory operands (r03): written as `if (ptr) { load; use }` per item, every load was followed by s_waitcnt vmcnt(0) -- three to four dependent L2 round trips per
+  // item, profiles/r03_epilogue_batching.md.  Now every operand is a buffer resource (empty when the pointer is null; out-of-range offset for a masked item), the loads
+  // are unconditional and issued in front of the arithmetic: the column constants of the thread's group once, before the first barrier; bias-table rows and residuals of
+  // U items together.  Residual resources start at the block's first row / image (`mb`, block-uniform) so that their offsets stay far below the 2 GiB range marker.
+  const int mb = t2 ? t2->b * HoWo : m0;
+  const __amdgpu_buffer_rsrc_t r_sc = epi_rsrc(oscale, (long)p.Cout * 4), r_cs = epi_rsrc(ln_stat ? P.ln_colsum : nullptr, (long)p.Cout * 4);
+  const __amdgpu_buffer_rsrc_t r_b = epi_rsrc(bias_tab ? bias_tab : P.bias, (long)p.Cout * (bias_tab ? 36 : 4));
+  const __amdgpu_buffer_rsrc_t r_q1 = epi_rsrc(res1 ? res1 + (long)mb * p.ldy : nullptr, (long)(p.M - mb) * p.ldy * 4);
+  const __amdgpu_buffer_rsrc_t r_q2 = epi_rsrc(res2 ? res2 + (long)mb * p.ldy : nullptr, (long)(p.M - mb) * p.ldy * 4);
+  const bool has_bias = bias_tab != nullptr || P.bias != nullptr, any_extra = bias_tab != nullptr || res1 != nullptr || res2 != nullptr;
+  const unsigned coff = (vec_ok && n_ok) ? (unsigned)n * 4u : OOB;
+  const float4 sc = buf_load16(r_sc, coff), cs = buf_load16(r_cs, coff), bb = buf_load16(r_b, coff);
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
     __syncthreads();  // previous chunk fully written back / K loop finished reading the operand tiles
@@ -67,78 +97,110 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
       for (int r = 0; r < 16; ++r)
         Cs[(wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CROW + wn0 + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-    for (int idx = tid; idx < CH_ROWS * F4_PER_ROW; idx += NT) {
-      const int row_l = idx / F4_PER_ROW, cq = idx - row_l * F4_PER_ROW;
-      const int lm0 = (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
-      int m = m0 + lm0;
-      const int n = n0 + cq * 4;
-      if (t2) {
-        const int lm = m - m0, ry = lm / t2->tx, rx = lm - ry * t2->tx;
-        const int oy = t2->oy0 + ry, ox = t2->ox0 + ((ry & 1) ? (rx + t2->odd_shift) % t2->tx : rx);
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        m = (t2->b * p.Ho + oy) * p.Wo + ox;
-      }
-      if (m >= p.M || n >= p.Cout) continue;
-      float4 v = *reinterpret_cast<const float4*>(Cs + row_l * CROW + cq * 4);
-      const float* bsrc = P.bias;
-      if (P.bias_tab) {  // position-dependent bias of a folded (Linear -> zero-padded 3x3) pair: 3x3 border cases
-        const int rem = m % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
-        bsrc = P.bias_tab + (cy * 3 + cx) * p.Cout;
-      }
-      const long o = (long)m * p.ldy + n;
-      if (vec_ok) {
-        if (oscale) { const float4 sc = *reinterpret_cast<const float4*>(oscale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
-        if (ln_stat) {  // y = rstd (x W' - mean colsum) (+ bias below): LayerNorm of the input rows, gamma / beta folded into W' / bias
-          const float mu = ln_stat[2 * lm0], rs = ln_stat[2 * lm0 + 1];
-          const float4 cs = *reinterpret_cast<const float4*>(P.ln_colsum + n);
-          v.x = rs * fmaf(-mu, cs.x, v.x); v.y = rs * fmaf(-mu, cs.y, v.y); v.z = rs * fmaf(-mu, cs.z, v.z); v.w = rs * fmaf(-mu, cs.w, v.w);
-        }
-        if (bsrc) { const float4 bb = *reinterpret_cast<const float4*>(bsrc + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-        if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        else if (p.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-        if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-        if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-        if (p.post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if constexpr (BN == 32) {
-          if (P.head_kind) {  // block-uniform.  The 8 lanes idx % 8 = 0..7 hold the 32 channels of one pixel (same row -> same branch)
-            const int sub = cq;  // channels 4 sub .. 4 sub + 3
-            const float4 w0 = reinterpret_cast<const float4*>(P.head_w)[sub];
-            float d0 = head_dot4(v, w0), d1 = 0.f;
-            if (P.head_kind == 1) d1 = head_dot4(v, reinterpret_cast<const float4*>(P.head_w)[8 + sub]);
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITERS; it0 += U) {
+      int mm[U], lm0s[U];
+      bool ok[U];
+      float4 v[U], bt[U], q1[U], q2[U];
 #pragma unroll
-            for (int sh = 4; sh > 0; sh >>= 1) { d0 += __shfl_xor(d0, sh, 8); d1 += __shfl_xor(d1, sh, 8); }
-            if (sub == 0) {
-              const int b_img = m / HoWo;
-              const int r = m - b_img * HoWo;
-              if (P.head_kind == 1) {
-                d0 += P.head_b[0]; d1 += P.head_b[1];
-                const float nrm = fmaxf(sqrtf(fmaf(d1, d1, __fmul_rn(d0, d0))), 1e-12f);  // F.normalize eps (same expression as pred_regression_kernel)
-                d0 /= nrm; d1 /= nrm;
-                P.head_out[((long)b_img * 2) * HoWo + r] = d0;
-                P.head_out[((long)b_img * 2 + 1) * HoWo + r] = d1;
-                if (P.head_pn) *reinterpret_cast<float2*>(P.head_pn + (long)m * 4) = make_float2(d0, d1);
-              } else {
-                d0 = fminf(fmaxf(d0 + P.head_b[0], -1.f), 1.f);
-                P.head_out[m] = d0;
-                if (P.head_pn) *reinterpret_cast<float2*>(P.head_pn + (long)m * 4 + 2) = make_float2(d0, 0.f);
-              }
-            }
-            continue;
-          }
+      for (int u = 0; u < U; ++u) {
+        const int row_l = row0 + (it0 + u) * RSTEP;
+        const int lm0 = (row_l >> 5) * (SM * 32) + i * 32 + (row_l & 31);
+        int m = m0 + lm0;
+        ok[u] = n_ok;
+        if (t2) {  // a spatial patch: local row -> pixel of image b
+          const int lm = m - m0, ry = lm / t2->tx, rx = lm - ry * t2->tx;
+          const int oy = t2->oy0 + ry, ox = t2->ox0 + ((ry & 1) ? (rx + t2->odd_shift) % t2->tx : rx);
+          if (oy >= p.Ho || ox >= p.Wo) ok[u] = false;
+          m = (t2->b * p.Ho + oy) * p.Wo + ox;
         }
-        if (P.y) *reinterpret_cast<float4*>(P.y + o) = v;
-        if (P.y_sb) store_sb4(P.y_sb, p.y_sb_plane, (size_t)o, v);  // split once here instead of per (tap, n-tile) in the consumer
-      } else {  // ragged channel count: scalar tail
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-          float x = vv[e] * (oscale ? oscale[n + e] : 1.f) + (bsrc ? bsrc[n + e] : 0.f);
-          if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
-          else if (p.act == ACT_GELU) x = gelu_erf(x);
-          if (P.res1) x += P.res1[o + e];
-          if (P.res2) x += P.res2[o + e];
-          if (p.post_relu) x = fmaxf(x, 0.f);
-          P.y[o + e] = x;
+        if (m >= p.M) ok[u] = false;
+        mm[u] = m; lm0s[u] = lm0;
+        v[u] = *reinterpret_cast<const float4*>(Cs + row_l * CROW + cq * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { bt[u] = zero4; q1[u] = zero4; q2[u] = zero4; }
+      if (any_extra) {  // ONE block-uniform branch around the loads of all U items (a branch per operand brings the wait after every load back); absent operands of a
+                        // launch that has some read their empty buffers, a launch with none (most convs) issues nothing
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool live = ok[u] && vec_ok;
+          unsigned boff = OOB;
+          if (bias_tab && live) {  // position-dependent bias of a folded (Linear -> zero-padded 3x3) pair: 3x3 border cases
+            const int rem = mm[u] % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
+            boff = (unsigned)((cy * 3 + cx) * p.Cout + n) * 4u;
+          }
+          const unsigned qoff = live ? (unsigned)(((long)(mm[u] - mb) * p.ldy + n) * 4) : OOB;
+          bt[u] = buf_load16(r_b, boff);
+          q1[u] = buf_load16(r_q1, qoff);
+          q2[u] = buf_load16(r_q2, qoff);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        const int m = mm[u];
+        const long o = (long)m * p.ldy + n;
+        float4 w = v[u];
+        if (vec_ok) {
+          if (oscale) { w.x *= sc.x; w.y *= sc.y; w.z *= sc.z; w.w *= sc.w; }
+          if (ln_stat) {  // y = rstd (x W' - mean colsum) (+ bias below): LayerNorm of the input rows, gamma / beta folded into W' / bias
+            const float mu = ln_stat[2 * lm0s[u]], rs = ln_stat[2 * lm0s[u] + 1];
+            w.x = rs * fmaf(-mu, cs.x, w.x); w.y = rs * fmaf(-mu, cs.y, w.y); w.z = rs * fmaf(-mu, cs.z, w.z); w.w = rs * fmaf(-mu, cs.w, w.w);
+          }
+          if (has_bias) { const float4 bv = bias_tab ? bt[u] : bb; w.x += bv.x; w.y += bv.y; w.z += bv.z; w.w += bv.w; }
+          if (act == ACT_RELU) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+          else if (act == ACT_GELU) { w.x = gelu_erf(w.x); w.y = gelu_erf(w.y); w.z = gelu_erf(w.z); w.w = gelu_erf(w.w); }
+          if (res1) { w.x += q1[u].x; w.y += q1[u].y; w.z += q1[u].z; w.w += q1[u].w; }
+          if (res2) { w.x += q2[u].x; w.y += q2[u].y; w.z += q2[u].z; w.w += q2[u].w; }
+          if (post_relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+          if constexpr (BN == 32) {
+            if (P.head_kind) {  // block-uniform.  The 8 lanes tid % 8 = 0..7 hold the 32 channels of one pixel (same row -> same branch)
+              const int sub = cq;  // channels 4 sub .. 4 sub + 3
+              const float4 w0 = reinterpret_cast<const float4*>(P.head_w)[sub];
+              float d0 = head_dot4(w, w0), d1 = 0.f;
+              if (P.head_kind == 1) d1 = head_dot4(w, reinterpret_cast<const float4*>(P.head_w)[8 + sub]);
+#pragma unroll
+              for (int sh = 4; sh > 0; sh >>= 1) { d0 += __shfl_xor(d0, sh, 8); d1 += __shfl_xor(d1, sh, 8); }
+              if (sub == 0) {
+                const int b_img = m / HoWo;
+                const int r = m - b_img * HoWo;
+                if (P.head_kind == 1) {
+                  d0 += P.head_b[0]; d1 += P.head_b[1];
+                  const float nrm = fmaxf(sqrtf(fmaf(d1, d1, __fmul_rn(d0, d0))), 1e-12f);  // F.normalize eps (same expression as pred_regression_kernel)
+                  d0 /= nrm; d1 /= nrm;
+                  P.head_out[((long)b_img * 2) * HoWo + r] = d0;
+                  P.head_out[((long)b_img * 2 + 1) * HoWo + r] = d1;
+                  if (P.head_pn) *reinterpret_cast<float2*>(P.head_pn + (long)m * 4) = make_float2(d0, d1);
+                } else {
+                  d0 = fminf(fmaxf(d0 + P.head_b[0], -1.f), 1.f);
+                  P.head_out[m] = d0;
+                  if (P.head_pn) *reinterpret_cast<float2*>(P.head_pn + (long)m * 4 + 2) = make_float2(d0, 0.f);
+                }
+              }
+              continue;
+            }
+          }
+          if (y) *reinterpret_cast<float4*>(y + o) = w;
+          if (y_sb) store_sb4(y_sb, p.y_sb_plane, (size_t)o, w);  // split once here instead of per (tap, n-tile) in the consumer
+        } else {  // ragged channel count: scalar tail
+          const float* bsrc = P.bias;
+          if (bias_tab) {
+            const int rem = m % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
+            bsrc = bias_tab + (cy * 3 + cx) * p.Cout;
+          }
+          const float vv[4] = {w.x, w.y, w.z, w.w};
+          for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+            float x = vv[e] * (oscale ? oscale[n + e] : 1.f) + (bsrc ? bsrc[n + e] : 0.f);
+            if (act == ACT_RELU) x = fmaxf(x, 0.f);
+            else if (act == ACT_GELU) x = gelu_erf(x);
+            if (res1) x += res1[o + e];
+            if (res2) x += res2[o + e];
+            if (post_relu) x = fmaxf(x, 0.f);
+            y[o + e] = x;
+          }
         }
       }
     }
@@ -151,59 +213,104 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
 // correction / bias / activation / residuals and store 16 bytes straight from registers -- no LDS staging, no barriers (the LDS form
 // above costs 2 barriers, 16 SN ds_write_b32 and SN/.. ds_read_b128 per lane and 32-row chunk).  A store instruction covers 32 rows x
 // 32 bytes; the four groups of a subtile complete each row's 128-byte line.  Same operation order as epilogue_nhwc: bit-identical.
+// Memory operands (r03): buffer resources (empty for a null pointer, out-of-range offset for a masked lane), loaded unconditionally in front of the arithmetic -- the
+// column constants (scale, LayerNorm column sum, bias) and the residuals of two of a subtile's four groups back to back.  Written as
+// `if (ptr) { load; use }` per group, every load was followed by s_waitcnt vmcnt(0): up to 16 dependent L2 round trips per wave, several microseconds on the launches
+// whose blocks are alone on their CU (profiles/r03_epilogue_batching.md).
 template <int SM, int SN>
-__device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[SM][SN], int mw0 /*first row of this wave's tile*/,
-                                                int nw0 /*first column*/, int ml0 /*mw0 - m0: row inside the block tile*/, const float* oscale, const float* ln_stat) {
+__device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[SM][SN], int m0 /*first row of the block tile (block-uniform)*/,
+                                                int ml0 /*first row of this wave's tile inside the block tile*/, int nw0 /*first column of this wave's tile*/,
+                                                const float* oscale, const float* ln_stat) {
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int HoWo = p.Ho * p.Wo;
   const bool vec_ok = (p.Cout & 3) == 0 && (p.ldy & 3) == 0;
+  const int act = p.act, post_relu = p.post_relu, Cout = p.Cout;
+  const float *res1 = P.res1, *res2 = P.res2, *bias_tab = P.bias_tab;
+  float* const y = P.y;
+  unsigned short* const y_sb = P.y_sb;
+  const __amdgpu_buffer_rsrc_t r_sc = epi_rsrc(oscale, (long)Cout * 4), r_cs = epi_rsrc(ln_stat ? P.ln_colsum : nullptr, (long)Cout * 4);
+  const __amdgpu_buffer_rsrc_t r_b = epi_rsrc(bias_tab ? bias_tab : P.bias, (long)Cout * (bias_tab ? 36 : 4));
+  const __amdgpu_buffer_rsrc_t r_q1 = epi_rsrc(res1 ? res1 + (long)m0 * p.ldy : nullptr, (long)(p.M - m0) * p.ldy * 4);
+  const __amdgpu_buffer_rsrc_t r_q2 = epi_rsrc(res2 ? res2 + (long)m0 * p.ldy : nullptr, (long)(p.M - m0) * p.ldy * 4);
+  const bool has_bias = bias_tab != nullptr || P.bias != nullptr;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
-    const int m = mw0 + i * 32 + l31;
-    if (m >= p.M) continue;
+    const int ml = ml0 + i * 32 + l31, m = m0 + ml;
+    const bool m_ok = m < p.M;
     float mu = 0.f, rs = 1.f;
-    if (ln_stat) { mu = ln_stat[2 * (ml0 + i * 32 + l31)]; rs = ln_stat[2 * (ml0 + i * 32 + l31) + 1]; }
-    const float* bsrc = P.bias;
-    if (P.bias_tab) {
+    if (ln_stat) { mu = ln_stat[2 * ml]; rs = ln_stat[2 * ml + 1]; }
+    int brow = 0;  // row of the bias table
+    if (bias_tab && m_ok) {
       const int rem = m % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
       const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
-      bsrc = P.bias_tab + (cy * 3 + cx) * p.Cout;
+      brow = (cy * 3 + cx) * Cout;
     }
 #pragma unroll
-    for (int j = 0; j < SN; ++j)
+    for (int j = 0; j < SN; ++j) {
+      if (vec_ok) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = nw0 + j * 32 + 8 * g + 4 * hi;
-        if (n >= p.Cout) continue;
-        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        const long o = (long)m * p.ldy + n;
-        if (vec_ok) {
-          if (oscale) { const float4 sc = *reinterpret_cast<const float4*>(oscale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
-          if (ln_stat) {
-            const float4 cs = *reinterpret_cast<const float4*>(P.ln_colsum + n);
-            v.x = rs * fmaf(-mu, cs.x, v.x); v.y = rs * fmaf(-mu, cs.y, v.y); v.z = rs * fmaf(-mu, cs.z, v.z); v.w = rs * fmaf(-mu, cs.w, v.w);
+        for (int g0 = 0; g0 < 4; g0 += 2) {
+          float4 sc[2], cs[2], bb[2], q1[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int n = nw0 + j * 32 + 8 * (g0 + u) + 4 * hi;
+            const bool live = m_ok && n < Cout;
+            sc[u] = buf_load16(r_sc, live ? (unsigned)n * 4u : OOB);
+            cs[u] = zero4;
+            if (ln_stat) cs[u] = buf_load16(r_cs, live ? (unsigned)n * 4u : OOB);  // a compile-time constant in every caller
+            bb[u] = buf_load16(r_b, live ? (unsigned)(brow + n) * 4u : OOB);
+            q1[u] = zero4;
           }
-          if (bsrc) { const float4 bb = *reinterpret_cast<const float4*>(bsrc + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-          if (p.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          else if (p.act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-          if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-          if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-          if (p.post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if (P.y) *reinterpret_cast<float4*>(P.y + o) = v;
-          if (P.y_sb) store_sb4(P.y_sb, p.y_sb_plane, (size_t)o, v);
-        } else {  // ragged channel count: scalar tail
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+          if (res1) {  // one block-uniform branch around both loads
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int n = nw0 + j * 32 + 8 * (g0 + u) + 4 * hi;
+              q1[u] = buf_load16(r_q1, (m_ok && n < Cout) ? (unsigned)(((long)ml * p.ldy + n) * 4) : OOB);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int g = g0 + u;
+            const int n = nw0 + j * 32 + 8 * g + 4 * hi;
+            if (!m_ok || n >= Cout) continue;
+            float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            const long o = (long)m * p.ldy + n;
+            if (oscale) { v.x *= sc[u].x; v.y *= sc[u].y; v.z *= sc[u].z; v.w *= sc[u].w; }
+            if (ln_stat) { v.x = rs * fmaf(-mu, cs[u].x, v.x); v.y = rs * fmaf(-mu, cs[u].y, v.y); v.z = rs * fmaf(-mu, cs[u].z, v.z); v.w = rs * fmaf(-mu, cs[u].w, v.w); }
+            if (has_bias) { v.x += bb[u].x; v.y += bb[u].y; v.z += bb[u].z; v.w += bb[u].w; }
+            if (act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (act == ACT_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+            if (res1) { v.x += q1[u].x; v.y += q1[u].y; v.z += q1[u].z; v.w += q1[u].w; }
+            if (res2) {  // second residual: not met on the maps these tiles serve (the fusion add of the large decoder maps goes through epilogue_nhwc); read in place
+              const float4 q2 = buf_load16(r_q2, (unsigned)(((long)ml * p.ldy + n) * 4));
+              v.x += q2.x; v.y += q2.y; v.z += q2.z; v.w += q2.w;
+            }
+            if (post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (y) *reinterpret_cast<float4*>(y + o) = v;
+            if (y_sb) store_sb4(y_sb, p.y_sb_plane, (size_t)o, v);
+          }
+        }
+      } else if (m_ok) {  // ragged channel count: scalar tail
+        const float* bsrc = bias_tab ? bias_tab + brow : P.bias;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nw0 + j * 32 + 8 * g + 4 * hi;
+          if (n >= Cout) continue;
+          const long o = (long)m * p.ldy + n;
+          const float vv[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          for (int e = 0; e < 4 && n + e < Cout; ++e) {
             float x = vv[e] * (oscale ? oscale[n + e] : 1.f) + (bsrc ? bsrc[n + e] : 0.f);
-            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
-            else if (p.act == ACT_GELU) x = gelu_erf(x);
-            if (P.res1) x += P.res1[o + e];
-            if (P.res2) x += P.res2[o + e];
-            if (p.post_relu) x = fmaxf(x, 0.f);
-            P.y[o + e] = x;
+            if (act == ACT_RELU) x = fmaxf(x, 0.f);
+            else if (act == ACT_GELU) x = gelu_erf(x);
+            if (res1) x += res1[o + e];
+            if (res2) x += res2[o + e];
+            if (post_relu) x = fmaxf(x, 0.f);
+            y[o + e] = x;
           }
         }
       }
+    }
   }
 }
 

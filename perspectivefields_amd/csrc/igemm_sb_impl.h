@@ -161,6 +161,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     rx2[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x2 ? P.x2 : P.x), 0, P.x2 ? p.x2_bytes : 0, 0x00020000);
   }
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(F16 ? P.w_h16 : P.w_sb), 0, (F16 ? 2u : 5u) * p.w_sb_plane_bytes, 0x00020000);
+  // 1x1 / stride 1 / unpadded layers (every nn.Linear: the small-M launches whose blocks are alone on their CU and pay the set-up below in full) skip the pixel
+  // arithmetic of the general convolution -- two integer divisions per staged row here, two per K step in load_tiles -- block-uniform branches around ALU code only
+  // (the 8-wave tiles with the 128-register cap serve large-M launches, where the set-up is hidden behind the other resident block: not offered there -- the extra
+  // live values cost them spills; the same holds for the 128 x 128 tiles of the bf16 schemes with their three operand planes)
+  const bool lin = MODE != 1 && WM * WN == 4 && (F16 || BM * BN < 128 * 128) && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
   int a_off1[A_ROWS], a_off2[A_ROWS];
   unsigned long long a_mask[A_ROWS];
 #pragma unroll
@@ -169,18 +174,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     const int m = m0 + rl;
     const bool ok = m < p.M && rl < BM;
     const int mm = ok ? m : 0;
-    const int b = mm / HoWo;
-    const int rem = mm - b * HoWo;
-    const int oy = rem / p.Wo;
-    const int ox = rem - oy * p.Wo;
-    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-    const int pix = (b * p.H + iy0) * p.W + ix0;
+    int iy0 = 0, ix0 = 0, pix = mm;  // a linear layer: output row m reads input pixel m
+    if (!lin) {
+      const int b = mm / HoWo;
+      const int rem = mm - b * HoWo;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      iy0 = oy * p.stride - p.pad; ix0 = ox * p.stride - p.pad;
+      pix = (b * p.H + iy0) * p.W + ix0;
+    }
     // MODE 1 (Cin == 4, the 3-channel stems padded to 4): a float4 is one PIXEL, the 32-float K chunk = 8 taps of one kernel row,
     // this thread's tap (kx = chunk offset / 4 + c4) is added per K step
     a_off1[i] = pix * p.C1 * ESZ + (MODE == 1 ? 0 : (ASB ? pc : c4) * 16);
     a_off2[i] = pix * p.C2 * ESZ + (ASB ? pc : c4) * 16;
-    unsigned long long mk = 0;
-    if (ok)
+    unsigned long long mk = (lin && ok) ? 1ull : 0ull;
+    if (ok && !lin)
       for (int ky = 0; ky < p.KH; ++ky)
         for (int kx = 0; kx < p.KW; ++kx)
           if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W) mk |= 1ull << (ky * p.KW + kx);
@@ -205,10 +213,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   // branch-free: a step at or past nK loads from the out-of-range offset (zeros, never stored)
   auto load_tiles = [&](int it, Raw& R) {
     const bool live = it < nK;
-    const int ky = it / nJ;
-    const int j0 = (it - ky * nJ) * BK;
-    const int kx = j0 / p.Cin;
-    const int ci0 = j0 - kx * p.Cin;
+    int ky = 0, j0 = it * BK, kx = 0, ci0 = j0;  // lin: one tap, K step = channel chunk
+    if (!lin) {
+      ky = it / nJ;
+      j0 = (it - ky * nJ) * BK;
+      kx = j0 / p.Cin;
+      ci0 = j0 - kx * p.Cin;
+    }
     const int bit = (ky * p.KW + kx) & 63;
     const bool first = MODE != 2 || ci0 < p.C1;
     const int toff = ((ky * p.W + kx) * (first ? p.C1 : p.C2) + (first ? ci0 : ci0 - p.C1)) * ESZ;
@@ -408,13 +419,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
     pp.act = ACT_NONE; pp.post_relu = 0;
     ConvPtrs Q;
     Q.y = P.partial + (size_t)sidx * p.M * p.ldy;
-    if constexpr (DIRECT) epilogue_direct<SM, SN>(pp, Q, acc, m0 + wm0, n0 + wn0, wm0, nullptr, nullptr);
+    if constexpr (DIRECT) epilogue_direct<SM, SN>(pp, Q, acc, m0, wm0, n0 + wn0, nullptr, nullptr);
     else epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(pp, Q, acc, reinterpret_cast<float*>(smem_u), m0, n0);
     return;
   }
   if constexpr (DIRECT) {
     if constexpr (LNF) __syncthreads();  // the row statistics written above
-    epilogue_direct<SM, SN>(p, P, acc, m0 + wm0, n0 + wn0, wm0, F16 ? P.w_h16_inv_scale : nullptr, LNF ? ln_stat : nullptr);
+    epilogue_direct<SM, SN>(p, P, acc, m0, wm0, n0 + wn0, F16 ? P.w_h16_inv_scale : nullptr, LNF ? ln_stat : nullptr);
   } else {
     epilogue_nhwc<BM, BN, WM, WN, SM, SN, NT, SMEM_USHORTS / 2>(p, P, acc, reinterpret_cast<float*>(smem_u), m0, n0, nullptr, F16 ? P.w_h16_inv_scale : nullptr,
                                                                 LNF ? ln_stat : nullptr);
