@@ -75,6 +75,8 @@ __device__ __forceinline__ void split4_hm(const float4 v, uint2& h, uint2& m) {
 // 1 = no split arithmetic while staging A, 4 = no barriers in the K loop, 8 = half the fragment reads, 16 / 32 = no global loads of A / B.
 // Measured and deleted in r03 (profiles/r03_sb_ablate.txt): the K-step position carried instead of two integer divisions per step ("sbI_*": 64x64 -3 %, 128x128 / 256x128 +3...+20 %)
 // and that plus scheduling barriers pinning the loads in front of the MFMAs ("sbPI_*": no better).
+// Also measured and deleted: two LDS operand buffers with ONE barrier per K step, the next tile's split + stores behind this tile's MFMAs ("sbD_*", bit-identical):
+// nothing at B = 32 (64x64 -1...+5 %, larger tiles +7...+42 %: twice the LDS), -3...-4 % per launch at B = 1 (profiles/r03_sbd_double_buffer.txt, patch in profiles/r03_rejected/).
 #ifdef PF_TUNING_BUILD
 #define SB_ABL_PARAM , int SABL = 0
 #else
