@@ -62,6 +62,7 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
   constexpr int RSTEP = NT / F4_PER_ROW, ITERS = CH_ROWS * F4_PER_ROW / NT;
   // U = 2 where the registers are there (the 8-wave halo tiles); elsewhere one item at a time: two items' operands cost the 4-wave linear tiles a resident block
   constexpr int U = (NT == 512 && BM * BN < 128 * 256) ? 2 : 1;
+  constexpr bool Q2B = U == 2;  // the second residual (the fusion add of the decoder's large maps: halo tiles) rides in the batch
   static_assert(NT % F4_PER_ROW == 0 && (CH_ROWS * F4_PER_ROW) % NT == 0 && ITERS % U == 0, "epilogue item mapping");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wave_m = wave / WN;
@@ -85,9 +86,9 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
   const __amdgpu_buffer_rsrc_t r_b = epi_rsrc(bias_tab ? bias_tab : P.bias, (long)p.Cout * (bias_tab ? 36 : 4));
   const __amdgpu_buffer_rsrc_t r_q1 = epi_rsrc(res1 ? res1 + (long)mb * p.ldy : nullptr, (long)(p.M - mb) * p.ldy * 4);
   const __amdgpu_buffer_rsrc_t r_q2 = epi_rsrc(res2 ? res2 + (long)mb * p.ldy : nullptr, (long)(p.M - mb) * p.ldy * 4);
-  const bool has_bias = bias_tab != nullptr || P.bias != nullptr, any_extra = bias_tab != nullptr || res1 != nullptr || res2 != nullptr;
+  const bool has_bias = bias_tab != nullptr || P.bias != nullptr, any_res = res1 != nullptr || (Q2B && res2 != nullptr);
   const unsigned coff = (vec_ok && n_ok) ? (unsigned)n * 4u : OOB;
-  const float4 sc = buf_load16(r_sc, coff), cs = buf_load16(r_cs, coff), bb = buf_load16(r_b, coff);
+  const float4 sc = buf_load16(r_sc, coff), cs = buf_load16(r_cs, coff);
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
     __syncthreads();  // previous chunk fully written back / K loop finished reading the operand tiles
@@ -118,23 +119,27 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
         mm[u] = m; lm0s[u] = lm0;
         v[u] = *reinterpret_cast<const float4*>(Cs + row_l * CROW + cq * 4);
       }
+      // bias: ONE load per item from the bias vector or from the item's row of the bias table (an empty buffer without bias) -- not kept across items: every
+      // register held through this loop is paid in resident blocks on the 4-wave tiles (profiles/r03_epilogue_batching.md, the B = 64 cliff)
+      unsigned qoff[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) { bt[u] = zero4; q1[u] = zero4; q2[u] = zero4; }
-      if (any_extra) {  // ONE block-uniform branch around the loads of all U items (a branch per operand brings the wait after every load back); absent operands of a
-                        // launch that has some read their empty buffers, a launch with none (most convs) issues nothing
+      for (int u = 0; u < U; ++u) {
+        const bool live = ok[u] && vec_ok;
+        unsigned boff = live ? coff : OOB;
+        if (bias_tab && live) {  // position-dependent bias of a folded (Linear -> zero-padded 3x3) pair: 3x3 border cases
+          const int rem = mm[u] % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
+          boff = (unsigned)((cy * 3 + cx) * p.Cout + n) * 4u;
+        }
+        qoff[u] = live ? (unsigned)(((long)(mm[u] - mb) * p.ldy + n) * 4) : OOB;
+        bt[u] = buf_load16(r_b, boff);
+        q1[u] = zero4; q2[u] = zero4;
+      }
+      if (any_res) {  // ONE block-uniform branch around the residual loads of all U items (a branch per operand brings the wait after every load back)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const bool live = ok[u] && vec_ok;
-          unsigned boff = OOB;
-          if (bias_tab && live) {  // position-dependent bias of a folded (Linear -> zero-padded 3x3) pair: 3x3 border cases
-            const int rem = mm[u] % HoWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            const int cy = oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1), cx = ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1);
-            boff = (unsigned)((cy * 3 + cx) * p.Cout + n) * 4u;
-          }
-          const unsigned qoff = live ? (unsigned)(((long)(mm[u] - mb) * p.ldy + n) * 4) : OOB;
-          bt[u] = buf_load16(r_b, boff);
-          q1[u] = buf_load16(r_q1, qoff);
-          q2[u] = buf_load16(r_q2, qoff);
+          q1[u] = buf_load16(r_q1, qoff[u]);
+          if constexpr (Q2B) q2[u] = buf_load16(r_q2, qoff[u]);
         }
       }
 #pragma unroll
@@ -149,11 +154,14 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
             const float mu = ln_stat[2 * lm0s[u]], rs = ln_stat[2 * lm0s[u] + 1];
             w.x = rs * fmaf(-mu, cs.x, w.x); w.y = rs * fmaf(-mu, cs.y, w.y); w.z = rs * fmaf(-mu, cs.z, w.z); w.w = rs * fmaf(-mu, cs.w, w.w);
           }
-          if (has_bias) { const float4 bv = bias_tab ? bt[u] : bb; w.x += bv.x; w.y += bv.y; w.z += bv.z; w.w += bv.w; }
+          if (has_bias) { w.x += bt[u].x; w.y += bt[u].y; w.z += bt[u].z; w.w += bt[u].w; }
           if (act == ACT_RELU) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
           else if (act == ACT_GELU) { w.x = gelu_erf(w.x); w.y = gelu_erf(w.y); w.z = gelu_erf(w.z); w.w = gelu_erf(w.w); }
           if (res1) { w.x += q1[u].x; w.y += q1[u].y; w.z += q1[u].z; w.w += q1[u].w; }
-          if (res2) { w.x += q2[u].x; w.y += q2[u].y; w.z += q2[u].z; w.w += q2[u].w; }
+          if (res2) {
+            if constexpr (!Q2B) q2[u] = buf_load16(r_q2, qoff[u]);  // the one-item tiles: a second residual is rare on their layers, read in place
+            w.x += q2[u].x; w.y += q2[u].y; w.z += q2[u].z; w.w += q2[u].w;
+          }
           if (post_relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
           if constexpr (BN == 32) {
             if (P.head_kind) {  // block-uniform.  The 8 lanes tid % 8 = 0..7 hold the 32 channels of one pixel (same row -> same branch)
@@ -214,7 +222,7 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
 // above costs 2 barriers, 16 SN ds_write_b32 and SN/.. ds_read_b128 per lane and 32-row chunk).  A store instruction covers 32 rows x
 // 32 bytes; the four groups of a subtile complete each row's 128-byte line.  Same operation order as epilogue_nhwc: bit-identical.
 // Memory operands (r03): buffer resources (empty for a null pointer, out-of-range offset for a masked lane), loaded unconditionally in front of the arithmetic -- the
-// column constants (scale, LayerNorm column sum, bias) and the residuals of two of a subtile's four groups back to back.  Written as
+// column constants (scale, LayerNorm column sum, bias) and the residual of one of a subtile's four column groups back to back.  Written as
 // `if (ptr) { load; use }` per group, every load was followed by s_waitcnt vmcnt(0): up to 16 dependent L2 round trips per wave, several microseconds on the launches
 // whose blocks are alone on their CU (profiles/r03_epilogue_batching.md).
 template <int SM, int SN>
@@ -234,6 +242,7 @@ __device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvP
   const __amdgpu_buffer_rsrc_t r_q2 = epi_rsrc(res2 ? res2 + (long)m0 * p.ldy : nullptr, (long)(p.M - m0) * p.ldy * 4);
   const bool has_bias = bias_tab != nullptr || P.bias != nullptr;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int EG = 1;  // column groups per batch of loads (2 costs the 64 x 64 tiles a resident block)
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
     const int ml = ml0 + i * 32 + l31, m = m0 + ml;
@@ -250,10 +259,10 @@ __device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvP
     for (int j = 0; j < SN; ++j) {
       if (vec_ok) {
 #pragma unroll
-        for (int g0 = 0; g0 < 4; g0 += 2) {
-          float4 sc[2], cs[2], bb[2], q1[2];
+        for (int g0 = 0; g0 < 4; g0 += EG) {
+          float4 sc[EG], cs[EG], bb[EG], q1[EG];
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
+          for (int u = 0; u < EG; ++u) {
             const int n = nw0 + j * 32 + 8 * (g0 + u) + 4 * hi;
             const bool live = m_ok && n < Cout;
             sc[u] = buf_load16(r_sc, live ? (unsigned)n * 4u : OOB);
@@ -264,13 +273,13 @@ __device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvP
           }
           if (res1) {  // one block-uniform branch around both loads
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < EG; ++u) {
               const int n = nw0 + j * 32 + 8 * (g0 + u) + 4 * hi;
               q1[u] = buf_load16(r_q1, (m_ok && n < Cout) ? (unsigned)(((long)ml * p.ldy + n) * 4) : OOB);
             }
           }
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
+          for (int u = 0; u < EG; ++u) {
             const int g = g0 + u;
             const int n = nw0 + j * 32 + 8 * g + 4 * hi;
             if (!m_ok || n >= Cout) continue;

@@ -166,8 +166,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   // 1x1 / stride 1 / unpadded layers (every nn.Linear: the small-M launches whose blocks are alone on their CU and pay the set-up below in full) skip the pixel
   // arithmetic of the general convolution -- two integer divisions per staged row here, two per K step in load_tiles -- block-uniform branches around ALU code only
   // (the 8-wave tiles with the 128-register cap serve large-M launches, where the set-up is hidden behind the other resident block: not offered there -- the extra
-  // live values cost them spills; the same holds for the 128 x 128 tiles of the bf16 schemes with their three operand planes)
-  const bool lin = MODE != 1 && WM * WN == 4 && (F16 || BM * BN < 128 * 128) && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
+  // live values cost them spills; the same holds for the 128 x 128 tiles of the bf16 schemes with their three operand planes.  Plain fp32 single-input form only:
+  // on the split-plane and concat forms the extra values cost a resident block)
+  const bool lin = MODE == 0 && !ASB && WM * WN == 4 && (F16 || BM * BN < 128 * 128) && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
   int a_off1[A_ROWS], a_off2[A_ROWS];
   unsigned long long a_mask[A_ROWS];
 #pragma unroll
