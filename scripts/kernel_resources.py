@@ -45,10 +45,33 @@ def kernels(lib):
     return sorted(rows, key=lambda r: r["kernel"])
 
 
+def blocks_per_cu(r):
+    """Resident blocks per CU of a kernel: 512 VGPRs per SIMD lane in granules of 8 (at most 8 waves per SIMD), 4 SIMDs, 160 KB of LDS."""
+    waves_per_simd = min(8, 512 // max(8, (r["vgpr"] + 7) // 8 * 8))
+    by_regs = waves_per_simd * 4 // max(1, r["max_threads"] // 64)
+    return min(by_regs, (160 * 1024) // r["lds"] if r["lds"] else by_regs)
+
+
+def compare(old_lib, new_lib):
+    """Kernels whose spills or resident blocks per CU differ between two builds (run after every change to a shared device function)."""
+    a = {r["kernel"]: r for r in kernels(old_lib)}
+    out = []
+    for r in kernels(new_lib):
+        o = a.get(r["kernel"])
+        if o and (blocks_per_cu(o) != blocks_per_cu(r) or o["spill"] != r["spill"]):
+            out.append(f"{o['vgpr']:4d} -> {r['vgpr']:4d} VGPRs  blocks/CU {blocks_per_cu(o)} -> {blocks_per_cu(r)}  spills {o['spill']} -> {r['spill']}  {r['kernel']}")
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--compare":  # kernel_resources.py --compare OLD.so [NEW.so]
+        new = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "perspectivefields_amd", "lib", "libpf_hip.so")
+        diff = compare(sys.argv[2], new)
+        print("\n".join(diff) if diff else "no kernel changed its spills or its resident blocks per CU")
+        sys.exit(0)
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "perspectivefields_amd", "lib", "libpf_hip.so")
     rows = kernels(lib)
     print(f"{len(rows)} gfx950 kernels in {os.path.relpath(lib, ROOT)}")
-    print(f"{'vgpr':>5} {'spill':>5} {'scratch':>7} {'lds':>7} {'thr':>5}  kernel")
+    print(f"{'vgpr':>5} {'spill':>5} {'scratch':>7} {'lds':>7} {'thr':>5} {'blk/CU':>6}  kernel")
     for r in rows:
-        print(f"{r['vgpr']:5d} {r['spill']:5d} {r['scratch']:7d} {r['lds']:7d} {r['max_threads']:5d}  {r['kernel']}")
+        print(f"{r['vgpr']:5d} {r['spill']:5d} {r['scratch']:7d} {r['lds']:7d} {r['max_threads']:5d} {blocks_per_cu(r):6d}  {r['kernel']}")

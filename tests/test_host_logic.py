@@ -437,9 +437,7 @@ def test_kernel_resources_static():
     assert by["pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 6, false>"]["vgpr"] <= 128
     # Resident blocks per CU of the default-path GEMM tiles (r03): a shared epilogue that grew by 16 registers took `sb128x64` from 4 to 3 blocks and
     # the B = 64 stage-3 launches (1000 blocks) from one round to two, -2.9 % end to end with no spill to warn about.  512 VGPRs per SIMD lane in granules of 8, 160 KB LDS.
-    def blocks_per_cu(r):
-        waves_per_simd = min(8, 512 // ((r["vgpr"] + 7) // 8 * 8))
-        return min(waves_per_simd * 4 // (r["max_threads"] // 64), (160 * 1024) // r["lds"] if r["lds"] else 99)
+    blocks_per_cu = kr.blocks_per_cu
     floor = {"pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 23, false>": 4, "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 2, 23, false>": 3,
              "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 23, false>": 7, "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 2, 23, false>": 5,
              "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 23, true>": 5, "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 2, 23, true>": 4,
