@@ -232,6 +232,11 @@ int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, 
  * :123-126 (sr norm -> kv) and convnext.py:50-51 (norm -> pwconv1).  K % 32 == 0, N % 4 == 0; tile_id as pf_op_conv2d (linear split tiles only). */
 int pf_op_linear_ln(int device, const float* d_x, long rows, int K, const float* h_weight /*[N][K]*/, const float* h_bias, const float* h_gamma, const float* h_beta,
                     float eps, int N, int act, const float* d_res1, int tile_id, float* d_y, int precision, void* stream);
+/* One nn.Linear of the MiT stage-3 / 4 blocks in the row-block form (rb_gemm.hip): y = act(Linear(LayerNorm?(x))) + res on blocks of 64 token rows of one image --
+ * mix_transformers.py:80-88 (q, kv, proj), :26-29 (fc1, fc2), with :199-200 / :125 (norm1, norm2, attn.norm) applied while the rows are staged when h_gamma != NULL.
+ * rows = images x tokens; (K, N) = (320, multiple of 320) or (multiple of 64 above 320, 320); res may alias y.  iters > 0 additionally times `iters` launches. */
+int pf_op_rb_linear(int device, const float* d_x, long rows, int tokens, int K, const float* h_weight /*[N][K]*/, const float* h_bias, const float* h_gamma, const float* h_beta,
+                    float eps, int N, int act, const float* d_res, float* d_y, int iters, float* ms_out, void* stream);
 /* One ConvNeXt block MLP in one kernel (cnx_mlp.hip): y += ls * pwconv2(GELU(pwconv1(LayerNorm(d)))), convnext.py:49-58; C = 96 or 192, weights
  * in the reference's shapes (pwconv1 [4C][C], pwconv2 [C][4C], layer scale ls [C]); y is read (residual) and written.  iters > 0 additionally times
  * `iters` launches (avg ms in *ms_out; y is then garbage). */

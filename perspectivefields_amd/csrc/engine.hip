@@ -66,7 +66,9 @@ struct ConvW {
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-6f; };
 struct DwW { float* w = nullptr; float* b = nullptr; int C = 0; };
 
-struct MitBlock { LNW n1, n2, srn; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */ };
+// a linear layer in the row-block form (rb_gemm.hip): weight stream + inverse scales + bias
+struct RbLin { unsigned short* w = nullptr; size_t bytes = 0; float* inv = nullptr; float* b = nullptr; int N = 0, K = 0; };
+struct MitBlock { LNW n1, n2, srn; RbLin rq, rkv, rproj, rfc1, rfc2; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */ };
 struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
 struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
@@ -307,6 +309,28 @@ void cnx_mlp_pack(const float* w1, const float* b1, const float* g, const float*
   for (int n = 0; n < C; ++n) { (*tab)[3 * H + n] = p2.inv_scale[n]; (*tab)[3 * H + C + n] = b2f[n]; }
 }
 
+// Weight stream of a row-block linear layer (rb_common.h): [pass of `cols` output channels][k16 step][column tile][plane hi / lo][lane][8 halfs],
+// value = Ws[pass * cols + 32 ct + (lane & 31)][16 step + 8 (lane >> 5) + e] with the per-output-channel power-of-two scale of the split-f16 scheme;
+// RB_D = 4 zero steps of padding behind the last pass (the register ring reads ahead).  `w` is [N][K] row-major (K = (ky, kx, ci) for a packed conv).
+void rb_pack_w(const float* w, int N, int K, int cols, std::vector<unsigned short>* stream, std::vector<float>* inv) {
+  std::vector<float> wv(w, w + (size_t)N * K);
+  const F16Planes pl = split_f16x2(wv, N);
+  const size_t n_all = wv.size();
+  const int npass = N / cols, nct = cols / 32, steps = K / 16;
+  const size_t step_us = (size_t)nct * 2 * 512;
+  stream->assign(((size_t)npass * steps + 4) * step_us, 0);
+  for (int ps = 0; ps < npass; ++ps)
+    for (int st = 0; st < steps; ++st) {
+      unsigned short* o = stream->data() + ((size_t)ps * steps + st) * step_us;
+      for (int ct = 0; ct < nct; ++ct)
+        for (int p = 0; p < 2; ++p)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e)
+              o[((size_t)(ct * 2 + p) * 64 + lane) * 8 + e] = pl.planes[p * n_all + (size_t)(ps * cols + 32 * ct + (lane & 31)) * K + 16 * st + 8 * (lane >> 5) + e];
+    }
+  *inv = pl.inv_scale;
+}
+
 // Weights of the fused MiT block Mlp (mit_mlp.hip), one chunk of mit_mlp_chunk_bytes(C) per 32 hidden units t (layout: the kernel's header):
 // LayerNorm (norm2) folded into fc1 as fold_ln_linear, split-f16 planes in MFMA fragment order, depthwise taps [ky * 3 + kx][hidden] + bias.
 void mit_mlp_pack(const float* w1, const float* b1, const float* g, const float* be, const float* wdw /*[H][1][3][3]*/, const float* bdw, const float* w2, const float* b2,
@@ -427,6 +451,9 @@ struct pf_engine {
   bool sba_heads = false;    // PF_SBA_HEADS=1: the tensors between the 3x3 convs of the decoders' ResidualConvUnits are written as split-f16 planes by the producing
                              // conv's epilogue (plus fp32 where a residual add reads them) and the halo kernel copies them (igemm_sbh ASB) instead of splitting
                              // every element once per n-tile and halo overlap; split-f16 scheme only
+  int rb_chain = 1;          // PF_RB_CHAIN: 0 = the linear layers of MiT stage 3 on the LDS tiles (igemm_sb), 1 (default) = row-block form (rb_gemm.hip) once the batch gives
+                             // at least rb_min_blocks row blocks (below that a launch of 64-row blocks leaves most of the chip idle and the 64 x 64 tiles win)
+  int rb_min_blocks = 96;
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
   bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
@@ -603,6 +630,19 @@ struct pf_engine {
     return d;
   }
 
+  RbLin make_rb(const std::string& pfx, int N, int K, int cols) {
+    RbLin r;
+    std::vector<unsigned short> st;
+    std::vector<float> inv;
+    rb_pack_w(get(pfx + ".weight", {N, K}).data.data(), N, K, cols, &st, &inv);
+    r.w = upload_u16(st);
+    r.bytes = st.size() * 2;
+    r.inv = upload(inv);
+    r.b = upload(get(pfx + ".bias", {N}).data);
+    r.N = N; r.K = K;
+    return r;
+  }
+
   void build_head(Head& hd, const std::string& name, int nout, bool cls) {
     const std::string p = "persformer_heads." + name + "_head.";
     for (int k = 0; k < 4; ++k) {
@@ -659,6 +699,13 @@ struct pf_engine {
         mb.fc1 = make_linear(b + ".mlp.fc1", 4 * C, C, nullptr, b + ".norm2", 1e-6f);
         mb.dw = make_dw(b + ".mlp.dwconv.dwconv", 4 * C, 3);
         mb.fc2 = make_linear(b + ".mlp.fc2", C, 4 * C);
+        if (rb_chain && split_bf16 && rb_linear_supported(C, C) && MIT_SR[s] > 1) {  // stage 3: the row-block form of the block's linear layers
+          mb.rq = make_rb(b + ".attn.q", C, C, 320);
+          mb.rkv = make_rb(b + ".attn.kv", 2 * C, C, 320);
+          mb.rproj = make_rb(b + ".attn.proj", C, C, 320);
+          mb.rfc1 = make_rb(b + ".mlp.fc1", 4 * C, C, 320);
+          mb.rfc2 = make_rb(b + ".mlp.fc2", C, 4 * C, 320);
+        }
         if (fuse_mit_mlp && mit_mlp_preferred(C)) {
           std::vector<unsigned short> wpk;
           std::vector<float> tab2;
@@ -884,6 +931,18 @@ struct pf_engine {
     launch_layernorm(x, l.g, l.b, y.f, rows, l.C, l.eps, c.s, y.s.p, y.s.plane);
   }
 
+  // a linear layer in the row-block form: y = act(LN?(x) W^T + b) + res on blocks of 64 tokens of one image (rb_gemm.hip)
+  void rb_linear(Ctx& c, const RbLin& r, const float* x, long M, int tokens, float* y, const LNW* lnw = nullptr, int act = ACT_NONE, const float* res = nullptr) {
+    range_in(c, fmt("rb_linear %d->%d%s", r.K, r.N, lnw ? " (LN input)" : ""), x, (size_t)M * r.K);
+    if (c.dry) return;
+    RbLinArgs a;
+    a.x = x; a.ln_g = lnw ? lnw->g : nullptr; a.ln_b = lnw ? lnw->b : nullptr; a.ln_eps = lnw ? lnw->eps : 0.f;
+    a.w = r.w; a.w_bytes = r.bytes; a.inv = r.inv; a.bias = r.b; a.res = res; a.y = y;
+    a.M = (int)M; a.tokens = tokens; a.bpi = (tokens + 63) / 64; a.N = r.N; a.act = act;
+    ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * M * (double)r.N * r.K, (int)M, r.N, r.K, 1);
+    launch_rb_linear(a, r.K, c.s);
+  }
+
   // MiT-B3 forward_features (mix_transformers.py:449-485); feats[s] = NHWC stage outputs.
   // With `sba` every tensor that only feeds GEMMs (LayerNorm outputs, attention output, the GELU'd hidden map) is
   // written as split planes by its producer and never exists in fp32.
@@ -928,10 +987,22 @@ struct pf_engine {
         if (blk >= 0) tap(c, fmt("mit.s%d.b%d", s + 1, blk), x, B, Ho, Wo, C);  // the previous block's output (token stream, pre stage norm)
         ++blk;
         // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
+        // row-block form of the block's linear layers (stage 3 at batch >= ~14): q, kv, proj, fc1, fc2
+        const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && (long)B * ((N + 63) / 64) >= rb_min_blocks;
         if (sr > 1) {
-          ln(c, mb.n1, x, xn, M);
           const bool fork = B >= 4 && can_fork(c);  // batch 1-3: a launch already under-fills the chip; the event pair would only add latency
-          if (fork) {  // q projection next to sr conv + kv GEMM: both read xn, attention needs both
+          if (use_rb && fork) {  // q = LN1(x) Wq with the LayerNorm inside the kernel: independent of the LayerNorm launch below
+            (void)hipEventRecord(ev_fork, c.s);
+            (void)hipStreamWaitEvent(side, ev_fork, 0);
+            Ctx c2 = c;
+            c2.s = side;
+            rb_linear(c2, mb.rq, x, M, (int)N, qb, &mb.n1);
+            (void)hipEventRecord(ev_join, side);
+          }
+          ln(c, mb.n1, x, xn, M);
+          if (use_rb) {
+            if (!fork) rb_linear(c, mb.rq, x, M, (int)N, qb, &mb.n1);
+          } else if (fork) {  // q projection next to sr conv + kv GEMM: both read xn, attention needs both
             (void)hipEventRecord(ev_fork, c.s);
             (void)hipStreamWaitEvent(side, ev_fork, 0);
             Ctx c2 = c;
@@ -942,7 +1013,9 @@ struct pf_engine {
             gemm(c, mb.q, xn, M, Ten(qb));
           }
           conv(c, mb.sr, xn, B, Ho, Wo, Ten(srb));
-          if (mb.kv.ln_s) {
+          if (use_rb) {
+            rb_linear(c, mb.rkv, srb, Mkv, kvh * kvw, kvb, &mb.srn);  // LayerNorm(sr conv) while the rows are staged
+          } else if (mb.kv.ln_s) {
             gemm(c, mb.kv, Ten(srb), Mkv, Ten(kvb));  // LayerNorm(sr conv) inside the kv GEMM
           } else {
             ln(c, mb.srn, srb, srn, Mkv);
@@ -974,7 +1047,8 @@ struct pf_engine {
           ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
           launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
         }
-        gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
+        if (use_rb) rb_linear(c, mb.rproj, ab.f, M, (int)N, x, nullptr, ACT_NONE, x);
+        else gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
         // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
         if (fused_mlp && mb.mlp_w) {                  // norm2 + fc1 + depthwise 3x3 + GELU + fc2 + residual in one kernel, x -> xalt
           range_in(c, fmt("mit_mlp s%d.b%d x (LN-fused)", s + 1, blk), x, (size_t)M * C);
@@ -985,7 +1059,9 @@ struct pf_engine {
           std::swap(x, xalt);
           continue;
         }
-        if (mb.fc1.ln_s) {
+        if (use_rb) {
+          rb_linear(c, mb.rfc1, x, M, (int)N, hb, &mb.n2);  // norm2 while the rows are staged
+        } else if (mb.fc1.ln_s) {
           gemm(c, mb.fc1, Ten(x), M, Ten(hb));        // norm2 inside fc1
         } else {
           ln(c, mb.n2, x, xn, M);
@@ -995,7 +1071,8 @@ struct pf_engine {
           ProfScope ps(c.prof, c.s, PC_DW3, (4.0 + (h2.f ? 4.0 : 0.0) + (h2.s.p ? 6.0 : 0.0)) * M * 4 * C);  // read + write of the hidden map
           launch_dwconv3x3_gelu(hb, mb.dw.w, mb.dw.b, h2.f, B, Ho, Wo, 4 * C, c.s, h2.s.p, h2.s.plane);
         }
-        gemm(c, mb.fc2, h2, M, Ten(x), ACT_NONE, x);
+        if (use_rb) rb_linear(c, mb.rfc2, h2.f, M, (int)N, x, nullptr, ACT_NONE, x);
+        else gemm(c, mb.fc2, h2, M, Ten(x), ACT_NONE, x);
       }
       c.release(mk);
       if (blk >= 0) tap(c, fmt("mit.s%d.b%d", s + 1, blk), x, B, Ho, Wo, C);
@@ -1310,6 +1387,8 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_LN")) e->fuse_ln = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
+  if (const char* v = getenv("PF_RB_CHAIN")) e->rb_chain = atoi(v);
+  if (const char* v = getenv("PF_RB_MIN_BLOCKS")) e->rb_min_blocks = atoi(v);
 #ifdef PF_TUNING_BUILD
 #endif
   if (const char* v = getenv("PF_SIDE_STREAM")) e->side_stream_mode = atoi(v);
@@ -1798,6 +1877,42 @@ int pf_op_linear_ln(int device, const float* x, long rows, int K, const float* h
   p.finish();
   if (tile_id >= 0 && !conv_tile_usable(p, tile_id)) { g_create_error = "pf_op_linear_ln: tile config cannot run the fused LayerNorm form"; return PF_ERR_ARG; }
   launch_conv_tile(p, tile_id, s);
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_rb_linear(int device, const float* x, long rows, int tokens, int K, const float* hw, const float* hb, const float* hgamma, const float* hbeta, float eps, int N,
+                    int act, const float* res, float* y, int iters, float* ms_out, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (!rb_linear_supported(K, N) || !x || !y || !hw || !hb || rows <= 0 || tokens <= 0 || rows % tokens != 0 || (hgamma && K != 320)) {
+    g_create_error = "pf_op_rb_linear: (K, N) must be (320, multiple of 320) or (multiple of 64 above 320, 320); rows a multiple of tokens; LayerNorm only with K = 320";
+    return PF_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  std::vector<unsigned short> st;
+  std::vector<float> inv;
+  rb_pack_w(hw, N, K, 320, &st, &inv);
+  RbLinArgs a;
+  a.x = x; a.ln_g = hgamma ? tmp.up(std::vector<float>(hgamma, hgamma + K)) : nullptr; a.ln_b = hgamma ? tmp.up(std::vector<float>(hbeta, hbeta + K)) : nullptr; a.ln_eps = eps;
+  a.w = tmp.up_u16(st); a.w_bytes = st.size() * 2; a.inv = tmp.up(inv); a.bias = tmp.up(std::vector<float>(hb, hb + N)); a.res = res; a.y = y;
+  a.M = (int)rows; a.tokens = tokens; a.bpi = (tokens + 63) / 64; a.N = N; a.act = act;
+  launch_rb_linear(a, K, s);
+  if (iters > 0 && ms_out) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) launch_rb_linear(a, K, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms_out = t / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   tmp.sync_free(s);
   return rc;

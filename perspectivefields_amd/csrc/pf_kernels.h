@@ -209,6 +209,23 @@ bool mit_mlp_supported(int C);
 bool mit_mlp_preferred(int C);  // the stages where the engine uses it
 int mit_mlp_chunk_bytes(int C);
 void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const float* tab2, int B, int Hs, int Ws, int C, float eps, hipStream_t s);
+// Row-block linear layers (rb_gemm.hip, rb_common.h): blocks of 64 token rows of one image, weights streamed from L2 into registers in MFMA fragment order
+struct RbLinArgs {
+  const float* x;            // [M][K] fp32 rows
+  const float* ln_g;         // LayerNorm over K (nullptr: none)
+  const float* ln_b;
+  float ln_eps;
+  const unsigned short* w;   // weight stream (rb_pack_w), N / COLS passes of K / 16 steps
+  size_t w_bytes;
+  const float* inv;          // [N] inverse weight scales
+  const float* bias;         // [N]
+  const float* res;          // [M][N] or nullptr (may alias y)
+  float* y;                  // [M][N]
+  int M, tokens, bpi;        // rows, tokens per image, blocks per image = ceil(tokens / 64)
+  int N, act;
+};
+bool rb_linear_supported(int K, int N);
+void launch_rb_linear(const RbLinArgs& a, int K, hipStream_t s);
 void launch_gap_ln_head(const float* x, const float* g, const float* b, const float* w, const float* hb, float* out, int B, int HW, int C, int nout, float eps, hipStream_t s);
 
 // camera parameters {roll, elevation (rad), focal_rel, cx_rel, cy_rel} (device) -> up [2][H][W], latitude [H][W] degrees

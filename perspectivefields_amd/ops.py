@@ -124,6 +124,25 @@ def linear_ln(x, weight, bias, gamma, beta, eps, act=0, res1=None, tile=-1, prec
     return y
 
 
+def rb_linear(x, weight, bias, tokens, gamma=None, beta=None, eps=1e-6, act=0, res=None, iters=0):
+    """act(Linear(LayerNorm?(x))) + res in the row-block form (pf_op_rb_linear).  x: (rows, K) with rows = images x tokens; weight (N, K).
+    iters > 0: returns the average ms per launch instead."""
+    import torch
+
+    lib = load_library()
+    x = x.contiguous()
+    K = x.shape[-1]
+    rows = x.numel() // K
+    w, b = _np(weight), _np(bias)
+    g, be = (_np(gamma), _np(beta)) if gamma is not None else (None, None)
+    N = w.shape[0]
+    y = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
+    ms = ctypes.c_float()
+    _check(lib.pf_op_rb_linear(x.device.index, x.data_ptr(), rows, tokens, K, _hp(w), _hp(b), _hp(g), _hp(be), float(eps), N,
+                               act, _dp(res), y.data_ptr(), iters, ctypes.byref(ms), _stream_ptr()), None, "pf_op_rb_linear")
+    return ms.value if iters > 0 else y
+
+
 def mit_mlp(x, fc1_w, fc1_b, ln_gamma, ln_beta, eps, dw_w, dw_b, fc2_w, fc2_b, iters=0):
     """One MiT block Mlp in one kernel: x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))).  x: (B, Hs, Ws, C) on the GPU, C = 64 or 128.
     iters > 0: returns the average ms per launch instead."""

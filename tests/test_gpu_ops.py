@@ -604,3 +604,43 @@ def test_upsample2x(ops, B, H, W, C):
     x = _rand((B, H, W, C), 30)
     ref = F.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1).contiguous()
     _close(ops.upsample2x(x.cuda()), ref, 2e-6, "upsample2x")
+
+
+def _region_report(got, ref):
+    """where a wrong result sits: worst |err| per 32-row x 32-column tile (debug aid for fragment-layout mistakes)"""
+    err = (got.double().cpu() - ref.double()).abs()
+    R, N = err.shape
+    out = []
+    for r0 in range(0, min(R, 128), 32):
+        out.append(" ".join(f"{float(err[r0:r0 + 32, c0:c0 + 32].max()):8.1e}" for c0 in range(0, min(N, 640), 32)))
+    return "\n".join(out)
+
+
+@pytest.mark.parametrize("K,N,tokens,images", [(320, 320, 400, 3), (320, 640, 100, 5), (320, 1280, 400, 2), (1280, 320, 400, 2), (320, 320, 50, 2), (640, 320, 70, 3)])
+def test_rb_linear(ops, K, N, tokens, images):
+    """Row-block linear layers (rb_gemm.hip): resident and streamed forms, full and ragged row blocks (400 = 6 x 64 + 16, 100 = 64 + 36, 50, 70 = 64 + 6),
+    with / without the staged LayerNorm (rows with offsets and outlier channels), GELU / residual epilogues, in-place residual.  Oracle: torch fp64."""
+    rows = tokens * images
+    x = _rand((rows, K), 231, 1.5)
+    w = _rand((N, K), 233, 1.0 / math.sqrt(K))
+    w[5] *= 37.0                                   # rows of very different scale: the per-output-channel power-of-two weight scale
+    w[N - 1] *= 1e-3
+    b = _rand((N,), 234, 0.1)
+    r = _rand((rows, N), 237)
+    ref = F.linear(x.double(), w.double(), b.double())
+    got = ops.rb_linear(x.cuda(), w, b, tokens)
+    try:
+        _close(got, ref, 3e-5 * math.sqrt(K / 320), "rb_linear")
+    except AssertionError as e:
+        raise AssertionError(str(e) + "\n" + _region_report(got, ref))
+    _close(ops.rb_linear(x.cuda(), w, b, tokens, act=2), pf_oracle.gelu(ref), 3e-5 * math.sqrt(K / 320), "rb_linear+gelu")
+    rc = r.cuda()
+    _close(ops.rb_linear(x.cuda(), w, b, tokens, res=rc), ref + r.double(), 3e-5 * math.sqrt(K / 320), "rb_linear+res")
+    if K == 320:
+        xo = _with_outlier_channels(x + 10.0 * _rand((rows, 1), 232), 238)
+        xo[3] = 0.0                                # a constant row: variance 0
+        g = 1 + _rand((K,), 235, 0.3)
+        be = _rand((K,), 236, 0.2)
+        for eps in (1e-6, 1e-5):
+            refl = F.linear(F.layer_norm(xo.double(), (K,), g.double(), be.double(), eps), w.double(), b.double())
+            _close(ops.rb_linear(xo.cuda(), w, b, tokens, gamma=g, beta=be, eps=eps), refl, 5e-5, "rb_linear with LayerNorm")
