@@ -234,7 +234,7 @@ int pf_op_linear_ln(int device, const float* d_x, long rows, int K, const float*
                     float eps, int N, int act, const float* d_res1, int tile_id, float* d_y, int precision, void* stream);
 /* One nn.Linear of the MiT stage-3 / 4 blocks in the row-block form (rb_gemm.hip): y = act(Linear(LayerNorm?(x))) + res on blocks of 64 token rows of one image --
  * mix_transformers.py:80-88 (q, kv, proj), :26-29 (fc1, fc2), with :199-200 / :125 (norm1, norm2, attn.norm) applied while the rows are staged when h_gamma != NULL.
- * rows = images x tokens; (K, N) = (320, multiple of 320) or (multiple of 64 above 320, 320); res may alias y.  iters > 0 additionally times `iters` launches. */
+ * rows = images x tokens; (K, N) = (320, multiple of 320) or (multiple of 256 above 320, 320); res may alias y.  iters > 0 additionally times `iters` launches. */
 int pf_op_rb_linear(int device, const float* d_x, long rows, int tokens, int K, const float* h_weight /*[N][K]*/, const float* h_bias, const float* h_gamma, const float* h_beta,
                     float eps, int N, int act, const float* d_res, float* d_y, int iters, float* ms_out, void* stream);
 /* One ConvNeXt block MLP in one kernel (cnx_mlp.hip): y += ls * pwconv2(GELU(pwconv1(LayerNorm(d)))), convnext.py:49-58; C = 96 or 192, weights

@@ -171,6 +171,10 @@ typedef unsigned int at_u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int AT_KS = 72;    // halfs per K row: 144 B -> 16 consecutive rows hit 16 distinct 16-byte slots (36 i mod 64)
 static constexpr int AT_VS = 136;   // halfs per V^T row: 128 kv positions + 8 (272 B = 68 words: 68 i mod 64 = 4 i)
 static constexpr float AT_KV_SCALE = 16.f;
+static constexpr float AT_Q_SCALE = 64.f;          // extra power of two on q d^-0.5 (keeps the low plane of the split out of the fp16 subnormals)
+static constexpr float AT_QS = 0.125f * AT_Q_SCALE;
+static constexpr float AT_P_EXP = 11.f;            // the probabilities are carried as 2^11 p in (0, 2048]: p = exp(s - max) is mostly far below 2^-3, where the unscaled low
+                                                   // plane would be a subnormal (absolute error 2^-25 per element, ~n_kv 2^-25 |v| on the P V product); 2^-11 cancels in 1 / sum
 
 __device__ __forceinline__ unsigned at_pack(float a, float b) {
   const at_h2 v = {(_Float16)a, (_Float16)b};
@@ -248,7 +252,9 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const float4 v0 = *reinterpret_cast<const float4*>(qp + 16 * t), v1 = *reinterpret_cast<const float4*>(qp + 16 * t + 4);
-    const float a[8] = {v0.x * 0.125f, v0.y * 0.125f, v0.z * 0.125f, v0.w * 0.125f, v1.x * 0.125f, v1.y * 0.125f, v1.z * 0.125f, v1.w * 0.125f};  // d^-0.5, exact
+    // d^-0.5 = 1/8 times AT_Q_SCALE = 64 (exact; undone on the exp2 constant below): q d^-0.5 is typically < 2^-3, where the unscaled low part of the split
+    // would be an fp16 subnormal (absolute error 2^-25, sb_split.h); at 8 q it is a normal number down to |q| = 2^-6
+    const float a[8] = {v0.x * AT_QS, v0.y * AT_QS, v0.z * AT_QS, v0.w * AT_QS, v1.x * AT_QS, v1.y * AT_QS, v1.z * AT_QS, v1.w * AT_QS};
     at_split8(a, qh[t], ql[t]);
   }
 
@@ -274,8 +280,8 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
   }
 
   // ---- softmax over kv for query column (lane & 31); rows held by this lane: kv = 32 c + (r & 3) + 8 (r >> 2) + 4 hi.
-  //      The accumulators hold 16 x the scores: the 1/16 rides on the exp2 constant.
-  constexpr float L2E = 1.4426950408889634f / AT_KV_SCALE;
+  //      The accumulators hold 16 x 64 x the scores: the factor rides on the exp2 constant.
+  constexpr float L2E = 1.4426950408889634f / (AT_KV_SCALE * AT_Q_SCALE);
   float mx = -3.0e38f;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
     }
   }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const float mx2 = mx * L2E;
+  const float mx2 = mx * L2E - AT_P_EXP;
   float sum = 0.f;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {

@@ -1887,8 +1887,8 @@ int pf_op_rb_linear(int device, const float* x, long rows, int tokens, int K, co
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
-  if (!rb_linear_supported(K, N) || !x || !y || !hw || !hb || rows <= 0 || tokens <= 0 || rows % tokens != 0 || (hgamma && K != 320)) {
-    g_create_error = "pf_op_rb_linear: (K, N) must be (320, multiple of 320) or (multiple of 64 above 320, 320); rows a multiple of tokens; LayerNorm only with K = 320";
+  if (!rb_linear_supported(K, N) || !x || !y || !hw || !hb || rows <= 0 || tokens <= 0 || rows % tokens != 0 || (hgamma && K != 320) || (K != 320 && act != ACT_NONE) || (act != ACT_NONE && act != ACT_GELU)) {
+    g_create_error = "pf_op_rb_linear: (K, N) must be (320, multiple of 320) or (multiple of 256 above 320, 320); rows a multiple of tokens; LayerNorm / GELU only with K = 320";
     return PF_ERR_ARG;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1901,6 +1901,23 @@ int pf_op_rb_linear(int device, const float* x, long rows, int tokens, int K, co
   a.w = tmp.up_u16(st); a.w_bytes = st.size() * 2; a.inv = tmp.up(inv); a.bias = tmp.up(std::vector<float>(hb, hb + N)); a.res = res; a.y = y;
   a.M = (int)rows; a.tokens = tokens; a.bpi = (tokens + 63) / 64; a.N = N; a.act = act;
   launch_rb_linear(a, K, s);
+  if (getenv("PF_RB_STAMPS") && !hgamma) {  // timing aid: the s_memtime stamps of block 17's four waves of one more launch, to stderr
+    unsigned long long* ds = nullptr;
+    if (hipMalloc(&ds, 4 * 64 * 8) == hipSuccess) {
+      (void)hipMemsetAsync(ds, 0, 4 * 64 * 8, s);
+      RbLinArgs b = a; b.stamps = ds; b.res = nullptr;
+      launch_rb_linear(b, K, s);
+      std::vector<unsigned long long> hs(4 * 64);
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(hs.data(), ds, 4 * 64 * 8, hipMemcpyDeviceToHost);
+      for (int w = 0; w < 4; ++w) {
+        fprintf(stderr, "rb stamps K=%d N=%d wave %d:", K, N, w);
+        for (int i = 1; i < 64; ++i) if (hs[w * 64 + i]) fprintf(stderr, " [%d]%lld", i, (long long)(hs[w * 64 + i] - hs[w * 64]));
+        fprintf(stderr, "\n");
+      }
+      (void)hipFree(ds);
+    }
+  }
   if (iters > 0 && ms_out) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);

@@ -223,6 +223,7 @@ struct RbLinArgs {
   float* y;                  // [M][N]
   int M, tokens, bpi;        // rows, tokens per image, blocks per image = ceil(tokens / 64)
   int N, act;
+  unsigned long long* stamps = nullptr;  // timing aid (scripts/tune_rb.py, PF_RB_STAMPS=1): s_memtime stamps of block 17, [wave][64]
 };
 bool rb_linear_supported(int K, int N);
 void launch_rb_linear(const RbLinArgs& a, int K, hipStream_t s);

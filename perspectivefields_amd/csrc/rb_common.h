@@ -16,7 +16,7 @@
 // NCT = 4 CTW + 2, one more tile 4 CTW + (w >> 1) for row tile (w & 1)  ->  320 columns = CTW 2 + extra: 5 accumulators (80 registers) per wave.
 // Weight stream (rb_pack_w in engine.hip): [pass][k16 step][column tile][plane hi / lo][lane 64][8 halfs], value = Ws[32 ct + (lane & 31)][16 step + 8 (lane >> 5) + e]
 // with the per-output-channel power-of-two scale of the split-f16 scheme (igemm_sb_impl.h, sb_split.h); RB_D zero steps of padding at the end (the ring reads ahead).
-// A fragments in LDS: chunk c (16 k values) at c * RB_CHS, inside it [row tile][plane][slot = (row & 31) + 32 khalf][8 halfs]; the 64 pad bytes per chunk make the
+// A fragments in LDS: chunk c (16 k values) at c * G::CHS, inside it [row tile][plane][slot = (row & 31) + 32 khalf][8 halfs]; the 64 pad bytes per chunk make the
 // staging writes of four threads that hold four different chunks of one row conflict-free.
 #pragma once
 #include "igemm_common.h"
@@ -25,7 +25,6 @@
 namespace pf {
 
 static constexpr int RB_ROWS = 64;         // token rows per block
-static constexpr int RB_CHS = 4096 + 64;   // bytes per k16 chunk of the A fragments in LDS
 static constexpr int RB_D = 4;             // weight prefetch depth in k16 steps (register ring)
 
 typedef _Float16 rb_f16x8 __attribute__((ext_vector_type(8)));
@@ -33,15 +32,18 @@ __device__ __forceinline__ f32x16 rb_mfma(const u32x4 a, const u32x4 b, const f3
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rb_f16x8, a), __builtin_bit_cast(rb_f16x8, b), c, 0, 0, 0);
 }
 
-template <int CTW_, bool EXTRA_>
+template <int CTW_, bool EXTRA_, int RT_ = 2>
 struct RbGeo {
   static constexpr int CTW = CTW_;
   static constexpr bool EXTRA = EXTRA_;
-  static constexpr int NW = CTW + (EXTRA ? 1 : 0);        // weight fragment pairs (hi, lo) per wave and k16 step
-  static constexpr int NACC = 2 * CTW + (EXTRA ? 1 : 0);  // 32 x 32 accumulators per wave
-  static constexpr int NCT = 4 * CTW + (EXTRA ? 2 : 0);   // column tiles per pass
+  static constexpr int RT = RT_;                           // row tiles of 32 per block: 2 (64-row blocks) or 1 (32-row blocks: the spatial-reduction branch, 100 rows per image)
+  static constexpr int NW = CTW + (EXTRA ? 1 : 0);         // weight fragment pairs (hi, lo) per wave and k16 step
+  static constexpr int NACC = RT * CTW + (EXTRA ? 1 : 0);  // 32 x 32 accumulators per wave
+  static constexpr int NCT = 4 * CTW + (EXTRA ? 2 : 0);    // column tiles per pass
   static constexpr int COLS = NCT * 32;
-  static constexpr int STEP_BYTES = NCT * 2048;           // weight bytes per k16 step of a pass
+  static constexpr int STEP_BYTES = NCT * 2048;            // weight bytes per k16 step of a pass
+  static constexpr int CHS = RT * 2048 + 64;               // bytes per k16 chunk of the A fragments in LDS
+  // RT == 1: the extra tile 4 CTW + (w >> 1) is computed by BOTH waves of a pair (w & 1 = 0, 1) on the same row tile; only the even wave's copy is used
 };
 
 // Per-wave state of the weight stream: one VGPR offset (lane * 16 + running step offset), NW wave-uniform tile offsets
@@ -73,21 +75,23 @@ struct RbW {
   }
 };
 
-// A fragments of one k16 chunk: both row tiles (+ the extra tile's row tile xr = wave & 1, read again: a run-time register select would cost more than two LDS reads)
+// A fragments of one k16 chunk: all row tiles (+ for 64-row blocks the extra tile's row tile xr = wave & 1, read again: a run-time register select would cost more
+// than two LDS reads)
 template <class G>
 struct RbA {
-  u32x4 a[2][2];   // [row tile][plane]
-  u32x4 x[2];      // extra tile's row tile
+  u32x4 a[G::RT][2];   // [row tile][plane]
+  u32x4 x[2];          // extra tile's row tile (RT == 2)
   __device__ __forceinline__ void read(const unsigned char* chunk, int lane, int xr) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < G::RT; ++rt)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) a[rt][pl] = *reinterpret_cast<const u32x4*>(chunk + (rt * 2 + pl) * 1024 + lane * 16);
-    if constexpr (G::EXTRA) {
+    if constexpr (G::EXTRA && G::RT == 2) {
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) x[pl] = *reinterpret_cast<const u32x4*>(chunk + (xr * 2 + pl) * 1024 + lane * 16);
     }
   }
+  __device__ __forceinline__ const u32x4& xa(int pl) const { if constexpr (G::RT == 2) return x[pl]; else return a[0][pl]; }
 };
 
 // One k16 step of a wave: the LDS reads of the NEXT step's A fragments first (they land under this step's MFMAs), then the step's MFMAs -- per accumulator the three
@@ -95,35 +99,79 @@ struct RbA {
 // fragment issued right behind the fragment's last use.  The scheduling fences pin that order: left alone hipcc issues the LDS reads behind the last MFMA (their latency
 // is then exposed at the head of the next step) and sinks all refills of an unrolled group to its end (the ring would run one step ahead, not RB_D).
 #define RB_FENCE() __builtin_amdgcn_sched_barrier(0)
-template <class G>
+// timing-only forms of a step (wrong results by construction): ABL & 1 no refill loads, & 2 no MFMAs (operands kept alive), & 4 no A fragment reads
+template <class G, int ABL>
+__device__ __forceinline__ void rb_step_abl(f32x16 (&acc)[G::NACC], RbW<G>& W, int d, const RbA<G>& A, RbA<G>& An, const unsigned char* next_chunk, int lane, int xr) {
+  if constexpr (ABL == 8 || ABL == 16) {  // correct results, other issue orders: 8 = product-major (MFMAs on one accumulator NACC apart), refills at the end of the step;
+                                          // 16 = the same without the fence behind the LDS reads
+    An.read(next_chunk, lane, xr);
+    if constexpr (ABL == 8) RB_FENCE();
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int ci = 0; ci < G::CTW; ++ci)
+#pragma unroll
+        for (int rt = 0; rt < G::RT; ++rt) acc[G::RT * ci + rt] = rb_mfma(W.f[d][ci][t == 1], A.a[rt][t == 0], acc[G::RT * ci + rt]);
+      if constexpr (G::EXTRA) acc[G::RT * G::CTW] = rb_mfma(W.f[d][G::CTW][t == 1], A.xa(t == 0), acc[G::RT * G::CTW]);
+    }
+#pragma unroll
+    for (int ci = 0; ci < G::NW; ++ci) { W.load_frag(d, ci, 0); W.load_frag(d, ci, 1); }
+    RB_FENCE();
+    W.advance();
+    return;
+  }
+  if constexpr ((ABL & 4) == 0) An.read(next_chunk, lane, xr);
+  RB_FENCE();
+#pragma unroll
+  for (int ci = 0; ci < G::NW; ++ci) {
+    if constexpr ((ABL & 2) == 0) {
+      if (ci < G::CTW) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int rt = 0; rt < G::RT; ++rt) acc[G::RT * ci + rt] = rb_mfma(W.f[d][ci][t == 1], A.a[rt][t == 0], acc[G::RT * ci + rt]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[G::RT * G::CTW] = rb_mfma(W.f[d][ci][t == 1], A.xa(t == 0), acc[G::RT * G::CTW]);
+      }
+    } else {
+      asm volatile("" :: "v"(W.f[d][ci][0]), "v"(W.f[d][ci][1]), "v"(A.a[0][0]), "v"(A.a[G::RT - 1][1]));
+    }
+    if constexpr ((ABL & 1) == 0) { W.load_frag(d, ci, 0); W.load_frag(d, ci, 1); }
+    RB_FENCE();
+  }
+  W.advance();
+}
+template <class G, int ABL = 0>
 __device__ __forceinline__ void rb_step(f32x16 (&acc)[G::NACC], RbW<G>& W, int d, const RbA<G>& A, RbA<G>& An, const unsigned char* next_chunk, int lane, int xr) {
-  constexpr int X = G::CTW, XA = 2 * G::CTW;  // the extra tile's fragment pair / accumulator
+  if constexpr (ABL != 0) { rb_step_abl<G, ABL>(acc, W, d, A, An, next_chunk, lane, xr); return; }
+  constexpr int X = G::CTW, XA = G::RT * G::CTW, RT = G::RT;  // the extra tile's fragment pair / accumulator
   An.read(next_chunk, lane, xr);
   RB_FENCE();
 #pragma unroll
   for (int ci = 0; ci < G::CTW; ++ci) {
     const u32x4 (&w)[2] = W.f[d][ci];
-    acc[2 * ci] = rb_mfma(w[0], A.a[0][1], acc[2 * ci]);
-    acc[2 * ci + 1] = rb_mfma(w[0], A.a[1][1], acc[2 * ci + 1]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[RT * ci + rt] = rb_mfma(w[0], A.a[rt][1], acc[RT * ci + rt]);
     if (G::EXTRA && ci == 0) {
-      acc[XA] = rb_mfma(W.f[d][X][0], A.x[1], acc[XA]);
+      acc[XA] = rb_mfma(W.f[d][X][0], A.xa(1), acc[XA]);
       RB_FENCE();
     }
-    acc[2 * ci] = rb_mfma(w[1], A.a[0][0], acc[2 * ci]);
-    acc[2 * ci + 1] = rb_mfma(w[1], A.a[1][0], acc[2 * ci + 1]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[RT * ci + rt] = rb_mfma(w[1], A.a[rt][0], acc[RT * ci + rt]);
     W.load_frag(d, ci, 1);
     RB_FENCE();
     if (G::EXTRA && ci == 0) {
-      acc[XA] = rb_mfma(W.f[d][X][1], A.x[0], acc[XA]);
+      acc[XA] = rb_mfma(W.f[d][X][1], A.xa(0), acc[XA]);
       W.load_frag(d, X, 1);
       RB_FENCE();
     }
-    acc[2 * ci] = rb_mfma(w[0], A.a[0][0], acc[2 * ci]);
-    acc[2 * ci + 1] = rb_mfma(w[0], A.a[1][0], acc[2 * ci + 1]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[RT * ci + rt] = rb_mfma(w[0], A.a[rt][0], acc[RT * ci + rt]);
     W.load_frag(d, ci, 0);
     RB_FENCE();
     if (G::EXTRA && ci == G::CTW - 1) {
-      acc[XA] = rb_mfma(W.f[d][X][0], A.x[0], acc[XA]);
+      acc[XA] = rb_mfma(W.f[d][X][0], A.xa(0), acc[XA]);
       W.load_frag(d, X, 0);
       RB_FENCE();
     }
@@ -131,11 +179,12 @@ __device__ __forceinline__ void rb_step(f32x16 (&acc)[G::NACC], RbW<G>& W, int d
   W.advance();
 }
 
-// (row tile, column tile) of accumulator idx for this wave
+// (row tile, column tile) of accumulator idx for this wave; `own` = false for the redundant copy of the extra tile in 32-row blocks
 template <class G>
-__device__ __forceinline__ void rb_tile_of(int idx, int wave, int& rt, int& ct) {
-  if (idx < 2 * G::CTW) { rt = idx & 1; ct = wave + 4 * (idx >> 1); }
-  else { rt = wave & 1; ct = 4 * G::CTW + (wave >> 1); }
+__device__ __forceinline__ void rb_tile_of(int idx, int wave, int& rt, int& ct, bool& own) {
+  own = true;
+  if (idx < G::RT * G::CTW) { rt = idx % G::RT; ct = wave + 4 * (idx / G::RT); }
+  else { rt = G::RT == 2 ? (wave & 1) : 0; ct = 4 * G::CTW + (wave >> 1); own = G::RT == 2 || (wave & 1) == 0; }
 }
 
 // 16 consecutive k values (one chunk) of a row -> the row's two 16-byte slots per plane.  v[0..3] = k 0-3, 4-7, 8-11, 12-15

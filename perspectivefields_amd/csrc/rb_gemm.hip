@@ -11,50 +11,83 @@
 namespace pf {
 
 
-// epilogue of one pass: lane owns row (rt * 32 + l31) and, per register group g, channels n0 + 32 ct + 8 g + 4 hi .. + 3
-template <class G>
-__device__ __forceinline__ void rb_epilogue_store(const RbLinArgs& p, f32x16 (&acc)[G::NACC], int n0, int m0, int nrows, int wave, int lane) {
+// s_memtime stamp of one block's waves (STAMP builds of the kernels only; a stamp drains lgkmcnt, i.e. it perturbs the step it sits in)
+#define RB_STAMP(i) do { if constexpr (STAMP) { if (blockIdx.x == 17 && lane == 0) p.stamps[wave * 64 + (i)] = __builtin_readcyclecounter(); } } while (0)
+static constexpr int RB_NMAX = 1280;  // widest layer of the resident form (fc1 of stage 3)
+// per-channel epilogue constants -> LDS (visible after the kernel's first barrier)
+__device__ __forceinline__ void rb_stage_tabs(float* tabs, const float* inv, const float* bias, int N, int tid) {
+  for (int i = tid; i < N / 4; i += 256) {
+    reinterpret_cast<float4*>(tabs)[i] = reinterpret_cast<const float4*>(inv)[i];
+    reinterpret_cast<float4*>(tabs + N)[i] = reinterpret_cast<const float4*>(bias)[i];
+  }
+}
+
+// Epilogue of one pass.  In the transposed accumulators a lane owns row (rt * 32 + l31) and, per register group g, channels 32 ct + 8 g + 4 hi .. + 3: stored straight
+// from there a wave instruction writes 32 rows x 32 bytes -- 32 partial cache lines, ~400 cycles of store issue each (the 20 stores of a pass took 8 000 cycles, as long
+// as 14 K steps: profiles/r04_rb_timeline.md).  So every 32 x 32 tile takes a turn through 4 KB of wave-private LDS (no block barrier: a wave's LDS instructions
+// execute in order) and leaves as FULL 128-byte lines, 8 rows per store instruction; bias / residual / activation are applied on the row-major side.
+// LDS tile: [32 rows][32 floats], the 16-byte column slot XOR-ed with (row & 7): conflict-free for the column-wise writes and the row-wise reads.
+// inv / bias come from an LDS copy made at kernel start ([N] inverse scales, then [N] biases): read from global memory they were 5 dependent L2 round trips per pass.
+// RES / ACT are compile-time: with run-time branches around the residual loads and the activation hipcc put an s_waitcnt vmcnt(0) at every join -- each tile then
+// waited for the previous tile's stores to be acknowledged (and for the ring's last, useless read-ahead): 7 000 of the 8 000 cycles above.
+template <class G, bool RES, int ACT>
+__device__ __forceinline__ void rb_epilogue_store(const RbLinArgs& p, const float* tabs, float* scratch /*this wave's 4 KB*/, f32x16 (&acc)[G::NACC], int n0, int m0, int nrows,
+                                                  int wave, int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
+  const int rrow = lane >> 3, c4 = lane & 7;
+  float4 rr[RES ? G::NACC : 1][4];
+  if constexpr (RES) {  // all residual rows of the pass in flight at once
+#pragma unroll
+    for (int idx = 0; idx < G::NACC; ++idx) {
+      int rt, ct;
+      bool own;
+      rb_tile_of<G>(idx, wave, rt, ct, own);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rr[idx][i] = *reinterpret_cast<const float4*>(p.res + (size_t)(m0 + min(rt * 32 + rrow + 8 * i, nrows - 1)) * p.N + n0 + ct * 32 + c4 * 4);
+    }
+  }
 #pragma unroll
   for (int idx = 0; idx < G::NACC; ++idx) {
     int rt, ct;
-    rb_tile_of<G>(idx, wave, rt, ct);
-    const int ml = rt * 32 + l31;
-    const bool ok = ml < nrows;
-    const size_t row = (size_t)(m0 + (ok ? ml : 0)) * p.N;
-    float4 iv[4], bb[4], rr[4];
+    bool own;
+    rb_tile_of<G>(idx, wave, rt, ct, own);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = n0 + ct * 32 + 8 * g + 4 * hi;
-      iv[g] = *reinterpret_cast<const float4*>(p.inv + n);
-      bb[g] = *reinterpret_cast<const float4*>(p.bias + n);
-      rr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(scratch + l31 * 32 + (((2 * g + hi) ^ (l31 & 7)) << 2)) = make_float4(acc[idx][4 * g], acc[idx][4 * g + 1], acc[idx][4 * g + 2], acc[idx][4 * g + 3]);
+    __builtin_amdgcn_wave_barrier();
+    const int n = n0 + ct * 32 + c4 * 4;
+    const float4 iv = *reinterpret_cast<const float4*>(tabs + n), bb = *reinterpret_cast<const float4*>(tabs + p.N + n);
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rrow + 8 * i;
+      v[i] = *reinterpret_cast<const float4*>(scratch + row * 32 + ((c4 ^ (row & 7)) << 2));
     }
-    if (p.res) {
+    __builtin_amdgcn_wave_barrier();  // the next tile's writes stay behind this tile's reads
 #pragma unroll
-      for (int g = 0; g < 4; ++g) rr[g] = *reinterpret_cast<const float4*>(p.res + row + n0 + ct * 32 + 8 * g + 4 * hi);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = n0 + ct * 32 + 8 * g + 4 * hi;
-      float4 v = make_float4(fmaf(acc[idx][4 * g], iv[g].x, bb[g].x), fmaf(acc[idx][4 * g + 1], iv[g].y, bb[g].y), fmaf(acc[idx][4 * g + 2], iv[g].z, bb[g].z),
-                             fmaf(acc[idx][4 * g + 3], iv[g].w, bb[g].w));
-      if (p.act == ACT_GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
-      else if (p.act == ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      v.x += rr[g].x; v.y += rr[g].y; v.z += rr[g].z; v.w += rr[g].w;
-      if (ok) *reinterpret_cast<float4*>(p.y + row + n) = v;
+    for (int i = 0; i < 4; ++i) {
+      const int ml = rt * 32 + rrow + 8 * i;
+      float4 w = make_float4(fmaf(v[i].x, iv.x, bb.x), fmaf(v[i].y, iv.y, bb.y), fmaf(v[i].z, iv.z, bb.z), fmaf(v[i].w, iv.w, bb.w));
+      if constexpr (ACT == ACT_GELU) w = make_float4(gelu_erf(w.x), gelu_erf(w.y), gelu_erf(w.z), gelu_erf(w.w));
+      if constexpr (RES) { w.x += rr[idx][i].x; w.y += rr[idx][i].y; w.z += rr[idx][i].z; w.w += rr[idx][i].w; }
+      if (own && ml < nrows) *reinterpret_cast<float4*>(p.y + (size_t)(m0 + ml) * p.N + n) = w;
     }
   }
 }
 
 // ---- resident form
-template <int K, bool LN, class G>
+template <int K, bool LN, class G, bool RES, int ACT, int ABL = 0, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void rb_linear_kernel(const RbLinArgs p) {
   constexpr int KC = K / 16;          // k16 chunks
   constexpr int CPT = KC / 4;         // chunks per staging thread (thread = row tid / 4, chunks (tid & 3) + 4 i)
   static_assert(KC % 4 == 0 && KC % RB_D == 0, "K must be a multiple of 64");
-  __shared__ __attribute__((aligned(16))) unsigned char As[KC * RB_CHS];
+  __shared__ __attribute__((aligned(16))) unsigned char As[KC * G::CHS];
+  __shared__ __attribute__((aligned(16))) float tabs[2 * RB_NMAX];
+  __shared__ __attribute__((aligned(16))) float escr[4 * 1024];  // epilogue transposition, 4 KB per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  RB_STAMP(0);
+  rb_stage_tabs(tabs, p.inv, p.bias, p.N, tid);
   const int img = blockIdx.x / p.bpi, j = blockIdx.x - img * p.bpi;
   const int nrows = min(RB_ROWS, p.tokens - j * RB_ROWS);
   const int m0 = img * p.tokens + j * RB_ROWS;
@@ -62,6 +95,7 @@ __global__ __launch_bounds__(256, 1) void rb_linear_kernel(const RbLinArgs p) {
   RbW<G> W;
   W.init(p.w, p.w_bytes, wave, lane);
   W.prologue();  // the first RB_D steps of the stream fly while the rows are staged
+  RB_STAMP(1);
 
   {  // ---- rows -> (LayerNorm) -> split-f16 fragments
     const int r = tid >> 2, q = tid & 3;
@@ -99,10 +133,12 @@ __global__ __launch_bounds__(256, 1) void rb_linear_kernel(const RbLinArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      rb_store_chunk(As + (q + 4 * i) * RB_CHS, r, v[i]);
+      rb_store_chunk(As + (q + 4 * i) * G::CHS, r, v[i]);
     }
   }
+  RB_STAMP(2);
   __syncthreads();
+  RB_STAMP(3);
 
   const int xr = wave & 1;
   RbA<G> A[2];
@@ -120,25 +156,32 @@ __global__ __launch_bounds__(256, 1) void rb_linear_kernel(const RbLinArgs p) {
 #pragma unroll
       for (int d = 0; d < RB_D; ++d) {
         const int nx = s + d + 1 == KC ? 0 : s + d + 1;  // the next pass starts over on the same rows
-        rb_step<G>(acc, W, d, A[d & 1], A[(d + 1) & 1], As + nx * RB_CHS, lane, xr);
+        rb_step<G, ABL>(acc, W, d, A[d & 1], A[(d + 1) & 1], As + nx * G::CHS, lane, xr);
       }
+      RB_STAMP(4 + ps * 8 + s / RB_D);
     }
-    rb_epilogue_store<G>(p, acc, ps * G::COLS, m0, nrows, wave, lane);
+    rb_epilogue_store<G, RES, ACT>(p, tabs, escr + wave * 1024, acc, ps * G::COLS, m0, nrows, wave, lane);
+    RB_STAMP(4 + ps * 8 + 6);
   }
 }
 
-// ---- streamed form (K a multiple of 64; one pass: N = G::COLS).  Three ring slots of one k64 stage each; the hand-over of stage t + 1 (ds_write + the only barrier of
-// the stage) sits in the MIDDLE of stage t, so that the look-ahead fragment reads never wait at a stage boundary: between two barriers a wave reads slots t - 1 (its last
-// step) and t, and writes slot t + 1.
-template <class G>
+// ---- streamed form (K a multiple of 64 L; one pass: N = G::COLS).  Three LDS ring slots of one k64 stage each; the hand-over of stage t + 1 (ds_write + the only
+// barrier of the stage) sits in the MIDDLE of stage t, so that the look-ahead fragment reads never wait at a stage boundary: between two barriers a wave reads slots
+// t - 1 (its last step) and t, and writes slot t + 1.  The rows come from HBM (the 65 MB hidden map of the Mlp): their loads run L stages (~L microseconds) ahead in L
+// register sets -- with one stage of lead the loop was a chain of exposed HBM round trips (profiles/r04_rb_ablation.md: 23 us with an EMPTY step body).
+template <class G, int L, bool RES, int ABL = 0, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void rb_linear_stream_kernel(const RbLinArgs p, int K) {
-  constexpr int SLOT = 4 * RB_CHS;
+  constexpr int SLOT = 4 * G::CHS;
   __shared__ __attribute__((aligned(16))) unsigned char As[3 * SLOT];
+  __shared__ __attribute__((aligned(16))) float tabs[2 * G::COLS];
+  __shared__ __attribute__((aligned(16))) float escr[4 * 1024];  // epilogue transposition, 4 KB per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  RB_STAMP(0);
+  rb_stage_tabs(tabs, p.inv, p.bias, p.N, tid);
   const int img = blockIdx.x / p.bpi, j = blockIdx.x - img * p.bpi;
   const int nrows = min(RB_ROWS, p.tokens - j * RB_ROWS);
   const int m0 = img * p.tokens + j * RB_ROWS;
-  const int T = K / 64;  // stages
+  const int T = K / 64;  // stages (a multiple of L)
 
   RbW<G> W;
   W.init(p.w, p.w_bytes, wave, lane);
@@ -146,15 +189,20 @@ __global__ __launch_bounds__(256, 1) void rb_linear_stream_kernel(const RbLinArg
 
   const int r = tid >> 2, q = tid & 3;
   const float* xr_ = p.x + (size_t)(m0 + min(r, nrows - 1)) * K + 16 * q;  // rows past the block's end: a valid row, never stored
-  float4 st[4];
-  auto stage_load = [&](int t) {
+  float4 st[L][4];  // stage s lives in set s % L from its loads until its ds_write
+  auto stage_load = [&](int t, float4 (&v)[4]) {
+    const int tc = min(t, T - 1);  // past the end: re-reads the last stage, never used
 #pragma unroll
-    for (int e = 0; e < 4; ++e) st[e] = *reinterpret_cast<const float4*>(xr_ + (size_t)t * 64 + 4 * e);
+    for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const float4*>(xr_ + (size_t)tc * 64 + 4 * e);
   };
-  stage_load(0);
-  rb_store_chunk(As + q * RB_CHS, r, st);
-  stage_load(T > 1 ? 1 : 0);
+  stage_load(0, st[0]);
+#pragma unroll
+  for (int u = 1; u < L; ++u) stage_load(u, st[u]);
+  rb_store_chunk(As + q * G::CHS, r, st[0]);
+  stage_load(L, st[0]);
+  RB_STAMP(1);
   __syncthreads();
+  RB_STAMP(2);
 
   f32x16 acc[G::NACC];
 #pragma unroll
@@ -166,40 +214,70 @@ __global__ __launch_bounds__(256, 1) void rb_linear_stream_kernel(const RbLinArg
   A[0].read(As, lane, xr);
   int cur = 0;  // slot of stage t
 #pragma unroll 1
-  for (int t = 0; t < T; ++t) {
-    const int nxt = cur == 2 ? 0 : cur + 1;
-    const unsigned char* base = As + cur * SLOT;
+  for (int t0 = 0; t0 < T; t0 += L) {
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      if (d == 2) {  // stage t + 1 (in registers since the middle of stage t - 1) -> its slot; the loads of stage t + 2 take the registers over
-        rb_store_chunk(As + nxt * SLOT + q * RB_CHS, r, st);
-        __syncthreads();
-        stage_load(min(t + 2, T - 1));  // past the end: re-reads the last stage, never used
-        __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < L; ++u) {  // stage t0 + u; the set of stage t0 + u + 1 is (u + 1) % L
+      const int t = t0 + u;
+      const int nxt = cur == 2 ? 0 : cur + 1;
+      const unsigned char* base = As + cur * SLOT;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        if (d == 2) {  // stage t + 1 (requested L stages ago) -> its slot; the loads of stage t + 1 + L take its registers over
+          rb_store_chunk(As + nxt * SLOT + q * G::CHS, r, st[(u + 1) % L]);
+          __syncthreads();
+          stage_load(t + 1 + L, st[(u + 1) % L]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        rb_step<G, ABL>(acc, W, d, A[d & 1], A[(d + 1) & 1], d < 3 ? base + (d + 1) * G::CHS : As + nxt * SLOT, lane, xr);
       }
-      rb_step<G>(acc, W, d, A[d & 1], A[(d + 1) & 1], d < 3 ? base + (d + 1) * RB_CHS : As + nxt * SLOT, lane, xr);
+      cur = nxt;
+      RB_STAMP(3 + t);
     }
-    cur = nxt;
   }
-  rb_epilogue_store<G>(p, acc, 0, m0, nrows, wave, lane);
+  RB_STAMP(40);
+  rb_epilogue_store<G, RES, ACT_NONE>(p, tabs, escr + wave * 1024, acc, 0, m0, nrows, wave, lane);
+  RB_STAMP(41);
 }
 
 // ---- launchers
+// act: ACT_NONE or ACT_GELU; the streamed form has no activation (fc2)
 bool rb_linear_supported(int K, int N) {
-  if (K == 320 && N % 320 == 0) return true;      // MiT stage 3: q / proj / kv / fc1
-  if (K % 64 == 0 && K > 320 && N == 320) return true;  // fc2 (K = 1280)
+  if (K == 320 && N % 320 == 0 && N <= RB_NMAX) return true;      // MiT stage 3: q / proj / kv / fc1
+  if (K % 256 == 0 && K > 320 && N == 320) return true;  // fc2 (K = 1280)
   return false;
 }
 
+template <bool LN, bool RES, int ACT>
+static void rb_launch_res(const RbLinArgs& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((rb_linear_kernel<320, LN, RbGeo<2, true>, RES, ACT>), grid, dim3(256), 0, s, a);
+}
 void launch_rb_linear(const RbLinArgs& a, int K, hipStream_t s) {
   const int B = a.M / a.tokens;
   const dim3 grid((unsigned)(B * a.bpi)), block(256);
   using G320 = RbGeo<2, true>;
+  static const int abl = [] { const char* e = getenv("PF_RB_ABL"); return e ? atoi(e) : 0; }();  // timing-only ablation forms (wrong results): scripts/tune_rb.py
+  if (abl) {
+#define RB_ABL_CASE(V) if (abl == V) { if (K == 320) hipLaunchKernelGGL((rb_linear_kernel<320, false, G320, false, ACT_NONE, V>), grid, block, 0, s, a); else hipLaunchKernelGGL((rb_linear_stream_kernel<G320, 2, false, V>), grid, block, 0, s, a, K); return; }
+    RB_ABL_CASE(1) RB_ABL_CASE(2) RB_ABL_CASE(3) RB_ABL_CASE(7)
+#undef RB_ABL_CASE
+  }
+  if (a.stamps) {
+    if (K == 320) hipLaunchKernelGGL((rb_linear_kernel<320, false, G320, false, ACT_NONE, 0, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((rb_linear_stream_kernel<G320, 2, false, 0, true>), grid, block, 0, s, a, K);
+    return;
+  }
+  const bool ln = a.ln_g != nullptr, res = a.res != nullptr, gelu = a.act == ACT_GELU;
   if (K == 320) {
-    if (a.ln_g) hipLaunchKernelGGL((rb_linear_kernel<320, true, G320>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((rb_linear_kernel<320, false, G320>), grid, block, 0, s, a);
+    if (ln) {
+      if (res) { if (gelu) rb_launch_res<true, true, ACT_GELU>(a, grid, s); else rb_launch_res<true, true, ACT_NONE>(a, grid, s); }
+      else { if (gelu) rb_launch_res<true, false, ACT_GELU>(a, grid, s); else rb_launch_res<true, false, ACT_NONE>(a, grid, s); }
+    } else {
+      if (res) { if (gelu) rb_launch_res<false, true, ACT_GELU>(a, grid, s); else rb_launch_res<false, true, ACT_NONE>(a, grid, s); }
+      else { if (gelu) rb_launch_res<false, false, ACT_GELU>(a, grid, s); else rb_launch_res<false, false, ACT_NONE>(a, grid, s); }
+    }
   } else {
-    hipLaunchKernelGGL((rb_linear_stream_kernel<G320>), grid, block, 0, s, a, K);
+    if (res) hipLaunchKernelGGL((rb_linear_stream_kernel<G320, 2, true>), grid, block, 0, s, a, K);
+    else hipLaunchKernelGGL((rb_linear_stream_kernel<G320, 2, false>), grid, block, 0, s, a, K);
   }
 }
 

@@ -195,11 +195,13 @@ class PerspectiveFields(nn.Module):
         beyond 65504 and keeps only an absolute 2^-25 per element below 2^-3: a layer input with saturated elements, or whose rms is below 2^-5 (an all-tiny tensor), is
         outside the window -- use precision="fp32_bf16x6" (exact bf16 split, no window) for such a checkpoint.  Returns {"ok", "saturated", "tiny", "non_finite", "layers"}."""
         _, _, rng = self.debug_forward(img_bgr_list, shadow=False, ranges=True)
-        sat = [r for r in rng if r["saturated"] > 0]
+        # attention operands carry extra powers of two inside the kernel (attn.hip: q x 8, k / v x 16): their window ends at 8188 / 4094
+        lim = lambda r: 8188.0 if r["name"].endswith(" q") and r["name"].startswith("attention") else (4094.0 if r["name"].endswith(" kv") and r["name"].startswith("attention") else 65504.0)
+        sat = [r for r in rng if r["saturated"] > 0 or r["max_abs"] > lim(r)]
         bad = [r for r in rng if r["non_finite"] > 0]
         tiny = [r for r in rng if 0.0 < r["rms"] < 2.0 ** -5]
         if verbose:
-            print(f"{len(rng)} dense-layer inputs: max |x| {max(r['max_abs'] for r in rng):.4g}, smallest rms {min(r['rms'] for r in rng):.4g}; "
+            print(f"{len(rng)} dense-layer inputs: max |x| {max((r['max_abs'] for r in rng), default=0.0):.4g}, smallest rms {min((r['rms'] for r in rng), default=0.0):.4g}; "
                   f"{len(sat)} with saturated elements, {len(tiny)} with rms < 2^-5, {len(bad)} with non-finite elements")
             for r in (sat + tiny + bad)[:20]:
                 print(f"  {r['name']}: max |x| {r['max_abs']:.4g} rms {r['rms']:.4g} saturated {r['saturated']} non-finite {r['non_finite']}")
