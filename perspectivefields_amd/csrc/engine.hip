@@ -451,8 +451,8 @@ struct pf_engine {
   bool sba_heads = false;    // PF_SBA_HEADS=1: the tensors between the 3x3 convs of the decoders' ResidualConvUnits are written as split-f16 planes by the producing
                              // conv's epilogue (plus fp32 where a residual add reads them) and the halo kernel copies them (igemm_sbh ASB) instead of splitting
                              // every element once per n-tile and halo overlap; split-f16 scheme only
-  int rb_chain = 1;          // PF_RB_CHAIN: 0 = the linear layers of MiT stage 3 on the LDS tiles (igemm_sb), 1 (default) = row-block form (rb_gemm.hip) once the batch gives
-                             // at least rb_min_blocks row blocks (below that a launch of 64-row blocks leaves most of the chip idle and the 64 x 64 tiles win)
+  int rb_chain = 28;         // PF_RB_CHAIN: which linear layers of MiT stage 3 run in the row-block form (rb_gemm.hip) instead of the LDS tiles (igemm_sb) once the batch gives
+                             // at least rb_min_blocks row blocks: bit mask 1 q, 2 kv, 4 proj, 8 fc1, 16 fc2 (0 = none)
   int rb_min_blocks = 96;
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
@@ -991,7 +991,7 @@ struct pf_engine {
         const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && (long)B * ((N + 63) / 64) >= rb_min_blocks;
         if (sr > 1) {
           const bool fork = B >= 4 && can_fork(c);  // batch 1-3: a launch already under-fills the chip; the event pair would only add latency
-          if (use_rb && fork) {  // q = LN1(x) Wq with the LayerNorm inside the kernel: independent of the LayerNorm launch below
+          if (use_rb && (rb_chain & 1) && fork) {  // q = LN1(x) Wq with the LayerNorm inside the kernel: independent of the LayerNorm launch below
             (void)hipEventRecord(ev_fork, c.s);
             (void)hipStreamWaitEvent(side, ev_fork, 0);
             Ctx c2 = c;
@@ -1000,7 +1000,7 @@ struct pf_engine {
             (void)hipEventRecord(ev_join, side);
           }
           ln(c, mb.n1, x, xn, M);
-          if (use_rb) {
+          if (use_rb && (rb_chain & 1)) {
             if (!fork) rb_linear(c, mb.rq, x, M, (int)N, qb, &mb.n1);
           } else if (fork) {  // q projection next to sr conv + kv GEMM: both read xn, attention needs both
             (void)hipEventRecord(ev_fork, c.s);
@@ -1013,7 +1013,7 @@ struct pf_engine {
             gemm(c, mb.q, xn, M, Ten(qb));
           }
           conv(c, mb.sr, xn, B, Ho, Wo, Ten(srb));
-          if (use_rb) {
+          if (use_rb && (rb_chain & 2)) {  // measured slower than the LDS tile on these 3 200 rows (50 row blocks: 20.6 vs 12.7 us, profiles/r04_rb_linear.md)
             rb_linear(c, mb.rkv, srb, Mkv, kvh * kvw, kvb, &mb.srn);  // LayerNorm(sr conv) while the rows are staged
           } else if (mb.kv.ln_s) {
             gemm(c, mb.kv, Ten(srb), Mkv, Ten(kvb));  // LayerNorm(sr conv) inside the kv GEMM
@@ -1047,7 +1047,7 @@ struct pf_engine {
           ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
           launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
         }
-        if (use_rb) rb_linear(c, mb.rproj, ab.f, M, (int)N, x, nullptr, ACT_NONE, x);
+        if (use_rb && (rb_chain & 4)) rb_linear(c, mb.rproj, ab.f, M, (int)N, x, nullptr, ACT_NONE, x);
         else gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
         // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
         if (fused_mlp && mb.mlp_w) {                  // norm2 + fc1 + depthwise 3x3 + GELU + fc2 + residual in one kernel, x -> xalt
@@ -1059,7 +1059,7 @@ struct pf_engine {
           std::swap(x, xalt);
           continue;
         }
-        if (use_rb) {
+        if (use_rb && (rb_chain & 8)) {
           rb_linear(c, mb.rfc1, x, M, (int)N, hb, &mb.n2);  // norm2 while the rows are staged
         } else if (mb.fc1.ln_s) {
           gemm(c, mb.fc1, Ten(x), M, Ten(hb));        // norm2 inside fc1
@@ -1071,7 +1071,7 @@ struct pf_engine {
           ProfScope ps(c.prof, c.s, PC_DW3, (4.0 + (h2.f ? 4.0 : 0.0) + (h2.s.p ? 6.0 : 0.0)) * M * 4 * C);  // read + write of the hidden map
           launch_dwconv3x3_gelu(hb, mb.dw.w, mb.dw.b, h2.f, B, Ho, Wo, 4 * C, c.s, h2.s.p, h2.s.plane);
         }
-        if (use_rb) rb_linear(c, mb.rfc2, h2.f, M, (int)N, x, nullptr, ACT_NONE, x);
+        if (use_rb && (rb_chain & 16)) rb_linear(c, mb.rfc2, h2.f, M, (int)N, x, nullptr, ACT_NONE, x);
         else gemm(c, mb.fc2, h2, M, Ten(x), ACT_NONE, x);
       }
       c.release(mk);

@@ -14,12 +14,24 @@ namespace pf {
 // s_memtime stamp of one block's waves (STAMP builds of the kernels only; a stamp drains lgkmcnt, i.e. it perturbs the step it sits in)
 #define RB_STAMP(i) do { if constexpr (STAMP) { if (blockIdx.x == 17 && lane == 0) p.stamps[wave * 64 + (i)] = __builtin_readcyclecounter(); } } while (0)
 static constexpr int RB_NMAX = 1280;  // widest layer of the resident form (fc1 of stage 3)
-// per-channel epilogue constants -> LDS (visible after the kernel's first barrier)
-__device__ __forceinline__ void rb_stage_tabs(float* tabs, const float* inv, const float* bias, int N, int tid) {
-  for (int i = tid; i < N / 4; i += 256) {
-    reinterpret_cast<float4*>(tabs)[i] = reinterpret_cast<const float4*>(inv)[i];
-    reinterpret_cast<float4*>(tabs + N)[i] = reinterpret_cast<const float4*>(bias)[i];
+// per-channel epilogue constants -> LDS (visible after the kernel's first barrier).  Two halves: the loads are issued with the kernel's other first loads (one
+// round trip for everything), the LDS writes after the rows have been staged.  N <= 1280: at most 2 float4 per thread and table.
+struct RbTabRegs { float4 iv[2], bb[2]; };
+__device__ __forceinline__ void rb_tabs_load(RbTabRegs& t, const float* inv, const float* bias, int N, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = min(tid + 256 * i, N / 4 - 1);
+    t.iv[i] = reinterpret_cast<const float4*>(inv)[k];
+    t.bb[i] = reinterpret_cast<const float4*>(bias)[k];
   }
+}
+__device__ __forceinline__ void rb_tabs_store(const RbTabRegs& t, float* tabs, int N, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (tid + 256 * i < N / 4) {
+      reinterpret_cast<float4*>(tabs)[tid + 256 * i] = t.iv[i];
+      reinterpret_cast<float4*>(tabs + N)[tid + 256 * i] = t.bb[i];
+    }
 }
 
 // Epilogue of one pass.  In the transposed accumulators a lane owns row (rt * 32 + l31) and, per register group g, channels 32 ct + 8 g + 4 hi .. + 3: stored straight
@@ -87,15 +99,13 @@ __global__ __launch_bounds__(256, 1) void rb_linear_kernel(const RbLinArgs p) {
   __shared__ __attribute__((aligned(16))) float escr[4 * 1024];  // epilogue transposition, 4 KB per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   RB_STAMP(0);
-  rb_stage_tabs(tabs, p.inv, p.bias, p.N, tid);
   const int img = blockIdx.x / p.bpi, j = blockIdx.x - img * p.bpi;
   const int nrows = min(RB_ROWS, p.tokens - j * RB_ROWS);
   const int m0 = img * p.tokens + j * RB_ROWS;
 
   RbW<G> W;
   W.init(p.w, p.w_bytes, wave, lane);
-  W.prologue();  // the first RB_D steps of the stream fly while the rows are staged
-  RB_STAMP(1);
+  RbTabRegs tr;
 
   {  // ---- rows -> (LayerNorm) -> split-f16 fragments
     const int r = tid >> 2, q = tid & 3;
@@ -105,6 +115,10 @@ __global__ __launch_bounds__(256, 1) void rb_linear_kernel(const RbLinArgs p) {
     for (int i = 0; i < CPT; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[i][e] = *reinterpret_cast<const float4*>(xr + 16 * (q + 4 * i) + 4 * e);
+    // everything the block needs first is in flight at once: its rows (HBM), the epilogue constants, the first RB_D steps of the weight stream
+    rb_tabs_load(tr, p.inv, p.bias, p.N, tid);
+    W.prologue();
+    RB_STAMP(1);
     if constexpr (LN) {  // two passes over the registers, like F.layer_norm: mean, then the variance of the centred row
       float s = 0.f;
 #pragma unroll
@@ -135,6 +149,7 @@ __global__ __launch_bounds__(256, 1) void rb_linear_kernel(const RbLinArgs p) {
     for (int i = 0; i < CPT; ++i) {
       rb_store_chunk(As + (q + 4 * i) * G::CHS, r, v[i]);
     }
+    rb_tabs_store(tr, tabs, p.N, tid);
   }
   RB_STAMP(2);
   __syncthreads();
@@ -177,7 +192,6 @@ __global__ __launch_bounds__(256, 1) void rb_linear_stream_kernel(const RbLinArg
   __shared__ __attribute__((aligned(16))) float escr[4 * 1024];  // epilogue transposition, 4 KB per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   RB_STAMP(0);
-  rb_stage_tabs(tabs, p.inv, p.bias, p.N, tid);
   const int img = blockIdx.x / p.bpi, j = blockIdx.x - img * p.bpi;
   const int nrows = min(RB_ROWS, p.tokens - j * RB_ROWS);
   const int m0 = img * p.tokens + j * RB_ROWS;
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void rb_linear_stream_kernel(const RbLinArg
 
   RbW<G> W;
   W.init(p.w, p.w_bytes, wave, lane);
-  W.prologue();
+  RbTabRegs tr;
 
   const int r = tid >> 2, q = tid & 3;
   const float* xr_ = p.x + (size_t)(m0 + min(r, nrows - 1)) * K + 16 * q;  // rows past the block's end: a valid row, never stored
@@ -195,10 +209,13 @@ __global__ __launch_bounds__(256, 1) void rb_linear_stream_kernel(const RbLinArg
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const float4*>(xr_ + (size_t)tc * 64 + 4 * e);
   };
-  stage_load(0, st[0]);
+  stage_load(0, st[0]);  // everything the block needs first in flight at once: stage 0, the epilogue constants, the weight ring, the next stages
+  rb_tabs_load(tr, p.inv, p.bias, p.N, tid);
+  W.prologue();
 #pragma unroll
   for (int u = 1; u < L; ++u) stage_load(u, st[u]);
   rb_store_chunk(As + q * G::CHS, r, st[0]);
+  rb_tabs_store(tr, tabs, p.N, tid);
   stage_load(L, st[0]);
   RB_STAMP(1);
   __syncthreads();

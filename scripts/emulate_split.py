@@ -70,8 +70,21 @@ def weight_scale(w):
     return torch.pow(torch.tensor(2.0, dtype=torch.float64), e)
 
 
+RED = ""  # reduced scheme of the decoders' 3x3 / stride-1 convs ("mix_*" modes): a1w2 = ah (wh + wl), a2w1 = (ah + al) wh, a1w1 = ah wh; everything else stays SCHEME
+
+
 def contract(op, x, w, **kw):
     xd, wd = x.double(), w.double()
+    if RED and op is _conv2d and tuple(w.shape[2:]) == (3, 3) and kw.get("stride", 1) in (1, (1, 1)):
+        s = weight_scale(w)
+        xh, xl = split_f16_unscaled(xd, False)
+        wh, wl = split_f16(wd * s.view(-1, 1, 1, 1))
+        y = op(xh, wh, **kw)
+        if RED == "a1w2":
+            y = y + op(xh, wl, **kw)
+        elif RED == "a2w1":
+            y = y + op(xl, wh, **kw)
+        return (y / s.view(1, -1, 1, 1)).to(torch.float32)
     if SCHEME in ("f16x3", "f16x3u", "f16x3uf"):
         s = weight_scale(w)
         sh = [-1] + [1] * (w.dim() - 1)
@@ -171,7 +184,10 @@ _attention = pf_oracle.mit_attention
 
 
 def run(sd, arch, imgs, mode):
-    global SCHEME, WINOGRAD
+    global SCHEME, WINOGRAD, RED
+    RED = ""
+    if mode.startswith("mix_"):
+        RED, mode = mode[4:], "f16x3u+attn"
     WINOGRAD = mode.endswith("+wino")
     if WINOGRAD:
         mode = mode[:-5]
