@@ -54,6 +54,8 @@ def parse(argv=None):
                          "fp32_bf16x6 = exact bf16 split; bf16x3 / bf16 are reduced-precision modes (reported, never the headline)")
     ap.add_argument("--autotune", type=int, default=0, help="1: time every tile configuration for this batch size before the warm-up (default: shipped tile table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--defer-params", type=int, default=1, help="1 (default): the ParamNet branch of step i runs on the engine's own stream next to step i + 1's backbone (pf_set_defer_params); "
+                    "every step's work still completes inside the timed region (join + device synchronize before the clock stops)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the device-resize figure, the latency numbers and the parity check")
     ap.add_argument("--events-in-timed", type=int, default=1, help="bracket the launches of >= 200 GFLOP (the dominant decoder convs) with HIP events inside the timed region (every timed step; "
@@ -154,6 +156,12 @@ class _StubEngine:
 
     def postprocess_batch(self, pg, pl, sizes):
         return [(torch.zeros((2, 2, 2)), torch.zeros((2, 2))) for _ in sizes]
+
+    def set_defer_params(self, on):
+        pass
+
+    def join_params(self):
+        pass
 
     def resize_batch_into(self, imgs, out):
         return out
@@ -276,16 +284,39 @@ def main(argv=None):
             dist.barrier()
         sync()
 
+    # Deferred ParamNet branch (--defer-params 1): forward i returns with its camera-parameter tensor still being computed on the engine's stream, next to forward i + 1's
+    # backbone; the tensor is complete in stream order once forward i + 1 has been issued, so the scalars of step i are gathered (N > 1) right after that -- one step
+    # late -- and the last step's after join_params().  Nothing is skipped: K steps' work is inside the timed region.
+    defer = bool(args.defer_params) and not dry
+    if defer:
+        eng.set_defer_params(True)
+    late = {"params": None}
+
     def step():
         if orig is not None:
             eng.resize_batch_into(orig, batch)  # bucketed bit-exact PIL resize on the device (inside the timed region for the mixed stream)
         pg, pl, params = eng.forward(batch)
         outs = eng.postprocess_batch(pg, pl, sizes)
-        allp = gather_params(params, counts) if (params is not None and world > 1) else params
+        if defer and params is not None and world > 1:
+            prev, late["params"] = late["params"], params
+            allp = gather_params(prev, counts) if prev is not None else None
+        else:
+            allp = gather_params(params, counts) if (params is not None and world > 1) else params
         return pg, pl, outs, allp
+
+    def drain(out):
+        """the tail of the pipeline: join the last forward's branch and gather its scalars"""
+        if not defer:
+            return out
+        eng.join_params()
+        if late["params"] is not None:
+            out = out[:3] + (gather_params(late["params"], counts),)
+            late["params"] = None
+        return out
 
     for _ in range(args.warmup):
         step()
+    drain((None, None, None, None))
     barrier()
     # Per-launch HIP events INSIDE the timed region on the launches of >= 200 GFLOP only (the dominant decoder convs: ~6 per step), in every timed step: a dozen event
     # records per step cost nothing, so `value` and `roofline` come from the same steps.  The per-class figures (all split GEMMs, depthwise, LayerNorm, attention) need an
@@ -298,8 +329,11 @@ def main(argv=None):
     out = None
     for i in range(args.steps):
         out = step()
+    out = drain(out)
     barrier()
     dt = time.perf_counter() - t0
+    if defer:
+        eng.set_defer_params(False)  # everything after the timed region (extra profiled step, latency figures, parity check) reads its results right away
     if use_events:
         eng.profile_end()
     recs = eng.profile_records() if use_events else []
@@ -402,6 +436,8 @@ def main(argv=None):
             "weights": "seeded synthetic checkpoint (no network for the trained .pth)", "precision": precision,
             "tiles": "autotuned on this device before the warm-up" if args.autotune else "shipped tile table + static heuristic (no tuning)",
             "gathered_param_rows": gathered_rows,
+            "step_pipeline": ("ParamNet branch of step i on the engine's own stream beside step i + 1's backbone (pf_set_defer_params); all K steps complete inside the timed region"
+                              if defer else "none: every forward joins its ParamNet branch before it returns"),
         },
     }
     if per_bucket is not None:

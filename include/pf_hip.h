@@ -119,6 +119,14 @@ int pf_forward_u8(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_p
 int pf_forward_f32(pf_handle h, int batch, const float* d_images_f32, float* d_pred_gravity, float* d_pred_latitude,
                    float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Deferred ParamNet branch (throughput option for callers that issue forward after forward on one stream; off by default).  With on != 0 the ConvNeXt branch of a
+ * forward (param_network.py:46-69, convnext.py:140-152) runs on a stream owned by the engine, behind that forward's decoders, and the call returns without joining it:
+ * the NEXT forward's backbone (other images, no dependency) runs beside it -- both are chains of small launches that leave most of the chip idle.  d_pred_gravity /
+ * d_pred_latitude are valid in `stream` order as always; d_params of a forward becomes valid in `stream` order once the next pf_forward_* has been issued on that
+ * stream (it waits for the branch before its decoders overwrite the branch's input) or after pf_join_params(h, stream).  The caller keeps d_params alive until then. */
+int pf_set_defer_params(pf_handle h, int on);
+int pf_join_params(pf_handle h, void* stream);
+
 /* Low-latency form of pf_forward_u8 for small batches: the ~430 launches of a forward are captured once per (batch, buffer
  * set) into a hipGraph and replayed with one launch (host launch cost, not GPU time, bounds a batch-1 forward).  Same
  * arguments and results; `stream` must be an explicit stream (not the legacy NULL stream); the graph is re-captured when

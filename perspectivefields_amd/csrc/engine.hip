@@ -438,6 +438,37 @@ struct pf_engine {
                              // Never forked while tuning or profiling (per-launch events time one stream)
   hipStream_t side = nullptr, side2 = nullptr;   // side: the q projections; side2: the low-level encoder conv, launched next to MiT stage 3
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_ll = nullptr;
+  // Deferred ParamNet (pf_set_defer_params): the ConvNeXt branch of forward i runs on an internal stream behind the decoders of forward i and is NOT joined at the
+  // end of the call -- forward i + 1's backbone (other images: no dependency) runs next to it.  Both are chains of small, latency-bound launches that leave most of
+  // the chip idle (MiT stage 3: 13 % MFMA-busy; ConvNeXt stages 3-4 likewise), and their kernels co-reside (small LDS, 4 waves).  d_params of forward i is valid in
+  // the caller's stream order once the NEXT pf_forward* has been issued on that stream (it waits for the branch before its decoders overwrite the branch's input),
+  // or after pf_join_params.  The branch works in its own workspace region (input map + activations), behind the main one.
+  int defer_params = 0;
+  hipStream_t pstream = nullptr;
+  hipEvent_t ev_pn_in = nullptr, ev_pn_done = nullptr;
+  bool pn_pending = false, in_capture = false;
+  // PF_DEFER_AT = k > 0: the deferred branch of forward i is ISSUED (on pstream) only when forward i + 1 reaches MiT stage k -- next to the stage whose launches leave
+  // the most room -- instead of right away (k = 0); pf_join_params / the decoders' wait issue it if no forward came
+  int defer_at = 0, defer_prio = 0;
+  struct PnLater { bool armed = false; int B = 0; const float* pn = nullptr; float* params = nullptr; Ctx ctx; } pn_later;
+  void issue_deferred() {
+    if (!pn_later.armed) return;
+    pn_later.armed = false;
+    paramnet(pn_later.ctx, pn_later.B, pn_later.pn, pn_later.params);
+    (void)hipEventRecord(ev_pn_done, pstream);
+  }
+  std::map<int, size_t> pn_off;   // batch -> byte offset of the ParamNet region in the workspace
+  bool pstream_ready() {
+    if (pstream) return true;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent (largest number)
+    const int prio = defer_prio > 0 ? hi : (defer_prio < 0 ? lo : 0);
+    if ((defer_prio ? hipStreamCreateWithPriority(&pstream, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking)) != hipSuccess) { pstream = nullptr; return false; }
+    if (hipEventCreateWithFlags(&ev_pn_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_pn_done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(pstream); pstream = nullptr; return false;
+    }
+    return true;
+  }
   bool ll_forked = false;
   bool side_ready() {
     if (side && side2) return true;
@@ -952,6 +983,7 @@ struct pf_engine {
     int H = NET, W = NET;
     for (int s = 0; s < 4; ++s) {
       MitStage& st = stages[s];
+      if (!c.dry && pn_later.armed && s + 1 == defer_at) issue_deferred();  // the previous forward's ParamNet branch goes beside this stage
       const int C = MIT_DIMS[s], heads_n = MIT_HEADS[s], sr = MIT_SR[s];
       const int Ho = (H + 2 * MIT_PP[s] - MIT_PK[s]) / MIT_PS[s] + 1, Wo = (W + 2 * MIT_PP[s] - MIT_PK[s]) / MIT_PS[s] + 1;
       const long N = (long)Ho * Wo, M = (long)B * N;
@@ -1264,7 +1296,17 @@ struct pf_engine {
     const bool pf = pred_fused();
     float* tg = pf ? nullptr : c.alloc((size_t)2 * B * NET * NET * 32);
     float* tl = pf ? nullptr : tg + (size_t)B * NET * NET * 32;
-    float* pn = has_param ? c.alloc((size_t)B * NET * NET * 4) : nullptr;
+    // ParamNet's input map and activations live in their own region behind the main one (run_pn_peak: its size, from the dry run), so that a deferred branch
+    // (defer_params) never shares memory with the next forward's backbone / decoders
+    Ctx cp = c;
+    cp.off = 0; cp.peak = 0;
+    if (!c.dry) cp.base = c.base + pn_off[B];
+    float* pn = has_param ? cp.alloc((size_t)B * NET * NET * 4) : nullptr;
+    if (!c.dry && pn_pending) {  // the previous forward's deferred branch still reads pn / writes its activations: the decoders below overwrite pn
+      issue_deferred();
+      (void)hipStreamWaitEvent(c.s, ev_pn_done, 0);
+      pn_pending = false;
+    }
     const size_t mk = c.mark();
     heads_fwd(c, B, feats, llf, tg, pg, pl, pn);
     c.release(mk);
@@ -1276,8 +1318,28 @@ struct pf_engine {
     }
     if (!c.dry && !pf)
       launch_pred_regression(tg, tl, heads[0].predw, heads[0].predb, heads[1].predw, heads[1].predb, pg, pl, pn, B, NET * NET, c.s);
-    if (has_param) paramnet(c, B, pn, params);
+    if (has_param) {
+      const bool defer = defer_params && !c.dry && (!c.prof || c.prof->min_work > 0.0) && !c.dbg && !c.tuning && !in_capture && pstream_ready();
+      if (defer) {
+        (void)hipEventRecord(ev_pn_in, c.s);
+        (void)hipStreamWaitEvent(pstream, ev_pn_in, 0);
+        cp.s = pstream;
+      }
+      if (defer && defer_at > 0) {  // issued by the next forward (mit(), stage defer_at) or by whoever needs the result first
+        pn_later.armed = true; pn_later.B = B; pn_later.pn = pn; pn_later.params = params; pn_later.ctx = cp;
+        pn_pending = true;
+      } else {
+        paramnet(cp, B, pn, params);
+        if (defer) {
+          (void)hipEventRecord(ev_pn_done, pstream);
+          pn_pending = true;
+        }
+      }
+    }
+    run_pn_peak = cp.peak;
+    if (cp.max_conv_out > c.max_conv_out) c.max_conv_out = cp.max_conv_out;
   }
+  size_t run_pn_peak = 0;
 
   // with_scratch: plus the target of the tuning launches (largest conv output as fp32 + 3 bf16 planes) -- pf_autotune only
   size_t workspace_bytes(int B, bool with_scratch = false) {
@@ -1286,8 +1348,10 @@ struct pf_engine {
       Ctx c{nullptr, 4096, 0, 0, true, nullptr};
       c.sb_planes = nterms == NT_F16X3 ? 2 : 3;
       run(c, B, nullptr, true, nullptr, nullptr, nullptr);
-      ws_cache[B] = c.peak + 4096;
-      scratch_off[B] = c.peak;
+      const size_t main_peak = (c.peak + 255) & ~(size_t)255, total = main_peak + ((run_pn_peak + 255) & ~(size_t)255);
+      pn_off[B] = main_peak;
+      ws_cache[B] = total + 4096;
+      scratch_off[B] = total;
       scratch_elems[B] = c.max_conv_out;
       it = ws_cache.find(B);
     }
@@ -1388,6 +1452,8 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_RB_CHAIN")) e->rb_chain = atoi(v);
+  if (const char* v = getenv("PF_DEFER_AT")) e->defer_at = atoi(v);
+  if (const char* v = getenv("PF_DEFER_PRIO")) e->defer_prio = atoi(v);
   if (const char* v = getenv("PF_RB_MIN_BLOCKS")) e->rb_min_blocks = atoi(v);
 #ifdef PF_TUNING_BUILD
 #endif
@@ -1415,6 +1481,18 @@ int pf_set_precision(pf_handle h, int mode) {
   return PF_OK;
 }
 
+int pf_set_defer_params(pf_handle h, int on) {
+  if (!h) return PF_ERR_ARG;
+  h->defer_params = on ? 1 : 0;
+  return PF_OK;
+}
+int pf_join_params(pf_handle h, void* stream) {
+  if (!h) return PF_ERR_ARG;
+  if (h->pn_pending) h->issue_deferred();
+  if (h->pn_pending && hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_pn_done, 0) != hipSuccess) return h->fail(PF_ERR_DEVICE, "pf_join_params: hipStreamWaitEvent failed");
+  return PF_OK;
+}
+
 int pf_destroy(pf_handle h) {
   if (!h) return PF_ERR_ARG;
   (void)hipSetDevice(h->device);
@@ -1426,6 +1504,9 @@ int pf_destroy(pf_handle h) {
   if (h->ev_ll) (void)hipEventDestroy(h->ev_ll);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->side2) (void)hipStreamDestroy(h->side2);
+  if (h->pstream) { (void)hipStreamSynchronize(h->pstream); (void)hipStreamDestroy(h->pstream); }
+  if (h->ev_pn_in) (void)hipEventDestroy(h->ev_pn_in);
+  if (h->ev_pn_done) (void)hipEventDestroy(h->ev_pn_done);
   delete h;
   return PF_OK;
 }
@@ -1503,8 +1584,11 @@ int pf_forward_u8_graph(pf_handle h, int batch, const uint8_t* in, float* pg, fl
   if (!exec) {
     if (hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
     (void)h->workspace_bytes(batch);  // dry run outside the capture
+    if (h->pn_pending) { h->issue_deferred(); (void)hipStreamWaitEvent(s, h->ev_pn_done, 0); h->pn_pending = false; }  // a deferred ParamNet branch is joined outside the capture
     if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipStreamBeginCapture failed");
+    h->in_capture = true;  // a captured forward keeps the branch on the capture stream
     const int rc = h->forward(batch, in, true, pg, pl, params, ws, ws_bytes, s);
+    h->in_capture = false;
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc != PF_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "pf_workspace_bytes": (_c.c_size_t, [_P, _c.c_int]),
     "pf_forward_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_forward_f32": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_set_defer_params": (_c.c_int, [_P, _c.c_int]),
+    "pf_join_params": (_c.c_int, [_P, _P]),
     "pf_forward_u8_graph": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_resize_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
     "pf_resize_bilinear_u8": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
@@ -187,6 +189,8 @@ class Engine:
         # (profiles/r02_latency.md): a batch-1 forward is bound by the GPU-side latency of its ~430 dependent small kernels
         # (6.4 ms eager, 6.8 ms replayed), not by host launch cost, so the replay buys nothing there.
         self.graph_max_batch = int(os.environ.get("PF_GRAPH_MAX_BATCH", "0"))
+        self.defer_params = False   # set_defer_params()
+        self._deferred = []
         self._graph_bufs = {}
         g, l, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self.lib.pf_output_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(p))
@@ -252,6 +256,19 @@ class Engine:
     def workspace_bytes(self, batch: int) -> int:
         return int(self.lib.pf_workspace_bytes(self._h, batch))
 
+    def set_defer_params(self, on: bool):
+        """Deferred ParamNet branch (pf_set_defer_params): the camera-parameter tensor of a forward is complete in stream order once the NEXT forward has been issued
+        or after join_params().  For loops that issue forward after forward (bench.py, inference_stream); inference / inference_batch leave it off."""
+        _check(self.lib.pf_set_defer_params(self._h, 1 if on else 0), self._h, "pf_set_defer_params")
+        self.defer_params = bool(on)
+        if not on:
+            self.join_params()
+
+    def join_params(self):
+        """Put the current stream behind a pending deferred ParamNet branch (no-op when none is pending)."""
+        _check(self.lib.pf_join_params(self._h, _stream_ptr()), self._h, "pf_join_params")
+        self._deferred = []
+
     def _order_scratch(self, name: str, buf):
         """Engine-owned scratch (forward workspace, resize / post-process tables) is reused call after call.  Calls on ONE
         stream are ordered by the stream; when the caller's current stream changes (inference_batch on the default stream,
@@ -312,6 +329,9 @@ class Engine:
                 params.data_ptr() if params is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr(),
             )
         _check(rc, self._h, "pf_forward")
+        if getattr(self, "defer_params", False) and params is not None:
+            # the branch writes `params` on the engine's stream: keep the tensor of the PREVIOUS forward alive until this one has been issued (it waits for that branch)
+            self._deferred = [params]
         return pg, pl, params
 
     def forward_debug(self, images, shadow=True, ranges=True):

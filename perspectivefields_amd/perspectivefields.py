@@ -212,12 +212,23 @@ class PerspectiveFields(nn.Module):
 
     @torch.no_grad()
     def inference_stream(self, batches, to_host: bool = True, depth: int = 2):
+        """Pipelined inference over an iterable of image lists (see _inference_stream); leaves the engine's deferred-ParamNet mode off however the iteration ends."""
+        try:
+            yield from self._inference_stream(batches, to_host, depth)
+        finally:
+            eng = self._engine
+            if eng is not None and getattr(eng, "defer_params", False):
+                eng.set_defer_params(False)
+
+    def _inference_stream(self, batches, to_host: bool = True, depth: int = 2):
         """Pipelined inference over an iterable of image lists: yields one `inference_batch`-style result list per input
         batch, in order.  Three HIP streams overlap the stages of consecutive batches -- upload (pinned staging buffer,
         async H2D), compute (forward + post-process), download -- because the reference's callers move the fields to the
         host right after inference (demo/demo.py:55-58, 4.9 MB per 640x640 image).  With `to_host` the four field tensors
         of every result are pinned CPU tensors (filled by async D2H; complete when the batch is yielded); the ParamNet
-        scalars stay 0-d device tensors as in `inference_batch`.  `depth` = batches in flight."""
+        scalars stay 0-d device tensors as in `inference_batch`.  `depth` = batches in flight.
+        With depth >= 2 the ParamNet branch of a batch runs on the engine's own stream beside the next batch's backbone (Engine.set_defer_params): a batch is yielded
+        only after the forward that follows it has been issued (or, for the last one, after the join), i.e. with its camera parameters complete."""
         dev = self.device
         if dev.type != "cuda":
             raise PfError(f"PerspectiveFields is on '{dev}': the MI355X engine has no CPU path. Call .cuda() first.")
@@ -229,7 +240,19 @@ class PerspectiveFields(nn.Module):
         slots = [{"buf": None, "done": None} for _ in range(nslots)]
         nbatch = 0
 
-        def finish(item):
+        defer = self.param_on and depth >= 2
+        if defer:
+            eng.set_defer_params(True)
+
+        def finish(item, nxt):
+            # the camera parameters of `item` are complete once the forward of the batch issued after it has run (its comp_done), or after the join
+            if defer:
+                if nxt is not None:
+                    nxt["comp_done"].synchronize()
+                else:
+                    with torch.cuda.stream(s_comp):
+                        eng.join_params()
+                    s_comp.synchronize()
             item["done"].synchronize()
             return item["results"]
 
@@ -288,11 +311,16 @@ class PerspectiveFields(nn.Module):
                             o += src.numel()
                     done = torch.cuda.Event()
                     done.record(s_down)
-            inflight.append({"results": results, "done": done})
+            inflight.append({"results": results, "done": done, "comp_done": comp_done})
             if len(inflight) >= max(1, depth):
-                yield finish(inflight.pop(0))
+                item = inflight.pop(0)
+                yield finish(item, inflight[0] if inflight else None)
         while inflight:
-            yield finish(inflight.pop(0))
+            item = inflight.pop(0)
+            yield finish(item, inflight[0] if inflight else None)
+        if defer:
+            with torch.cuda.stream(s_comp):
+                eng.set_defer_params(False)
 
     def fields_from_prediction(self, pred: dict, height: int, width: int):
         """Perspective fields implied by the ParamNet scalars of one inference() result (see fields_from_params)."""

@@ -420,3 +420,36 @@ def test_split_k_agrees_with_single_pass(monkeypatch):
         d = max(abs(float(a[k]) - float(b[k])) for k in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
         print(f"[split-K vs single pass] 1-cos {c:.2e} latL1 {e:.2e} param {d:.2e}")
         assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
+
+
+@pytest.mark.parametrize("tag", ["centered", "uncentered"])
+def test_deferred_paramnet_branch_equals_joined_forward(tag):
+    """pf_set_defer_params: the ParamNet branch of a forward runs on the engine's own stream beside the NEXT forward's backbone.  The camera parameters of forward i
+    are complete in stream order once forward i + 1 has been issued (read here right behind it, without a join) and, for the last forward, after join_params();
+    fields and parameters equal the ones of ordinary (joined) forwards bit for bit, also when the batch size changes between the calls."""
+    m = model(tag)
+    eng = m._get_engine()
+    xs = [torch.from_numpy(np.stack([m.aug.apply_image(synthetic_image(80, 100, seed=900 + 20 * j + i)) for i in range(n)])).cuda() for j, n in enumerate((16, 16, 5, 16))]
+    ref = []
+    for x in xs:
+        ref.append([t.clone() for t in eng.forward(x)])
+        torch.cuda.synchronize()
+    try:
+        eng.set_defer_params(True)
+        for trial in range(2):
+            outs, snaps = [], []
+            for i, x in enumerate(xs):
+                outs.append(eng.forward(x))
+                if i > 0:
+                    snaps.append(outs[i - 1][2].clone())   # stream-ordered read of the PREVIOUS forward's parameters: valid now that this forward has been issued
+            eng.join_params()
+            snaps.append(outs[-1][2].clone())
+            torch.cuda.synchronize()
+            for i, (o, r) in enumerate(zip(outs, ref)):
+                assert torch.equal(o[0], r[0]) and torch.equal(o[1], r[1]), (trial, i)
+                assert torch.equal(snaps[i], r[2]), (trial, i)
+    finally:
+        eng.set_defer_params(False)
+    again = eng.forward(xs[0])   # back to joined forwards
+    torch.cuda.synchronize()
+    assert torch.equal(again[2], ref[0][2])
