@@ -470,12 +470,17 @@ struct pf_engine {
     return true;
   }
   bool ll_forked = false;
+  // Streams are a scarce resource: the runtime multiplexes a process's streams onto a few hardware queues (4 by default), and two streams that share a queue do not
+  // overlap -- the engine therefore creates only the streams its mode needs (side2 only for PF_SIDE_STREAM=2); with the null stream, `side` and the ParamNet stream
+  // a forward uses three queues (profiles/r04_defer_params.md: with nine streams in one process the deferred branch lost its whole gain).
   bool side_ready() {
-    if (side && side2) return true;
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
-    if (hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess) { side2 = nullptr; return false; }
-    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_ll, hipEventDisableTiming) != hipSuccess) return false;
+    if (side && (side2 || side_stream_mode < 2)) return true;
+    if (!side) {
+      if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+      if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_ll, hipEventDisableTiming) != hipSuccess) return false;
+    }
+    if (side_stream_mode >= 2 && !side2 && hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess) { side2 = nullptr; return false; }
     return true;
   }
   bool can_fork(const Ctx& c) { return side_stream_mode && !c.dry && !c.tuning && (!c.prof || c.prof->min_work > 0.0) && side_ready(); }  // (a full per-launch profile keeps one stream: its event pairs must bracket what they name)

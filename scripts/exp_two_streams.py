@@ -1,5 +1,6 @@
-"""Experiment: the B = 32 step as TWO half-batches on two streams (two engine handles, own workspaces) against one B = 32 forward.  Hypothesis: the small-M launches of
-the backbone / ParamNet (~1000 blocks, latency-bound) of the two halves overlap with each other, and -- once the halves drift apart -- with the other half's decoder.
+"""Experiment: step-level pipelining on two streams.  (a) r03: the B = 32 step as TWO half-batches on two streams (rejected: half batches run their launches less
+efficiently).  (b) r04: FULL batches alternating between two engines on two streams (two workspaces, weights twice), with and without the deferred ParamNet branch --
+do the launch gaps of one forward get filled by the other's kernels beyond what the deferred branch already harvests?
 Output: gpurun_out/exp_two_streams.txt"""
 import os, sys, time
 import numpy as np, torch
@@ -20,30 +21,32 @@ def one(n):
     for _ in range(n):
         pg, pl, par = engs[0].forward(x)
         engs[0].postprocess_batch(pg, pl, sizes)
+    engs[0].join_params()
 
-def two(n, skew=False):
-    h = B // 2
+def two_full(n):
     for it in range(n):
-        for k in (0, 1):
-            with torch.cuda.stream(streams[k]):
-                pg, pl, par = engs[k].forward(x[k * h:(k + 1) * h])
-                engs[k].postprocess_batch(pg, pl, sizes[:h])
+        k = it & 1
+        with torch.cuda.stream(streams[k]):
+            pg, pl, par = engs[k].forward(x)
+            engs[k].postprocess_batch(pg, pl, sizes)
+    for k in (0, 1):
+        with torch.cuda.stream(streams[k]):
+            engs[k].join_params()
 
 def timed(fn, n=10):
-    fn(3); torch.cuda.synchronize()
+    fn(4); torch.cuda.synchronize()
     t = time.perf_counter(); fn(n); torch.cuda.synchronize()
     return (time.perf_counter() - t) / n
 
-for rep in range(2):
-    t1 = timed(one)
-    t2 = timed(two)
-    out.append(f"rep {rep}: one B={B} forward {t1 * 1e3:.2f} ms ({B / t1:.0f} img/s) | two B={B // 2} halves on two streams {t2 * 1e3:.2f} ms ({B / t2:.0f} img/s)  -> {t1 / t2:.3f}x")
-# results identical?
-pg, pl, par = engs[0].forward(x)
-with torch.cuda.stream(streams[1]):
-    pg2, pl2, par2 = engs[1].forward(x[B // 2:])
-torch.cuda.synchronize()
-out.append(f"second half vs full-batch forward: max |d pred_gravity| {float((pg[B // 2:] - pg2).abs().max()):.2e}, params {float((par[B // 2:] - par2).abs().max()):.2e}")
+for defer in (False, True):
+    for e in engs:
+        e.set_defer_params(defer)
+    for rep in range(2):
+        t1 = timed(one)
+        t2 = timed(two_full)
+        out.append(f"defer {int(defer)} rep {rep}: one stream {t1 * 1e3:.2f} ms/step ({B / t1:.0f} img/s) | full batches alternating on two streams {t2 * 1e3:.2f} ms/step ({B / t2:.0f} img/s)  -> {t1 / t2:.3f}x")
+for e in engs:
+    e.set_defer_params(False)
 os.makedirs("gpurun_out", exist_ok=True)
 open("gpurun_out/exp_two_streams.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
