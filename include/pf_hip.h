@@ -69,6 +69,10 @@ const char* pf_version(void);
 const char* pf_build_digest(void); /* digest of the sources this library was built from (stale-library check of the loader) */
 const char* pf_last_error(pf_handle h); /* h may be NULL: error of the last failed pf_create on this thread */
 
+/* device = PF_DEVICE_NONE: the engine's HOST side only -- checkpoint loading, weight repack / folds / splits (kept in host memory), the workspace dry run and the tile
+ * table work; every entry point that needs a GPU returns PF_ERR_DEVICE.  The seam the sanitizer build is tested through (PF_ASAN=1 python -m perspectivefields_amd.build,
+ * tests/test_host_asan.py); not a CPU path of the network. */
+#define PF_DEVICE_NONE (-1)
 int pf_create(pf_handle* out, int device, int arch);
 int pf_destroy(pf_handle h);
 
@@ -245,6 +249,12 @@ int pf_op_linear_ln(int device, const float* d_x, long rows, int K, const float*
  * rows = images x tokens; (K, N) = (320, multiple of 320) or (multiple of 256 above 320, 320); res may alias y.  iters > 0 additionally times `iters` launches. */
 int pf_op_rb_linear(int device, const float* d_x, long rows, int tokens, int K, const float* h_weight /*[N][K]*/, const float* h_bias, const float* h_gamma, const float* h_beta,
                     float eps, int N, int act, const float* d_res, float* d_y, int iters, float* ms_out, void* stream);
+/* The key / value branch of a MiT block with 2 x 2 spatial reduction in one launch (rb_chain.hip): kv = Linear_kv(LayerNorm(Conv2d_2x2s2(LayerNorm_1(x)))),
+ * mix_transformers.py:119-127 (norm1 of :199 applied to the gathered source tokens).  x: (B, 2 Hr, 2 Wr, C) NHWC token map, C = 320; weights in the reference's shapes
+ * (sr [C][C][2][2], kv [2C][C]); kv out: (B, Hr Wr, 2C).  iters > 0 additionally times `iters` launches. */
+int pf_op_rb_srkv(int device, const float* d_x, int B, int Hr, int Wr, int C, const float* h_ln1_gamma, const float* h_ln1_beta, float eps1, const float* h_sr_w,
+                  const float* h_sr_b, const float* h_srn_gamma, const float* h_srn_beta, float eps2, const float* h_kv_w, const float* h_kv_b, float* d_kv, int iters,
+                  float* ms_out, void* stream);
 /* One ConvNeXt block MLP in one kernel (cnx_mlp.hip): y += ls * pwconv2(GELU(pwconv1(LayerNorm(d)))), convnext.py:49-58; C = 96 or 192, weights
  * in the reference's shapes (pwconv1 [4C][C], pwconv2 [C][4C], layer scale ls [C]); y is read (residual) and written.  iters > 0 additionally times
  * `iters` launches (avg ms in *ms_out; y is then garbage). */

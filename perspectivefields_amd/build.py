@@ -12,10 +12,13 @@ CSRC = os.path.join(HERE, "csrc")
 # The product library lives in lib/.  The tuning build (PF_TUNING_BUILD=1: ablation kernels, rejected variants) gets its own directory, lib_tune/, so that both can
 # be prebuilt in the tree and travel to the GPU box together.
 # PF_LIB_SUFFIX=<s> (with PF_SKIP_DIGEST_CHECK=1) selects lib<s>/: a library built from OTHER sources kept next to the product for a same-box A/B.
-_VARIANT = ("_tune" if os.environ.get("PF_TUNING_BUILD", "0") == "1" else "") + os.environ.get("PF_LIB_SUFFIX", "")
+# PF_ASAN=1: lib_asan/ -- the HOST code of every translation unit under AddressSanitizer + UndefinedBehaviorSanitizer (device code unchanged), for the host-side
+# orchestration of engine.hip (stack allocator, checkpoint / tile-table parsers, weight repack): driven on CPU through pf_create(PF_DEVICE_NONE) by tests/test_host_asan.py
+ASAN = os.environ.get("PF_ASAN", "0") == "1"
+_VARIANT = ("_tune" if os.environ.get("PF_TUNING_BUILD", "0") == "1" else "") + ("_asan" if ASAN else "") + os.environ.get("PF_LIB_SUFFIX", "")
 LIBDIR = os.path.join(HERE, "lib" + _VARIANT)
 LIB = os.path.join(LIBDIR, "libpf_hip.so")
-SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sb3.hip", "igemm_sb1.hip", "igemm_sbf.hip", "igemm_sbh.hip", "attn.hip", "elem.hip", "dw7.hip", "cnx_mlp.hip", "mit_mlp.hip", "rb_gemm.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sb3.hip", "igemm_sb1.hip", "igemm_sbf.hip", "igemm_sbh.hip", "attn.hip", "elem.hip", "dw7.hip", "cnx_mlp.hip", "mit_mlp.hip", "rb_gemm.hip", "rb_chain.hip", "engine.hip"]
 # dw7.hip: the scalar one-channel-per-lane kernel must not be SLP-vectorised (see the file header)
 EXTRA_FLAGS = {"dw7.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
@@ -23,6 +26,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # the scripts under scripts/ can select; the product build carries the default path and its parity alternatives only
 if os.environ.get("PF_TUNING_BUILD", "0") == "1":
     FLAGS.append("-DPF_TUNING_BUILD")
+ASAN_HOST_FLAGS = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-Xarch_host", "-fno-sanitize-recover=undefined"]
+if ASAN:
+    FLAGS = FLAGS + ASAN_HOST_FLAGS
+
+
+def asan_runtime() -> str:
+    """the shared ASan runtime of hipcc's clang: LD_PRELOAD it into the python process that loads lib_asan/libpf_hip.so"""
+    clang = os.path.join(os.path.dirname(os.path.realpath(_hipcc())), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    return subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True, check=True).stdout.strip()
 
 
 def _hipcc() -> str:
@@ -74,7 +88,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(f"hipcc failed on {src}:\n{out}", file=sys.stderr)
     if failed:
         raise RuntimeError("libpf_hip.so build failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB] + (["-fsanitize=address,undefined", "-shared-libsan"] if ASAN else [])
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -68,7 +68,9 @@ struct DwW { float* w = nullptr; float* b = nullptr; int C = 0; };
 
 // a linear layer in the row-block form (rb_gemm.hip): weight stream + inverse scales + bias
 struct RbLin { unsigned short* w = nullptr; size_t bytes = 0; float* inv = nullptr; float* b = nullptr; int N = 0, K = 0; };
-struct MitBlock { LNW n1, n2, srn; RbLin rq, rkv, rproj, rfc1, rfc2; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */ };
+// the key / value branch of a stage-3 block as one launch (rb_chain.hip): combined weight stream (conv as GEMM, then kv) + the two layers' scales / biases
+struct RbSrKv { unsigned short* w = nullptr; size_t bytes = 0; float *sr_inv = nullptr, *sr_b = nullptr, *kv_inv = nullptr, *kv_b = nullptr; };
+struct MitBlock { LNW n1, n2, srn; RbLin rq, rkv, rproj, rfc1, rfc2; RbSrKv rsrkv; ConvW qln /*q with norm1 folded (used next to rsrkv: no LayerNorm-1 launch)*/; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */ };
 struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
 struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
@@ -443,6 +445,8 @@ struct pf_engine {
   // the chip idle (MiT stage 3: 13 % MFMA-busy; ConvNeXt stages 3-4 likewise), and their kernels co-reside (small LDS, 4 waves).  d_params of forward i is valid in
   // the caller's stream order once the NEXT pf_forward* has been issued on that stream (it waits for the branch before its decoders overwrite the branch's input),
   // or after pf_join_params.  The branch works in its own workspace region (input map + activations), behind the main one.
+  bool host_only = false;    // pf_create(.., PF_DEVICE_NONE, ..): the host side only (weight repack / folds / splits, workspace dry run, tile table) with the "device" copies of the
+                             // weights in host memory -- the sanitizer build's test seam; every entry point that would touch a GPU fails with PF_ERR_DEVICE
   int defer_params = 0;
   hipStream_t pstream = nullptr;
   hipEvent_t ev_pn_in = nullptr, ev_pn_done = nullptr;
@@ -487,8 +491,8 @@ struct pf_engine {
   bool sba_heads = false;    // PF_SBA_HEADS=1: the tensors between the 3x3 convs of the decoders' ResidualConvUnits are written as split-f16 planes by the producing
                              // conv's epilogue (plus fp32 where a residual add reads them) and the halo kernel copies them (igemm_sbh ASB) instead of splitting
                              // every element once per n-tile and halo overlap; split-f16 scheme only
-  int rb_chain = 28;         // PF_RB_CHAIN: which linear layers of MiT stage 3 run in the row-block form (rb_gemm.hip) instead of the LDS tiles (igemm_sb) once the batch gives
-                             // at least rb_min_blocks row blocks: bit mask 1 q, 2 kv, 4 proj, 8 fc1, 16 fc2 (0 = none)
+  int rb_chain = 60;         // PF_RB_CHAIN: which linear layers of MiT stage 3 run in the row-block form (rb_gemm.hip) instead of the LDS tiles (igemm_sb) once the batch gives
+                             // at least rb_min_blocks row blocks: bit mask 1 q, 2 kv, 4 proj, 8 fc1, 16 fc2, 32 the whole key / value branch as one launch (rb_chain.hip; overrides 2) (0 = none)
   int rb_min_blocks = 96;
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
@@ -532,6 +536,13 @@ struct pf_engine {
   }
   float* upload(const std::vector<float>& v) {
     void* d = nullptr;
+    if (host_only) {
+      d = malloc(v.size() * sizeof(float) + 1);
+      if (!d) throw std::string("malloc failed for weights");
+      std::memcpy(d, v.data(), v.size() * sizeof(float));
+      dev_allocs.push_back(d);
+      return static_cast<float*>(d);
+    }
     if (hipMalloc(&d, v.size() * sizeof(float)) != hipSuccess) throw std::string("hipMalloc failed for weights");
     if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) throw std::string("hipMemcpy H2D failed for weights");
     dev_allocs.push_back(d);
@@ -539,6 +550,13 @@ struct pf_engine {
   }
   unsigned short* upload_u16(const std::vector<unsigned short>& v) {
     void* d = nullptr;
+    if (host_only) {
+      d = malloc(v.size() * 2 + 1);
+      if (!d) throw std::string("malloc failed for weights");
+      std::memcpy(d, v.data(), v.size() * 2);
+      dev_allocs.push_back(d);
+      return static_cast<unsigned short*>(d);
+    }
     if (hipMalloc(&d, v.size() * 2) != hipSuccess) throw std::string("hipMalloc failed for weights");
     if (hipMemcpy(d, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess) throw std::string("hipMemcpy H2D failed for weights");
     dev_allocs.push_back(d);
@@ -741,6 +759,20 @@ struct pf_engine {
           mb.rproj = make_rb(b + ".attn.proj", C, C, 320);
           mb.rfc1 = make_rb(b + ".mlp.fc1", 4 * C, C, 320);
           mb.rfc2 = make_rb(b + ".mlp.fc2", C, 4 * C, 320);
+          if (rb_srkv_supported(C, MIT_SR[s])) {
+            int kwc = 0, kwcp = 0;
+            const std::vector<float> srp = pack_conv(get(b + ".attn.sr.weight", {C, C, MIT_SR[s], MIT_SR[s]}).data.data(), C, C, MIT_SR[s], MIT_SR[s], C, nullptr, &kwc, &kwcp);  // [C][ky][kx C + ci]
+            std::vector<unsigned short> st1, st2;
+            std::vector<float> inv1, inv2;
+            rb_pack_w(srp.data(), C, MIT_SR[s] * kwcp, 320, &st1, &inv1);
+            rb_pack_w(get(b + ".attn.kv.weight", {2 * C, C}).data.data(), 2 * C, C, 320, &st2, &inv2);
+            st1.resize(st1.size() - (size_t)4 * 10 * 2 * 512);  // drop the first stream's read-ahead padding: the kv steps follow directly
+            st1.insert(st1.end(), st2.begin(), st2.end());
+            mb.rsrkv.w = upload_u16(st1); mb.rsrkv.bytes = st1.size() * 2;
+            mb.rsrkv.sr_inv = upload(inv1); mb.rsrkv.sr_b = upload(get(b + ".attn.sr.bias", {C}).data);
+            mb.rsrkv.kv_inv = upload(inv2); mb.rsrkv.kv_b = upload(get(b + ".attn.kv.bias", {2 * C}).data);
+            mb.qln = make_linear(b + ".attn.q", C, C, nullptr, b + ".norm1", 1e-6f);
+          }
         }
         if (fuse_mit_mlp && mit_mlp_preferred(C)) {
           std::vector<unsigned short> wpk;
@@ -1026,7 +1058,31 @@ struct pf_engine {
         // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
         // row-block form of the block's linear layers (stage 3 at batch >= ~14): q, kv, proj, fc1, fc2
         const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && (long)B * ((N + 63) / 64) >= rb_min_blocks;
-        if (sr > 1) {
+        if (sr > 1 && use_rb && (rb_chain & 32) && mb.rsrkv.w && mb.qln.ln_s && fuse_ln) {
+          // key / value branch in ONE launch (LayerNorm-1 of the gathered source tokens, 2 x 2 conv, LayerNorm, kv: rb_chain.hip); q with LayerNorm-1 folded into its
+          // GEMM beside it: no LayerNorm-1 launch, no split-K conv + reduce, no normalised map in HBM
+          const bool fork = B >= 4 && can_fork(c);
+          if (fork) {
+            (void)hipEventRecord(ev_fork, c.s);
+            (void)hipStreamWaitEvent(side, ev_fork, 0);
+            Ctx c2 = c;
+            c2.s = side;
+            gemm(c2, mb.qln, Ten(x), M, Ten(qb));
+            (void)hipEventRecord(ev_join, side);
+          } else {
+            gemm(c, mb.qln, Ten(x), M, Ten(qb));
+          }
+          range_in(c, fmt("rb_srkv s%d.b%d x (LN-fused)", s + 1, blk), x, (size_t)M * C);
+          if (!c.dry) {
+            RbSrKvArgs a;
+            a.x = x; a.ln1_g = mb.n1.g; a.ln1_b = mb.n1.b; a.ln1_eps = mb.n1.eps;
+            a.w = mb.rsrkv.w; a.w_bytes = mb.rsrkv.bytes; a.sr_inv = mb.rsrkv.sr_inv; a.sr_bias = mb.rsrkv.sr_b;
+            a.srn_g = mb.srn.g; a.srn_b = mb.srn.b; a.srn_eps = mb.srn.eps; a.kv_inv = mb.rsrkv.kv_inv; a.kv_bias = mb.rsrkv.kv_b;
+            a.kv = kvb; a.B = B; a.Hr = kvh; a.Wr = kvw; a.bpi = (kvh * kvw + 31) / 32;
+            ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * Mkv * (double)C * (sr * sr * C + 2 * C), (int)Mkv, 3 * C, sr * sr * C + 2 * C, sr);
+            launch_rb_srkv(a, C, c.s);
+          }
+        } else if (sr > 1) {
           const bool fork = B >= 4 && can_fork(c);  // batch 1-3: a launch already under-fills the chip; the event pair would only add latency
           if (use_rb && (rb_chain & 1) && fork) {  // q = LN1(x) Wq with the LayerNorm inside the kernel: independent of the LayerNorm launch below
             (void)hipEventRecord(ev_fork, c.s);
@@ -1363,6 +1419,7 @@ struct pf_engine {
     return it->second + ((with_scratch || autotune) ? scratch_elems[B] * 10 + 4096 : 0);
   }
   int forward(int B, const void* in, bool is_u8, float* pg, float* pl, float* params, void* ws, size_t ws_bytes, hipStream_t s, bool tune = false) {
+    if (host_only) return fail(PF_ERR_DEVICE, "this engine was created with PF_DEVICE_NONE (host side only): no forward");
     if (!finalized) return fail(PF_ERR_WEIGHTS, "pf_forward called before pf_finalize_weights");
     if (B <= 0 || !in || !pg || !pl || !ws) return fail(PF_ERR_ARG, "pf_forward: null pointer or batch <= 0");
     if (has_param && !params) return fail(PF_ERR_ARG, "pf_forward: d_params is required for a ParamNet architecture");
@@ -1445,10 +1502,14 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (!out) { g_create_error = "pf_create: out is NULL"; return PF_ERR_ARG; }
   *out = nullptr;
   if (arch < 0 || arch > 2) { g_create_error = fmt("pf_create: unknown arch %d", arch); return PF_ERR_ARG; }
-  const int rc = check_device(device, &g_create_error);
-  if (rc != PF_OK) return rc;
+  const bool host_only = device == PF_DEVICE_NONE;
+  if (!host_only) {
+    const int rc = check_device(device, &g_create_error);
+    if (rc != PF_OK) return rc;
+  }
   pf_engine* e = new pf_engine();
   e->device = device;
+  e->host_only = host_only;
   e->arch = arch;
   if (const char* v = getenv("PF_FOLD_MLP")) e->fold_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_UPSAMPLE")) e->fuse_upsample = atoi(v) != 0;
@@ -1481,6 +1542,7 @@ int pf_set_precision(pf_handle h, int mode) {
   if (!h) return PF_ERR_ARG;
   if (mode < PF_PRECISION_FP32 || mode > PF_PRECISION_FP32_BF16X6) return h->fail(PF_ERR_ARG, "pf_set_precision: unknown mode");
   if (mode != PF_PRECISION_FP32 && !h->split_bf16) return h->fail(PF_ERR_ARG, "pf_set_precision: this mode needs the split kernels (PF_SPLIT_BF16=0 is set)");
+  if (h->pn_pending) { h->issue_deferred(); (void)hipStreamSynchronize(h->pstream); h->pn_pending = false; }  // a deferred ParamNet branch still works in the old layout
   h->ws_cache.clear();  // the split-plane activation format (2 fp16 / 3 bf16 planes) follows the scheme
   h->nterms = mode == PF_PRECISION_BF16 ? 1 : (mode == PF_PRECISION_BF16X3 ? 3 : (mode == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
   return PF_OK;
@@ -1500,6 +1562,11 @@ int pf_join_params(pf_handle h, void* stream) {
 
 int pf_destroy(pf_handle h) {
   if (!h) return PF_ERR_ARG;
+  if (h->host_only) {
+    for (void* d : h->dev_allocs) free(d);
+    delete h;
+    return PF_OK;
+  }
   (void)hipSetDevice(h->device);
   for (void* d : h->dev_allocs) (void)hipFree(d);
   if (h->dbg.stats) (void)hipFree(h->dbg.stats);
@@ -1530,7 +1597,7 @@ int pf_load_tensor(pf_handle h, const char* key, const float* data, const int64_
 int pf_finalize_weights(pf_handle h) {
   if (!h) return PF_ERR_ARG;
   if (h->finalized) return h->fail(PF_ERR_WEIGHTS, "weights already finalized");
-  if (hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
+  if (!h->host_only && hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
   try {
     h->build();
   } catch (const std::string& m) {
@@ -2012,6 +2079,48 @@ int pf_op_rb_linear(int device, const float* x, long rows, int tokens, int K, co
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters; ++i) launch_rb_linear(a, K, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms_out = t / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_rb_srkv(int device, const float* x, int B, int Hr, int Wr, int C, const float* ln1_g, const float* ln1_b, float eps1, const float* sr_w, const float* sr_b,
+                  const float* srn_g, const float* srn_b, float eps2, const float* kv_w, const float* kv_b, float* kv, int iters, float* ms_out, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (!rb_srkv_supported(C, 2) || !x || !kv || !ln1_g || !ln1_b || !sr_w || !sr_b || !srn_g || !srn_b || !kv_w || !kv_b || B <= 0 || Hr <= 0 || Wr <= 0) {
+    g_create_error = "pf_op_rb_srkv: C must be 320 (2 x 2 spatial reduction); all weights required";
+    return PF_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  int kwc = 0, kwcp = 0;
+  const std::vector<float> srp = pack_conv(sr_w, C, C, 2, 2, C, nullptr, &kwc, &kwcp);
+  std::vector<unsigned short> st1, st2;
+  std::vector<float> inv1, inv2;
+  rb_pack_w(srp.data(), C, 2 * kwcp, 320, &st1, &inv1);
+  rb_pack_w(kv_w, 2 * C, C, 320, &st2, &inv2);
+  st1.resize(st1.size() - (size_t)4 * 10 * 2 * 512);
+  st1.insert(st1.end(), st2.begin(), st2.end());
+  RbSrKvArgs a;
+  a.x = x; a.ln1_g = tmp.up(ln1_g, C); a.ln1_b = tmp.up(ln1_b, C); a.ln1_eps = eps1;
+  a.w = tmp.up_u16(st1); a.w_bytes = st1.size() * 2; a.sr_inv = tmp.up(inv1); a.sr_bias = tmp.up(sr_b, C);
+  a.srn_g = tmp.up(srn_g, C); a.srn_b = tmp.up(srn_b, C); a.srn_eps = eps2; a.kv_inv = tmp.up(inv2); a.kv_bias = tmp.up(kv_b, 2 * C);
+  a.kv = kv; a.B = B; a.Hr = Hr; a.Wr = Wr; a.bpi = (Hr * Wr + 31) / 32;
+  launch_rb_srkv(a, C, s);
+  if (iters > 0 && ms_out) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) launch_rb_srkv(a, C, s);
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     float t = 0.f;

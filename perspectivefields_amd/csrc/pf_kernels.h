@@ -226,6 +226,20 @@ struct RbLinArgs {
   unsigned long long* stamps = nullptr;  // timing aid (scripts/tune_rb.py, PF_RB_STAMPS=1): s_memtime stamps of block 17, [wave][64]
 };
 bool rb_linear_supported(int K, int N);
+// The key / value branch of a MiT block with 2 x 2 spatial reduction in one launch (rb_chain.hip): kv = Linear(LN_sr(Conv2x2s2(LN_1(x)))), mix_transformers.py:119-127
+struct RbSrKvArgs {
+  const float* x;             // [B][2 Hr][2 Wr][C] token map (pre-norm1)
+  const float* ln1_g; const float* ln1_b; float ln1_eps;
+  const unsigned short* w;    // weight stream: the conv as a GEMM over K = (ky, kx, ci) (80 steps), then the kv layer's two 320-column passes (2 x 20 steps), RB_D pad steps
+  size_t w_bytes;
+  const float* sr_inv; const float* sr_bias;   // [C]
+  const float* srn_g; const float* srn_b; float srn_eps;
+  const float* kv_inv; const float* kv_bias;   // [2 C]
+  float* kv;                  // [B][Hr Wr][2 C]
+  int B, Hr, Wr, bpi;         // bpi = ceil(Hr Wr / 32) blocks per image
+};
+bool rb_srkv_supported(int C, int sr);
+void launch_rb_srkv(const RbSrKvArgs& a, int C, hipStream_t s);
 void launch_rb_linear(const RbLinArgs& a, int K, hipStream_t s);
 void launch_gap_ln_head(const float* x, const float* g, const float* b, const float* w, const float* hb, float* out, int B, int HW, int C, int nout, float eps, hipStream_t s);
 

@@ -46,6 +46,9 @@ struct RbGeo {
   // RT == 1: the extra tile 4 CTW + (w >> 1) is computed by BOTH waves of a pair (w & 1 = 0, 1) on the same row tile; only the even wave's copy is used
 };
 
+// (Measured and removed, profiles/r04_rb_linear.md: an L2 warm-up of the whole weight stream at kernel start -- one 4-byte LDS-DMA load per 128-byte line, the blocks
+// of an XCD covering disjoint slices -- made the layers SLOWER in the pipeline: fc1 49 -> 63 us, proj 20 -> 30 us.  The warm-up loads are younger than the ring's
+// first steps, so the first counted vmcnt wait of the K loop also waits for every one of them, i.e. for HBM.)
 // Per-wave state of the weight stream: one VGPR offset (lane * 16 + running step offset), NW wave-uniform tile offsets
 template <class G>
 struct RbW {

@@ -143,6 +143,22 @@ def rb_linear(x, weight, bias, tokens, gamma=None, beta=None, eps=1e-6, act=0, r
     return ms.value if iters > 0 else y
 
 
+def rb_srkv(x, ln1_g, ln1_b, eps1, sr_w, sr_b, srn_g, srn_b, eps2, kv_w, kv_b, iters=0):
+    """Key / value branch of a MiT block with 2 x 2 spatial reduction in one launch (pf_op_rb_srkv).  x: (B, 2 Hr, 2 Wr, C) on the GPU, C = 320.
+    Returns kv (B, Hr Wr, 2 C); iters > 0: the average ms per launch instead."""
+    import torch
+
+    lib = load_library()
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    kv = torch.empty((B, (H // 2) * (W // 2), 2 * C), dtype=torch.float32, device=x.device)
+    ms = ctypes.c_float()
+    a = [_np(t) for t in (ln1_g, ln1_b, sr_w, sr_b, srn_g, srn_b, kv_w, kv_b)]
+    _check(lib.pf_op_rb_srkv(x.device.index, x.data_ptr(), B, H // 2, W // 2, C, _hp(a[0]), _hp(a[1]), float(eps1), _hp(a[2]), _hp(a[3]), _hp(a[4]), _hp(a[5]), float(eps2),
+                             _hp(a[6]), _hp(a[7]), kv.data_ptr(), iters, ctypes.byref(ms), _stream_ptr()), None, "pf_op_rb_srkv")
+    return ms.value if iters > 0 else kv
+
+
 def mit_mlp(x, fc1_w, fc1_b, ln_gamma, ln_beta, eps, dw_w, dw_b, fc2_w, fc2_b, iters=0):
     """One MiT block Mlp in one kernel: x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))).  x: (B, Hs, Ws, C) on the GPU, C = 64 or 128.
     iters > 0: returns the average ms per launch instead."""

@@ -26,7 +26,7 @@ def step1():
     return [eng.postprocess(pg[i], pl[i], 640, 640) for i in range(B)]
 ref = None
 modes = {}
-for prec in ("fp32", "bf16x3", "bf16"):
+for prec in ("fp32", "bf16"):
     eng.set_precision(prec)
     dt = timed(step1)
     pg, pl, _ = eng.forward(x)
@@ -49,7 +49,7 @@ for prec in ("fp32", "bf16x3", "bf16"):
 eng.set_precision("fp32")
 out.append({"config": "configs[1]: batch 8, 640x640, PersNet-360Cities (73/180-way logits + argmax decode)",
             "images_per_sec": modes["fp32"]["images_per_sec"], "ms_per_step": modes["fp32"]["ms_per_step"], "precision_modes": modes,
-            "note": "headline = fp32-accurate contractions (the parity mode); bf16x3 / bf16 are the optional reduced-precision modes "
+            "note": "headline = fp32-accurate contractions (the parity mode); bf16 is the optional reduced-precision mode "
                     "(pf_set_precision), compared here against the parity mode on the same inputs"})
 del m, eng
 # ---- configs[4]

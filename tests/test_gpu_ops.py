@@ -650,3 +650,24 @@ def test_rb_linear(ops, K, N, tokens, images):
         for eps in (1e-6, 1e-5):
             refl = F.linear(F.layer_norm(xo.double(), (K,), g.double(), be.double(), eps), w.double(), b.double())
             _close(ops.rb_linear(xo.cuda(), w, b, tokens, gamma=g, beta=be, eps=eps), refl, 5e-5, "rb_linear with LayerNorm")
+
+
+@pytest.mark.parametrize("B,Hr,Wr", [(3, 10, 10), (2, 6, 7), (1, 2, 2)])
+def test_rb_srkv(ops, B, Hr, Wr):
+    """The key / value branch of a stage-3 MiT block as one launch (rb_chain.hip): LayerNorm-1 of the gathered source tokens, 2 x 2 / stride-2 conv, LayerNorm, kv --
+    100 reduced tokens per image (blocks of 32 / 32 / 32 / 4), ragged maps, rows with offsets and outlier channels.  Oracle: torch fp64 (mix_transformers.py:119-127)."""
+    C = 320
+    x = _with_outlier_channels(_rand((B, 2 * Hr, 2 * Wr, C), 301, 1.5) + 5.0 * _rand((B, 2 * Hr, 2 * Wr, 1), 302), 303)
+    g1, b1 = 1 + _rand((C,), 304, 0.3), _rand((C,), 305, 0.2)
+    wsr, bsr = _rand((C, C, 2, 2), 306, 1.0 / math.sqrt(4 * C)), _rand((C,), 307, 0.1)
+    g2, b2 = 1 + _rand((C,), 308, 0.3), _rand((C,), 309, 0.2)
+    wkv, bkv = _rand((2 * C, C), 310, 1.0 / math.sqrt(C)), _rand((2 * C,), 311, 0.1)
+    wkv[7] *= 29.0
+    xn = F.layer_norm(x.double(), (C,), g1.double(), b1.double(), 1e-6)
+    y = F.conv2d(xn.permute(0, 3, 1, 2), wsr.double(), bsr.double(), stride=2).permute(0, 2, 3, 1).reshape(B, Hr * Wr, C)
+    ref = F.linear(F.layer_norm(y, (C,), g2.double(), b2.double(), 1e-5), wkv.double(), bkv.double())
+    got = ops.rb_srkv(x.cuda(), g1, b1, 1e-6, wsr, bsr, g2, b2, 1e-5, wkv, bkv)
+    try:
+        _close(got, ref, 6e-5, "rb_srkv")
+    except AssertionError as e:
+        raise AssertionError(str(e) + "\n" + _region_report(got.reshape(-1, 2 * C), ref.reshape(-1, 2 * C)))
