@@ -102,7 +102,7 @@ size_t pf_workspace_bytes(pf_handle h, int batch);
  */
 /* Arithmetic of the dense contractions (everything else is always fp32).
  *   FP32 (default, the parity mode): "split-f16" -- every fp32 activation is split on the fly into two fp16 values
- *     (a ~ ah + al 2^-11, 22-23 significant bits), the weights (scaled per output channel by a power of two) into wh + wl,
+ *     (a ~ ah + al with ah = fp16(a), al = fp16(a - ah) UNSCALED: 22-23 significant bits for |a| >= 2^-3, an absolute 2^-25 per element below -- the matrix cores keep fp16 subnormals), the weights (scaled per output channel by a power of two) into wh + wl,
  *     and a product is three fp16 MFMA partial products (ah wh + ah wl + al wh) accumulated in fp32: per-product error
  *     <= 3 * 2^-22, below the fp32 accumulation noise of the contraction itself (scripts/emulate_split.py).
  *     Activations beyond the fp16 range (|x| > 65504) saturate.
@@ -227,7 +227,7 @@ int pf_fields_from_params(int device, const float* d_cam5, int H, int W, float* 
  * "planes": the engine's internal split activation formats -- an fp32 tensor stored as planes of 16-bit values, plane k at
  * `planes + k * (plane_elems & ~1)`, each laid out like the fp32 tensor.  Bit 0 of every *_plane_elems argument selects the
  * format: 0 = three bf16 planes (x == h + m + l exactly; read by the bf16 schemes), 1 = two fp16 planes of the split-f16
- * scheme (x ~ hi + lo 2^-11: what that scheme's GEMM computes from fp32 while staging; 4 bytes per element).
+ * scheme (x ~ hi + lo, lo = fp16(x - hi) unscaled: what that scheme's GEMM computes from fp32 while staging; 4 bytes per element).
  * Producers write them for tensors that only feed GEMMs (PF_SBA=1); every *_planes argument is optional (NULL). */
 int pf_op_conv2d(int device, const float* d_x, const float* d_x2, int B, int H, int W, int C1, int C2,
                  const float* h_weight /*[Cout][C1+C2][KH][KW]*/, const float* h_bias /*[Cout] or NULL*/,

@@ -159,9 +159,9 @@ __global__ __launch_bounds__(256) void sr_attention_kernel(const float* __restri
 // Split-f16 form (default): both products on v_mfma_f32_32x32x16_f16 with the 2-way fp16 split of the conv kernels
 // (igemm_sb_impl.h): 3 MFMAs per product at 16x the fp32-MFMA rate = 5.3x less matrix-core time, fp32-class accuracy
 // (scripts/emulate_split.py: no measurable change end to end).  K and V play the "weight" role: scaled by 16 (exact) and
-// split as hi + lo with lo = fp16(16 x - hi) UNSCALED, so that  qh kh + qh kl + ql (kh 2^-11)  accumulates in one
+// split as hi + lo with lo = fp16(16 x - hi) UNSCALED, so that  ql kh + qh kl + qh kh  accumulates in one
 // accumulator (|k|, |v| < 4094, saturating beyond; entries below 2^-6 keep an absolute accuracy of 2^-29); q d^-0.5 and the probabilities
-// are split as hi + lo 2^-11.  Same transposed formulation as above: S^T = K Q^T leaves a query's scores in one lane
+// are split as hi + lo (unscaled), after an exact power-of-two factor that keeps lo a normal fp16 number (AT_Q_SCALE, AT_P_EXP).  Same transposed formulation as above: S^T = K Q^T leaves a query's scores in one lane
 // pair, and P^T in accumulator layout feeds O^T = V^T P^T directly -- the MFMA k index of that product is then a fixed
 // PERMUTATION of the kv index (lane half hi, element e of 16-chunk cc  <->  kv = 16 cc + (e & 3) + 8 (e >> 2) + 4 hi), so
 // V is staged TRANSPOSED and in that permuted kv order: every A fragment is one 16-byte LDS read.

@@ -13,7 +13,7 @@
 //   * GEMM 2 accumulates y^T (channels x rows) in registers over all hidden chunks; the epilogue adds bias + residual and stores float4s.
 // The weights stream through LDS in fragment order (a wave-wide ds_read_b128 of a fragment is one contiguous KB: conflict-free), one
 // 32-hidden-unit chunk (W1 rows + W2 columns) per step, double-buffered: one barrier per chunk, shared by the block's 4 waves (128 rows).
-// Contractions: the split-f16 scheme of igemm_sb_impl.h (a ~ ah + al 2^-11, w = wh + wl, three fp16 MFMAs per product into one fp32
+// Contractions: the split-f16 scheme of igemm_sb_impl.h (a ~ ah + al, al = fp16(a - ah) unscaled, w = wh + wl, three fp16 MFMAs per product into one fp32
 // accumulator, per-output-channel power-of-two weight scale).  Same mathematics as LayerNorm-fused pwconv1 + pwconv2 (ConvParams::ln).
 #include <stdlib.h>
 

@@ -290,6 +290,9 @@ __global__ __launch_bounds__(NC == 2 ? 320 : 256) void dwconv7x7_lds_kernel(cons
       const int e = tid + nthr * i;
       if (e < npieces) *reinterpret_cast<float4*>(tile + (size_t)e * 4) = v[i];
     }
+    // the NC - 1 spare pixels behind the tile (read by the last column group of an odd-width map; their products feed accumulators that are never stored) hold zeros,
+    // not whatever the previous block left in LDS
+    if (tid < (NC - 1) * 8) *reinterpret_cast<float4*>(tile + (size_t)npieces * 4 + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int g = tid >> 5, cl = tid & 31;
   const int c = slab * 32 + cl;
@@ -368,7 +371,8 @@ void launch_dwconv7x7_lds(const float* x, const float* w49c, const float* bias, 
   // strip height: the tallest tile whose pieces fit 13 float4 per thread (20^2: TH = 10 -> 16 x 26 x 8 = 3328 pieces / 320 threads = 11; 10^2: the whole map, 2048 / 160 = 13)
   int TH = th > 0 ? std::min(th, H) : H;
   auto pieces = [&](int t) { return (long)(std::min(t, H) + 6) * (W + 6) * 8; };
-  while (TH > 1 && (pieces(TH) + threads - 1) / threads > 13) --TH;
+  auto lds_bytes = [&](int t) { return ((size_t)(std::min(t, H) + 6) * (W + 6) + (NC - 1)) * 32 * 4; };
+  while (TH > 1 && ((pieces(TH) + threads - 1) / threads > 13 || lds_bytes(TH) > 64 * 1024)) --TH;  // <= 64 KB of dynamic LDS: no hipFuncSetAttribute needed (20^2: 53 KB, 10^2: 32 KB)
   if (th <= 0) {  // prefer equal strips
     const int strips = (H + TH - 1) / TH;
     TH = (H + strips - 1) / strips;

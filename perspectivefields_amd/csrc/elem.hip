@@ -698,15 +698,17 @@ __global__ __launch_bounds__(256) void fill_random_kernel(float* __restrict__ p,
   }
 }
 // Range record of one tensor (debug forward, DebugSink in engine.hip): out[0] = max |x| (atomicMax on the bit pattern of a non-negative float), out[1] = sum x^2,
-// out[2] = elements with |x| > 65504 (saturate in the split-f16 scheme), out[3] = non-finite elements.  `out` must be zeroed before the launch.
+// out[2] = elements with |x| > 65504 (saturate in the split-f16 scheme), out[3] = non-finite elements -- both COUNTS as unsigned integers in the float slots (float
+// atomics would stop counting exactly at 2^24; pf_debug_ranges converts them for the caller).  `out` must be zeroed before the launch.
 __global__ __launch_bounds__(256) void range_stats_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
-  float mx = 0.f, ss = 0.f, sat = 0.f, bad = 0.f;
+  float mx = 0.f, ss = 0.f;
+  unsigned sat = 0u, bad = 0u;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float v = x[i], a = fabsf(v);
-    if (!(a <= 3.4e38f)) { bad += 1.f; continue; }
+    if (!(a <= 3.4e38f)) { ++bad; continue; }
     mx = fmaxf(mx, a);
     ss = fmaf(v, v, ss);
-    if (a > 65504.f) sat += 1.f;
+    if (a > 65504.f) ++sat;
   }
 #pragma unroll
   for (int sh = 32; sh > 0; sh >>= 1) {
@@ -718,8 +720,8 @@ __global__ __launch_bounds__(256) void range_stats_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) {
     atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(mx));
     atomicAdd(out + 1, ss);
-    if (sat > 0.f) atomicAdd(out + 2, sat);
-    if (bad > 0.f) atomicAdd(out + 3, bad);
+    if (sat) atomicAdd(reinterpret_cast<unsigned*>(out) + 2, sat);
+    if (bad) atomicAdd(reinterpret_cast<unsigned*>(out) + 3, bad);
   }
 }
 void launch_range_stats(const float* x, long n, float* out4, hipStream_t s) {

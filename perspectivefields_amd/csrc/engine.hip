@@ -1730,6 +1730,9 @@ int pf_debug_ranges(pf_handle h, int max_records, char* names /*[max][96]*/, lon
   for (int i = 0; i < n; ++i) {
     if (names) { std::strncpy(names + 96 * i, d.ranges[i].name.c_str(), 95); names[96 * i + 95] = 0; }
     if (elems) elems[i] = d.ranges[i].elems;
+    if (stats && d.stats) {  // the two counters are unsigned integers on the device (range_stats_kernel): hand them out as the floats the interface declares
+      for (int k = 2; k < 4; ++k) { uint32_t u; std::memcpy(&u, &stats[4 * i + k], 4); stats[4 * i + k] = (float)u; }
+    }
   }
   return (int)d.ranges.size();
 }

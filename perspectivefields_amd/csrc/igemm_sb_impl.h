@@ -93,17 +93,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   constexpr int A_ROWS = ASB ? (BM + RPB - 1) / RPB : BM / RPP;
   // NTERM partial products per element product: 6 = fp32-accurate (3 planes per operand), 3 = h*h + h*m + m*h (2 planes,
   // ~16 significant bits), 1 = plain bf16 (1 plane)
-  // NT_F16X3 (split-f16, the default parity scheme): a ~ ah + al 2^-11 (two fp16 planes, sb_split.h), weights pre-scaled per output
-  // channel and split as wh + wl (two fp16 planes in global memory); the third operand wh2 = wh 2^-11 is made from the
-  // wh fragment in registers, so that  ah wh + ah wl + al wh2  accumulates in ONE accumulator: 3 MFMAs per product.
+  // NT_F16X3 (split-f16, the default parity scheme): a ~ ah + al with al = fp16(a - ah) UNSCALED (two fp16 planes, sb_split.h), weights pre-scaled per output
+  // channel and split as wh + wl (two fp16 planes in global memory):  al wh + ah wl + ah wh  accumulates in ONE accumulator, 3 MFMAs per product
+  // (r02 carried al 2^11 and a third weight operand wh 2^-11 made in registers; gone since r03).
   constexpr bool F16 = NTERM == NT_F16X3;
   // DIRECT: MFMA operands swapped (transposed accumulators) + register epilogue (igemm_common.h epilogue_direct) on the 64 x 64 tiles, i.e. the
   // small-M / latency-bound layers (+2...7 % there, profiles/r02_tune_conv_v3_direct_epilogue.txt).  The larger tiles keep the LDS-staged
   // epilogue: their layers are write-heavy (M >= 51 200, short K) and the 32-byte store granules of the direct form cost them 5-20 %
   constexpr bool DIRECT = BM == 64 && BN == 64;
   constexpr int NPL = F16 ? 2 : (NTERM == 6 ? 3 : (NTERM == 3 ? 2 : 1));  // A planes in LDS
-  constexpr int NPB = NPL;                                                // B planes in LDS (split-f16: wh, wl; wh2 = wh 2^-11 is made in registers
-                                                                          // from the wh fragment -- 4 v_pk_mul_f16 instead of an LDS plane, its stores and its reads)
+  constexpr int NPB = NPL;                                                // B planes in LDS (split-f16: wh, wl; r02's third operand wh 2^-11 is gone: the low plane is unscaled)
   constexpr int NPG = F16 ? 2 : NPL;                                      // B planes loaded from global memory
   constexpr int NMF = F16 ? 3 : NTERM;                                    // MFMAs per element product
   constexpr int A_REGS = ASB ? A_ROWS * NPL : A_ROWS;  // float4 registers per staged A tile

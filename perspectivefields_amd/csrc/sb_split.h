@@ -49,7 +49,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2
 // third weight operand wh 2^-11 made per fragment in registers: 72 of the 242 VALU instructions of a halo-kernel chunk).  The matrix cores of gfx950 keep fp16
 // subnormal inputs (measured, profiles/r02_mfma_f16_subnormals.md), so lo stays usable below 2^-14.  Representation error: <= 2^-22 |x| for |x| >= 2^-3 (lo is a
 // normal fp16 number there), <= 2^-25 ABSOLUTE below (lo is a subnormal: quantum 2^-24) -- an error of 3e-8 per element, i.e. fp32 rounding at unit scale; it is a
-// RELATIVE loss only for a tensor whose every element is << 0.1 (pf_check_range reports such tensors; precision "fp32_bf16x6" has no such window).  |x| is clamped to
+// RELATIVE loss only for a tensor whose every element is << 0.1 (PerspectiveFields.check_range / pf_debug_forward_u8 report such tensors; precision "fp32_bf16x6" has no such window).  |x| is clamped to
 // the fp16 range (65504) first, so an out-of-range activation saturates instead of turning into inf - inf.
 // Instruction count: v_med3 + (half a) v_cvt_pk_f16_f32 + one v_fma_mix{lo,hi}_f16 per element -- the mixed-precision fma takes the fp32 value and the fp16 hi part
 // (fp16 source operand, negated) and rounds x - hi straight to fp16: 2.5 VALU instructions per element where the C expression compiles to 4.25 (cvt back to fp32,

@@ -43,7 +43,7 @@ class Planes:
         return self.data.data_ptr()
 
     def merge(self):
-        """back to fp32: h + m + l (exact) or hi + lo 2^-11 (the value the split-f16 GEMM works with)."""
+        """back to fp32: h + m + l (exact) or hi + lo, lo unscaled (the value the split-f16 GEMM works with)."""
         import torch
 
         lib = load_library()

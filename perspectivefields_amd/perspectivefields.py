@@ -72,14 +72,26 @@ def _resolve_weights(version: str, weights) -> Dict[str, np.ndarray]:
     return OrderedDict(ckpt["model"] if "model" in ckpt else ckpt)
 
 
+def _window_limit(r) -> float:
+    """upper end of the split-f16 window for one range record: 65504, except the attention operands, which carry extra powers of two inside the kernel
+    (attn.hip: q x 8, k / v x 16) -- their window ends at 8188 / 4094"""
+    name = r["name"]
+    if name.startswith("attention") and name.endswith(" q"):
+        return 8188.0
+    if name.startswith("attention") and name.endswith(" kv"):
+        return 4094.0
+    return 65504.0
+
+
 class PerspectiveFields(nn.Module):
-    def __init__(self, version: str = "Paramnet-360Cities-edina-centered", weights=None, precision: str = "fp32"):
+    def __init__(self, version: str = "Paramnet-360Cities-edina-centered", weights=None, precision: str = "auto"):
         super().__init__()
-        # 'fp32' (default) is the parity mode: fp32-class contractions on the 2-way fp16 split -- full accuracy for activations in [2^-3, 65504], saturation
-        # beyond, an absolute 2^-25 per element below (sb_split.h).  'fp32_bf16x6' is the exact bf16 split (no window, ~1.5x the MFMA work).  'auto' decides between
-        # the two ONCE, on the first batch the model sees: a range-recording forward (pf_debug_forward_u8) and 'fp32_bf16x6' if any dense-layer input saturates or is
-        # all-tiny, 'fp32' otherwise (`self.precision` then holds the decision).  'bf16x3' / 'bf16' are faster reduced-precision modes of the dense contractions
-        # (Engine.set_precision); their outputs are not held to the parity tolerances.
+        # 'fp32' is the parity mode: fp32-class contractions on the 2-way fp16 split -- full accuracy for activations in [2^-3, 65504], saturation beyond, an
+        # absolute 2^-25 per element below (sb_split.h).  'fp32_bf16x6' is the exact bf16 split (no window, ~1.5x the MFMA work).  'auto' (the DEFAULT: a checkpoint
+        # outside the window must not give wrong fields silently) decides between the two ONCE, on the first batch inference() / inference_batch() / forward() see:
+        # a range-recording forward (pf_debug_forward_u8) and 'fp32_bf16x6' if any dense-layer input saturates or is all-tiny, 'fp32' otherwise (`self.precision`
+        # then holds the decision, `self.precision_reason` why).  'bf16' is the reduced-precision mode of the dense contractions (Engine.set_precision); its outputs
+        # are not held to the parity tolerances.
         self.precision = precision
         cfg = get_cfg(version)  # KeyError on an unknown version, as the reference (:127)
         self.version = version
@@ -195,9 +207,7 @@ class PerspectiveFields(nn.Module):
         beyond 65504 and keeps only an absolute 2^-25 per element below 2^-3: a layer input with saturated elements, or whose rms is below 2^-5 (an all-tiny tensor), is
         outside the window -- use precision="fp32_bf16x6" (exact bf16 split, no window) for such a checkpoint.  Returns {"ok", "saturated", "tiny", "non_finite", "layers"}."""
         _, _, rng = self.debug_forward(img_bgr_list, shadow=False, ranges=True)
-        # attention operands carry extra powers of two inside the kernel (attn.hip: q x 8, k / v x 16): their window ends at 8188 / 4094
-        lim = lambda r: 8188.0 if r["name"].endswith(" q") and r["name"].startswith("attention") else (4094.0 if r["name"].endswith(" kv") and r["name"].startswith("attention") else 65504.0)
-        sat = [r for r in rng if r["saturated"] > 0 or r["max_abs"] > lim(r)]
+        sat = [r for r in rng if r["saturated"] > 0 or r["max_abs"] > _window_limit(r)]
         bad = [r for r in rng if r["non_finite"] > 0]
         tiny = [r for r in rng if 0.0 < r["rms"] < 2.0 ** -5]
         if verbose:
@@ -352,7 +362,7 @@ class PerspectiveFields(nn.Module):
         if self.precision == "auto":  # first batch: look at the activations this checkpoint produces, then settle on a precision for the model's lifetime
             probe = batch if batch.dtype == torch.uint8 else batch.permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8)  # forward(): (B,3,320,320) float -> the u8 NHWC form of the debug entry
             _, _, _, _, rng = eng.forward_debug(probe.contiguous(), shadow=False, ranges=True)
-            outside = [r for r in rng if r["saturated"] > 0 or r["non_finite"] > 0 or 0.0 < r["rms"] < 2.0 ** -5]
+            outside = [r for r in rng if r["saturated"] > 0 or r["max_abs"] > _window_limit(r) or r["non_finite"] > 0 or 0.0 < r["rms"] < 2.0 ** -5]
             self.precision = "fp32_bf16x6" if outside else "fp32"
             self.precision_reason = (f"{len(outside)} of {len(rng)} dense-layer inputs outside the split-f16 window, first: {outside[0]['name']} "
                                      f"(max |x| {outside[0]['max_abs']:.4g}, rms {outside[0]['rms']:.4g})") if outside else f"all {len(rng)} dense-layer inputs inside the split-f16 window"

@@ -501,7 +501,7 @@ def test_dwconv3x3_gelu(ops, B, H, W, C):
             assert torch.equal(ops.dwconv3x3_gelu(xd, w, b, variant=1000 + 100 * shape + code, planes_out=True), ops.dwconv3x3_gelu(xd, w, b, planes_out=True)), "dwconv3x3 mc planes"
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 80, 80, 96), (1, 40, 40, 192), (2, 20, 20, 384), (3, 10, 10, 768), (1, 2, 2, 768), (1, 5, 11, 96), (2, 20, 13, 96), (1, 33, 20, 96)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 80, 80, 96), (1, 40, 40, 192), (2, 20, 20, 384), (3, 10, 10, 768), (1, 2, 2, 768), (1, 5, 11, 96), (2, 20, 13, 96), (1, 33, 20, 96), (1, 17, 20, 96), (2, 15, 19, 96), (1, 14, 7, 96)])
 def test_dwconv7x7(ops, B, H, W, C):
     x = _rand((B, H, W, C), 23)
     w = _rand((C, 1, 7, 7), 24, 0.15)
