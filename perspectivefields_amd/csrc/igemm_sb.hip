@@ -31,13 +31,16 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {256, 64, 0, "sbh256x64w8t3"}, {128, 64, 0, "sbh128x64t3"},
 #endif
                              {256, 32, 0, "sbh256x32"},  // split-f16 scheme: 16 x 16 patch, N = 32, 4 waves
+#ifndef PF_TUNING_BUILD
+                             {256, 64, 0, "sbh256x64"},  // split-f16 scheme: 16 x 16 patch, N = 64, 4 waves as 4 x 1: wave tile 64 x 64 (conv_fuse_conv0: fused x2 up-sampling needs a 4-wave tile)
+#endif
 #ifdef PF_TUNING_BUILD
                              {256, 256, 0, "sbh256x256w8"}, {256, 256, 0, "sbhd256x256w8"},  // split-f16 scheme: 16 x 16 patch x all 256 output channels, 8 waves (rejected)
                              // ablation forms of sbh256x64w8 (igemm_sbh.hip SBH_ABL_PARAM): wrong results by construction, timing only
                              {256, 64, 0, "sbhA1"}, {256, 64, 0, "sbhA2"}, {256, 64, 0, "sbhA3"}, {256, 64, 0, "sbhA4"}, {256, 64, 0, "sbhA8"}, {256, 64, 0, "sbhA48"},
                              {256, 64, 0, "sbhA12"}, {256, 64, 0, "sbhA11"}, {256, 64, 0, "sbhA15"}, {256, 64, 0, "sbhA63"},
                              {256, 64, 0, "sbhAa"}, {256, 64, 0, "sbhAb"}, {256, 64, 0, "sbhLA0"}, {256, 64, 0, "sbhLA2"}, {256, 64, 0, "sbhLAbf"}, {256, 64, 0, "sbhLAbf0"}, {256, 64, 0, "sbhDMA"}, {256, 64, 0, "sbhREG"},
-                             {256, 128, 0, "sbh256x128w8"}, {256, 128, 0, "sbh256x128w8u"},  // 16 x 16 patch x 128 channels, 8 waves: wave tile 64 x 64 (683 B of LDS fragment reads per MFMA instead of 1024); "u" = no 128-VGPR cap
+                             {256, 128, 0, "sbh256x128w8"}, {256, 128, 0, "sbh256x128w8u"}, {256, 64, 0, "sbh256x64"},  // 16 x 16 patch x 128 channels, 8 waves: wave tile 64 x 64 (683 B of LDS fragment reads per MFMA instead of 1024); "u" = no 128-VGPR cap
 #endif
 };
 #ifdef PF_TUNING_BUILD

@@ -51,7 +51,7 @@ template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE,
                              staging is a plain 16-byte copy per plane -- no split arithmetic in this kernel (VALU instructions are paid in MFMA issue time,
                              DESIGN.md 4.7), and an element is split once by its producer instead of once per n-tile and halo overlap here.  MODE 0, no UPS.*/
           SBH_ABL_PARAM>
-__global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256 && (ABL & 0x8000) == 0) || (SCH == NT_F16X3 && TPG == 1 && !DB && (ABL & 0xa000) == 0 && BN <= 64)) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD (the DMA-ring forms of the 4-wave tiles with BN <= 64 stay inside 128 VGPRs: four resident blocks; tuning builds: 0x8000 lifts that)
+__global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256 && (ABL & 0x8000) == 0) || (SCH == NT_F16X3 && TPG == 1 && !DB && (ABL & 0xa000) == 0 && BN <= 64 && !(H_TY == 16 && BN == 64 && WM * WN == 4))) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD (the DMA-ring forms of the 4-wave tiles with BN <= 64 stay inside 128 VGPRs: four resident blocks; tuning builds: 0x8000 lifts that)
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo
   constexpr int H_ROWS = H_HX * H_HY;              // 180 halo pixels for 8 x 16, 324 for 16 x 16
   constexpr int BM = H_TY * H_TX;
@@ -530,12 +530,12 @@ bool conv_sbh_ok(const ConvParams& p) {
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile) {
   if (!conv_sbh_ok(p)) return false;
 #ifdef PF_TUNING_BUILD
-  constexpr int kWide32 = 10;  // "sbh256x32": after the tuning-only tiles
+  constexpr int kWide32 = 10, kWide64 = 33;  // "sbh256x32": after the tuning-only tiles; "sbh256x64": last
 #else
-  constexpr int kWide32 = 4;
+  constexpr int kWide32 = 4, kWide64 = 5;
 #endif
-  if (p.g[0].x_sb) return h_tile < 4 || h_tile == kWide32;  // plane input: the plain-tap-loop tiles
-  if (p.ups) return (h_tile < 3 || h_tile == kWide32) && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
+  if (p.g[0].x_sb) return h_tile < 4 || h_tile == kWide32 || h_tile == kWide64;  // plane input: the plain-tap-loop tiles
+  if (p.ups) return (h_tile < 3 || h_tile == kWide32 || h_tile == kWide64) && p.nterms == NT_F16X3 && (p.H % 2) == 0 && (p.W % 2) == 0;
 #ifdef PF_TUNING_BUILD
   if (h_tile >= 13) return p.nterms == NT_F16X3 && p.C2 == 0;  // ablation forms: one plain fp32 input
 #endif
@@ -555,7 +555,9 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s) {
     case 2: launch_sbh_cfg<8, 16, 32, 4, 1>(p, s); break;
 #ifndef PF_TUNING_BUILD
     case 4: launch_sbh_cfg<16, 16, 32, 4, 1>(p, s); break;  // "sbh256x32": 16 x 16 patch for the N = 32 layer (twice the MFMAs per barrier)
+    case 5: launch_sbh_cfg<16, 16, 64, 4, 1>(p, s); break;  // "sbh256x64": 16 x 16 patch, wave tile 64 x 64, 4 waves (r04: for the fused-up-sampling conv0)
 #else
+    case 33: launch_sbh_cfg<16, 16, 64, 4, 1>(p, s); break;
     case 10: launch_sbh_cfg<16, 16, 32, 4, 1>(p, s); break;
     // whole N = 256 per block (256 x 256 / 8-wave geometry, wave tile 128 x 64): the halo is staged and split ONCE per patch instead of once
     // per n-tile, 0.58 fragment reads per MFMA instead of 1.17 -- but one block per CU at 256 VGPRs (33 / 52 spilled) with the plain
