@@ -525,6 +525,13 @@ def main(argv=None):
                     "traffic": None, "kernel": kernel, "launches_per_step": dw["launches"],
                     "algorithmic_mb_per_step": round(dw["work"] / 1e6, 1), "ms_per_step": round(dw["ms"], 3), "measured": "extra profiled step after the timed region",
                 }
+        d3, d7 = prof["dwconv3x3_gelu"], prof["dwconv7x7"]
+        if d3["ms"] + d7["ms"] > 0:  # both depthwise classes together (north_star's "depthwise stages")
+            gbps = (d3["work"] + d7["work"]) / ((d3["ms"] + d7["ms"]) * 1e-3) / 1e9
+            line["roofline_depthwise_all"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                                              "launches_per_step": d3["launches"] + d7["launches"], "algorithmic_mb_per_step": round((d3["work"] + d7["work"]) / 1e6, 1),
+                                              "ms_per_step": round(d3["ms"] + d7["ms"], 3), "measured": "extra profiled step after the timed region",
+                                              "note": "in the timed steps the depthwise 7x7 launches belong to the ParamNet branch, which runs beside the next step's backbone"}
         at = prof["attention"]
         if at["ms"] > 0:
             line["attention"] = {"achieved_tflops": round(at["work"] / (at["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(at["ms"], 3),

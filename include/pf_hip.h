@@ -249,6 +249,11 @@ int pf_op_linear_ln(int device, const float* d_x, long rows, int K, const float*
  * rows = images x tokens; (K, N) = (320, multiple of 320) or (multiple of 256 above 320, 320); res may alias y.  iters > 0 additionally times `iters` launches. */
 int pf_op_rb_linear(int device, const float* d_x, long rows, int tokens, int K, const float* h_weight /*[N][K]*/, const float* h_bias, const float* h_gamma, const float* h_beta,
                     float eps, int N, int act, const float* d_res, float* d_y, int iters, float* ms_out, void* stream);
+/* The seam between the attention half and the Mlp half of a MiT block in one launch (rb_chain.hip): x += proj(attn_out), hidden = fc1(LayerNorm_2(x)) --
+ * mix_transformers.py:137-139 (proj), :199 (residual), :200 / :52 (norm2 -> fc1).  attn (B tokens, C), x (B tokens, C) read and written, hidden (B tokens, 4C);
+ * C = 320; weights in the reference's shapes.  iters > 0 additionally times `iters` launches (x is then garbage). */
+int pf_op_rb_proj_fc1(int device, const float* d_attn, float* d_x, int B, int tokens, int C, const float* h_proj_w, const float* h_proj_b, const float* h_ln2_gamma,
+                      const float* h_ln2_beta, float eps, const float* h_fc1_w, const float* h_fc1_b, float* d_hidden, int iters, float* ms_out, void* stream);
 /* The key / value branch of a MiT block with 2 x 2 spatial reduction in one launch (rb_chain.hip): kv = Linear_kv(LayerNorm(Conv2d_2x2s2(LayerNorm_1(x)))),
  * mix_transformers.py:119-127 (norm1 of :199 applied to the gathered source tokens).  x: (B, 2 Hr, 2 Wr, C) NHWC token map, C = 320; weights in the reference's shapes
  * (sr [C][C][2][2], kv [2C][C]); kv out: (B, Hr Wr, 2C).  iters > 0 additionally times `iters` launches. */

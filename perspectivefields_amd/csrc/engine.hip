@@ -70,7 +70,8 @@ struct DwW { float* w = nullptr; float* b = nullptr; int C = 0; };
 struct RbLin { unsigned short* w = nullptr; size_t bytes = 0; float* inv = nullptr; float* b = nullptr; int N = 0, K = 0; };
 // the key / value branch of a stage-3 block as one launch (rb_chain.hip): combined weight stream (conv as GEMM, then kv) + the two layers' scales / biases
 struct RbSrKv { unsigned short* w = nullptr; size_t bytes = 0; float *sr_inv = nullptr, *sr_b = nullptr, *kv_inv = nullptr, *kv_b = nullptr; };
-struct MitBlock { LNW n1, n2, srn; RbLin rq, rkv, rproj, rfc1, rfc2; RbSrKv rsrkv; ConvW qln /*q with norm1 folded (used next to rsrkv: no LayerNorm-1 launch)*/; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */ };
+struct RbProjFc1 { unsigned short* w = nullptr; size_t bytes = 0; };  // combined weight stream of rb_proj_fc1_kernel (scales / biases: rproj, rfc1)
+struct MitBlock { LNW n1, n2, srn; RbLin rq, rkv, rproj, rfc1, rfc2; RbSrKv rsrkv; RbProjFc1 rpf; ConvW qln /*q with norm1 folded (used next to rsrkv: no LayerNorm-1 launch)*/; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */ };
 struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
 struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
@@ -492,7 +493,7 @@ struct pf_engine {
                              // conv's epilogue (plus fp32 where a residual add reads them) and the halo kernel copies them (igemm_sbh ASB) instead of splitting
                              // every element once per n-tile and halo overlap; split-f16 scheme only
   int rb_chain = 60;         // PF_RB_CHAIN: which linear layers of MiT stage 3 run in the row-block form (rb_gemm.hip) instead of the LDS tiles (igemm_sb) once the batch gives
-                             // at least rb_min_blocks row blocks: bit mask 1 q, 2 kv, 4 proj, 8 fc1, 16 fc2, 32 the whole key / value branch as one launch (rb_chain.hip; overrides 2) (0 = none)
+                             // at least rb_min_blocks row blocks: bit mask 1 q, 2 kv, 4 proj, 8 fc1, 16 fc2, 32 the whole key / value branch as one launch (rb_chain.hip; overrides 2), 64 proj + norm2 + fc1 as one launch (overrides 4, 8) (0 = none)
   int rb_min_blocks = 96;
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
@@ -759,6 +760,15 @@ struct pf_engine {
           mb.rproj = make_rb(b + ".attn.proj", C, C, 320);
           mb.rfc1 = make_rb(b + ".mlp.fc1", 4 * C, C, 320);
           mb.rfc2 = make_rb(b + ".mlp.fc2", C, 4 * C, 320);
+          {  // proj followed by fc1 as ONE stream (rb_proj_fc1_kernel)
+            std::vector<unsigned short> st1, st2;
+            std::vector<float> inv1, inv2;
+            rb_pack_w(get(b + ".attn.proj.weight", {C, C}).data.data(), C, C, 320, &st1, &inv1);
+            rb_pack_w(get(b + ".mlp.fc1.weight", {4 * C, C}).data.data(), 4 * C, C, 320, &st2, &inv2);
+            st1.resize(st1.size() - (size_t)4 * 10 * 2 * 512);
+            st1.insert(st1.end(), st2.begin(), st2.end());
+            mb.rpf.w = upload_u16(st1); mb.rpf.bytes = st1.size() * 2;
+          }
           if (rb_srkv_supported(C, MIT_SR[s])) {
             int kwc = 0, kwcp = 0;
             const std::vector<float> srp = pack_conv(get(b + ".attn.sr.weight", {C, C, MIT_SR[s], MIT_SR[s]}).data.data(), C, C, MIT_SR[s], MIT_SR[s], C, nullptr, &kwc, &kwcp);  // [C][ky][kx C + ci]
@@ -1140,7 +1150,18 @@ struct pf_engine {
           ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
           launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
         }
-        if (use_rb && (rb_chain & 4)) rb_linear(c, mb.rproj, ab.f, M, (int)N, x, nullptr, ACT_NONE, x);
+        const bool pf_fused = use_rb && (rb_chain & 64) && mb.rpf.w;  // x += proj(attn); hidden = fc1(LN2(x)) in one launch (rb_chain.hip)
+        if (pf_fused) {
+          range_in(c, fmt("rb_proj_fc1 s%d.b%d attn", s + 1, blk), ab.f, (size_t)M * C);
+          if (!c.dry) {
+            RbProjFc1Args a;
+            a.attn = ab.f; a.x = x; a.w = mb.rpf.w; a.w_bytes = mb.rpf.bytes; a.proj_inv = mb.rproj.inv; a.proj_bias = mb.rproj.b;
+            a.ln2_g = mb.n2.g; a.ln2_b = mb.n2.b; a.ln2_eps = mb.n2.eps; a.fc1_inv = mb.rfc1.inv; a.fc1_bias = mb.rfc1.b; a.hidden = hb;
+            a.B = B; a.tokens = (int)N; a.bpi = ((int)N + 63) / 64;
+            ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * M * (double)C * 5 * C, (int)M, 5 * C, C, 1);
+            launch_rb_proj_fc1(a, C, c.s);
+          }
+        } else if (use_rb && (rb_chain & 4)) rb_linear(c, mb.rproj, ab.f, M, (int)N, x, nullptr, ACT_NONE, x);
         else gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
         // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
         if (fused_mlp && mb.mlp_w) {                  // norm2 + fc1 + depthwise 3x3 + GELU + fc2 + residual in one kernel, x -> xalt
@@ -1152,7 +1173,8 @@ struct pf_engine {
           std::swap(x, xalt);
           continue;
         }
-        if (use_rb && (rb_chain & 8)) {
+        if (pf_fused) {
+        } else if (use_rb && (rb_chain & 8)) {
           rb_linear(c, mb.rfc1, x, M, (int)N, hb, &mb.n2);  // norm2 while the rows are staged
         } else if (mb.fc1.ln_s) {
           gemm(c, mb.fc1, Ten(x), M, Ten(hb));        // norm2 inside fc1
@@ -2082,6 +2104,45 @@ int pf_op_rb_linear(int device, const float* x, long rows, int tokens, int K, co
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters; ++i) launch_rb_linear(a, K, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms_out = t / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
+int pf_op_rb_proj_fc1(int device, const float* attn, float* x, int B, int tokens, int C, const float* proj_w, const float* proj_b, const float* ln2_g, const float* ln2_b,
+                      float eps, const float* fc1_w, const float* fc1_b, float* hidden, int iters, float* ms_out, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (C != 320 || !attn || !x || !hidden || !proj_w || !proj_b || !ln2_g || !ln2_b || !fc1_w || !fc1_b || B <= 0 || tokens <= 0) {
+    g_create_error = "pf_op_rb_proj_fc1: C must be 320; all operands required";
+    return PF_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  std::vector<unsigned short> st1, st2;
+  std::vector<float> inv1, inv2;
+  rb_pack_w(proj_w, C, C, 320, &st1, &inv1);
+  rb_pack_w(fc1_w, 4 * C, C, 320, &st2, &inv2);
+  st1.resize(st1.size() - (size_t)4 * 10 * 2 * 512);
+  st1.insert(st1.end(), st2.begin(), st2.end());
+  RbProjFc1Args a;
+  a.attn = attn; a.x = x; a.w = tmp.up_u16(st1); a.w_bytes = st1.size() * 2; a.proj_inv = tmp.up(inv1); a.proj_bias = tmp.up(proj_b, C);
+  a.ln2_g = tmp.up(ln2_g, C); a.ln2_b = tmp.up(ln2_b, C); a.ln2_eps = eps; a.fc1_inv = tmp.up(inv2); a.fc1_bias = tmp.up(fc1_b, 4 * C); a.hidden = hidden;
+  a.B = B; a.tokens = tokens; a.bpi = (tokens + 63) / 64;
+  launch_rb_proj_fc1(a, C, s);
+  if (iters > 0 && ms_out) {  // timing loop (x keeps accumulating: values are meaningless afterwards)
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) launch_rb_proj_fc1(a, C, s);
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     float t = 0.f;

@@ -239,6 +239,19 @@ struct RbSrKvArgs {
   int B, Hr, Wr, bpi;         // bpi = ceil(Hr Wr / 32) blocks per image
 };
 bool rb_srkv_supported(int C, int sr);
+// The seam between the attention half and the Mlp half of a MiT block in one launch (rb_chain.hip): x += proj(attn_out); hidden = fc1(LayerNorm_2(x))
+struct RbProjFc1Args {
+  const float* attn;          // [M][C] attention output
+  float* x;                   // [M][C] token stream: residual in, x1 out (in place)
+  const unsigned short* w;    // weight stream: proj (C / 16 steps), then fc1's four 320-column passes, RB_D pad steps
+  size_t w_bytes;
+  const float* proj_inv; const float* proj_bias;   // [C]
+  const float* ln2_g; const float* ln2_b; float ln2_eps;
+  const float* fc1_inv; const float* fc1_bias;     // [4 C]
+  float* hidden;              // [M][4 C]
+  int B, tokens, bpi;         // bpi = ceil(tokens / 64)
+};
+void launch_rb_proj_fc1(const RbProjFc1Args& a, int C, hipStream_t s);
 void launch_rb_srkv(const RbSrKvArgs& a, int C, hipStream_t s);
 void launch_rb_linear(const RbLinArgs& a, int K, hipStream_t s);
 void launch_gap_ln_head(const float* x, const float* g, const float* b, const float* w, const float* hb, float* out, int B, int HW, int C, int nout, float eps, hipStream_t s);

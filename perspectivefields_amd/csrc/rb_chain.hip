@@ -222,7 +222,188 @@ __global__ __launch_bounds__(256, 1) void rb_srkv_kernel(const RbSrKvArgs p) {
   }
 }
 
+// rb_proj_fc1_kernel -- the seam between the two halves of a transformer block in one launch (mix_transformers.py:199-200, :137-139, :52):
+//     x1 = x + proj(attn_out);   hidden = fc1(LayerNorm_2(x1))
+// A block owns 64 tokens.  The attention output is staged as fragments, the projection runs (20 steps), its accumulators + bias + residual ARE the new token rows: they
+// are stored (through the transposing LDS path: full lines) and, still in registers, normalised -- row sums exchanged between the four waves through LDS, two passes --
+// and written back as the fragments of fc1's A operand, which then runs its four 320-column passes.  One weight stream (proj, then fc1); the ring reads on through the
+// LayerNorm.  Replaces two launches, one staging prologue and the read-back of x1.
+template <int C>
+__global__ __launch_bounds__(256, 1) void rb_proj_fc1_kernel(const RbProjFc1Args p) {
+  using G = RbGeo<2, true, 2>;
+  static_assert(C == 320, "geometry: 320-column passes");
+  constexpr int KC = C / 16, CPT = KC / 4, H4 = 4 * C;
+  __shared__ __attribute__((aligned(16))) unsigned char As[KC * G::CHS];
+  __shared__ __attribute__((aligned(16))) float tabs[2 * C + 2 * H4];   // proj: inv, bias [C]; fc1: inv [4C], bias [4C]
+  __shared__ __attribute__((aligned(16))) float red[2][4][64];          // LayerNorm row sums: [pass][wave][row]
+  __shared__ __attribute__((aligned(16))) float escr[4 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int img = blockIdx.x / p.bpi, j = blockIdx.x - img * p.bpi;
+  const int nrows = min(RB_ROWS, p.tokens - j * RB_ROWS);
+  const int m0 = img * p.tokens + j * RB_ROWS;
+
+  RbW<G> W;
+  W.init(p.w, p.w_bytes, wave, lane);
+  {  // ---- attention output rows -> fragments
+    const int r = tid >> 2, q = tid & 3;
+    const float* ar = p.attn + (size_t)(m0 + min(r, nrows - 1)) * C;
+    float4 v[CPT][4];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = *reinterpret_cast<const float4*>(ar + 16 * (q + 4 * i) + 4 * e);
+    for (int i = tid; i < C / 4; i += 256) {
+      reinterpret_cast<float4*>(tabs)[i] = reinterpret_cast<const float4*>(p.proj_inv)[i];
+      reinterpret_cast<float4*>(tabs + C)[i] = reinterpret_cast<const float4*>(p.proj_bias)[i];
+    }
+    for (int i = tid; i < H4 / 4; i += 256) {
+      reinterpret_cast<float4*>(tabs + 2 * C)[i] = reinterpret_cast<const float4*>(p.fc1_inv)[i];
+      reinterpret_cast<float4*>(tabs + 2 * C + H4)[i] = reinterpret_cast<const float4*>(p.fc1_bias)[i];
+    }
+    W.prologue();
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) rb_store_chunk(As + (q + 4 * i) * G::CHS, r, v[i]);
+  }
+  __syncthreads();
+
+  const int xr = wave & 1;
+  f32x16 acc[G::NACC];
+#pragma unroll
+  for (int i = 0; i < G::NACC; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  RbA<G> A[2];
+  A[0].read(As, lane, xr);
+#pragma unroll 1
+  for (int s = 0; s < KC; s += RB_D) {
+#pragma unroll
+    for (int d = 0; d < RB_D; ++d) {
+      const int nx = s + d + 1 == KC ? 0 : s + d + 1;
+      rb_step<G>(acc, W, d, A[d & 1], A[(d + 1) & 1], As + nx * G::CHS, lane, xr);
+    }
+  }
+
+  // ---- x1 = acc inv + bias + x in the accumulator layout (lane: row rt 32 + l31; register 4 g + e of tile (rt, ct): channel 32 ct + 8 g + 4 hi + e)
+  float ps[2] = {0.f, 0.f};
+#pragma unroll
+  for (int idx = 0; idx < G::NACC; ++idx) {
+    int rt, ct;
+    bool own;
+    rb_tile_of<G>(idx, wave, rt, ct, own);
+    const float* xrow = p.x + (size_t)(m0 + min(rt * 32 + l31, nrows - 1)) * C;
+    float4 rr[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rr[g] = *reinterpret_cast<const float4*>(xrow + ct * 32 + 8 * g + 4 * hi);
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = ct * 32 + 8 * g + 4 * hi;
+      const float4 iv = *reinterpret_cast<const float4*>(tabs + n), bb = *reinterpret_cast<const float4*>(tabs + C + n);
+      acc[idx][4 * g] = fmaf(acc[idx][4 * g], iv.x, bb.x) + rr[g].x; acc[idx][4 * g + 1] = fmaf(acc[idx][4 * g + 1], iv.y, bb.y) + rr[g].y;
+      acc[idx][4 * g + 2] = fmaf(acc[idx][4 * g + 2], iv.z, bb.z) + rr[g].z; acc[idx][4 * g + 3] = fmaf(acc[idx][4 * g + 3], iv.w, bb.w) + rr[g].w;
+      t += (acc[idx][4 * g] + acc[idx][4 * g + 1]) + (acc[idx][4 * g + 2] + acc[idx][4 * g + 3]);
+    }
+    if (idx < 2 * G::CTW) ps[idx & 1] += t;           // compile-time row tile
+    else { if (xr) ps[1] += t; else ps[0] += t; }     // the extra tile's row tile is wave-uniform
+  }
+  // the new token rows leave as full 128-byte lines (transposing LDS path, as rb_epilogue_store)
+  {
+    const int rrow = lane >> 3, c4 = lane & 7;
+    float* scratch = escr + wave * 1024;
+#pragma unroll
+    for (int idx = 0; idx < G::NACC; ++idx) {
+      int rt, ct;
+      bool own;
+      rb_tile_of<G>(idx, wave, rt, ct, own);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(scratch + l31 * 32 + (((2 * g + hi) ^ (l31 & 7)) << 2)) = make_float4(acc[idx][4 * g], acc[idx][4 * g + 1], acc[idx][4 * g + 2], acc[idx][4 * g + 3]);
+      __builtin_amdgcn_wave_barrier();
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = rrow + 8 * i;
+        v[i] = *reinterpret_cast<const float4*>(scratch + row * 32 + ((c4 ^ (row & 7)) << 2));
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ml = rt * 32 + rrow + 8 * i;
+        if (ml < nrows) *reinterpret_cast<float4*>(p.x + (size_t)(m0 + ml) * C + ct * 32 + c4 * 4) = v[i];
+      }
+    }
+  }
+  // ---- LayerNorm_2 of the rows held in the accumulators
+  ps[0] += __shfl_xor(ps[0], 32); ps[1] += __shfl_xor(ps[1], 32);
+  if (hi == 0) { red[0][wave][l31] = ps[0]; red[0][wave][32 + l31] = ps[1]; }
+  __syncthreads();  // also: every wave is done with the projection's A fragments
+  float mu[2], pq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) mu[rt] = ((red[0][0][rt * 32 + l31] + red[0][1][rt * 32 + l31]) + (red[0][2][rt * 32 + l31] + red[0][3][rt * 32 + l31])) * (1.0f / C);
+#pragma unroll
+  for (int idx = 0; idx < G::NACC; ++idx) {
+    const float m = idx < 2 * G::CTW ? mu[idx & 1] : (xr ? mu[1] : mu[0]);
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[idx][r] -= m; t = fmaf(acc[idx][r], acc[idx][r], t); }
+    if (idx < 2 * G::CTW) pq[idx & 1] += t;
+    else { if (xr) pq[1] += t; else pq[0] += t; }
+  }
+  pq[0] += __shfl_xor(pq[0], 32); pq[1] += __shfl_xor(pq[1], 32);
+  if (hi == 0) { red[1][wave][l31] = pq[0]; red[1][wave][32 + l31] = pq[1]; }
+  __syncthreads();
+  float rs[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+    rs[rt] = 1.0f / sqrtf(((red[1][0][rt * 32 + l31] + red[1][1][rt * 32 + l31]) + (red[1][2][rt * 32 + l31] + red[1][3][rt * 32 + l31])) * (1.0f / C) + p.ln2_eps);
+#pragma unroll
+  for (int idx = 0; idx < G::NACC; ++idx) {
+    int rt, ct;
+    bool own;
+    rb_tile_of<G>(idx, wave, rt, ct, own);
+    const float r_ = idx < 2 * G::CTW ? rs[idx & 1] : (xr ? rs[1] : rs[0]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = ct * 32 + 8 * g + 4 * hi;
+      const float4 gm = *reinterpret_cast<const float4*>(p.ln2_g + n), be = *reinterpret_cast<const float4*>(p.ln2_b + n);
+      const float4 y = make_float4(fmaf(acc[idx][4 * g] * r_, gm.x, be.x), fmaf(acc[idx][4 * g + 1] * r_, gm.y, be.y), fmaf(acc[idx][4 * g + 2] * r_, gm.z, be.z),
+                                   fmaf(acc[idx][4 * g + 3] * r_, gm.w, be.w));
+      uint2 h, l;
+      split4_f16(y, h, l);
+      unsigned char* d = As + (2 * ct + (g >> 1)) * G::CHS + rt * 2048 + (l31 + 32 * (g & 1)) * 16 + 8 * hi;
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + 1024) = l;
+    }
+  }
+  __syncthreads();
+
+  // ---- hidden = LN2(x1) W1^T + b1: four passes of 320 columns
+  A[0].read(As, lane, xr);
+#pragma unroll 1
+  for (int ps2 = 0; ps2 < 4; ++ps2) {
+#pragma unroll
+    for (int i = 0; i < G::NACC; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll 1
+    for (int s = 0; s < KC; s += RB_D) {
+#pragma unroll
+      for (int d = 0; d < RB_D; ++d) {
+        const int nx = s + d + 1 == KC ? 0 : s + d + 1;
+        rb_step<G>(acc, W, d, A[d & 1], A[(d + 1) & 1], As + nx * G::CHS, lane, xr);
+      }
+    }
+    rb_chain_epilogue_store<G, false, ACT_NONE>(p.hidden, H4, tabs + 2 * C, tabs + 2 * C + H4, escr + wave * 1024, acc, ps2 * G::COLS, m0, nrows, wave, lane);
+  }
+}
+
 bool rb_srkv_supported(int C, int sr) { return C == 320 && sr == 2; }
+
+void launch_rb_proj_fc1(const RbProjFc1Args& a, int C, hipStream_t s) {
+  const dim3 grid((unsigned)(a.B * a.bpi)), block(256);
+  if (C == 320) hipLaunchKernelGGL((rb_proj_fc1_kernel<320>), grid, block, 0, s, a);
+}
 
 void launch_rb_srkv(const RbSrKvArgs& a, int C, hipStream_t s) {
   const dim3 grid((unsigned)(a.B * a.bpi)), block(256);

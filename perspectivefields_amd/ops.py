@@ -143,6 +143,23 @@ def rb_linear(x, weight, bias, tokens, gamma=None, beta=None, eps=1e-6, act=0, r
     return ms.value if iters > 0 else y
 
 
+def rb_proj_fc1(attn, x, proj_w, proj_b, ln2_g, ln2_b, eps, fc1_w, fc1_b, tokens, iters=0):
+    """x1 = x + proj(attn); hidden = fc1(LayerNorm_2(x1)) in one launch (pf_op_rb_proj_fc1).  attn, x: (rows, C) on the GPU, rows = images x tokens, C = 320.
+    Returns (x1, hidden); iters > 0: the average ms per launch instead."""
+    import torch
+
+    lib = load_library()
+    attn = attn.contiguous()
+    x1 = x.contiguous().clone()
+    rows, C = attn.shape
+    hidden = torch.empty((rows, 4 * C), dtype=torch.float32, device=attn.device)
+    ms = ctypes.c_float()
+    a = [_np(t) for t in (proj_w, proj_b, ln2_g, ln2_b, fc1_w, fc1_b)]
+    _check(lib.pf_op_rb_proj_fc1(attn.device.index, attn.data_ptr(), x1.data_ptr(), rows // tokens, tokens, C, _hp(a[0]), _hp(a[1]), _hp(a[2]), _hp(a[3]), float(eps), _hp(a[4]), _hp(a[5]),
+                                 hidden.data_ptr(), iters, ctypes.byref(ms), _stream_ptr()), None, "pf_op_rb_proj_fc1")
+    return ms.value if iters > 0 else (x1, hidden)
+
+
 def rb_srkv(x, ln1_g, ln1_b, eps1, sr_w, sr_b, srn_g, srn_b, eps2, kv_w, kv_b, iters=0):
     """Key / value branch of a MiT block with 2 x 2 spatial reduction in one launch (pf_op_rb_srkv).  x: (B, 2 Hr, 2 Wr, C) on the GPU, C = 320.
     Returns kv (B, Hr Wr, 2 C); iters > 0: the average ms per launch instead."""

@@ -671,3 +671,25 @@ def test_rb_srkv(ops, B, Hr, Wr):
         _close(got, ref, 6e-5, "rb_srkv")
     except AssertionError as e:
         raise AssertionError(str(e) + "\n" + _region_report(got.reshape(-1, 2 * C), ref.reshape(-1, 2 * C)))
+
+
+@pytest.mark.parametrize("tokens,images", [(400, 2), (100, 3), (70, 2)])
+def test_rb_proj_fc1(ops, tokens, images):
+    """x1 = x + proj(attn); hidden = fc1(LayerNorm_2(x1)) as one launch (rb_chain.hip): full and ragged row blocks, residual rows with offsets and outlier channels
+    (the LayerNorm runs on the projection's accumulators).  Oracle: torch fp64 (mix_transformers.py:137-139, :199-200, :52)."""
+    C = 320
+    rows = tokens * images
+    attn = _rand((rows, C), 401, 1.2)
+    x = _with_outlier_channels(_rand((rows, C), 402, 1.5) + 8.0 * _rand((rows, 1), 403), 404)
+    wp, bp = _rand((C, C), 405, 1.0 / math.sqrt(C)), _rand((C,), 406, 0.1)
+    g, be = 1 + _rand((C,), 407, 0.3), _rand((C,), 408, 0.2)
+    w1, b1 = _rand((4 * C, C), 409, 1.0 / math.sqrt(C)), _rand((4 * C,), 410, 0.1)
+    w1[11] *= 23.0
+    x1_ref = x.double() + F.linear(attn.double(), wp.double(), bp.double())
+    h_ref = F.linear(F.layer_norm(x1_ref, (C,), g.double(), be.double(), 1e-6), w1.double(), b1.double())
+    x1, hid = ops.rb_proj_fc1(attn.cuda(), x.cuda(), wp, bp, g, be, 1e-6, w1, b1, tokens)
+    _close(x1, x1_ref, 3e-5, "rb_proj_fc1 x1")
+    try:
+        _close(hid, h_ref, 6e-5, "rb_proj_fc1 hidden")
+    except AssertionError as e:
+        raise AssertionError(str(e) + "\n" + _region_report(hid, h_ref))
