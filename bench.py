@@ -287,7 +287,7 @@ def main(argv=None):
     # Deferred ParamNet branch (--defer-params 1): forward i returns with its camera-parameter tensor still being computed on the engine's stream, next to forward i + 1's
     # backbone; the tensor is complete in stream order once forward i + 1 has been issued, so the scalars of step i are gathered (N > 1) right after that -- one step
     # late -- and the last step's after join_params().  Nothing is skipped: K steps' work is inside the timed region.
-    defer = bool(args.defer_params) and not dry
+    defer = bool(args.defer_params)  # also in the CPU dry run: the one-step-late gather of the scalars is rank logic the gloo test walks
     if defer:
         eng.set_defer_params(True)
     late = {"params": None}

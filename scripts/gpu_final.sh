@@ -8,8 +8,10 @@ echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -q -m gpu -p no:cac
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 echo "== bench"; timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -1 | tee gpurun_out/bench.json | cut -c1-300
 echo "== bench noevents"; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_noevents.json | cut -c1-160
+echo "== bench joined forwards (no deferred ParamNet branch)"; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 --defer-params 0 2>&1 | tail -1 | tee gpurun_out/bench_nodefer.json | cut -c1-160
+echo "== bench LDS tiles only (PF_RB_CHAIN=0)"; PF_RB_CHAIN=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_norb.json | cut -c1-160
 echo "== bench mixed (configs[4])"; timeout 300 python bench.py --workload mixed --batch 64 --steps 8 --warmup 2 --no-cpu-baseline --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_mixed.json | cut -c1-400
-for P in fp32_bf16x6 bf16x3 bf16; do
+for P in fp32_bf16x6 bf16; do
   echo "== bench $P"; timeout 300 python bench.py --precision $P --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_$P.json | cut -c1-160
 done
 echo "== configs"; timeout 600 python scripts/bench_configs.py 2>&1 | grep -E "config|images_per_sec|agreement" | head -30

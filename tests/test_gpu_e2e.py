@@ -453,3 +453,25 @@ def test_deferred_paramnet_branch_equals_joined_forward(tag):
     again = eng.forward(xs[0])   # back to joined forwards
     torch.cuda.synchronize()
     assert torch.equal(again[2], ref[0][2])
+
+
+@pytest.mark.parametrize("mask", [0, 31, 127])
+def test_row_block_forms_of_mit_stage3_agree(monkeypatch, mask):
+    """PF_RB_CHAIN: the linear layers of MiT stage 3 in the row-block form (rb_gemm.hip / rb_chain.hip) against the default engine at a batch whose 64-token blocks
+    fill the chip (B = 32: the form is active by default with mask 60; 0 = LDS tiles only, 31 = every single layer incl. q / kv, 127 = + the fused key / value branch
+    and the fused proj + norm2 + fc1 launch): same mathematics, other summation orders -- far inside the parity tolerances; and the row-block engine itself against
+    the CPU oracle on one image of the batch."""
+    from perspectivefields_amd import PerspectiveFields
+
+    imgs = [synthetic_image(72, 96, seed=520 + (i % 5)) for i in range(32)]
+    base = model("centered").inference_batch(imgs)
+    monkeypatch.setenv("PF_RB_CHAIN", str(mask))
+    alt_model = PerspectiveFields(CASES["centered"], weights="synthetic:0").eval().cuda()
+    alt = alt_model.inference_batch(imgs)
+    for i in (0, 13, 31):
+        a, b = base[i], alt[i]
+        c = one_minus_cos(a["pred_gravity"].cpu().numpy(), b["pred_gravity"].cpu().numpy()).max()
+        e = l1(a["pred_latitude"].cpu().numpy(), b["pred_latitude"].cpu().numpy())
+        d = max(abs(float(a[k2]) - float(b[k2])) for k2 in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
+        print(f"[PF_RB_CHAIN={mask} vs default img{i}] 1-cos {c:.2e} latL1 {e:.2e} param {d:.2e}")
+        assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
