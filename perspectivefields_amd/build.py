@@ -18,9 +18,9 @@ ASAN = os.environ.get("PF_ASAN", "0") == "1"
 _VARIANT = ("_tune" if os.environ.get("PF_TUNING_BUILD", "0") == "1" else "") + ("_asan" if ASAN else "") + os.environ.get("PF_LIB_SUFFIX", "")
 LIBDIR = os.path.join(HERE, "lib" + _VARIANT)
 LIB = os.path.join(LIBDIR, "libpf_hip.so")
-SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sb3.hip", "igemm_sb1.hip", "igemm_sbf.hip", "igemm_sbh.hip", "attn.hip", "elem.hip", "dw7.hip", "cnx_mlp.hip", "mit_mlp.hip", "rb_gemm.hip", "rb_chain.hip", "engine.hip"]
+SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sb3.hip", "igemm_sb1.hip", "igemm_sbf.hip", "igemm_sbh.hip", "attn.hip", "elem.hip", "dw7.hip", "dw7_pk.hip", "cnx_mlp.hip", "mit_mlp.hip", "rb_gemm.hip", "rb_chain.hip", "engine.hip"]
 # dw7.hip: the scalar one-channel-per-lane kernel must not be SLP-vectorised (see the file header)
-EXTRA_FLAGS = {"dw7.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"dw7.hip": ["-fno-slp-vectorize"], "dw7_pk.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 # PF_TUNING_BUILD=1: also compile the measured-and-rejected kernel variants and the ablation (no-load / no-store) kernels that
 # the scripts under scripts/ can select; the product build carries the default path and its parity alternatives only

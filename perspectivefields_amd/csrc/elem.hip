@@ -112,10 +112,10 @@ void launch_layernorm(const float* x, const float* g, const float* b, float* y, 
 // Block = 8x8 output pixels x 128 channels.  The 10x10x128 input tile (with halo) is staged
 // in LDS once (51.2 KB); thread (q = channel quad, y = row) then marches along x keeping a
 // 3x3 window of float4 in registers: 3 ds_read_b128 + 9 fma4 + erf per output float4.
+#ifdef PF_TUNING_BUILD
 static constexpr int DW3_T = 8;
 static constexpr int DW3_CQ = 32;  // channel quads per block (128 channels)
 
-#ifdef PF_TUNING_BUILD
 __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const float* __restrict__ x, const float* __restrict__ w9c,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              unsigned short* __restrict__ y_sb, size_t sb_plane,
@@ -616,9 +616,14 @@ void launch_dwconv7x7_cb(const float* x, const float* w49c, const float* bias, f
 void launch_dwconv7x7_cb_cfg(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int nc, int nb, int th, hipStream_t s);
 bool dwconv7x7_lds_ok(int H, int W, int C);
 void launch_dwconv7x7_lds(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int th, hipStream_t s);
-static int g_dw7_variant = -1;
+// packed-fp32 forms (dw7_pk.hip)
+void launch_dwconv7x7_cbp_cfg(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int nc, int nb, int th, hipStream_t s);
+bool launch_dwconv7x7_ldsp(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int ch, int th, hipStream_t s);
+static int g_dw7_variant = -1, g_dw7_pk_ch = 0, g_dw7_pk_th = 0;
 // explicit variant / column-blocked configuration (tests, tuning); variant < 0: the default path
 void launch_dwconv7x7_cfg(int variant, int nc, int nb, int th, const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
+  if (variant == 6 && C % 32 == 0 && launch_dwconv7x7_ldsp(x, w49c, bias, y, B, H, W, C, nc /*channels per block*/, th, s)) return;  // packed LDS-tile kernel; shapes it does not cover fall through
+  if ((variant == 5 || variant == 6) && C % 32 == 0) { launch_dwconv7x7_cbp_cfg(x, w49c, bias, y, B, H, W, C, variant == 5 ? nc : 0, variant == 5 ? nb : 0, variant == 5 ? th : 0, s); return; }
   if (variant == 4 && dwconv7x7_lds_ok(H, W, C)) { launch_dwconv7x7_lds(x, w49c, bias, y, B, H, W, C, th, s); return; }
   if (variant == 3 || variant == 4) { launch_dwconv7x7_cb_cfg(x, w49c, bias, y, B, H, W, C, nc, nb, th, s); return; }
   if (variant == 2) { launch_dwconv7x7_lane(x, w49c, bias, y, B, H, W, C, s); return; }
@@ -627,7 +632,15 @@ void launch_dwconv7x7_cfg(int variant, int nc, int nb, int th, const float* x, c
 void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
   if (g_dw7_variant == -1) {
     const char* e = getenv("PF_DW7_VARIANT");
-    g_dw7_variant = e ? atoi(e) : 4;  // 4: LDS-tile kernel on maps of <= 20 columns, column-blocked streaming kernel otherwise (dw7.hip); 3: column-blocked everywhere; 2: one column per lane; 1: ring, 0: LDS halo tile (tuning builds)
+    g_dw7_variant = e ? atoi(e) : 4;  // 4: LDS-tile kernel on maps of <= 20 columns, column-blocked streaming kernel otherwise (dw7.hip); 7: the packed-fp32 forms of both (dw7_pk.hip); 3: column-blocked everywhere; 2: one column per lane; 1: ring, 0: LDS halo tile (tuning builds)
+    const char* ch = getenv("PF_DW7_PK_CH"); g_dw7_pk_ch = ch ? atoi(ch) : 0;
+    const char* th = getenv("PF_DW7_PK_TH"); g_dw7_pk_th = th ? atoi(th) : 0;
+  }
+  if (g_dw7_variant == 7 && C % 32 == 0) {
+    if (launch_dwconv7x7_ldsp(x, w49c, bias, y, B, H, W, C, g_dw7_pk_ch, g_dw7_pk_th, s)) return;
+    if (!dwconv7x7_lds_ok(H, W, C)) { launch_dwconv7x7_cbp_cfg(x, w49c, bias, y, B, H, W, C, 0, 0, 0, s); return; }
+    launch_dwconv7x7_lds(x, w49c, bias, y, B, H, W, C, 0, s);  // small maps the packed tile kernel does not cover (ragged strips, < 8 columns)
+    return;
   }
   if (g_dw7_variant == 4 && dwconv7x7_lds_ok(H, W, C)) { launch_dwconv7x7_lds(x, w49c, bias, y, B, H, W, C, 0, s); return; }
   if (g_dw7_variant == 3 || g_dw7_variant == 4) { launch_dwconv7x7_cb(x, w49c, bias, y, B, H, W, C, s); return; }

@@ -501,7 +501,7 @@ def test_dwconv3x3_gelu(ops, B, H, W, C):
             assert torch.equal(ops.dwconv3x3_gelu(xd, w, b, variant=1000 + 100 * shape + code, planes_out=True), ops.dwconv3x3_gelu(xd, w, b, planes_out=True)), "dwconv3x3 mc planes"
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 80, 80, 96), (1, 40, 40, 192), (2, 20, 20, 384), (3, 10, 10, 768), (1, 2, 2, 768), (1, 5, 11, 96), (2, 20, 13, 96), (1, 33, 20, 96), (1, 17, 20, 96), (2, 15, 19, 96), (1, 14, 7, 96)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 80, 80, 96), (1, 40, 40, 192), (2, 20, 20, 384), (3, 10, 10, 768), (1, 2, 2, 768), (1, 5, 11, 96), (2, 20, 13, 96), (1, 33, 20, 96), (1, 17, 20, 96), (2, 15, 19, 96), (1, 14, 7, 96), (2, 40, 13, 96), (1, 20, 9, 96)])
 def test_dwconv7x7(ops, B, H, W, C):
     x = _rand((B, H, W, C), 23)
     w = _rand((C, 1, 7, 7), 24, 0.15)
@@ -521,6 +521,18 @@ def test_dwconv7x7(ops, B, H, W, C):
         got = ops.dwconv7x7(xd, w, b, variant=4, th=th)
         _close(got, ref, 1e-5, f"dwconv7x7 lds th{th}")
         assert torch.equal(got, cb), f"dwconv7x7 lds th{th} differs from the streaming kernel"
+    # packed-fp32 forms (dw7_pk.hip): the same fused multiply-adds in the same order, two output columns per v_pk_fma_f32 -> identical bits.  Streaming kernel (run-time
+    # strips and the straight-line strips of 10 / 20 rows) and the tile-in-parts LDS kernel (32 / 16 channels per block; configurations a shape does not admit fall
+    # back inside the library and must still be right)
+    for nc in (4, 2):
+        for nb in (2, 3):
+            for th in (0, 1, 3, 7, 10, 20, H):
+                got = ops.dwconv7x7(xd, w, b, variant=5, nc=nc, nb=nb, th=th)
+                assert torch.equal(got, cb), f"dwconv7x7 packed cb nc{nc} nb{nb} th{th} differs from the scalar kernel"
+    for ch in (0, 32, 16):
+        for th in (0, 5, 10, 20):
+            got = ops.dwconv7x7(xd, w, b, variant=6, nc=ch, th=th)
+            assert torch.equal(got, cb), f"dwconv7x7 packed lds ch{ch} th{th} differs from the scalar kernel"
 
 
 @pytest.mark.parametrize("B,N,heads,M", [(2, 6400, 1, 100), (1, 1600, 2, 100), (2, 400, 5, 100), (3, 100, 8, 100), (1, 70, 2, 37)])
