@@ -91,25 +91,28 @@ __global__ __launch_bounds__(256) void dwconv7x7_cbp_kernel(const float* __restr
   for (int j = 0; j < NC; ++j) voff_out[j] = (g_ok && x0 + j < W) ? (unsigned)((x0 + j) * C + c) * 4u : 0x80000000u;
   const unsigned row_bytes = (unsigned)(W * C) * 4u;
   pk2 acc[7][NP];
-  float in[NB][NI];
+  pk2 in[NB][NI / 2];  // the input row as aligned pairs (columns 2k, 2k + 1)
 #pragma unroll
   for (int s = 0; s < 7; ++s)
 #pragma unroll
     for (int j = 0; j < NP; ++j) acc[s][j] = pk2{bv, bv};
-  auto load_row = [&](int iy, float (&v)[NI]) {
+  auto load_row = [&](int iy, pk2 (&v)[NI / 2]) {
     const bool ok = (unsigned)iy < (unsigned)H;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(xb, 0, ok ? img_bytes : 0u, 0x00020000);
     const unsigned soff = ok ? (unsigned)iy * row_bytes : 0u;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff[j], soff, 0));
+    for (int j = 0; j < NI / 2; ++j) {
+      v[j].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff[2 * j], soff, 0));
+      v[j].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff[2 * j + 1], soff, 0));
+    }
   };
   const int nrows = (y1 - y0) + 6;
   auto do_row = [&](int tt, int r) {
     const int iy = y0 - 3 + tt;
     load_row(iy + NB - 1, in[(r + NB - 1) % NB]);  // prefetch; rows past the strip are loaded but never used
-    pk2 pr[NI - 1];                                // (column k, column k + 1) of this input row: built once, used by the 7 vertical taps
+    pk2 pr[NI - 1];                                // (column k, column k + 1) of this input row: the even ones are the row's own pairs, an odd one is one v_pk_mov_b32 (hi of pair k / 2, lo of the next)
 #pragma unroll
-    for (int k = 0; k < NI - 1; ++k) pr[k] = pk2{in[r % NB][k], in[r % NB][k + 1]};
+    for (int k = 0; k < NI - 1; ++k) pr[k] = (k & 1) ? __builtin_shufflevector(in[r % NB][k >> 1], in[r % NB][(k >> 1) + 1], 1, 2) : in[r % NB][k >> 1];
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
       const int oy = iy - ky + 3;
@@ -186,13 +189,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC == 2 ? 4
 #pragma unroll
   for (int j = 0; j < NC; ++j) voff_out[j] = (g_ok && x0 + j < W) ? (unsigned)((x0 + j) * C + c) * 4u : 0x80000000u;
   const unsigned row_bytes = (unsigned)(W * C) * 4u;
-  float in[NB][NI];
-  auto load_row = [&](int iy, float (&v)[NI]) {
+  pk2 in[NB][NI / 2];  // the input row as aligned pairs (columns 2k, 2k + 1)
+  auto load_row = [&](int iy, pk2 (&v)[NI / 2]) {
     const bool ok = (unsigned)iy < (unsigned)H;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(xb, 0, ok ? img_bytes : 0u, 0x00020000);
     const unsigned soff = ok ? (unsigned)iy * row_bytes : 0u;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff[j], soff, 0));
+    for (int j = 0; j < NI / 2; ++j) {
+      v[j].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff[2 * j], soff, 0));
+      v[j].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff[2 * j + 1], soff, 0));
+    }
   };
 #pragma unroll
   for (int d = 0; d < NB - 1; ++d) load_row(y0 - 3 + d, in[d]);  // the first rows' loads go out before the weights'
@@ -209,9 +215,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC == 2 ? 4
 #pragma unroll
   for (int tt = 0; tt < R; ++tt) {
     if (tt + NB - 1 < R) load_row(y0 - 3 + tt + NB - 1, in[(tt + NB - 1) % NB]);
-    pk2 pr[NI - 1];
+    pk2 pr[NI - 1];  // (column k, column k + 1) of this input row: the even ones are the row's own pairs, an odd one is one v_pk_mov_b32 (hi of pair k / 2, lo of the next)
 #pragma unroll
-    for (int k = 0; k < NI - 1; ++k) pr[k] = pk2{in[tt % NB][k], in[tt % NB][k + 1]};
+    for (int k = 0; k < NI - 1; ++k) pr[k] = (k & 1) ? __builtin_shufflevector(in[tt % NB][k >> 1], in[tt % NB][(k >> 1) + 1], 1, 2) : in[tt % NB][k >> 1];
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
       const int o = tt - ky;
@@ -248,9 +254,10 @@ static void launch_cbp(const float* x, const float* w49c, const float* bias, flo
 
 // nc / nb / th <= 0: the automatic choice (same table as the scalar kernel until scripts/tune_dw7.py says otherwise)
 void launch_dwconv7x7_cbp_cfg(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int nc, int nb, int th, hipStream_t s) {
-  const int NC = nc > 0 ? nc : (W >= 20 ? 4 : 2);
-  const int NB = nb > 0 ? nb : (W >= 20 ? 2 : 3);
-  int TH = th > 0 ? std::min(th, H) : std::min(H, H >= 80 ? 20 : 10);
+  // measured on MI355X at B = 32 (profiles/r04_dw7_packed.md): 80^2: nc4 nb3 th20, 40^2: nc4 nb2 th20, 20^2: nc2 nb3 th20, 10^2: nc2 nb3 th10
+  const int NC = nc > 0 ? nc : (W >= 40 ? 4 : 2);
+  const int NB = nb > 0 ? nb : (W >= 80 || W < 40 ? 3 : 2);
+  int TH = th > 0 ? std::min(th, H) : (H % 20 == 0 ? 20 : (H % 10 == 0 ? 10 : std::min(H, 20)));
   if (th <= 0) {  // small batches: more strips until the chip is full
     const long per_strip = (long)B * C * ((W + NC - 1) / NC) / 64;
     while (TH > 5 && per_strip * ((H + TH - 1) / TH) < 2048) TH = (TH + 1) / 2;
@@ -328,8 +335,6 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(CH == 32 ? 
   pk2 wk2[25];
   const lds_f32* const wlr = (const lds_f32*)wl + cl;
   const lds_f32* trow = (const lds_f32*)tile + x0 * CH + cl;
-  const lds_f32* trow_odd = trow;
-  asm volatile("" : "+v"(trow_odd));  // a second name for the same tile: the pairs (1,2), (3,4), (5,6) are read on their own (ds_read2_b32 straight into an aligned pair) instead of being assembled with v_mov from the even pairs' registers
 #pragma unroll
   for (int tt = 0; tt < R; ++tt) {
     if (tt % 7 == 0) {  // ---- part tt / 7 lands
@@ -358,12 +363,11 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(CH == 32 ? 
     // ---- input row tt of the tile feeds output rows o = tt - ky (slot (r - ky + 3) mod 7, r = tt mod 7); after it output row tt - 6 is complete
     const int r = tt % 7;
     const lds_f32* te = trow + tt * TW * CH;
-    const lds_f32* to = trow_odd + tt * TW * CH;
-    pk2 pe[4], po[3];
+    pk2 pe[4], po[3];  // tile columns (2i, 2i + 1): one ds_read2_b32 each, straight into an aligned pair; (2i + 1, 2i + 2): one v_pk_mov_b32 (reading them from LDS as well measured the same)
 #pragma unroll
     for (int i = 0; i < 4; ++i) pe[i] = pk2{te[(2 * i) * CH], te[(2 * i + 1) * CH]};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) po[i] = pk2{to[(2 * i + 1) * CH], to[(2 * i + 2) * CH]};
+    for (int i = 0; i < 3; ++i) po[i] = __builtin_shufflevector(pe[i], pe[i + 1], 1, 2);
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
       const int o = tt - ky;
@@ -399,10 +403,11 @@ static bool try_ldsp(const float* x, const float* w49c, const float* bias, float
   return true;
 }
 
-// maps of 8 .. 20 columns; ch in {0 (automatic), 16, 32}; th in {0 (automatic), 5, 10, 20}.  false: shape / configuration not covered (the caller falls back)
+// maps of 8 .. 20 columns with 32 channels per block, up to 40 columns with 16; ch in {0 (automatic), 16, 32, < 0: never}; th in {0 (automatic), 5, 10, 20}.
+// false: shape / configuration not covered (the caller falls back)
 bool launch_dwconv7x7_ldsp(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int ch, int th, hipStream_t s) {
-  if (W > 20 || W < 8 || H < 5) return false;
-  if (ch <= 0) ch = 32;
+  if (W > 40 || W < 8 || H < 5 || ch < 0) return false;  // ch < 0: the caller wants the streaming kernel
+  if (ch == 0) ch = W > 20 ? 16 : 32;
   if (th > H) th = 0;  // a preference that does not apply to this map
   if (th <= 0) th = H % 10 == 0 ? 10 : (H % 5 == 0 ? 5 : 0);
   if (ch == 32) {
@@ -411,6 +416,7 @@ bool launch_dwconv7x7_ldsp(const float* x, const float* w49c, const float* bias,
   } else if (ch == 16) {
     if (th == 20) return try_ldsp<16, 20, 5>(x, w49c, bias, y, B, H, W, C, s);
     if (th == 10) return try_ldsp<16, 10, 5>(x, w49c, bias, y, B, H, W, C, s);
+    if (th == 5) return try_ldsp<16, 5, 5>(x, w49c, bias, y, B, H, W, C, s);
   }
   return false;
 }

@@ -619,7 +619,7 @@ void launch_dwconv7x7_lds(const float* x, const float* w49c, const float* bias, 
 // packed-fp32 forms (dw7_pk.hip)
 void launch_dwconv7x7_cbp_cfg(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int nc, int nb, int th, hipStream_t s);
 bool launch_dwconv7x7_ldsp(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int ch, int th, hipStream_t s);
-static int g_dw7_variant = -1, g_dw7_pk_ch = 0, g_dw7_pk_th = 0;
+static int g_dw7_variant = -1, g_dw7_pk_ch = 0, g_dw7_pk_th = 0, g_dw7_pk_wmax = 20;
 // explicit variant / column-blocked configuration (tests, tuning); variant < 0: the default path
 void launch_dwconv7x7_cfg(int variant, int nc, int nb, int th, const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
   if (variant == 6 && C % 32 == 0 && launch_dwconv7x7_ldsp(x, w49c, bias, y, B, H, W, C, nc /*channels per block*/, th, s)) return;  // packed LDS-tile kernel; shapes it does not cover fall through
@@ -632,12 +632,13 @@ void launch_dwconv7x7_cfg(int variant, int nc, int nb, int th, const float* x, c
 void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
   if (g_dw7_variant == -1) {
     const char* e = getenv("PF_DW7_VARIANT");
-    g_dw7_variant = e ? atoi(e) : 4;  // 4: LDS-tile kernel on maps of <= 20 columns, column-blocked streaming kernel otherwise (dw7.hip); 7: the packed-fp32 forms of both (dw7_pk.hip); 3: column-blocked everywhere; 2: one column per lane; 1: ring, 0: LDS halo tile (tuning builds)
+    g_dw7_variant = e ? atoi(e) : 7;  // 7 (default since r04): the packed-fp32 kernels of dw7_pk.hip -- tile-in-parts LDS kernel on maps of <= 20 columns, streaming kernel otherwise; 4: their scalar forms (dw7.hip: LDS-tile / column-blocked); 3: column-blocked everywhere; 2: one column per lane; 1: ring, 0: LDS halo tile (tuning builds)
     const char* ch = getenv("PF_DW7_PK_CH"); g_dw7_pk_ch = ch ? atoi(ch) : 0;
     const char* th = getenv("PF_DW7_PK_TH"); g_dw7_pk_th = th ? atoi(th) : 0;
+    const char* wm = getenv("PF_DW7_PK_WMAX"); g_dw7_pk_wmax = wm ? atoi(wm) : 20;  // widest map on the packed tile kernel (wider ones stream)
   }
   if (g_dw7_variant == 7 && C % 32 == 0) {
-    if (launch_dwconv7x7_ldsp(x, w49c, bias, y, B, H, W, C, g_dw7_pk_ch, g_dw7_pk_th, s)) return;
+    if (W <= g_dw7_pk_wmax && launch_dwconv7x7_ldsp(x, w49c, bias, y, B, H, W, C, g_dw7_pk_ch, g_dw7_pk_th, s)) return;
     if (!dwconv7x7_lds_ok(H, W, C)) { launch_dwconv7x7_cbp_cfg(x, w49c, bias, y, B, H, W, C, 0, 0, 0, s); return; }
     launch_dwconv7x7_lds(x, w49c, bias, y, B, H, W, C, 0, s);  // small maps the packed tile kernel does not cover (ragged strips, < 8 columns)
     return;

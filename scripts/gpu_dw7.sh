@@ -10,7 +10,7 @@ echo "==== tests"; timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -k "
 echo "==== isolated sweep"; TUNE_PK_ONLY=${TUNE_PK_ONLY:-1} timeout 600 python scripts/tune_dw7.py 2>&1 | grep -v amdgpu.ids
 echo "==== in the forward"
 for V in 4 7; do echo "== PF_DW7_VARIANT=$V"; PF_DW7_VARIANT=$V timeout 300 python scripts/profile_layers.py --out gpurun_out/layers_dw7_$V.txt 2>&1 | grep "dwconv7x7\|total"; done
-for A in ${DW7_ALTS:-16:10 16:20 32:5}; do echo "== PF_DW7_VARIANT=7 ch:th $A"; PF_DW7_VARIANT=7 PF_DW7_PK_CH=${A%%:*} PF_DW7_PK_TH=${A##*:} timeout 300 python scripts/profile_layers.py --out gpurun_out/layers_dw7_7_$A.txt 2>&1 | grep "dwconv7x7\|total"; done
+for A in ${DW7_ALTS:-0:10 0:5}; do echo "== PF_DW7_VARIANT=7 WMAX=40 ch:th $A"; PF_DW7_VARIANT=7 PF_DW7_PK_WMAX=40 PF_DW7_PK_CH=${A%%:*} PF_DW7_PK_TH=${A##*:} timeout 300 python scripts/profile_layers.py --out gpurun_out/layers_dw7_7_$A.txt 2>&1 | grep "dwconv7x7\|total"; done
 echo "==== bench A/B"
 for rep in 1 2 3; do for V in 4 7; do PF_DW7_VARIANT=$V $BENCH 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('dw7 variant', $V, d['value'], d['ms_per_step'])"; done; done
 for V in 4 7; do PF_DW7_VARIANT=$V $BENCH --defer-params 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('joined forwards: dw7 variant', $V, d['value'], d['ms_per_step'])"; done

@@ -27,8 +27,8 @@ for (H, C) in ((80, 96), (40, 192), (20, 384), (10, 768)):
     res = [(t(5, H, C, nc=nc, nb=nb, th=th), nc, nb, th) for nc in (4, 2) for nb in (2, 3) for th in sorted({5, 10, 20, 40} - {x for x in (5, 10, 20, 40) if x > H})]
     best = min(res)
     line += f" best packed cb nc{best[1]} nb{best[2]} th{best[3]} {1e3 * best[0]:.1f} us {mb / best[0] / 1e3:.2f} TB/s [" + " ".join(f"nc{nc}nb{nb}th{th}:{1e3 * ms:.1f}" for ms, nc, nb, th in res) + "]"
-    if H <= 20:
-        res = [(t(6, H, C, nc=ch, th=th), ch, th) for ch in (32, 16) for th in (5, 10, 20) if th <= H and not (ch == 32 and th == 20)]
+    if H <= 40:
+        res = [(t(6, H, C, nc=ch, th=th), ch, th) for ch in (32, 16) for th in (5, 10, 20) if th <= H and not (ch == 32 and (th == 20 or H > 20))]
         best = min(res)
         line += f" | best packed lds ch{best[1]} th{best[2]} {1e3 * best[0]:.1f} us {mb / best[0] / 1e3:.2f} TB/s [" + " ".join(f"ch{ch}th{th}:{1e3 * ms:.1f}" for ms, ch, th in res) + "]"
     out.append(line)

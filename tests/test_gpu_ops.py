@@ -515,8 +515,9 @@ def test_dwconv7x7(ops, B, H, W, C):
             for th in (0, 1, 3, 7, H):
                 _close(ops.dwconv7x7(xd, w, b, variant=3, nc=nc, nb=nb, th=th), ref, 1e-5, f"dwconv7x7 cb nc{nc} nb{nb} th{th}")
     _close(ops.dwconv7x7(xd, w, b, variant=2), ref, 1e-5, "dwconv7x7 lane")
-    # LDS-tile kernel (maps of <= 20 columns; the default there): strips of every kind, same accumulation order as the streaming kernel -> identical bits
+    # LDS-tile kernel (maps of <= 20 columns): strips of every kind, same accumulation order as the streaming kernel -> identical bits
     cb = ops.dwconv7x7(xd, w, b, variant=3)
+    assert torch.equal(ops.dwconv7x7(xd, w, b), cb), "the default path (packed kernels) differs from the scalar streaming kernel"
     for th in (0, 1, 3, 7, H):
         got = ops.dwconv7x7(xd, w, b, variant=4, th=th)
         _close(got, ref, 1e-5, f"dwconv7x7 lds th{th}")
