@@ -26,10 +26,15 @@ typedef __attribute__((address_space(3))) float lds_f32;  // the tile reads keep
 // c += a * w2[HI] (both halves of a by the same weight).  The weights live TWO PER REGISTER PAIR and the instruction's op_sel bits pick the half: written as
 // __builtin_elementwise_fma(a, pk2{w, w}, c) the compiler folds the splat into op_sel only where it has a single use and otherwise materialises all 49 weights as
 // (w, w) pairs -- 98 registers and a v_mov per weight, which is what this form is here to avoid.
+// THE WEIGHT PAIR MUST BE src0.  With the pair as src1 and the HIGH half broadcast (op_sel:[0,1,0] op_sel_hi:[1,1,1]) the instruction returned wrong low-lane results in
+// lanes 32-63 -- only while this library's MFMA kernels ran on the same CUs from another stream (8-20 of 30 launches differing, ~10 % relative error in the affected
+// outputs), never alone, never beside rocBLAS GEMMs or a streaming kernel; the same operands as src0 (op_sel:[1,0,0]), the low-half broadcast on either source, and the
+// compiler's own packed FMAs are clean (profiles/r04_dw7_packed.md; found by tests/test_gpu_e2e.py::test_deferred_paramnet_branch_equals_joined_forward, pinned by
+// ::test_packed_dwconv7x7_beside_forward).
 template <int HI>
 static __device__ __forceinline__ void pk_fma_w(pk2& c, pk2 a, pk2 w2) {
-  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(c) : "v"(a), "v"(w2));
-  else    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "v"(w2));
+  if (HI) asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(c) : "v"(a), "v"(w2));
+  else    asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "v"(a), "v"(w2));
 }
 template <int K>
 static __device__ __forceinline__ void pk_tap(pk2& c, pk2 a, const pk2 (&wk2)[25]) { pk_fma_w<K & 1>(c, a, wk2[K >> 1]); }

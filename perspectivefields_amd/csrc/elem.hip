@@ -619,7 +619,7 @@ void launch_dwconv7x7_lds(const float* x, const float* w49c, const float* bias, 
 // packed-fp32 forms (dw7_pk.hip)
 void launch_dwconv7x7_cbp_cfg(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int nc, int nb, int th, hipStream_t s);
 bool launch_dwconv7x7_ldsp(const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, int ch, int th, hipStream_t s);
-static int g_dw7_variant = -1, g_dw7_pk_ch = 0, g_dw7_pk_th = 0, g_dw7_pk_wmax = 20;
+static int g_dw7_variant = -1, g_dw7_pk_ch = 0, g_dw7_pk_th = 0, g_dw7_pk_wmax = 20, g_dw7_pk_onlyw = 0;
 // explicit variant / column-blocked configuration (tests, tuning); variant < 0: the default path
 void launch_dwconv7x7_cfg(int variant, int nc, int nb, int th, const float* x, const float* w49c, const float* bias, float* y, int B, int H, int W, int C, hipStream_t s) {
   if (variant == 6 && C % 32 == 0 && launch_dwconv7x7_ldsp(x, w49c, bias, y, B, H, W, C, nc /*channels per block*/, th, s)) return;  // packed LDS-tile kernel; shapes it does not cover fall through
@@ -635,16 +635,17 @@ void launch_dwconv7x7(const float* x, const float* w49c, const float* bias, floa
     g_dw7_variant = e ? atoi(e) : 7;  // 7 (default since r04): the packed-fp32 kernels of dw7_pk.hip -- tile-in-parts LDS kernel on maps of <= 20 columns, streaming kernel otherwise; 4: their scalar forms (dw7.hip: LDS-tile / column-blocked); 3: column-blocked everywhere; 2: one column per lane; 1: ring, 0: LDS halo tile (tuning builds)
     const char* ch = getenv("PF_DW7_PK_CH"); g_dw7_pk_ch = ch ? atoi(ch) : 0;
     const char* th = getenv("PF_DW7_PK_TH"); g_dw7_pk_th = th ? atoi(th) : 0;
+    const char* ow = getenv("PF_DW7_PK_ONLYW"); g_dw7_pk_onlyw = ow ? atoi(ow) : 0;  // diagnosis: packed kernels only on maps of this width
     const char* wm = getenv("PF_DW7_PK_WMAX"); g_dw7_pk_wmax = wm ? atoi(wm) : 20;  // widest map on the packed tile kernel (wider ones stream)
   }
-  if (g_dw7_variant == 7 && C % 32 == 0) {
+  if (g_dw7_variant == 7 && C % 32 == 0 && (g_dw7_pk_onlyw == 0 || W == g_dw7_pk_onlyw)) {
     if (W <= g_dw7_pk_wmax && launch_dwconv7x7_ldsp(x, w49c, bias, y, B, H, W, C, g_dw7_pk_ch, g_dw7_pk_th, s)) return;
     if (!dwconv7x7_lds_ok(H, W, C)) { launch_dwconv7x7_cbp_cfg(x, w49c, bias, y, B, H, W, C, 0, 0, 0, s); return; }
     launch_dwconv7x7_lds(x, w49c, bias, y, B, H, W, C, 0, s);  // small maps the packed tile kernel does not cover (ragged strips, < 8 columns)
     return;
   }
-  if (g_dw7_variant == 4 && dwconv7x7_lds_ok(H, W, C)) { launch_dwconv7x7_lds(x, w49c, bias, y, B, H, W, C, 0, s); return; }
-  if (g_dw7_variant == 3 || g_dw7_variant == 4) { launch_dwconv7x7_cb(x, w49c, bias, y, B, H, W, C, s); return; }
+  if ((g_dw7_variant == 4 || g_dw7_variant == 7) && dwconv7x7_lds_ok(H, W, C)) { launch_dwconv7x7_lds(x, w49c, bias, y, B, H, W, C, 0, s); return; }
+  if (g_dw7_variant == 3 || g_dw7_variant == 4 || g_dw7_variant == 7) { launch_dwconv7x7_cb(x, w49c, bias, y, B, H, W, C, s); return; }
   if (g_dw7_variant == 2) { launch_dwconv7x7_lane(x, w49c, bias, y, B, H, W, C, s); return; }
 #ifdef PF_TUNING_BUILD
   const int CQ = C / 4;

@@ -452,6 +452,7 @@ struct pf_engine {
   hipStream_t pstream = nullptr;
   hipEvent_t ev_pn_in = nullptr, ev_pn_done = nullptr;
   bool pn_pending = false, in_capture = false;
+  int pn_pending_B = 0; uintptr_t pn_pending_base = 0;   // batch and workspace of the pending branch: another batch size lays the regions out differently
   // PF_DEFER_AT = k > 0: the deferred branch of forward i is ISSUED (on pstream) only when forward i + 1 reaches MiT stage k -- next to the stage whose launches leave
   // the most room -- instead of right away (k = 0); pf_join_params / the decoders' wait issue it if no forward came
   int defer_at = 0, defer_prio = 0;
@@ -1365,6 +1366,13 @@ struct pf_engine {
   }
 
   void run(Ctx& c, int B, const void* in, bool is_u8, float* pg, float* pl, float* params) {
+    if (!c.dry && pn_pending && (B != pn_pending_B || c.base != pn_pending_base)) {
+      // a deferred branch works at an offset that depends on ITS batch size (behind that batch's main region): a forward with another batch size, or in another
+      // workspace buffer, would lay its main region over it (or leave it behind in a buffer the caller may free) -- join before anything of this forward is issued
+      issue_deferred();
+      (void)hipStreamWaitEvent(c.s, ev_pn_done, 0);
+      pn_pending = false;
+    }
     float* x0 = c.alloc((size_t)B * NET * NET * 4);
     if (!c.dry) {
       if (is_u8) launch_prep_u8(static_cast<const uint8_t*>(in), x0, (long)B * NET * NET, mean3, std3, c.s);
@@ -1413,12 +1421,12 @@ struct pf_engine {
       }
       if (defer && defer_at > 0) {  // issued by the next forward (mit(), stage defer_at) or by whoever needs the result first
         pn_later.armed = true; pn_later.B = B; pn_later.pn = pn; pn_later.params = params; pn_later.ctx = cp;
-        pn_pending = true;
+        pn_pending = true; pn_pending_B = B; pn_pending_base = c.base;
       } else {
         paramnet(cp, B, pn, params);
         if (defer) {
           (void)hipEventRecord(ev_pn_done, pstream);
-          pn_pending = true;
+          pn_pending = true; pn_pending_B = B; pn_pending_base = c.base;
         }
       }
     }

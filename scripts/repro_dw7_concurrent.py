@@ -1,0 +1,52 @@
+"""Diagnosis: do the depthwise 7x7 kernels give the same bits while THIS library's forward runs on another stream (a background thread keeps issuing B = 32 forwards)?
+(found through tests/test_gpu_e2e.py::test_deferred_paramnet_branch_equals_joined_forward: the packed kernels of dw7_pk.hip differed from joined forwards only while
+the next forward's backbone ran beside them; beside rocBLAS GEMMs / a streaming kernel they did not.)  Prints the pattern of the differing outputs."""
+import os, sys, threading
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from perspectivefields_amd import ops, PerspectiveFields
+from perspectivefields_amd.synth import synthetic_image
+
+m = PerspectiveFields("Paramnet-360Cities-edina-centered", weights="synthetic:0").eval().cuda()
+eng = m._get_engine()
+xb = torch.from_numpy(np.stack([m.aug.apply_image(synthetic_image(80, 100, seed=i)) for i in range(32)])).cuda()
+eng.forward(xb); torch.cuda.synchronize()
+stop = False
+bg_stream = torch.cuda.Stream()
+
+def background():
+    with torch.cuda.stream(bg_stream):
+        while not stop:
+            eng.forward(xb)
+            bg_stream.synchronize()
+
+side = torch.cuda.Stream()
+CFG = [("scalar lds", dict(variant=4)), ("packed lds: asm, weights src1, lo + HI broadcast (shipped form)", dict(variant=6, nc=32, th=10)), ("packed lds: compiler's packed FMA", dict(variant=6, nc=232, th=10)),
+       ("packed lds: asm, weights src0, lo + hi broadcast", dict(variant=6, nc=432, th=10)), ("packed lds: asm, low-half broadcast only", dict(variant=6, nc=532, th=10))]
+torch.manual_seed(0)
+cases = []
+for (B, H, C) in ((16, 20, 384), (16, 10, 768)):
+    x = torch.randn(B, H, H, C, device="cuda"); w = torch.randn(C, 1, 7, 7) * 0.15; b = torch.randn(C) * 0.1
+    cases.append((B, H, C, x, w, b, ops.dwconv7x7(x, w, b, variant=3)))
+torch.cuda.synchronize()
+for phase in ("alone", "beside this library's B=32 forward"):
+    if phase != "alone":
+        t = threading.Thread(target=background); t.start()
+    for (B, H, C, x, w, b, ref) in cases:
+        for name, kw in CFG:
+            bad, worst, pat = 0, 0.0, ""
+            with torch.cuda.stream(side):
+                for it in range(30):
+                    y = ops.dwconv7x7(x, w, b, **kw)
+                    side.synchronize()
+                    if not torch.equal(y, ref):
+                        bad += 1
+                        d = (y - ref).abs()
+                        worst = max(worst, float(d.max()))
+                        if not pat:
+                            idx = (d > 0).nonzero()
+                            pat = (f"first mismatch: {idx.shape[0]} of {y.numel()} outputs differ; images {sorted(set(idx[:, 0].tolist()))[:8]} rows {sorted(set(idx[:, 1].tolist()))[:12]} "
+                                   f"cols {sorted(set(idx[:, 2].tolist()))[:12]} channels {len(set(idx[:, 3].tolist()))} distinct; rel err median {float((d[d > 0] / (ref[d > 0].abs() + 1e-6)).median()):.2e}")
+            print(f"[{phase}] {H}x{H}x{C} B={B} {name:65s}: {bad}/30 differ (max|d| {worst:.2e}) {pat}", flush=True)
+    if phase != "alone":
+        stop = True; t.join()

@@ -455,6 +455,58 @@ def test_deferred_paramnet_branch_equals_joined_forward(tag):
     assert torch.equal(again[2], ref[0][2])
 
 
+def test_packed_dwconv7x7_beside_forward():
+    """The packed-fp32 depthwise kernels (dw7_pk.hip) while THIS library's forward runs on another stream (a background thread keeps issuing B = 32 forwards): the
+    deferred ParamNet branch runs them exactly like that.  Their first form (weight pair as src1 of v_pk_fma_f32 with the high half broadcast) returned wrong values
+    in lanes 32-63 only in this situation -- bit-identical to the scalar kernels alone, beside rocBLAS GEMMs and beside a streaming kernel -- which no op test could
+    see; the shipped form (weight pair as src0) must stay bit-identical to the scalar kernel here."""
+    import threading
+    from perspectivefields_amd import ops
+
+    m = model("centered")
+    eng = m._get_engine()
+    xb = torch.from_numpy(np.stack([m.aug.apply_image(synthetic_image(80, 100, seed=i)) for i in range(32)])).cuda()
+    ref_fwd = [t.clone() for t in eng.forward(xb)]
+    torch.cuda.synchronize()
+    cases = []
+    g = torch.Generator().manual_seed(5)
+    for (B, H, C) in ((16, 80, 96), (16, 40, 192), (16, 20, 384), (16, 10, 768)):
+        x = torch.randn(B, H, H, C, generator=g).cuda()
+        w = torch.randn(C, 1, 7, 7, generator=g) * 0.15
+        b = torch.randn(C, generator=g) * 0.1
+        cases.append((x, w, b, ops.dwconv7x7(x, w, b, variant=3)))
+    torch.cuda.synchronize()
+    stop = threading.Event()
+    bg_stream, side = torch.cuda.Stream(), torch.cuda.Stream()
+    bg_bad = []
+
+    def background():
+        with torch.cuda.stream(bg_stream):
+            while not stop.is_set():
+                o = eng.forward(xb)
+                bg_stream.synchronize()
+                if not all(torch.equal(a, r) for a, r in zip(o, ref_fwd)):
+                    bg_bad.append(1)
+
+    t = threading.Thread(target=background)
+    t.start()
+    try:
+        bad = []
+        with torch.cuda.stream(side):
+            for (x, w, b, ref) in cases:
+                for kw in (dict(), dict(variant=5, nc=4, nb=3, th=10), dict(variant=5, nc=4, nb=2, th=20), dict(variant=5, nc=2, nb=3, th=5), dict(variant=6, nc=32, th=10), dict(variant=6, nc=16, th=10)):
+                    for it in range(12):
+                        y = ops.dwconv7x7(x, w, b, **kw)
+                        side.synchronize()
+                        if not torch.equal(y, ref):
+                            bad.append((tuple(x.shape), kw, it, float((y - ref).abs().max())))
+    finally:
+        stop.set()
+        t.join()
+    assert not bad, f"packed depthwise 7x7 differs from the scalar kernel beside the forward: {bad[:4]} ({len(bad)} launches)"
+    assert not bg_bad, "the forward itself was not reproducible while the depthwise kernels ran beside it"
+
+
 @pytest.mark.parametrize("mask", [0, 31, 127])
 def test_row_block_forms_of_mit_stage3_agree(monkeypatch, mask):
     """PF_RB_CHAIN: the linear layers of MiT stage 3 in the row-block form (rb_gemm.hip / rb_chain.hip) against the default engine at a batch whose 64-token blocks
