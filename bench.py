@@ -297,6 +297,8 @@ def main(argv=None):
             eng.resize_batch_into(orig, batch)  # bucketed bit-exact PIL resize on the device (inside the timed region for the mixed stream)
         pg, pl, params = eng.forward(batch)
         outs = eng.postprocess_batch(pg, pl, sizes)
+        if defer and params is not None:  # references only (no GPU work): the local scalars of the last two steps, for the check after the timed region
+            late["overlapped"], late["last_local"] = late.get("last_local"), params
         if defer and params is not None and world > 1:
             prev, late["params"] = late["params"], params
             allp = gather_params(prev, counts) if prev is not None else None
@@ -332,6 +334,12 @@ def main(argv=None):
     out = drain(out)
     barrier()
     dt = time.perf_counter() - t0
+    # Every step runs the same batch, so the scalars of a step whose ParamNet branch ran BESIDE the next step's backbone must equal, bit for bit, those of the last
+    # step, whose branch ran alone after the join -- the parity check below only sees the last step (round 4: a packed-FMA operand form that was only wrong beside
+    # other kernels went through exactly that gap, tests/test_gpu_e2e.py::test_deferred_paramnet_branch_equals_joined_forward caught it)
+    deferred_identical = None
+    if defer and not dry and late.get("overlapped") is not None and late.get("last_local") is not None and args.steps >= 2:
+        deferred_identical = bool(torch.equal(late["overlapped"], late["last_local"]))
     if defer:
         eng.set_defer_params(False)  # everything after the timed region (extra profiled step, latency figures, parity check) reads its results right away
     if use_events:
@@ -538,6 +546,8 @@ def main(argv=None):
                                  "launches_per_step": at["launches"], "measured": "extra profiled step after the timed region"}
         line["achieved_tflops_ref_graph"] = round(value / world * GFLOP_PER_IMAGE_REF / 1e3, 2)
     line["host_resize_ms_per_image"] = round(1000.0 * t_resize, 3)
+    if deferred_identical is not None:
+        line["deferred_branch_bit_identical"] = deferred_identical  # scalars of the step before the last (branch beside the last step's backbone) == the last step's (branch alone)
 
     if not dry and not args.no_extras:
         # ---- (1) parity of the timed configuration: one image of the LAST timed step against the CPU oracle
