@@ -21,11 +21,13 @@ def background():
             bg_stream.synchronize()
 
 side = torch.cuda.Stream()
-CFG = [("scalar lds", dict(variant=4)), ("packed lds: asm, weights src1, lo + HI broadcast (shipped form)", dict(variant=6, nc=32, th=10)), ("packed lds: compiler's packed FMA", dict(variant=6, nc=232, th=10)),
-       ("packed lds: asm, weights src0, lo + hi broadcast", dict(variant=6, nc=432, th=10)), ("packed lds: asm, low-half broadcast only", dict(variant=6, nc=532, th=10))]
+# (the diagnosis builds of round 4 added template modes for the operand forms listed in profiles/r04_dw7_packed.md -- selected as nc = 132 / 232 / 332 / 432 / 532 --
+# and were removed with the fix; the shipped configurations are what this script addresses now)
+CFG = [("scalar cb", dict(variant=3)), ("scalar lds", dict(variant=4)), ("packed cb nc4 nb3 th10", dict(variant=5, nc=4, nb=3, th=10)), ("packed cb nc4 nb2 th20", dict(variant=5, nc=4, nb=2, th=20)),
+       ("packed cb nc2 nb3 th5 (run-time strips)", dict(variant=5, nc=2, nb=3, th=5)), ("packed lds ch32 th10", dict(variant=6, nc=32, th=10)), ("packed lds ch16 th10", dict(variant=6, nc=16, th=10))]
 torch.manual_seed(0)
 cases = []
-for (B, H, C) in ((16, 20, 384), (16, 10, 768)):
+for (B, H, C) in ((16, 80, 96), (16, 40, 192), (16, 20, 384), (16, 10, 768)):
     x = torch.randn(B, H, H, C, device="cuda"); w = torch.randn(C, 1, 7, 7) * 0.15; b = torch.randn(C) * 0.1
     cases.append((B, H, C, x, w, b, ops.dwconv7x7(x, w, b, variant=3)))
 torch.cuda.synchronize()
