@@ -45,6 +45,31 @@ def kernels(lib):
     return sorted(rows, key=lambda r: r["kernel"])
 
 
+_PK_SRC1_HI = re.compile(r"v_pk_(?:fma|mul|add)_f32 (v\[\d+:\d+\]), (\S+), (\S+?)(?:,| ).*op_sel:\[(\d),(\d)")
+
+
+def packed_src1_high_forms(lib):
+    """Packed-fp32 instructions whose LOW lane reads the HIGH half of src1 (op_sel[1] = 1) with src1 != src0, per kernel: [(mangled kernel name, instruction)].
+    On MI355X these forms returned wrong low-lane results in the upper lanes of a wave while kernels of this library ran on the same CUs from another stream -- exact
+    alone (profiles/r04_dw7_packed.md, scripts/microbench/pk_opsel_beside.hip: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  The compiler's horizontal reductions
+    (`v_pk_add_f32 d, x, x op_sel:[0,1] op_sel_hi:[1,0]`: the same register pair twice) have not shown the fault and are not reported."""
+    hits = []
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co); f.flush()
+            p = subprocess.Popen([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", f.name], stdout=subprocess.PIPE, text=True)
+            cur = None
+            for line in p.stdout:
+                if line.endswith(">:\n"):
+                    cur = line.split("<")[1][:-3]
+                elif "v_pk_" in line and "op_sel:[" in line:
+                    m = _PK_SRC1_HI.search(line)
+                    if m and m.group(5) == "1" and m.group(2) != m.group(3):
+                        hits.append((cur, line.split("//")[0].strip()))
+            p.wait()
+    return hits
+
+
 def blocks_per_cu(r):
     """Resident blocks per CU of a kernel: 512 VGPRs per SIMD lane in granules of 8 (at most 8 waves per SIMD), 4 SIMDs, 160 KB of LDS."""
     waves_per_simd = min(8, 512 // max(8, (r["vgpr"] + 7) // 8 * 8))

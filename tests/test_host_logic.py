@@ -388,6 +388,31 @@ def test_halo_kernel_lane_mapping_is_bank_conflict_free():
     assert extra_cycles(0) > 0
 
 
+def test_no_packed_fp32_src1_high_half_forms_in_the_default_path():
+    """ISA scan of the built library (no GPU): packed-fp32 instructions whose low lane reads the HIGH half of src1 (src1 != src0).  Round 4 found them exact alone
+    and wrong beside this library's kernels on another stream (profiles/r04_dw7_packed.md; reproduced for v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 by
+    scripts/microbench/pk_opsel_beside.hip) -- and every forward with the deferred ParamNet branch or the side stream is exactly that situation.  hipcc emits these
+    forms on its own when it packs scalar code, so this pins the set: only the two kernels below (neither runs beside another stream in the product: the
+    proj + norm2 + fc1 launch is off by default, PF_RB_CHAIN bit 64; fields_from_params is a stand-alone entry point) may contain them."""
+    import importlib.util
+    import shutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    from perspectivefields_amd import build as _b
+
+    lib = _b.build(verbose=False)
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    hits = kr.packed_src1_high_forms(lib)
+    allowed = ("rb_proj_fc1_kernel", "fields_from_params_kernel")
+    bad = [h for h in hits if not any(a in h[0] for a in allowed)]
+    assert not bad, bad[:8]
+    assert not any("dwconv7x7" in h[0] for h in hits)
+
+
 def test_kernel_resources_static():
     """Static check of the built library (no GPU): every kernel is there for gfx950, fits the 160 KB LDS, and the kernels
     of the default path do not spill (scripts/kernel_resources.py reads the AMDGPU metadata of the embedded code objects)."""
