@@ -5,6 +5,9 @@ Mirrors what the reference exposes through `PerspectiveFields.cfg` and
 perspective2d/config/config.py:4-137 and the five YAML overlays in
 perspective2d/config/).  Only keys that influence inference are modelled; the
 reference's training/FPN/visualisation keys are not part of the hot path.
+YAML files in the reference's format are read (`CfgNode.merge_from_file`,
+`get_cfg_from_file`) and written (`CfgNode.dump`, `write_zoo_yamls`): the
+reference's five files load to exactly the zoo configs below.
 
 The config object supports attribute access (`cfg.MODEL.GRAVITY_DECODER.LOSS_TYPE`)
 like the reference's yacs CfgNode, and is frozen after construction.
@@ -40,6 +43,36 @@ class CfgNode(dict):
 
     def is_frozen(self):
         return self.__dict__.get("_frozen", False)
+
+    # ---- YAML in the reference's format (perspective2d/config/*.yaml are yacs dumps: nested mappings, keys sorted) ----
+    def to_dict(self):
+        return {k: (v.to_dict() if isinstance(v, CfgNode) else copy.deepcopy(v)) for k, v in self.items()}
+
+    def dump(self) -> str:
+        """YAML text of this config, keys sorted at every level -- what yacs' `cfg.dump()` writes and what `merge_from_file` reads back."""
+        import yaml
+
+        return yaml.safe_dump(self.to_dict(), default_flow_style=False, sort_keys=True)
+
+    def merge_from_file(self, path: str):
+        """Overlay a YAML file in the reference's format (the way the reference builds its config: defaults, then `cfg.merge_from_file(<zoo yaml>)`,
+        perspectivefields.py:129-132).  Keys of the modelled sections must exist, as with yacs ("Non-existent config key"); the sections of a reference YAML that
+        only matter to training / evaluation (TRAINING_ONLY_SECTIONS) are not part of this config and are skipped -- their names are returned."""
+        import yaml
+
+        if self.is_frozen():
+            raise AttributeError("config is frozen; cannot merge")
+        with open(path) as f:
+            src = yaml.safe_load(f) or {}
+        if not isinstance(src, dict):
+            raise ValueError(f"{path}: a config file is a YAML mapping")
+        skipped = sorted(k for k in src if k in TRAINING_ONLY_SECTIONS)
+        _merge(self, {k: v for k, v in src.items() if k not in TRAINING_ONLY_SECTIONS})
+        return skipped
+
+
+# top-level sections of the reference's YAML files / detectron2-style defaults that do not influence inference (data sets, optimiser, evaluation schedule)
+TRAINING_ONLY_SECTIONS = ("DATASETS", "SOLVER", "TEST", "SEED", "OUTPUT_DIR", "CUDNN_BENCHMARK", "VERSION", "GLOBAL")
 
 
 def _node(d):
@@ -117,6 +150,29 @@ _OVERLAYS = {
             },
         }
     },
+    # paramnet_gsv_rpf.yaml: as "rpf", but PARAM_DECODER.INPUT_SIZE stays 320 in that file (ParamNet does not read it: its input is the 320x320 field map)
+    "rpf_gsv": {
+        "MODEL": {
+            **_REG_HEADS,
+            "RECOVER_RPF": True,
+            "RECOVER_PP": False,
+            "PARAM_DECODER": {"NAME": "ParamNet", "PREDICT_PARAMS": ["roll", "pitch", "vfov"], "INPUT_SIZE": 320},
+        }
+    },
+    # paramnet_gsv_rpfpp.yaml: as "rpfpp" with PARAM_DECODER.LOSS_WEIGHT 0.1 (a training value; kept so that the config equals the file's)
+    "rpfpp_gsv": {
+        "MODEL": {
+            **_REG_HEADS,
+            "RECOVER_RPF": True,
+            "RECOVER_PP": True,
+            "PARAM_DECODER": {
+                "NAME": "ParamNetConvNextRegress",
+                "PREDICT_PARAMS": ["roll", "pitch", "general_vfov", "rel_cx", "rel_cy"],
+                "INPUT_SIZE": 64,
+                "LOSS_WEIGHT": 0.1,
+            },
+        }
+    },
     # cvpr2023.yaml
     "cvpr2023": {
         "MODEL": {
@@ -156,14 +212,14 @@ model_zoo = {
     "PersNet_Paramnet-GSV-uncentered": {
         "weights": _HF + "paramnet_gsv_rpfpp.pth",
         "config_file": "paramnet_gsv_rpfpp.yaml",
-        "overlay": "rpfpp",
+        "overlay": "rpfpp_gsv",
         "param": True,
         "description": "Trained on GSV. Predicts roll, pitch, fov and principal point.",
     },
     "PersNet_Paramnet-GSV-centered": {
         "weights": _HF + "paramnet_gsv_rpf.pth",
         "config_file": "paramnet_gsv_rpf.yaml",
-        "overlay": "rpf",
+        "overlay": "rpf_gsv",
         "param": True,
         "description": "Trained on GSV. Assumes centered principal point. Predicts roll, pitch and fov.",
     },
@@ -182,6 +238,33 @@ def _merge(dst: CfgNode, src: dict):
 
 def get_cfg_defaults() -> CfgNode:
     return _node(_DEFAULTS)
+
+
+def get_cfg_from_file(path: str) -> CfgNode:
+    """Frozen config from a YAML file in the reference's format (defaults + the file, like the reference's constructor)."""
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(path)
+    return cfg.freeze()
+
+
+def write_zoo_yamls(directory: str):
+    """Write the zoo configs as YAML files in the reference's format and under the reference's file names (one per distinct config_file) into `directory`;
+    returns {file name: path}.  The files are generated from the overlays above, not shipped: `get_cfg_from_file` reads them back to exactly `get_cfg(version)`,
+    and it reads the reference's own perspective2d/config/*.yaml to the same configs (tests/test_host_logic.py)."""
+    import os
+
+    os.makedirs(directory, exist_ok=True)
+    done = {}
+    for version, entry in model_zoo.items():
+        if entry["config_file"] in done:
+            continue
+        cfg = get_cfg_defaults()
+        _merge(cfg, _OVERLAYS[entry["overlay"]])
+        path = os.path.join(directory, entry["config_file"])
+        with open(path, "w") as f:
+            f.write(cfg.dump())
+        done[entry["config_file"]] = path
+    return done
 
 
 def get_cfg(version: str) -> CfgNode:

@@ -388,6 +388,41 @@ def test_halo_kernel_lane_mapping_is_bank_conflict_free():
     assert extra_cycles(0) > 0
 
 
+def test_config_yaml_files_in_the_reference_format(tmp_path):
+    """The config as YAML, the way the reference keeps it (perspective2d/config/*.yaml are yacs dumps; its constructor does defaults + merge_from_file,
+    perspectivefields.py:129-132): write_zoo_yamls() files read back to the zoo configs, dump() -> merge_from_file() round-trips, a key the config does not model raises like
+    yacs, training-only sections are skipped by name -- and, where the reference tree is present, ITS five files load to exactly the zoo configs."""
+    files = cfgmod.write_zoo_yamls(str(tmp_path / "zoo"))
+    assert sorted(files) == sorted({e["config_file"] for e in model_zoo.values()})
+    for v, entry in model_zoo.items():
+        written = cfgmod.get_cfg_from_file(files[entry["config_file"]])
+        assert written == get_cfg(v) and written.is_frozen(), v
+        p = tmp_path / f"{v}.yaml"
+        p.write_text(get_cfg(v).dump())
+        assert cfgmod.get_cfg_from_file(str(p)) == get_cfg(v)
+        assert arch_of(written) == arch_of(get_cfg(v))
+    # dump() has the reference files' layout: nested mappings, block lists, keys sorted
+    text = get_cfg("PersNet-360Cities").dump()
+    assert text.startswith("DATALOADER:\n  RESIZE:\n  - 320\n  - 320\n") and "LOSS_TYPE: classification" in text and "NUM_CLASSES: 180" in text
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("MODEL:\n  NO_SUCH_KEY: 1\n")
+    with pytest.raises(KeyError):
+        cfgmod.get_cfg_from_file(str(bad))
+    extra = tmp_path / "extra.yaml"
+    extra.write_text("DATASETS:\n  TRAIN:\n  - x\nSOLVER:\n  BASE_LR: 0.1\nMODEL:\n  RECOVER_RPF: true\n")
+    cfg = cfgmod.get_cfg_defaults()
+    assert cfg.merge_from_file(str(extra)) == ["DATASETS", "SOLVER"] and cfg.MODEL.RECOVER_RPF is True
+    with pytest.raises(AttributeError):
+        get_cfg("PersNet-360Cities").merge_from_file(str(extra))   # frozen
+    ref_dir = "/root/reference/perspective2d/config"
+    if os.path.isdir(ref_dir):   # this container only; the GPU box has no reference tree
+        for v, entry in model_zoo.items():
+            cfg = cfgmod.get_cfg_defaults()
+            skipped = cfg.merge_from_file(os.path.join(ref_dir, entry["config_file"]))
+            assert skipped == ["DATASETS"], (v, skipped)
+            assert cfg.freeze() == get_cfg(v), v
+
+
 def test_no_packed_fp32_src1_high_half_forms_in_the_default_path():
     """ISA scan of the built library (no GPU): packed-fp32 instructions whose low lane reads the HIGH half of src1 (src1 != src0).  Round 4 found them exact alone
     and wrong beside this library's kernels on another stream (profiles/r04_dw7_packed.md; reproduced for v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 by
