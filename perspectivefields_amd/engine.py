@@ -291,6 +291,8 @@ class Engine:
         import torch
 
         if self._ws is None or self._ws.numel() < nbytes:
+            if self._ws is not None and getattr(self, "defer_params", False):
+                self.join_params()  # a pending deferred ParamNet branch still works in the buffer that is about to be released: the allocator does not know the engine's stream
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._order_scratch("ws", self._ws)
