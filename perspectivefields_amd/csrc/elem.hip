@@ -1052,7 +1052,7 @@ void launch_gap_ln_head(const float* x, const float* g, const float* b, const fl
 // output (utils/utils.py:325-381).  cam = {roll, elevation (radians), focal_rel, cx_rel, cy_rel} on the device.
 // Quirks kept: up vectors at pixel centres (j + 0.5); latitude on linspace(-c, size - c, size) (end points included);
 // elevation == 0 -> constant up field.  Output layout matches pred_*_original: up [2][H][W], latitude [H][W] degrees.
-__global__ __launch_bounds__(256) void fields_from_params_kernel(const float* __restrict__ cam, int H, int W, float* __restrict__ up,
+__global__ __launch_bounds__(256) PF_NO_PK_F32 void fields_from_params_kernel(const float* __restrict__ cam, int H, int W, float* __restrict__ up,
                                                                  float* __restrict__ lat) {
   const float roll = cam[0], el = cam[1], f = cam[2] * (float)H;
   const float cx = (cam[3] + 0.5f) * (float)W, cy = (cam[4] + 0.5f) * (float)H;

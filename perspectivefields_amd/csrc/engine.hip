@@ -495,7 +495,8 @@ struct pf_engine {
                              // every element once per n-tile and halo overlap; split-f16 scheme only
   int rb_chain = 60;         // PF_RB_CHAIN: which linear layers of MiT stage 3 run in the row-block form (rb_gemm.hip) instead of the LDS tiles (igemm_sb) once the batch gives
                              // at least rb_min_blocks row blocks: bit mask 1 q, 2 kv, 4 proj, 8 fc1, 16 fc2, 32 the whole key / value branch as one launch (rb_chain.hip; overrides 2), 64 proj + norm2 + fc1 as one launch (overrides 4, 8) (0 = none)
-  int rb_min_blocks = 192;
+  int rb_min_blocks = 192;   // default for 256 CUs; pf_create rescales it to 3/4 of the device's CU count
+  int num_cus = 256;         // hipDeviceProp_t::multiProcessorCount (partitioned / smaller gfx950 configurations: CPX / DPX modes)
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
   bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
@@ -1071,7 +1072,7 @@ struct pf_engine {
         // one 64-row block per CU: the form pays only when the last round of blocks nearly fills the 256 CUs (same-box A/Bs, profiles/r04_rb_linear.md: B = 32 -> 224 blocks
         // +1.2 %, B = 64 -> 448 +1.2 %; B = 48 -> 336 -0.4 %, B = 24 -> 168 -0.9 %, B = 16 -> 112 -4.5 %)
         const long rb_blocks = (long)B * ((N + 63) / 64);
-        const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && rb_blocks >= rb_min_blocks && (rb_blocks % 256 == 0 || rb_blocks % 256 >= 192);
+        const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && rb_blocks >= rb_min_blocks && (rb_blocks % num_cus == 0 || rb_blocks % num_cus >= num_cus * 3 / 4);
         if (sr > 1 && use_rb && (rb_chain & 32) && mb.rsrkv.w && mb.qln.ln_s && fuse_ln) {
           // key / value branch in ONE launch (LayerNorm-1 of the gathered source tokens, 2 x 2 conv, LayerNorm, kv: rb_chain.hip); q with LayerNorm-1 folded into its
           // GEMM beside it: no LayerNorm-1 launch, no split-K conv + reduce, no normalised map in HBM
@@ -1553,6 +1554,11 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_RB_CHAIN")) e->rb_chain = atoi(v);
   if (const char* v = getenv("PF_DEFER_AT")) e->defer_at = atoi(v);
   if (const char* v = getenv("PF_DEFER_PRIO")) e->defer_prio = atoi(v);
+  if (!host_only) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
+    e->rb_min_blocks = e->num_cus * 3 / 4;  // "the last round of blocks nearly fills the chip": 192 of 256 CUs
+  }
   if (const char* v = getenv("PF_RB_MIN_BLOCKS")) e->rb_min_blocks = atoi(v);
 #ifdef PF_TUNING_BUILD
 #endif
@@ -1704,6 +1710,8 @@ int pf_forward_u8_graph(pf_handle h, int batch, const uint8_t* in, float* pg, fl
     if (h->graphs.size() >= 16) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
     h->graphs.push_back({key, exec});
   }
+  // a replay, too, overwrites the ParamNet input map (or, with another batch size, the region) a pending deferred branch is still working in
+  if (h->pn_pending) { h->issue_deferred(); (void)hipStreamWaitEvent(s, h->ev_pn_done, 0); h->pn_pending = false; }
   if (hipGraphLaunch(exec, s) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipGraphLaunch failed");
   return PF_OK;
 }

@@ -11,6 +11,17 @@
 namespace pf {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+// Packed fp32 (v_pk_*_f32) whose LOW lane reads the HIGH half of src1 -- hipcc's horizontal reductions `v_pk_add_f32 d, x, x op_sel:[0,1] op_sel_hi:[1,0]`, packed scalar
+// FMAs -- was exact alone and wrong in lanes 48..63 on MI355X while this library's kernels ran on another stream (profiles/r04_dw7_packed.md,
+// profiles/r05_pk_opsel_beside.txt), which is what every forward with the deferred ParamNet branch is.  tests/test_host_logic.py scans the built library and allows NO such
+// form anywhere.  Two remedies: translation units whose kernels hipcc packed that way (cnx_mlp / mit_mlp / rb_gemm / rb_chain) are compiled without the feature
+// (build.py NO_PK_F32_FLAGS: every function of the unit, so inlining stays legal -- a per-kernel attribute left the device helpers outlined and their arrays in
+// scratch); a single stand-alone kernel without helpers may carry this attribute instead.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PF_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define PF_NO_PK_F32  // host pass: the x86 target has no such feature
+#endif
 static constexpr int NT_F16X3 = 23;  // ConvParams::nterms value of the split-f16 scheme
 // Split-plane tensors: every `plane` stride argument is (elements between consecutive planes, always even) | format bit:
 // 0 = three exact bf16 planes (x == h + m + l), SB_FMT_F16 = the two fp16 planes of the split-f16 scheme (sb_split.h)

@@ -271,6 +271,18 @@ class Engine:
         _check(self.lib.pf_join_params(self._h, _stream_ptr()), self._h, "pf_join_params")
         self._deferred = []
 
+    def params_ready_event(self, stream):
+        """With the deferred branch on: an event that completes when the camera parameters of the forward issued LAST are complete.  `stream` (a torch stream of its own,
+        not the compute stream) is put behind the branch and the event is recorded there -- the compute stream is not touched, so a host thread can wait for the
+        parameters of batch i while batch i + 1 is still running.  The branch stays pending for the engine (the next forward still joins it in stream order)."""
+        import torch
+
+        with torch.cuda.stream(stream):
+            _check(self.lib.pf_join_params(self._h, ctypes.c_void_p(stream.cuda_stream)), self._h, "pf_join_params")
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return ev
+
     def _order_scratch(self, name: str, buf):
         """Engine-owned scratch (forward workspace, resize / post-process tables) is reused call after call.  Calls on ONE
         stream are ordered by the stream; when the caller's current stream changes (inference_batch on the default stream,
@@ -334,8 +346,10 @@ class Engine:
             )
         _check(rc, self._h, "pf_forward")
         if getattr(self, "defer_params", False) and params is not None:
-            # the branch writes `params` on the engine's stream: keep the tensor of the PREVIOUS forward alive until this one has been issued (it waits for that branch)
-            self._deferred = [params]
+            # The branch writes `params` on the engine's own stream, which the caching allocator knows nothing about: if the caller dropped its reference, the block could be
+            # handed out again on the caller's stream while the branch is still writing.  The branch of forward i is joined by forward i + 1 (in stream order, in front of
+            # its decoders), so the tensor of forward i must stay alive until forward i + 1 HAS BEEN ISSUED: keep the last two.
+            self._deferred = self._deferred[-1:] + [params]
         return pg, pl, params
 
     def forward_debug(self, images, shadow=True, ranges=True):

@@ -237,8 +237,8 @@ class PerspectiveFields(nn.Module):
         host right after inference (demo/demo.py:55-58, 4.9 MB per 640x640 image).  With `to_host` the four field tensors
         of every result are pinned CPU tensors (filled by async D2H; complete when the batch is yielded); the ParamNet
         scalars stay 0-d device tensors as in `inference_batch`.  `depth` = batches in flight.
-        With depth >= 2 the ParamNet branch of a batch runs on the engine's own stream beside the next batch's backbone (Engine.set_defer_params): a batch is yielded
-        only after the forward that follows it has been issued (or, for the last one, after the join), i.e. with its camera parameters complete."""
+        With depth >= 2 the ParamNet branch of a batch runs on the engine's own stream beside the next batch's backbone (Engine.set_defer_params); a batch is yielded
+        once ITS fields and ITS branch are complete (an event behind the branch, Engine.params_ready_event), with the scalar entries built after that."""
         dev = self.device
         if dev.type != "cuda":
             raise PfError(f"PerspectiveFields is on '{dev}': the MI355X engine has no CPU path. Call .cuda() first.")
@@ -253,16 +253,20 @@ class PerspectiveFields(nn.Module):
         defer = self.param_on and depth >= 2
         if defer:
             eng.set_defer_params(True)
+        s_join = torch.cuda.Stream(device=dev) if defer else None  # waits for the deferred branches only (Engine.params_ready_event)
 
-        def finish(item, nxt):
-            # the camera parameters of `item` are complete once the forward of the batch issued after it has run (its comp_done), or after the join
+        def finish(item):
+            # With the deferred branch the camera parameters of `item` are written on the engine's own stream.  Wait for THAT branch only (an event recorded behind it on
+            # s_join right after the forward was issued) -- not for the compute of the batch submitted after it, which would leave the GPU idle while the host prepares
+            # the next batch -- and only then build the scalar entries: for ParamNetConvNextRegress they are arithmetic on `params` (factors, general_vfov -> focal on the
+            # host), which must not be launched before the branch has written them.
             if defer:
-                if nxt is not None:
-                    nxt["comp_done"].synchronize()
-                else:
-                    with torch.cuda.stream(s_comp):
-                        eng.join_params()
-                    s_comp.synchronize()
+                item["params_done"].synchronize()
+                with torch.cuda.stream(s_join):  # NOT the compute stream: it already holds the next batch's forward
+                    for res, params in item["lazy"]:
+                        for r, extra in zip(res, self._param_dicts(params)):
+                            r.update(extra)
+                s_join.synchronize()
             item["done"].synchronize()
             return item["results"]
 
@@ -300,10 +304,12 @@ class PerspectiveFields(nn.Module):
             slot["done"] = up_done
             batch.record_stream(s_comp)
             s_comp.wait_event(up_done)
+            lazy = [] if defer else None
             with torch.cuda.stream(s_comp):
-                results = self._run(batch, sizes)
+                results = self._run(batch, sizes, lazy_params=lazy)
                 comp_done = torch.cuda.Event()
                 comp_done.record(s_comp)
+            params_done = eng.params_ready_event(s_join) if defer else None
             done = comp_done
             if to_host:
                 s_down.wait_event(comp_done)
@@ -321,13 +327,11 @@ class PerspectiveFields(nn.Module):
                             o += src.numel()
                     done = torch.cuda.Event()
                     done.record(s_down)
-            inflight.append({"results": results, "done": done, "comp_done": comp_done})
+            inflight.append({"results": results, "done": done, "comp_done": comp_done, "params_done": params_done, "lazy": lazy})
             if len(inflight) >= max(1, depth):
-                item = inflight.pop(0)
-                yield finish(item, inflight[0] if inflight else None)
+                yield finish(inflight.pop(0))
         while inflight:
-            item = inflight.pop(0)
-            yield finish(item, inflight[0] if inflight else None)
+            yield finish(inflight.pop(0))
         if defer:
             with torch.cuda.stream(s_comp):
                 eng.set_defer_params(False)
@@ -351,13 +355,15 @@ class PerspectiveFields(nn.Module):
     # pf_forward call is limited to PF_MAX_BATCH = 81 images by its 32-bit activation offsets, include/pf_hip.h)
     MAX_CHUNK = 64
 
-    def _run(self, batch, sizes) -> List[dict]:
+    def _run(self, batch, sizes, lazy_params=None) -> List[dict]:
+        """lazy_params: a list -> the ParamNet entries are NOT added to the result dicts here; (results of the chunk, raw (B,8) params) pairs are appended instead and
+        the caller adds them once the parameters are complete (inference_stream with the deferred branch)."""
         eng = self._get_engine()
         chunk = max(1, min(int(os.environ.get("PF_MAX_CHUNK", self.MAX_CHUNK)), eng.max_batch))
         if len(sizes) > chunk:
             out: List[dict] = []
             for i0 in range(0, len(sizes), chunk):
-                out.extend(self._run(batch[i0:i0 + chunk], sizes[i0:i0 + chunk]))
+                out.extend(self._run(batch[i0:i0 + chunk], sizes[i0:i0 + chunk], lazy_params))
             return out
         if self.precision == "auto":  # first batch: look at the activations this checkpoint produces, then settle on a precision for the model's lifetime
             probe = batch if batch.dtype == torch.uint8 else batch.permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8)  # forward(): (B,3,320,320) float -> the u8 NHWC form of the debug entry
@@ -368,9 +374,9 @@ class PerspectiveFields(nn.Module):
                                      f"(max |x| {outside[0]['max_abs']:.4g}, rms {outside[0]['rms']:.4g})") if outside else f"all {len(rng)} dense-layer inputs inside the split-f16 window"
             eng.set_precision(self.precision)
         pg, pl, params = eng.forward(batch)
-        return self._assemble(eng, pg, pl, params, sizes)
+        return self._assemble(eng, pg, pl, params, sizes, lazy_params)
 
-    def _assemble(self, eng, pg, pl, params, sizes) -> List[dict]:
+    def _assemble(self, eng, pg, pl, params, sizes, lazy_params=None) -> List[dict]:
         results = []
         fields = eng.postprocess_batch(pg, pl, sizes)  # the reference's per-image post-process loop as one launch
         for i, (h, w) in enumerate(sizes):
@@ -385,8 +391,11 @@ class PerspectiveFields(nn.Module):
                 }
             )
         if params is not None:
-            for i, extra in enumerate(self._param_dicts(params)):
-                results[i].update(extra)
+            if lazy_params is not None:
+                lazy_params.append((results, params))
+            else:
+                for i, extra in enumerate(self._param_dicts(params)):
+                    results[i].update(extra)
         return results
 
     def _param_dicts(self, params) -> List[dict]:

@@ -49,10 +49,11 @@ _PK_SRC1_HI = re.compile(r"v_pk_(?:fma|mul|add)_f32 (v\[\d+:\d+\]), (\S+), (\S+?
 
 
 def packed_src1_high_forms(lib):
-    """Packed-fp32 instructions whose LOW lane reads the HIGH half of src1 (op_sel[1] = 1) with src1 != src0, per kernel: [(mangled kernel name, instruction)].
+    """Packed-fp32 instructions whose LOW lane reads the HIGH half of src1 (op_sel[1] = 1), per kernel: [(mangled kernel name, instruction)] -- ANY such form,
+    including the compiler's horizontal reductions `v_pk_add_f32 d, x, x op_sel:[0,1] op_sel_hi:[1,0]` (the same register pair twice).
     On MI355X these forms returned wrong low-lane results in the upper lanes of a wave while kernels of this library ran on the same CUs from another stream -- exact
-    alone (profiles/r04_dw7_packed.md, scripts/microbench/pk_opsel_beside.hip: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  The compiler's horizontal reductions
-    (`v_pk_add_f32 d, x, x op_sel:[0,1] op_sel_hi:[1,0]`: the same register pair twice) have not shown the fault and are not reported."""
+    alone (profiles/r04_dw7_packed.md, scripts/microbench/pk_opsel_beside.hip: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32; form 7 = the x, x reduction).  Since r05
+    the kernels hipcc packed this way are compiled with PF_NO_PK_F32 (pf_kernels.h) and the library is expected to contain none."""
     hits = []
     for co in code_objects(lib):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
@@ -64,7 +65,7 @@ def packed_src1_high_forms(lib):
                     cur = line.split("<")[1][:-3]
                 elif "v_pk_" in line and "op_sel:[" in line:
                     m = _PK_SRC1_HI.search(line)
-                    if m and m.group(5) == "1" and m.group(2) != m.group(3):
+                    if m and m.group(5) == "1":
                         hits.append((cur, line.split("//")[0].strip()))
             p.wait()
     return hits

@@ -8,6 +8,8 @@
 //   form 4: v_pk_mul_f32 d, a, w     op_sel:[0,1] op_sel_hi:[1,1]; c += d (scalar adds)
 //   form 5: v_pk_add_f32 c, c, w     op_sel:[0,1] op_sel_hi:[1,0]       (the compiler's horizontal-reduction form: c.lo += w.hi, c.hi += w.lo)
 //   form 6: v_pk_fma_f32 c, a, w, c2 op_sel:[0,0,1] op_sel_hi:[1,1,0]   (src2 halves swapped), c2 = previous c
+//   form 7: v_pk_add_f32 d, x, x     op_sel:[0,1] op_sel_hi:[1,0]       (r05: the SAME register pair twice -- exactly what hipcc emitted 95 times for the horizontal sums of
+//                                                                        the LayerNorm code in cnx_mlp / mit_mlp / rb_*: d.lo = x.lo + x.hi, d.hi = x.hi + x.lo)
 #include <hip/hip_runtime.h>
 
 typedef float pk2 __attribute__((ext_vector_type(2)));
@@ -32,6 +34,8 @@ __global__ __launch_bounds__(256) void pk_form_kernel(const pk2* __restrict__ a_
     else if (FORM == 3) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "v"(w)); r0 = sfma(a.x, w.y, r0); r1 = sfma(a.y, w.x, r1); }
     else if (FORM == 4) { pk2 d; asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(w)); c.x = sadd(c.x, d.x); c.y = sadd(c.y, d.y); r0 = sadd(r0, smul(a.x, w.y)); r1 = sadd(r1, smul(a.y, w.y)); }
     else if (FORM == 5) { asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(c) : "v"(w)); r0 = sadd(r0, w.y); r1 = sadd(r1, w.x); }
+    else if (FORM == 7) { pk2 d; asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(c)); c.x = smul(d.x, w.x); c.y = sadd(smul(d.y, w.y), a.y);
+                          const float t0 = sadd(r0, r1), t1 = sadd(r1, r0); r0 = smul(t0, w.x); r1 = sadd(smul(t1, w.y), a.y); }
     else                { pk2 c2 = c; asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(c) : "v"(a), "v"(w), "v"(c2)); const float n0 = sfma(a.x, w.x, r1), n1 = sfma(a.y, w.y, r0); r0 = n0; r1 = n1; }
   }
   out_pk[t] = c;
@@ -49,6 +53,7 @@ extern "C" int pk_form_launch(int form, const void* a, const void* w, void* out_
     case 4: hipLaunchKernelGGL(pk_form_kernel<4>, dim3(blocks), dim3(256), 0, s, A, W, P, R, iters); break;
     case 5: hipLaunchKernelGGL(pk_form_kernel<5>, dim3(blocks), dim3(256), 0, s, A, W, P, R, iters); break;
     case 6: hipLaunchKernelGGL(pk_form_kernel<6>, dim3(blocks), dim3(256), 0, s, A, W, P, R, iters); break;
+    case 7: hipLaunchKernelGGL(pk_form_kernel<7>, dim3(blocks), dim3(256), 0, s, A, W, P, R, iters); break;
     default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -12,7 +12,9 @@ lib.pk_form_launch.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c
 FORMS = ["0: pk_fma  w = src1, both lanes x w.hi   op_sel:[0,1,0] op_sel_hi:[1,1,1]", "1: pk_fma  w = src0, both lanes x w.hi   op_sel:[1,0,0] op_sel_hi:[1,1,1]",
          "2: pk_fma  w = src1, both lanes x w.lo   op_sel_hi:[1,0,1]", "3: pk_fma  w = src1, halves swapped      op_sel:[0,1,0] op_sel_hi:[1,0,1]",
          "4: pk_mul  w = src1, both lanes x w.hi   op_sel:[0,1] op_sel_hi:[1,1]", "5: pk_add  src1 halves swapped          op_sel:[0,1] op_sel_hi:[1,0]",
-         "6: pk_fma  src2 halves swapped          op_sel:[0,0,1] op_sel_hi:[1,1,0]"]
+         "6: pk_fma  src2 halves swapped          op_sel:[0,0,1] op_sel_hi:[1,1,0]",
+         "7: pk_add  d, x, x (same pair twice)    op_sel:[0,1] op_sel_hi:[1,0]   <- hipcc's horizontal-sum form"]
+LAUNCHES = {7: 200}   # the form the product used to contain: 200 launches, 40 for the others
 m = PerspectiveFields("Paramnet-360Cities-edina-centered", weights="synthetic:0").eval().cuda()
 eng = m._get_engine()
 xb = torch.from_numpy(np.stack([m.aug.apply_image(synthetic_image(80, 100, seed=i)) for i in range(32)])).cuda()
@@ -36,7 +38,7 @@ for phase in ("alone", "beside this library's B=32 forward"):
     for f, name in enumerate(FORMS):
         bad, pat = 0, ""
         with torch.cuda.stream(side):
-            for it in range(40):
+            for it in range(LAUNCHES.get(f, 40)):
                 rc = lib.pk_form_launch(f, a.data_ptr(), w.data_ptr(), out_pk.data_ptr(), out_ref.data_ptr(), BLOCKS, ITERS, side.cuda_stream)
                 assert rc == 0
                 side.synchronize()
@@ -47,7 +49,7 @@ for phase in ("alone", "beside this library's B=32 forward"):
                         idx = d.nonzero()
                         lanes = sorted(set((idx[:, 0] % 64).tolist()))
                         pat = f" first: {idx.shape[0]} of {out_pk.numel()} values; element (0 = lo, 1 = hi) {sorted(set(idx[:, 1].tolist()))}; lanes {lanes[0]}..{lanes[-1]} ({len(lanes)} distinct); max|d| {float((out_pk - out_ref).abs().max()):.2e}"
-        lines.append(f"[{phase}] form {name}: {bad}/40 launches differ{pat}")
+        lines.append(f"[{phase}] form {name}: {bad}/{LAUNCHES.get(f, 40)} launches differ{pat}")
         print(lines[-1], flush=True)
     if phase != "alone":
         stop.set(); t.join()
