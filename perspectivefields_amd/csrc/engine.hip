@@ -59,6 +59,8 @@ struct ConvW {
   unsigned short* wsb = nullptr;  // weights split exactly into 3 bf16 planes (split-bf16 kernel), when Cin % 32 == 0
   unsigned short* wh16 = nullptr; // split-f16 scheme: per-channel power-of-two scaled weights as two fp16 planes wh, wl
   float* wh16_inv = nullptr;      //   and the inverse scale per output channel
+  unsigned short* wwino = nullptr; // Winograd F(2x2, 3x3) form of a 3x3 / stride-1 conv (wino.hip): transformed weights in fragment order
+  float* wwino_inv = nullptr;      //   and their inverse scale per output channel
   float* ln_s = nullptr;          // fused input LayerNorm (ConvParams::ln): column sums of the gamma-folded weights; nullptr = no fusion
   float ln_eps = 0.f;
   int Cout = 0, Cin = 0 /*padded*/, CinReal = 0, KH = 1, KW = 1, stride = 1, pad = 0, KWC = 0, KWCp = 0;
@@ -497,6 +499,9 @@ struct pf_engine {
                              // at least rb_min_blocks row blocks: bit mask 1 q, 2 kv, 4 proj, 8 fc1, 16 fc2, 32 the whole key / value branch as one launch (rb_chain.hip; overrides 2), 64 proj + norm2 + fc1 as one launch (overrides 4, 8) (0 = none)
   int rb_min_blocks = 192;   // default for 256 CUs; pf_create rescales it to 3/4 of the device's CU count
   int num_cus = 256;         // hipDeviceProp_t::multiProcessorCount (partitioned / smaller gfx950 configurations: CPX / DPX modes)
+  int wino_min_hw = 80;      // PF_WINO=<n>: 3x3 / stride-1 convs with Cin, Cout multiples of 64 on maps of at least n x n run as Winograd F(2x2, 3x3) (wino.hip; split-f16
+                             // scheme only; 0 = never).  Their inputs' window ends at 65504 / 4 (the input transform adds four values)
+  int wino_tile = -1;        // tile id of "wino256x64"
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
   bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
@@ -593,7 +598,8 @@ struct pf_engine {
     ConvW c;
     const int CinP = roundup(Cin, 4);
     const HostTensor& w = get(wkey, {Cout, Cin, K, K});
-    upload_conv_weights(c, pack_conv(w.data.data(), Cout, Cin, K, K, CinP, out_scale, &c.KWC, &c.KWCp), CinP, Cout);
+    const std::vector<float> packed = pack_conv(w.data.data(), Cout, Cin, K, K, CinP, out_scale, &c.KWC, &c.KWCp);
+    upload_conv_weights(c, packed, CinP, Cout);
     if (bias_override) c.b = upload(*bias_override);
     else if (!bkey.empty()) {
       std::vector<float> b = get(bkey, {Cout}).data;
@@ -601,6 +607,13 @@ struct pf_engine {
       c.b = upload(b);
     }
     c.Cout = Cout; c.Cin = CinP; c.CinReal = Cin; c.KH = c.KW = K; c.stride = stride; c.pad = pad;
+    if (wino_min_hw > 0 && split_bf16 && K == 3 && stride == 1 && pad == 1 && CinP % 64 == 0 && Cout % 64 == 0 && c.KWCp == c.KWC) {
+      std::vector<unsigned short> planes;
+      std::vector<float> inv;
+      wino_pack_weights(packed.data(), Cout, CinP, c.KWCp, &planes, &inv);
+      c.wwino = upload_u16(planes);
+      c.wwino_inv = upload(inv);
+    }
     return c;
   }
   // ln_pfx != "" (and fuse_ln): the LayerNorm `ln_pfx` in front of this Linear is folded into it (fold_ln_linear)
@@ -916,6 +929,7 @@ struct pf_engine {
       const ConvW& wg = *calls[g].w;
       ConvPtrs& q = p.g[g];
       q.x = calls[g].x.f; q.x2 = calls[g].x2.f; q.w = wg.w; q.w_sb = wg.wsb; q.w_h16 = wg.wh16; q.w_h16_inv_scale = wg.wh16_inv; q.bias = wg.b; q.bias_tab = wg.btab;
+      q.w_wino = wg.wwino; q.w_wino_inv = wg.wwino_inv;
       q.res1 = calls[g].res1; q.res2 = calls[g].res2; q.y = calls[g].y.f;
       q.x_sb = calls[g].x.s.p; q.x2_sb = calls[g].x2.s.p; q.y_sb = calls[g].y.s.p;
       q.ln_colsum = wg.ln_s;
@@ -955,6 +969,8 @@ struct pf_engine {
       else if (c.tuning && c.tune_scratch) { tile = tune_conv(p, c); tile_cache[key] = tile; }
     }
     if (!conv_tile_usable(p, tile)) tile = conv_default_tile(p);
+    // Winograd form where it exists and the map is large enough (the tile table knows the direct tiles only); never while tuning (tune_conv times the direct tiles)
+    if (wino_min_hw > 0 && wino_tile >= 0 && !(c.tuning && c.tune_scratch) && p.Ho >= wino_min_hw && p.Wo >= wino_min_hw && conv_tile_usable(p, wino_tile)) tile = wino_tile;
     ProfScope ps(c.prof, c.s, conv_tile_is_sb(tile) ? PC_IGEMM_SB : PC_IGEMM, 2.0 * ngroups * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal, p.M * ngroups, w.Cout, w.KH * w.KW * w.CinReal, w.KH);
     launch_conv_tile(p, tile, c.s);
   }
@@ -1551,6 +1567,8 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_LN")) e->fuse_ln = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
+  if (const char* v = getenv("PF_WINO")) e->wino_min_hw = atoi(v);
+  for (int t = 0; t < conv_num_tiles(); ++t) if (strcmp(conv_tile_name(t), "wino256x64") == 0) e->wino_tile = t;
   if (const char* v = getenv("PF_RB_CHAIN")) e->rb_chain = atoi(v);
   if (const char* v = getenv("PF_DEFER_AT")) e->defer_at = atoi(v);
   if (const char* v = getenv("PF_DEFER_PRIO")) e->defer_prio = atoi(v);
@@ -2024,6 +2042,12 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
     const F16Planes f = split_f16x2(packed, Cout);
     p.g[0].w_h16 = tmp.up_u16(f.planes); p.g[0].w_h16_inv_scale = tmp.up(f.inv_scale);
   }
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && C2 == 0 && Cin % 16 == 0 && Cout % 64 == 0 && p.KWCp == p.KWC) {  // Winograd form (tile "wino256x64")
+    std::vector<unsigned short> planes;
+    std::vector<float> inv;
+    wino_pack_weights(packed.data(), Cout, Cin, p.KWCp, &planes, &inv);
+    p.g[0].w_wino = tmp.up_u16(planes); p.g[0].w_wino_inv = tmp.up(inv);
+  }
   p.g[0].bias = tmp.up(hb, Cout);
   p.g[0].x = x; p.g[0].x2 = x2; p.g[0].res1 = res1; p.g[0].res2 = res2; p.g[0].y = y;
   p.g[0].x_sb = x_planes; p.g[0].x2_sb = x2_planes; p.g[0].y_sb = y_planes;
@@ -2294,6 +2318,9 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   float *dx = nullptr, *dw = nullptr, *dy = nullptr, *db = nullptr;
   unsigned short *dsb = nullptr, *dxs = nullptr, *dys = nullptr, *dh16 = nullptr;
   float* dinv = nullptr;
+  TmpDev wino_tmp;                    // Winograd weights (freed below)
+  unsigned short* dwino = nullptr;
+  float* dwino_inv = nullptr;
   if (hipMalloc(&dx, nx * 4) != hipSuccess || hipMalloc(&dw, nw * 4) != hipSuccess || hipMalloc(&dy, ny * 4) != hipSuccess ||
       hipMalloc(&db, (size_t)Cout * 4) != hipSuccess || hipMalloc(&dsb, nw * 10) != hipSuccess || hipMalloc(&dh16, nw * 4) != hipSuccess ||
       hipMalloc(&dinv, (size_t)Cout * 4) != hipSuccess ||
@@ -2312,14 +2339,22 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
     const F16Planes f = split_f16x2(hw, Cout);
     (void)hipMemcpy(dh16, f.planes.data(), nw * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dinv, f.inv_scale.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
+    if (K == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 && Cout % 64 == 0 && p.KWCp == p.KWC) {  // Winograd form (tile "wino256x64")
+      std::vector<unsigned short> planes;
+      std::vector<float> inv;
+      wino_pack_weights(hw.data(), Cout, Cin, p.KWCp, &planes, &inv);
+      wino_tmp.sync_free(nullptr);
+      dwino = wino_tmp.up_u16(planes); dwino_inv = wino_tmp.up(inv);
+    }
   }
   p.g[0].x = dx; p.g[0].w = dw; p.g[0].bias = db; p.g[0].y = dy;
   if (Cin % 32 == 0 || Cin == 4) { p.g[0].w_sb = dsb; p.g[0].w_h16 = dh16; p.g[0].w_h16_inv_scale = dinv; }
+  p.g[0].w_wino = dwino; p.g[0].w_wino_inv = dwino_inv;
   // fmt 1: A operand as split planes (fp32 copy withheld); fmt 2: split planes in and out
   const size_t fbit = p.nterms == NT_F16X3 ? SB_FMT_F16 : 0;  // plane format of the scheme under test (nx, ny are multiples of 4)
   if (fmt >= 1) { launch_split_planes(dx, dxs, nx | fbit, (long)nx, nullptr); p.g[0].x_sb = dxs; p.x_sb_plane = nx | fbit; p.g[0].x = nullptr; }
   if (fmt >= 2) { p.g[0].y_sb = dys; p.y_sb_plane = ny | fbit; p.g[0].y = nullptr; }
-  if (!conv_tile_usable(p, tile_id) && tile_id >= 0) { *ms_out = -1.f; (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys); (void)hipFree(dh16); (void)hipFree(dinv); return PF_OK; }
+  if (!conv_tile_usable(p, tile_id) && tile_id >= 0) { *ms_out = -1.f; (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys); (void)hipFree(dh16); (void)hipFree(dinv); wino_tmp.sync_free(nullptr); return PF_OK; }
   hipEvent_t a, b;
   (void)hipEventCreate(&a); (void)hipEventCreate(&b);
   launch_conv_tile(p, tile_id, nullptr);
@@ -2331,9 +2366,28 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   float t = 0.f;
   (void)hipEventElapsedTime(&t, a, b);
   *ms_out = t / iters;
+  if (getenv("PF_WINO_STAMPS") && strcmp(conv_tile_name(tile_id), "wino256x64") == 0) {  // timing aid: s_memtime stamps of block 17's eight waves of one more launch, to stderr
+    unsigned long long* ds = nullptr;
+    if (hipMalloc(&ds, 8 * 128 * 8) == hipSuccess) {
+      (void)hipMemset(ds, 0, 8 * 128 * 8);
+      p.stamps = ds;
+      launch_conv_tile(p, tile_id, nullptr);
+      p.stamps = nullptr;
+      std::vector<unsigned long long> hs(8 * 128);
+      (void)hipMemcpy(hs.data(), ds, hs.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(ds);
+      for (int w = 0; w < 8; ++w) {
+        const unsigned long long t0 = hs[w * 128];
+        fprintf(stderr, "wino stamps %dx%d Cin=%d wave %d:", H, W, Cin, w);
+        for (int i = 1; i < 128; ++i) if (hs[w * 128 + i]) fprintf(stderr, " [%d]%llu", i, hs[w * 128 + i] - t0);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   (void)hipFree(dx); (void)hipFree(dw); (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dsb); (void)hipFree(dxs); (void)hipFree(dys); (void)hipFree(dh16); (void)hipFree(dinv);
+  wino_tmp.sync_free(nullptr);
   return rc;
 }
 

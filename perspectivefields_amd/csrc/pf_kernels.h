@@ -41,6 +41,9 @@ struct ConvPtrs {
   // [2^13, 2^14)) as two fp16 planes [2][Cout][KH][KWCp]: wh = fp16(w S), wl = fp16(w S - wh); w_h16_inv_scale = 1 / S
   const unsigned short* w_h16 = nullptr;
   const float* w_h16_inv_scale = nullptr;  // [Cout]: applied to the accumulators before the bias
+  // Winograd F(2x2, 3x3) form of a 3x3 / stride-1 conv (wino.hip): U = G g G^T, per-channel power-of-two scale, two fp16 planes in MFMA fragment order
+  const unsigned short* w_wino = nullptr;
+  const float* w_wino_inv = nullptr;       // [Cout]
   const float* bias = nullptr;      // [Cout] or nullptr
   const float* bias_tab = nullptr;  // [9][Cout]: bias per 3x3 border case (folded Linear->conv), overrides bias
   const float* res1 = nullptr;      // [M][Cout] or nullptr (may alias y)
@@ -90,6 +93,7 @@ struct ConvParams {
   unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)
   unsigned w_sb_plane_bytes;            // bytes of one bf16 weight plane
   size_t x_sb_plane = 0, x2_sb_plane = 0, y_sb_plane = 0;  // elements between consecutive planes of x_sb / x2_sb / y_sb
+  unsigned long long* stamps = nullptr;  // timing aid (wino.hip, PF_WINO_STAMPS=1 in pf_op_conv2d_bench): s_memtime stamps of block 17, [wave][128]
   // fills the derived fields (Ho, Wo, M, Cin, *_bytes) from the primary ones
   void finish() {
     Cin = C1 + C2;
@@ -127,6 +131,10 @@ void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s);
 int conv_splitk_factor(const ConvParams& p);
 int conv_splitk_shape(long M, int Cout, int KH, int KWCp, int groups);  // its shape-only part
 const char* conv_tile_name(int tile_id);
+// Winograd F(2x2, 3x3) kernel (wino.hip; tile "wino256x64" of the split family)
+bool conv_wino_ok(const ConvParams& p);
+void launch_conv_wino(const ConvParams& p, hipStream_t s);
+void wino_pack_weights(const float* packed /*[Cout][3][KWCp], k = (kx, ci)*/, int Cout, int Cin, int KWCp, std::vector<unsigned short>* planes, std::vector<float>* inv_scale);
 
 // rows x C LayerNorm (biased variance), y may alias x
 // Optional split-plane output (sb_split.h) of the elementwise / attention kernels: y_sb != nullptr writes the result as

@@ -1,0 +1,372 @@
+// Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions of the decoders (decode_head.py:224-256 ResidualConvUnit, gravity_head.py:139-176), split-f16
+// arithmetic: 16 "position" GEMMs of K = Cin instead of 9 taps x 4 pixels -- 2.25x fewer MFMAs than the halo kernel (igemm_sbh.hip) for the same output.
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A      d: 4 x 4 input tile (2 x 2 outputs + halo), g: 3 x 3 filter
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]    G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]    A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// U = G g G^T is made once on the host (fp64), scaled per output channel by a power of two and split into two fp16 planes like every split-f16 weight (engine.hip
+// split_f16x2), and stored in MFMA FRAGMENT ORDER so that a wave streams it from L2 straight into registers (no LDS, as rb_gemm.hip does).
+// V = B^T d B is adds only (fp32), then the usual 2-way fp16 split (sb_split.h); |V| <= 4 max|d|, so this kernel's window ends at 65504 / 4 (conv_wino_ok's caller).
+//
+// Block = 16 x 16 output pixels of one image (8 x 8 tiles = 64 GEMM columns) x 64 output channels x all 16 positions, 8 waves, one block per CU (LDS):
+//   wave w owns positions 2w, 2w + 1: accumulators [2 pos][2 cout sub-tiles][2 tile sub-tiles] x 16 = 128 registers; M^T = U V^T, i.e. the WEIGHTS are the MFMA's
+//   A operand (rows = output channels) -- four consecutive accumulator registers are then four consecutive channels of one tile: 16-byte LDS / global accesses.
+//   K loop in chunks of 16 input channels (one MFMA k step):
+//     G  global -> registers: the 18 x 18 input halo of chunk c + 2 (3 float4 per thread, out-of-image pixels read as zero through the buffer range check)
+//     S  registers -> raw LDS tile (pixel pitch 96 B: conflict-free ds_read_b128 for the transform's lane map)
+//     T  raw LDS -> V: thread = (tile, half nu_h of the four columns, 4 channels): 12 pixels in, row transform (3 columns), column transform (2 of 4 columns),
+//        split, 16 x ds_write_b64 into the A-operand buffer of chunk c + 1 ([pos][plane][tile][16 ch] fp16, 32-byte rows, 16-byte pieces XOR-swizzled by bit 3
+//        of the tile index: conflict-free fragment reads).  nu_h is WAVE-uniform (no divergent formulas).
+//     M  per position: 4 fragment reads + 4 weight fragments (global, loaded one position ahead) -> 12 MFMAs
+//   T(c + 1) and M(c) sit in the same loop body (two A buffers); two barriers per chunk.
+//   Epilogue: per cout sub-tile the 16 position accumulators go through LDS ([pos][tile][32 ch] fp32, 128 KB); thread = (tile, 4 channels) reads its 16 values,
+//   applies A^T . A, the weight scale, bias / activation / residuals (the same order as epilogue_nhwc) and stores 4 pixels x 16 bytes.
+#include <cmath>
+#include <cstring>
+
+#include "igemm_common.h"
+#include "sb_split.h"
+
+namespace pf {
+
+namespace {
+
+typedef _Float16 wf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int W_TY = 8, W_TX = 8;             // tiles per block
+constexpr int W_PY = 2 * W_TY, W_PX = 2 * W_TX;  // output pixels per block
+constexpr int W_HY = W_PY + 2, W_HX = W_PX + 2;  // input halo
+constexpr int W_NPIX = W_HY * W_HX;           // 324
+constexpr int W_BN = 64;                      // output channels per block
+constexpr int W_KC = 16;                      // input channels per chunk
+constexpr int W_NT = 512;
+constexpr int RAW_PITCH = 96;                 // bytes per halo pixel (64 used)
+constexpr int RAW_BYTES = W_NPIX * RAW_PITCH; // 31104
+constexpr int A_PLANE = 64 * 32;              // bytes of one (position, plane): 64 tiles x 16 fp16
+constexpr int A_POS = 2 * A_PLANE;
+constexpr int A_BUF = 16 * A_POS;             // 65536
+constexpr int M_POS = 64 * 128;               // epilogue: bytes of one position: 64 tiles x 32 fp32
+constexpr int W_SMEM = 2 * A_BUF + RAW_BYTES; // 162176 <= 163840
+static_assert(16 * M_POS <= 2 * A_BUF, "epilogue staging reuses the operand buffers");
+constexpr int RAW_F4 = (W_NPIX * 4 + W_NT - 1) / W_NT;  // float4 loads per thread per chunk (3)
+
+__device__ __forceinline__ float4 f4add(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(const float4 a, const float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+}  // namespace
+
+// s_memtime stamps of block 17's waves (STAMP instantiation only: PF_WINO_STAMPS=1 in pf_op_conv2d_bench; a stamp drains lgkmcnt, i.e. it perturbs the step it sits in)
+#define WINO_STAMP(i) do { if constexpr (STAMP) { if (blockIdx.x == 17 && lane == 0) p.stamps[wave * 128 + (i)] = __builtin_readcyclecounter(); } } while (0)
+
+template <bool STAMP>
+__global__ __launch_bounds__(W_NT, 2) void wino_f2x2_kernel(const ConvParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char wsm[W_SMEM];
+  unsigned char* const Ab = wsm;                  // [2][16 pos][2 planes][64 tiles][32 B]
+  unsigned char* const Raw = wsm + 2 * A_BUF;     // [324 px][96 B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;  // wave in an SGPR: nuh below selects formulas by scalar branches
+  const int tilesN = p.Cout / W_BN;
+  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
+  const int nblk1 = p.B * tilesY * tilesX * tilesN;
+  int t = xcd_tile_index(nblk1 * p.groups);
+  const bool g1 = t >= nblk1;
+  if (g1) t -= nblk1;
+  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
+  const int nt = t % tilesN;
+  int mt = t / tilesN;
+  const int bx = mt % tilesX; mt /= tilesX;
+  const int by = mt % tilesY;
+  const int bimg = mt / tilesY;
+  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
+  const int nC = p.Cin / W_KC;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
+
+  // ---- G / S: raw halo element e = tid + 512 i -> (pixel e / 4, float4 e % 4 of the 16-channel chunk)
+  unsigned g_off[RAW_F4];
+#pragma unroll
+  for (int i = 0; i < RAW_F4; ++i) {
+    const int e = tid + W_NT * i, pix = e >> 2, c4 = e & 3;
+    const int hy = pix / W_HX, hx = pix - hy * W_HX;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
+  }
+  float4 ra[RAW_F4];
+  auto load_raw = [&](int c) {
+    const bool live = c < nC;
+#pragma unroll
+    for (int i = 0; i < RAW_F4; ++i) ra[i] = buf_load16(rx, (live && g_off[i] != OOB) ? g_off[i] + (unsigned)c * (W_KC * 4) : OOB);
+  };
+  auto store_raw = [&]() {
+#pragma unroll
+    for (int i = 0; i < RAW_F4; ++i) {
+      const int e = tid + W_NT * i, pix = e >> 2, c4 = e & 3;
+      if (pix < W_NPIX) *reinterpret_cast<float4*>(Raw + pix * RAW_PITCH + c4 * 16) = ra[i];
+    }
+  };
+
+  // ---- T: thread -> (tile tt = 16 (wave / 2) + lane / 4, column half nuh = wave & 1, channel quad cg = lane & 3)
+  // The two column halves differ only in WHICH three of the tile's four pixel columns a thread holds and in one sign, so they share one instruction stream:
+  //   nuh = 0: X, Y, Z = columns 0, 1, 2, s = +1:  nu 0 = c0 - c2 = X - Z,  nu 1 = c1 + c2 = Z + s Y
+  //   nuh = 1: X, Y, Z = columns 2, 3, 1, s = -1:  nu 2 = c2 - c1 = X - Z,  nu 3 = c1 - c3 = Z + s Y
+  // (wave-uniform column offsets and sign: no per-element selects, no second copy of the code)
+  const int nuh = wave & 1, cg = lane & 3;
+  const int tt = (wave >> 1) * 16 + (lane >> 2), tty = tt >> 3, ttx = tt & 7;
+  const unsigned char* const t_src = Raw + ((2 * tty) * W_HX + 2 * ttx) * RAW_PITCH + cg * 16;
+  const int t_col[3] = {(nuh ? 2 : 0) * RAW_PITCH, (nuh ? 3 : 1) * RAW_PITCH, (nuh ? 1 : 2) * RAW_PITCH};
+  const float t_sgn = nuh ? -1.f : 1.f;
+  const int t_dst = tt * 32 + (((cg >> 1) ^ ((tt >> 3) & 1)) * 16) + (cg & 1) * 8 + 2 * nuh * A_POS;  // inside one (position, plane); positions xi * 4 + 2 nuh (+ 1)
+  auto transform = [&](int buf) {
+    unsigned char* const dst = Ab + buf * A_BUF + t_dst;
+    auto ld_row = [&](int i, float4 (&d)[3]) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) d[j] = *reinterpret_cast<const float4*>(t_src + i * (W_HX * RAW_PITCH) + t_col[j]);
+    };
+    auto emit = [&](int xi, const float4 (&r)[3]) {  // row xi of B^T d for the columns X, Y, Z -> positions xi * 4 + 2 nuh (+ 1)
+      const float4 o0 = f4sub(r[0], r[2]);
+      const float4 o1 = make_float4(fmaf(t_sgn, r[1].x, r[2].x), fmaf(t_sgn, r[1].y, r[2].y), fmaf(t_sgn, r[1].z, r[2].z), fmaf(t_sgn, r[1].w, r[2].w));  // +-1: exact, one rounding like the add
+      uint2 h0, l0, h1, l1;
+      split4_f16(o0, h0, l0);
+      split4_f16(o1, h1, l1);
+      *reinterpret_cast<uint2*>(dst + (xi * 4) * A_POS) = h0;
+      *reinterpret_cast<uint2*>(dst + (xi * 4) * A_POS + A_PLANE) = l0;
+      *reinterpret_cast<uint2*>(dst + (xi * 4 + 1) * A_POS) = h1;
+      *reinterpret_cast<uint2*>(dst + (xi * 4 + 1) * A_POS + A_PLANE) = l1;
+    };
+    // rows 1 and 2 first (xi = 1: d1 + d2, xi = 2: d2 - d1), then row 0 (xi = 0: d0 - d2), then row 3 (xi = 3: d1 - d3): at most three pixel rows (36 registers) live
+    float4 d1[3], d2[3], dx[3], r[3];
+    ld_row(1, d1);
+    ld_row(2, d2);
+    ld_row(0, dx);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r[j] = f4add(d1[j], d2[j]);
+    emit(1, r);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r[j] = f4sub(d2[j], d1[j]);
+    emit(2, r);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r[j] = f4sub(dx[j], d2[j]);
+    asm volatile("" ::: "memory");  // keep row 3's reads behind row 0's use (register pressure: the block sits at the 256-register limit)
+    ld_row(3, dx);
+    emit(0, r);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r[j] = f4sub(d1[j], dx[j]);
+    emit(3, r);
+  };
+
+  // ---- M: weights in fragment order [n tile][chunk][pos][cout sub-tile][plane][lane][8 fp16]
+  const unsigned short* const wbase = P.w_wino + ((size_t)nt * nC * 16) * 2048 + lane * 8;  // 2048 ushorts = 4 KB per (chunk, pos)
+  u32x4 bw[2][2][2];  // [position slot][cout sub-tile][plane]
+  auto load_w = [&](int c, int slot) {
+    const int cc = c < nC ? c : nC - 1;  // past the end: a harmless reload
+    const unsigned short* src = wbase + ((size_t)cc * 16 + 2 * wave + slot) * 2048;
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bw[slot][ns][pl] = *reinterpret_cast<const u32x4*>(src + (ns * 2 + pl) * 512);
+  };
+  f32x16 acc[2][2][2];  // [position slot][cout sub-tile][tile sub-tile]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][m][e] = 0.f;
+  const int a_frag = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16);  // tile row l31 of a 32-tile sub-tile, this lane's 8 channels (the swizzle bit is the same for rows r and r + 32)
+  auto mma_pos = [&](int buf, int slot) {
+    asm volatile("" ::: "memory");  // one position's fragments at a time
+    const unsigned char* src = Ab + buf * A_BUF + (2 * wave + slot) * A_POS + a_frag;
+    u32x4 av[2][2];  // [tile sub-tile][plane]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) av[m][pl] = *reinterpret_cast<const u32x4*>(src + pl * A_PLANE + m * (32 * 32));
+    constexpr int TW[3] = {0, 1, 0}, TV[3] = {1, 0, 0};  // wh al, wl ah, wh ah (smallest terms first); consecutive MFMAs are independent
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+      for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          acc[slot][ns][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, bw[slot][ns][TW[t3]]), __builtin_bit_cast(wf16x8, av[m][TV[t3]]), acc[slot][ns][m], 0, 0, 0);
+  };
+
+  // ---- prologue: raw(0) -> LDS -> V(0); raw(1) -> LDS; raw(2) in registers; weights of (0, slot 0)
+  load_raw(0);
+  store_raw();
+  load_raw(1);
+  __syncthreads();
+  transform(0);
+  __syncthreads();
+  store_raw();
+  load_raw(2);
+  __syncthreads();
+
+  // The two waves of a SIMD (waves w and w + 4: a block's waves go to the SIMDs cyclically) run the chunk's two phases in OPPOSITE order -- one transforms (VALU + LDS)
+  // while the other multiplies (MFMA): with all eight waves in step the matrix cores idled through every transform phase (profiles/r05_winograd.md).
+  const int t_half = (wave >> 2) & 1;  // the half step in which this wave transforms
+  WINO_STAMP(0);
+  // two complete copies of the loop (same number of barriers in each): a branch INSIDE one loop body made hipcc spill > 100 registers, either order alone needs none
+  auto tail = [&](int c) {
+    if (c < 16) WINO_STAMP(10 + 6 * c);
+    __syncthreads();                      // V(c + 1) complete, raw(c + 1) consumed, A buffer `buf` free
+    if (c < 16) WINO_STAMP(11 + 6 * c);
+    store_raw();                          // raw(c + 2)
+    load_raw(c + 3);
+    if (c < 16) WINO_STAMP(12 + 6 * c);
+    __syncthreads();
+    if (c < 16) WINO_STAMP(13 + 6 * c);
+  };
+  if (t_half == 0) {
+#pragma unroll 1
+    for (int c = 0; c < nC; ++c) {
+      const int buf = c & 1;
+      if (c < 16) WINO_STAMP(8 + 6 * c);
+      if (c + 1 < nC) transform(buf ^ 1);  // block-uniform
+      if (c < 16) WINO_STAMP(9 + 6 * c);
+      load_w(c, 0);
+      load_w(c, 1);
+      mma_pos(buf, 0);
+      mma_pos(buf, 1);
+      tail(c);
+    }
+  } else {
+#pragma unroll 1
+    for (int c = 0; c < nC; ++c) {
+      const int buf = c & 1;
+      if (c < 16) WINO_STAMP(8 + 6 * c);
+      load_w(c, 0);
+      load_w(c, 1);
+      mma_pos(buf, 0);
+      mma_pos(buf, 1);
+      if (c < 16) WINO_STAMP(9 + 6 * c);
+      if (c + 1 < nC) transform(buf ^ 1);
+      tail(c);
+    }
+  }
+  WINO_STAMP(1);
+
+  // ---- epilogue: per cout sub-tile, the 16 positions through LDS
+  float* const Ms = reinterpret_cast<float*>(wsm);
+  const int e_c4 = tid & 7, e_tile = tid >> 3, e_ty = e_tile >> 3, e_tx = e_tile & 7;
+  const int act = p.act, post_relu = p.post_relu;
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns) {
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int tile = m * 32 + l31;
+        unsigned char* dstp = reinterpret_cast<unsigned char*>(Ms) + (2 * wave + slot) * M_POS + tile * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x16& a = acc[slot][ns][m];
+          *reinterpret_cast<float4*>(dstp + (((2 * j + hi) ^ (tile & 7)) * 16)) = make_float4(a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]);
+        }
+      }
+    __syncthreads();
+    {
+      const unsigned char* srcp = reinterpret_cast<const unsigned char*>(Ms) + e_tile * 128 + ((e_c4 ^ (e_tile & 7)) * 16);
+      float4 s0[4], s1[4];  // A^T M: rows 0 / 1, columns nu = 0..3
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        const float4 m0 = *reinterpret_cast<const float4*>(srcp + (0 * 4 + nu) * M_POS), m1 = *reinterpret_cast<const float4*>(srcp + (1 * 4 + nu) * M_POS);
+        const float4 m2 = *reinterpret_cast<const float4*>(srcp + (2 * 4 + nu) * M_POS), m3 = *reinterpret_cast<const float4*>(srcp + (3 * 4 + nu) * M_POS);
+        s0[nu] = f4add(f4add(m0, m1), m2);
+        s1[nu] = f4sub(f4sub(m1, m2), m3);
+      }
+      float4 yv[2][2];
+      yv[0][0] = f4add(f4add(s0[0], s0[1]), s0[2]); yv[0][1] = f4sub(f4sub(s0[1], s0[2]), s0[3]);
+      yv[1][0] = f4add(f4add(s1[0], s1[1]), s1[2]); yv[1][1] = f4sub(f4sub(s1[1], s1[2]), s1[3]);
+      const int n = n0 + ns * 32 + e_c4 * 4;
+      const float4 sc = *reinterpret_cast<const float4*>(P.w_wino_inv + n);
+      float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P.bias) bb = *reinterpret_cast<const float4*>(P.bias + n);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int oy = oy0 + 2 * e_ty + a, ox = ox0 + 2 * e_tx + b;
+          if (oy >= p.Ho || ox >= p.Wo) continue;
+          const long o = ((long)(bimg * p.Ho + oy) * p.Wo + ox) * p.ldy + n;
+          float4 w = yv[a][b];
+          w.x = fmaf(w.x, sc.x, bb.x); w.y = fmaf(w.y, sc.y, bb.y); w.z = fmaf(w.z, sc.z, bb.z); w.w = fmaf(w.w, sc.w, bb.w);
+          if (act == ACT_RELU) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+          else if (act == ACT_GELU) { w.x = gelu_erf(w.x); w.y = gelu_erf(w.y); w.z = gelu_erf(w.z); w.w = gelu_erf(w.w); }
+          if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
+          if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
+          if (post_relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+          *reinterpret_cast<float4*>(P.y + o) = w;
+        }
+    }
+    __syncthreads();
+    WINO_STAMP(2 + ns);
+  }
+}
+
+// 3x3 / stride 1 / pad 1, split-f16 scheme, one fp32 NHWC input, fp32 NHWC output, Winograd weights present
+bool conv_wino_ok(const ConvParams& p) {
+  if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nterms != NT_F16X3 || p.nchw_out || p.ups || p.ln || p.splitk > 1) return false;
+  if (p.C2 != 0 || (p.Cin % W_KC) != 0 || (p.Cout % W_BN) != 0 || (p.ldy & 3) != 0) return false;
+  for (int g = 0; g < p.groups; ++g) {
+    const ConvPtrs& q = p.g[g];
+    if (!q.w_wino || !q.w_wino_inv || !q.x || !q.y || q.x_sb || q.y_sb || q.head_kind || q.bias_tab) return false;
+  }
+  return true;
+}
+
+void launch_conv_wino(const ConvParams& p, hipStream_t s) {
+  const int tilesN = p.Cout / W_BN, tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
+  const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(W_NT);
+  if (p.stamps) hipLaunchKernelGGL(wino_f2x2_kernel<true>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(wino_f2x2_kernel<false>, grid, block, 0, s, p);
+}
+
+// Host side: packed fp32 weights [Cout][3][KWCp] (k = (kx, ci), ci fastest) -> U = G g G^T per (cout, cin) in fp64, scaled per output channel by a power of two
+// (largest |U| of the channel in [2^13, 2^14)), split into wh = fp16(U S), wl = fp16(U S - wh), laid out in the kernel's fragment order.
+void wino_pack_weights(const float* packed, int Cout, int Cin, int KWCp, std::vector<unsigned short>* planes, std::vector<float>* inv_scale) {
+  const int nC = Cin / W_KC, tilesN = Cout / W_BN;
+  planes->assign((size_t)tilesN * nC * 16 * 2048, 0);
+  inv_scale->assign(Cout, 1.f);
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  std::vector<double> U((size_t)Cin * 16);
+  auto bits16 = [](_Float16 h) { unsigned short u; std::memcpy(&u, &h, 2); return u; };
+  for (int n = 0; n < Cout; ++n) {
+    double mx = 0.0;
+    for (int ci = 0; ci < Cin; ++ci) {
+      double g[3][3], t[4][3];
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = packed[((size_t)n * 3 + ky) * KWCp + kx * Cin + ci];
+      for (int i = 0; i < 4; ++i)
+        for (int kx = 0; kx < 3; ++kx) t[i][kx] = G[i][0] * g[0][kx] + G[i][1] * g[1][kx] + G[i][2] * g[2][kx];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+          U[(size_t)ci * 16 + i * 4 + j] = u;
+          mx = std::max(mx, std::fabs(u));
+        }
+    }
+    int e = 0;
+    if (mx > 0.0 && std::isfinite(mx)) { int ex; (void)std::frexp(mx, &ex); e = 14 - ex; }
+    e = std::max(-100, std::min(100, e));
+    const double S = std::ldexp(1.0, e);
+    (*inv_scale)[n] = std::ldexp(1.0f, -e);
+    const int nt = n / W_BN, ns = (n % W_BN) / 32, row = n % 32;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const int c = ci / W_KC, k = ci % W_KC, lane = row + 32 * (k / 8), el = k % 8;
+      for (int pos = 0; pos < 16; ++pos) {
+        const double us = U[(size_t)ci * 16 + pos] * S;
+        const _Float16 hi = (_Float16)us;
+        const _Float16 lo = (_Float16)(us - (double)hi);
+        const size_t base = (((size_t)nt * nC + c) * 16 + pos) * 2048 + (size_t)(ns * 2) * 512 + (size_t)lane * 8 + el;
+        (*planes)[base] = bits16(hi);
+        (*planes)[base + 512] = bits16(lo);
+      }
+    }
+  }
+}
+
+}  // namespace pf

@@ -22,12 +22,17 @@ CASES = {
 _models = {}
 
 
-def model(tag):
-    if tag not in _models:
+PRECISIONS = ["fp32", "fp32_bf16x6"]   # the windowed default (2-way fp16 split) and the exact bf16 split `precision="auto"` falls to outside the window: same tolerances
+
+
+def model(tag, precision=None):
+    """precision None: the class default ("auto": decided on the first batch); otherwise a model pinned to that mode"""
+    key = tag if precision is None else (tag, precision)
+    if key not in _models:
         from perspectivefields_amd import PerspectiveFields
 
-        _models[tag] = PerspectiveFields(CASES[tag], weights="synthetic:0").eval().cuda()
-    return _models[tag]
+        _models[key] = PerspectiveFields(CASES[tag], weights="synthetic:0", **({} if precision is None else {"precision": precision})).eval().cuda()
+    return _models[key]
 
 
 def _golden_inputs(g):
@@ -39,10 +44,12 @@ def _golden_inputs(g):
     return batched
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("tag", ["centered", "uncentered"])
-def test_regression_vs_golden(tag, golden_dir):
+def test_regression_vs_golden(tag, precision, golden_dir):
     g = np.load(os.path.join(golden_dir, f"{tag}.npz"))
-    m = model(tag)
+    m = model(tag, precision)
+    assert m._get_engine().precision == precision
     res = m.forward(_golden_inputs(g))
     names = [str(n) for n in g["param_names"]]
     for i, r in enumerate(res):
@@ -55,7 +62,7 @@ def test_regression_vs_golden(tag, golden_dir):
         )
         got = np.array([float(r[n]) for n in names])
         d = np.abs(got - g[f"params_{i}"])
-        print(f"[{tag} img{i}] 1-cos {c:.2e}/{c2:.2e} latL1 {e:.2e}/{e2:.2e} param max|d| {d.max():.2e}")
+        print(f"[{tag} {precision} img{i}] 1-cos {c:.2e}/{c2:.2e} latL1 {e:.2e}/{e2:.2e} param max|d| {d.max():.2e}")
         assert d.max() <= TOL_PARAM, dict(zip(names, d))
         assert r["pred_latitude_original_mode"] == "deg"
 
@@ -72,9 +79,10 @@ def test_key_order_and_types():
     assert float(r["pred_rel_cx"]) == 0.0 and float(r["pred_general_vfov"]) == float(r["pred_vfov"])
 
 
-def test_persnet_vs_golden(golden_dir):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_persnet_vs_golden(precision, golden_dir):
     g = np.load(os.path.join(golden_dir, "persnet.npz"))
-    m = model("persnet")
+    m = model("persnet", precision)
     res = m.forward(_golden_inputs(g))
     for i, r in enumerate(res):
         assert list(r.keys()) == ["pred_gravity", "pred_gravity_original", "pred_latitude", "pred_latitude_original", "pred_latitude_original_mode"]
@@ -84,7 +92,7 @@ def test_persnet_vs_golden(golden_dir):
         np.testing.assert_allclose(pl[:, 8::16, 8::16].cpu().numpy(), g[f"lat_logit_g_{i}"], atol=3e-4, rtol=2e-4)
         fg = float((pg.argmax(0).cpu().numpy() != g[f"grav_argmax_{i}"]).mean())
         fl = float((pl.argmax(0).cpu().numpy() != g[f"lat_argmax_{i}"]).mean())
-        print(f"[persnet img{i}] argmax mismatch fraction gravity {fg:.2e} latitude {fl:.2e}")
+        print(f"[persnet {precision} img{i}] argmax mismatch fraction gravity {fg:.2e} latitude {fl:.2e}")
         assert fg <= 2e-3 and fl <= 2e-3
         d = np.abs(r["pred_latitude_original"].cpu().numpy() - g[f"lat_orig_{i}"])
         assert np.mean(d > 1e-3) <= 5e-3

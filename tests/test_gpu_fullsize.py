@@ -25,22 +25,29 @@ CASES = {
     "uncentered": "Paramnet-360Cities-edina-uncentered",
 }
 _models = {}
+_oracle_cache = {}
 
 
-def model(tag):
-    if tag not in _models:
+PRECISIONS = ["fp32", "fp32_bf16x6"]   # the windowed default (2-way fp16 split) and the exact bf16 split `precision="auto"` falls to outside the window: same tolerances
+
+
+def model(tag, precision=None):
+    key = tag if precision is None else (tag, precision)
+    if key not in _models:
         from perspectivefields_amd import PerspectiveFields
 
-        _models[tag] = PerspectiveFields(CASES[tag], weights="synthetic:0").eval().cuda()
-    return _models[tag]
+        _models[key] = PerspectiveFields(CASES[tag], weights="synthetic:0", **({} if precision is None else {"precision": precision})).eval().cuda()
+    return _models[key]
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("tag", ["centered", "uncentered", "persnet"])
-def test_fullsize_vs_reference_golden(tag, golden_dir):
+def test_fullsize_vs_reference_golden(tag, precision, golden_dir):
     g = np.load(os.path.join(golden_dir, "fullsize.npz"))
     pre = f"fs_{tag}_"
     n = int(g[pre + "n"])
-    m = model(tag)
+    m = model(tag, precision)
+    assert m._get_engine().precision == precision
     batched = []
     for k in range(n):
         H, W = (int(v) for v in g[f"{pre}size_{k}"])
@@ -65,7 +72,7 @@ def test_fullsize_vs_reference_golden(tag, golden_dir):
                 assert np.mean(np.abs(b - b_ref) > 1e-3) <= 5e-3, (tag, k, what)
             else:
                 c, e = assert_fields_close(a, a_ref, b, b_ref, f"{tag} img{k} {H}x{W} {what}")
-                print(f"[fullsize {tag} img{k} {H}x{W} {what}] 1-cos max {c:.2e}  latitude L1 {e:.2e} deg")
+                print(f"[fullsize {tag} {precision} img{k} {H}x{W} {what}] 1-cos max {c:.2e}  latitude L1 {e:.2e} deg")
         if cls:
             fg = float((r["pred_gravity"].argmax(0).cpu().numpy() != g[f"{pre}grav_argmax_{k}"]).mean())
             fl = float((r["pred_latitude"].argmax(0).cpu().numpy() != g[f"{pre}lat_argmax_{k}"]).mean())
@@ -76,7 +83,7 @@ def test_fullsize_vs_reference_golden(tag, golden_dir):
             assert_fields_close(pg[:, ::2, ::2], g[f"{pre}grav_s2_{k}"], pl[:, ::2, ::2], g[f"{pre}lat_s2_{k}"], f"{tag} img{k} 320^2")
         if names:
             d = np.abs(np.array([float(r[nm]) for nm in names]) - g[f"{pre}params_{k}"])
-            print(f"[fullsize {tag} img{k}] ParamNet max|d| {d.max():.2e}")
+            print(f"[fullsize {tag} {precision} img{k}] ParamNet max|d| {d.max():.2e}")
             assert d.max() <= TOL_PARAM, dict(zip(names, d))
 
 
@@ -114,32 +121,35 @@ def test_postprocess_every_pixel_vs_oracle(tag):
                 assert one_minus_cos(up[(slice(None),) + sl][:, None], up_ref[(slice(None),) + sl][:, None]).max() <= 1e-6
 
 
-def test_batch32_vs_oracle_and_single():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_batch32_vs_oracle_and_single(precision):
     """BASELINE configs[2]: a batch of 32 640x640 images (the bench batch, with its own tile choices).  Images 0 / 15 /
     31 against the CPU oracle run on the same images, and against the same images run as batches of 1."""
     tag = "centered"
-    m = model(tag)
+    m = model(tag, precision)
     imgs = [synthetic_image(640, 640, seed=1000 + i) for i in range(32)]
     res = m.inference_batch(imgs)
     assert len(res) == 32
     pick = [0, 15, 31]
     arch = arch_of(get_cfg(CASES[tag]))
     sd = to_torch(synthetic_state_dict(CASES[tag], 0))
-    with torch.no_grad():
-        ref = pf_oracle.inference_batch(sd, arch, [imgs[i] for i in pick])
+    if "b32" not in _oracle_cache:   # one CPU oracle run for both precisions
+        with torch.no_grad():
+            _oracle_cache["b32"] = pf_oracle.inference_batch(sd, arch, [imgs[i] for i in pick])
+    ref = _oracle_cache["b32"]
     for i, o in zip(pick, ref):
         r = res[i]
         c, e = assert_fields_close(r["pred_gravity_original"].cpu().numpy(), o["pred_gravity_original"].numpy(),
                                    r["pred_latitude_original"].cpu().numpy(), o["pred_latitude_original"].numpy(), f"B=32 img{i} 640x640 vs oracle")
         assert_fields_close(r["pred_gravity"].cpu().numpy(), o["pred_gravity"].numpy(), r["pred_latitude"].cpu().numpy(), o["pred_latitude"].numpy(), f"B=32 img{i} 320^2")
         d = max(abs(float(r[k]) - float(o[k])) for k in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
-        print(f"[B=32 img{i} vs oracle] 1-cos max {c:.2e}  latitude L1 {e:.2e} deg  ParamNet max|d| {d:.2e}")
+        print(f"[B=32 {precision} img{i} vs oracle] 1-cos max {c:.2e}  latitude L1 {e:.2e} deg  ParamNet max|d| {d:.2e}")
         assert d <= TOL_PARAM
         s = m.inference(imgs[i])
         c1 = one_minus_cos(r["pred_gravity_original"].cpu().numpy(), s["pred_gravity_original"].cpu().numpy()).max()
         e1 = l1(r["pred_latitude_original"].cpu().numpy(), s["pred_latitude_original"].cpu().numpy())
         d1 = max(abs(float(r[k]) - float(s[k])) for k in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
-        print(f"[B=32 img{i} vs B=1] 1-cos max {c1:.2e}  latitude L1 {e1:.2e} deg  ParamNet max|d| {d1:.2e}")
+        print(f"[B=32 {precision} img{i} vs B=1] 1-cos max {c1:.2e}  latitude L1 {e1:.2e} deg  ParamNet max|d| {d1:.2e}")
         assert c1 <= 1e-6 and e1 <= 2e-4 and d1 <= 5e-5
 
 

@@ -706,3 +706,47 @@ def test_rb_proj_fc1(ops, tokens, images):
         _close(hid, h_ref, 6e-5, "rb_proj_fc1 hidden")
     except AssertionError as e:
         raise AssertionError(str(e) + "\n" + _region_report(hid, h_ref))
+
+
+WINO_CASES = [
+    # name, B, H, W, Cin, Cout: the four decoder map sizes (80^2 = whole blocks of 16 x 16 pixels; 40^2, 20^2, 10^2: ragged last blocks), odd sizes, other channel counts
+    ("rcu80", 1, 80, 80, 256, 256),
+    ("rcu40", 2, 40, 40, 256, 256),
+    ("rcu20", 2, 20, 20, 256, 256),
+    ("rcu10", 3, 10, 10, 256, 256),
+    ("odd23x37", 2, 23, 37, 64, 128),
+    ("one_tile_row", 1, 1, 33, 128, 64),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_conv2d_winograd_tile(ops, case):
+    """Winograd F(2x2, 3x3) tile "wino256x64" (wino.hip: 16 position GEMMs on the split-f16 MFMA, input / output transforms in fp32) against fp64, with the whole
+    epilogue (bias, ReLU, two residuals, ReLU after the residuals -- the ResidualConvUnit forms of decode_head.py:242-256) and without; error measured against the
+    natural scale of a dot product, sum |x||w|, and held to 4x the direct halo tile's error + an fp32 floor (the transforms add a few fp32 roundings)."""
+    name, B, H, W, Cin, Cout = case
+    names = ops.conv_tiles()
+    assert "wino256x64" in names
+    tw = names.index("wino256x64")
+    th = names.index("sbh128x64")
+    assert ops.conv2d_bench(1, 16, 16, 64, 64, 3, 1, 1, tile=tw, iters=1) > 0   # the tile really runs such shapes (an unusable tile id would fall back silently)
+    x = _rand((B, H, W, Cin), 300)
+    w = _rand((Cout, Cin, 3, 3), 301, 1.0 / math.sqrt(Cin * 9))
+    b = _rand((Cout,), 302, 0.1)
+    r1 = _rand((B, H, W, Cout), 303)
+    r2 = _rand((B, H, W, Cout), 304)
+    ref0 = _ref_conv(x, w, b, 1, 1)
+    scale = _ref_conv(x.abs(), w.abs(), None, 1, 1)
+    xd = x.cuda()
+    got = ops.conv2d(xd, w, b, pad=1, tile=tw).double().cpu()
+    direct = ops.conv2d(xd, w, b, pad=1, tile=th).double().cpu()
+    ew, ed = ((got - ref0).abs() / scale).max().item(), ((direct - ref0).abs() / scale).max().item()
+    print(f"[winograd {name}] |err| / sum|x||w|: winograd {ew:.2e}, direct halo tile {ed:.2e}")
+    assert ew <= 4 * ed + 2.0 ** -20, (name, ew, ed)
+    # full epilogue: y = relu(relu(conv + bias) + res1 + res2)
+    ref1 = torch.relu(torch.relu(ref0) + r1.double() + r2.double())
+    got1 = ops.conv2d(xd, w, b, pad=1, act=1, res1=r1.cuda(), res2=r2.cuda(), post_relu=True, tile=tw).double().cpu()
+    assert ((got1 - ref1).abs() / (scale + 1.0)).max().item() <= 4 * ed + 2.0 ** -20, name
+    # no bias
+    got2 = ops.conv2d(xd, w, None, pad=1, tile=tw).double().cpu()
+    assert ((got2 - _ref_conv(x, w, None, 1, 1)).abs() / scale).max().item() <= 4 * ed + 2.0 ** -20, name
