@@ -499,7 +499,7 @@ struct pf_engine {
                              // at least rb_min_blocks row blocks: bit mask 1 q, 2 kv, 4 proj, 8 fc1, 16 fc2, 32 the whole key / value branch as one launch (rb_chain.hip; overrides 2), 64 proj + norm2 + fc1 as one launch (overrides 4, 8) (0 = none)
   int rb_min_blocks = 192;   // default for 256 CUs; pf_create rescales it to 3/4 of the device's CU count
   int num_cus = 256;         // hipDeviceProp_t::multiProcessorCount (partitioned / smaller gfx950 configurations: CPX / DPX modes)
-  int wino_min_hw = 80;      // PF_WINO=<n>: 3x3 / stride-1 convs with Cin, Cout multiples of 64 on maps of at least n x n run as Winograd F(2x2, 3x3) (wino.hip; split-f16
+  int wino_min_hw = 40;      // PF_WINO=<n>: 3x3 / stride-1 convs with Cin, Cout multiples of 64 on maps of at least n x n run as Winograd F(2x2, 3x3) (wino.hip; split-f16
                              // scheme only; 0 = never).  Their inputs' window ends at 65504 / 4 (the input transform adds four values)
   int wino_tile = -1;        // tile id of "wino256x64"
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
@@ -1568,7 +1568,10 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_WINO")) e->wino_min_hw = atoi(v);
-  for (int t = 0; t < conv_num_tiles(); ++t) if (strcmp(conv_tile_name(t), "wino256x64") == 0) e->wino_tile = t;
+  {
+    const char* wt = getenv("PF_WINO_TILE");  // "wino256x64w4" (default: 4 waves, transform interleaved with the MFMAs) or "wino256x64" (8 waves)
+    for (int t = 0; t < conv_num_tiles(); ++t) if (strcmp(conv_tile_name(t), wt ? wt : "wino256x64w4") == 0) e->wino_tile = t;
+  }
   if (const char* v = getenv("PF_RB_CHAIN")) e->rb_chain = atoi(v);
   if (const char* v = getenv("PF_DEFER_AT")) e->defer_at = atoi(v);
   if (const char* v = getenv("PF_DEFER_PRIO")) e->defer_prio = atoi(v);
@@ -2366,7 +2369,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   float t = 0.f;
   (void)hipEventElapsedTime(&t, a, b);
   *ms_out = t / iters;
-  if (getenv("PF_WINO_STAMPS") && strcmp(conv_tile_name(tile_id), "wino256x64") == 0) {  // timing aid: s_memtime stamps of block 17's eight waves of one more launch, to stderr
+  if (getenv("PF_WINO_STAMPS") && strncmp(conv_tile_name(tile_id), "wino", 4) == 0) {  // timing aid: s_memtime stamps of block 17's eight waves of one more launch, to stderr
     unsigned long long* ds = nullptr;
     if (hipMalloc(&ds, 8 * 128 * 8) == hipSuccess) {
       (void)hipMemset(ds, 0, 8 * 128 * 8);
@@ -2378,7 +2381,8 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
       (void)hipFree(ds);
       for (int w = 0; w < 8; ++w) {
         const unsigned long long t0 = hs[w * 128];
-        fprintf(stderr, "wino stamps %dx%d Cin=%d wave %d:", H, W, Cin, w);
+        if (!t0) continue;
+        fprintf(stderr, "%s stamps %dx%d Cin=%d wave %d:", conv_tile_name(tile_id), H, W, Cin, w);
         for (int i = 1; i < 128; ++i) if (hs[w * 128 + i]) fprintf(stderr, " [%d]%llu", i, hs[w * 128 + i] - t0);
         fprintf(stderr, "\n");
       }

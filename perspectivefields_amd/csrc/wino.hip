@@ -307,6 +307,315 @@ __global__ __launch_bounds__(W_NT, 2) void wino_f2x2_kernel(const ConvParams p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// "wino256x64w4": the same block (16 x 16 pixels x 64 channels x 16 positions), FOUR waves -- one per SIMD, 512 registers each: wave w owns row xi = w of the
+// transformed tile (positions 4w .. 4w + 3: 256 accumulator registers), and the transform of chunk c + 1 is INTERLEAVED, instruction by instruction, with the MFMAs of
+// chunk c in the wave's own stream (a wave issues in order: an MFMA occupies the matrix core for 32 cycles but the issue port for 4-8, the ~7 VALU / LDS instructions
+// that follow it in program order run in its shadow).  The stamped timeline of the 8-wave form (profiles/r05_winograd.md) showed why: each of its phases is latency
+// bound (transform 1 950 cycles for 640 cycles of VALU issue, multiply 1 500 for 768 cycles of MFMA), and the second wave of a SIMD cannot cover both.
+//   chunk loop, 24 sub-steps of {MFMA, ~8 VALU, MFMA, ~8 VALU (+ LDS)}, fixed by sched_group_barrier inside and sched_barrier between the sub-steps:
+//     k = 0..3   transform: pixel column k of the 4 x 4 input tile (4 LDS reads issued one sub-step ahead) -> rows of B^T d
+//     k = 4..19  transform: output (xi, nu) = ((k - 4) / 4, (k - 4) % 4): column combination, split, two 8-byte LDS writes into the A buffer of chunk c + 1
+//     weights of (c + 1, position q) are requested right after position q's last MFMA of chunk c (three quarters of a chunk ahead), the fragments of position q + 1
+//     during position q's MFMAs; the raw halo of chunk c + 2 goes to LDS behind a barrier in sub-step 4 (all waves have read chunk c + 1's by then)
+//   Epilogue: A over nu is applied in registers (4 positions -> 2 values), so the exchange between the waves moves 128 KB through LDS once (the 8-wave form: twice).
+namespace {
+constexpr int W4_NT = 256;
+constexpr int RAW4_F4 = (W_NPIX * 4 + W4_NT - 1) / W4_NT;  // 6
+}  // namespace
+
+#define WINO4_STAMP(i) do { if constexpr (STAMP) { if (blockIdx.x == 17 && lane == 0) p.stamps[wave * 128 + (i)] = __builtin_readcyclecounter(); } } while (0)
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+typedef float wf2 __attribute__((ext_vector_type(2)));
+struct WF4 { wf2 lo, hi; };  // four channels as two packed pairs: the transform's adds are v_pk_add_f32 (plain operand forms only: no op_sel)
+// 2-way fp16 split WITHOUT the clamp of split2_f16 (sb_split.h): one v_cvt_pk_f16_f32 + two v_fma_mix per pair instead of also two v_med3 -- the transform's VALU
+// instructions are paid in MFMA issue time (profiles/r05_winograd.md).  |v| > 65504 then gives inf / NaN instead of saturating: the inputs of a Winograd layer must
+// stay below 65504 / 4 (PerspectiveFields.check_range and precision = "auto" hold them to that limit; the engine's saturation counter watches their producers)
+__device__ __forceinline__ void split2_f16_nc(const wf2 v, unsigned& h, unsigned& l) {
+  const sb_h2 hv = {(_Float16)v.x, (_Float16)v.y};
+  h = __builtin_bit_cast(unsigned, hv);
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v.x), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v.y), "v"(h));
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(W4_NT, 1) void wino4_f2x2_kernel(const ConvParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char wsm[W_SMEM];
+  unsigned char* const Ab = wsm;
+  unsigned char* const Raw = wsm + 2 * A_BUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+  const int tilesN = p.Cout / W_BN;
+  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
+  const int nblk1 = p.B * tilesY * tilesX * tilesN;
+  int t = xcd_tile_index(nblk1 * p.groups);
+  const bool g1 = t >= nblk1;
+  if (g1) t -= nblk1;
+  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
+  const int nt = t % tilesN;
+  int mt = t / tilesN;
+  const int bx = mt % tilesX; mt /= tilesX;
+  const int by = mt % tilesY;
+  const int bimg = mt / tilesY;
+  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
+  const int nC = p.Cin / W_KC;
+
+  // raw halo: element e = tid + 256 i -> (pixel tid / 4 + 64 i, float4 tid % 4): one voffset per element (out-of-image pixels: the out-of-range marker), the chunk
+  // goes into the instruction's SGPR offset; LDS side: one base + immediates
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
+  unsigned g_off[RAW4_F4];
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) {
+    const int pix = (tid >> 2) + 64 * i, c4 = tid & 3;
+    const int hy = pix / W_HX, hx = pix - hy * W_HX;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
+  }
+  unsigned char* const s_base = Raw + (tid >> 2) * RAW_PITCH + (tid & 3) * 16;
+  const bool s_last = tid < 4 * (W_NPIX - 64 * (RAW4_F4 - 1));  // the last round covers pixels 320 .. 323 only
+  u32x4 ra[RAW4_F4];
+  auto load_raw = [&](int c) {
+    const int soff = (c < nC ? c : nC - 1) * (W_KC * 4);  // past the end: a harmless reload of the last chunk (never consumed)
+#pragma unroll
+    for (int i = 0; i < RAW4_F4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], soff, 0);
+  };
+  auto store_raw = [&]() {
+#pragma unroll
+    for (int i = 0; i < RAW4_F4; ++i)
+      if (i + 1 < RAW4_F4 || s_last) *reinterpret_cast<u32x4*>(s_base + i * (64 * RAW_PITCH)) = ra[i];
+  };
+  auto raw_soff = [&](int c) { return (c < nC ? c : nC - 1) * (W_KC * 4); };
+
+  // transform: thread -> (tile tt = 16 wave + lane / 4, channel quad cg = lane & 3), all 16 positions
+  const int cg = lane & 3, tt = wave * 16 + (lane >> 2), tty = tt >> 3, ttx = tt & 7;
+  const unsigned char* const t_src = Raw + ((2 * tty) * W_HX + 2 * ttx) * RAW_PITCH + cg * 16;
+  unsigned char* const t_dst0 = Ab + tt * 32 + (((cg >> 1) ^ ((tt >> 3) & 1)) * 16) + (cg & 1) * 8;
+  WF4 dcol[2][4];  // one pixel column of the 4 x 4 tile (read one sub-step ahead)
+  WF4 rr[4][4];    // B^T d: [xi][column]
+  auto t_load_col = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dcol[j & 1][i] = *reinterpret_cast<const WF4*>(t_src + (i * W_HX + j) * RAW_PITCH);
+  };
+  auto w_add = [](const WF4& a, const WF4& b) { WF4 r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return r; };
+  auto w_sub = [](const WF4& a, const WF4& b) { WF4 r; r.lo = a.lo - b.lo; r.hi = a.hi - b.hi; return r; };
+  auto t_emit = [&](int buf, int xi, int nu) {
+    const WF4(&r)[4] = rr[xi];
+    const WF4 o = nu == 0 ? w_sub(r[0], r[2]) : (nu == 1 ? w_add(r[1], r[2]) : (nu == 2 ? w_sub(r[2], r[1]) : w_sub(r[1], r[3])));
+    uint2 h, l;
+    split2_f16_nc(o.lo, h.x, l.x);
+    split2_f16_nc(o.hi, h.y, l.y);
+    unsigned char* const dst = t_dst0 + buf * A_BUF + (xi * 4 + nu) * A_POS;
+    *reinterpret_cast<uint2*>(dst) = h;
+    *reinterpret_cast<uint2*>(dst + A_PLANE) = l;
+  };
+
+  // multiply: positions 4 wave + q; weight fragments through a buffer resource: lane offset in a VGPR, (chunk, position) in the SGPR offset, fragment in the immediate
+  const int w_frags = tilesN * nC * 16;  // (chunk, position) slices of 4 KB
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_wino), 0, w_frags * 4096, 0x00020000);
+  const int w_s0 = (nt * nC * 16 + 4 * wave) * 4096;
+  u32x4 bw[4][2][2];  // [q][cout sub-tile][plane]
+  auto load_w = [&](int c, int q) {
+    const int cc = c < nC ? c : nC - 1;
+    const int soff = w_s0 + (cc * 16 + q) * 4096;
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bw[q][ns][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + (ns * 2 + pl) * 1024, soff, 0);
+  };
+  auto load_w1 = [&](int c, int q, int piece) {  // one of the four fragments of (chunk c, position q)
+    const int cc = c < nC ? c : nC - 1;
+    bw[q][piece >> 1][piece & 1] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + piece * 1024, w_s0 + (cc * 16 + q) * 4096, 0);
+  };
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][b][m][e] = 0.f;
+  const unsigned char* const a_frag0 = Ab + (4 * wave) * A_POS + l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16);
+  u32x4 av[2][2][2];  // [q & 1][tile sub-tile][plane]
+  auto load_frag = [&](int buf, int q) {
+    const unsigned char* src = a_frag0 + buf * A_BUF + q * A_POS;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) av[q & 1][m][pl] = *reinterpret_cast<const u32x4*>(src + pl * A_PLANE + m * (32 * 32));
+  };
+  auto mma_one = [&](int q, int i) {  // MFMA i = 0..11 of position q: product t3 = i / 4 (wh al, wl ah, wh ah), accumulator (i % 4): consecutive MFMAs are independent
+    const int t3 = i >> 2, ns = (i >> 1) & 1, m = i & 1;
+    const int tw = t3 == 1 ? 1 : 0, tv = t3 == 0 ? 1 : 0;
+    acc[q][ns][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, bw[q][ns][tw]), __builtin_bit_cast(wf16x8, av[q & 1][m][tv]), acc[q][ns][m], 0, 0, 0);
+  };
+  auto t_rows_a = [&](int j) { const WF4(&d)[4] = dcol[j & 1]; rr[0][j] = w_sub(d[0], d[2]); rr[1][j] = w_add(d[1], d[2]); };
+  auto t_rows_b = [&](int j) { const WF4(&d)[4] = dcol[j & 1]; rr[2][j] = w_sub(d[2], d[1]); rr[3][j] = w_sub(d[1], d[3]); };
+
+  // ---- prologue: raw(0) -> LDS -> V(0) -> A[0]; raw(1) -> LDS; raw(2) in registers; weights of chunk 0; fragments of (0, position 0)
+  // The order of the LAST vector-memory requests in front of the loop must be the steady state's (raw halo first, then the four weight requests): hipcc's s_waitcnt
+  // insertion merges the loop's two entry states, and with the weights requested first it made every chunk's halo store wait for vmcnt(0) -- i.e. for the weight
+  // loads issued a moment earlier: 600 of a chunk's 3 700 cycles (profiles/r05_winograd.md)
+  load_raw(0);
+  store_raw();
+  load_raw(1);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { t_load_col(j); t_rows_a(j); t_rows_b(j); }
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) t_emit(0, xi, nu);
+  __syncthreads();
+  store_raw();
+  load_raw(2);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) load_w(0, q);
+  __syncthreads();
+  load_frag(0, 0);
+  t_load_col(0);
+  WINO4_STAMP(0);
+
+#pragma unroll 1
+  for (int c = 0; c < nC; ++c) {
+    const int buf = c & 1;
+    if (c < 16) WINO4_STAMP(8 + 4 * c);
+    // entering: av[0] = fragments of (c, position 0) and dcol[0] = pixel column 0 of raw(c + 1) are in flight
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      const int q = k / 6, i0 = 2 * (k % 6);
+      // ---- chores of this sub-step (memory instructions, placed by hand -- nothing crosses the sched_barrier below -- and at most two per sub-step: six LDS stores +
+      //      six buffer loads in ONE sub-step cost 600 cycles of issue time that no MFMA covered, profiles/r05_winograd.md)
+      if (k < 3) t_load_col(k + 1);                                   // next pixel column of raw(c + 1)
+      if (k % 6 == 2 && q < 3) load_frag(buf, q + 1);                 // next position's fragments
+      if (k == 4) {                                                  // every wave has read raw(c + 1): the halo of chunk c + 2 may overwrite it
+        __syncthreads();
+        if (c < 16) WINO4_STAMP(9 + 4 * c);
+      }
+      if (k >= 5 && k < 5 + RAW4_F4) {                                // raw(c + 2) -> LDS and the request for raw(c + 3), one element per sub-step
+        const int i = k - 5;
+        if (i + 1 < RAW4_F4 || s_last) *reinterpret_cast<u32x4*>(s_base + i * (64 * RAW_PITCH)) = ra[i];
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], raw_soff(c + 3), 0);
+      }
+      // weights, one 16-byte request per sub-step: (c, position 3) in k = 0..3 (its registers were last read in k = 23 of the previous chunk), (c + 1, position q - 1)
+      // in k = 6q .. 6q + 3
+      if (k < 4) load_w1(c, 3, k);
+      else if (k >= 6 && (k % 6) < 4) load_w1(c + 1, q - 1, k % 6);
+      // ---- two MFMAs and one piece of the transform
+      mma_one(q, i0);
+      if (k < 4) t_rows_a(k);
+      else if (k < 20) t_emit(buf ^ 1, (k - 4) >> 2, (k - 4) & 3);
+      mma_one(q, i0 + 1);
+      if (k < 4) t_rows_b(k);
+      SGB(0x008, 1); SGB(0x002, 5); SGB(0x008, 1); SGB(0x002, 5); SGB(0x200, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c == 2) WINO4_STAMP(80 + k);   // STAMP build: every sub-step of one chunk
+    }
+    if (c < 16) WINO4_STAMP(10 + 4 * c);
+    __syncthreads();                       // V(c + 1) complete in A[buf ^ 1], raw(c + 2) in LDS, A[buf] free
+    if (c < 16) WINO4_STAMP(11 + 4 * c);
+    load_frag(buf ^ 1, 0);
+    t_load_col(0);
+  }
+  WINO4_STAMP(1);
+
+  // item = (tile, channel quad): 64 x 16 = 1024 items, 4 per thread; item = tid + 256 it -> the SAME channel quad (tid & 15) for all four: scale / bias once.
+  // Every global operand (scale, bias, the residuals of all 16 output pixels) is requested BEFORE the LDS reads and the arithmetic: one load latency per block, not one
+  // per item (the first form of this loop spent 12 000 cycles here -- profiles/r05_winograd.md)
+  const int act = p.act, post_relu = p.post_relu;
+  const int e_c4 = tid & 15, n = n0 + e_c4 * 4;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 sc = *reinterpret_cast<const float4*>(P.w_wino_inv + n);
+  float4 bb = zero4;
+  if (P.bias) bb = *reinterpret_cast<const float4*>(P.bias + n);
+  const bool has_r1 = P.res1 != nullptr, has_r2 = P.res2 != nullptr;
+  float4 q1[4][2][2], q2[4][2][2];
+  unsigned oo[4][2][2];  // element offsets (every activation of the engine stays below 2 GiB)
+  bool okp[4][2][2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e_tile = (tid >> 4) + 16 * it, e_ty = e_tile >> 3, e_tx = e_tile & 7;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oy = oy0 + 2 * e_ty + a, ox = ox0 + 2 * e_tx + b;
+        okp[it][a][b] = oy < p.Ho && ox < p.Wo;
+        oo[it][a][b] = (unsigned)(((bimg * p.Ho + oy) * p.Wo + ox) * p.ldy + n);
+        q1[it][a][b] = zero4; q2[it][a][b] = zero4;
+      }
+  }
+  if (has_r1 || has_r2) {  // block-uniform
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (has_r1 && okp[it][a][b]) q1[it][a][b] = *reinterpret_cast<const float4*>(P.res1 + oo[it][a][b]);
+          if (has_r2 && okp[it][a][b]) q2[it][a][b] = *reinterpret_cast<const float4*>(P.res2 + oo[it][a][b]);
+        }
+  }
+  // ---- epilogue: A over nu in registers (this wave's row xi: 4 positions -> 2 values per accumulator element), then the four rows meet in LDS
+  //      Es[xi][b][tile 64][64 channels] fp32 = 128 KB (row pitch 256 B, 16-byte pieces XOR-swizzled by the tile index)
+  __syncthreads();
+  unsigned char* const Es = wsm;
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int tile = m * 32 + l31;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 s0, s1;
+        {
+          const f32x16 &a0 = acc[0][ns][m], &a1 = acc[1][ns][m], &a2 = acc[2][ns][m], &a3 = acc[3][ns][m];
+          s0 = make_float4((a0[4 * j] + a1[4 * j]) + a2[4 * j], (a0[4 * j + 1] + a1[4 * j + 1]) + a2[4 * j + 1], (a0[4 * j + 2] + a1[4 * j + 2]) + a2[4 * j + 2], (a0[4 * j + 3] + a1[4 * j + 3]) + a2[4 * j + 3]);
+          s1 = make_float4((a1[4 * j] - a2[4 * j]) - a3[4 * j], (a1[4 * j + 1] - a2[4 * j + 1]) - a3[4 * j + 1], (a1[4 * j + 2] - a2[4 * j + 2]) - a3[4 * j + 2], (a1[4 * j + 3] - a2[4 * j + 3]) - a3[4 * j + 3]);
+        }
+        const int piece = (ns * 8 + 2 * j + hi) ^ (tile & 15);  // 16 pieces of 16 bytes per 256-byte row
+        unsigned char* dstp = Es + (wave * 2) * (64 * 256) + tile * 256 + piece * 16;
+        *reinterpret_cast<float4*>(dstp) = s0;
+        *reinterpret_cast<float4*>(dstp + 64 * 256) = s1;
+      }
+    }
+  __syncthreads();
+  WINO4_STAMP(2);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e_tile = (tid >> 4) + 16 * it;
+    const unsigned char* srcp = Es + e_tile * 256 + ((e_c4 ^ (e_tile & 15)) * 16);
+    float4 sb[4][2];
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) sb[xi][b] = *reinterpret_cast<const float4*>(srcp + (xi * 2 + b) * (64 * 256));
+    float4 yv[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      yv[0][b] = f4add(f4add(sb[0][b], sb[1][b]), sb[2][b]);
+      yv[1][b] = f4sub(f4sub(sb[1][b], sb[2][b]), sb[3][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float4 w = yv[a][b];
+        w.x = fmaf(w.x, sc.x, bb.x); w.y = fmaf(w.y, sc.y, bb.y); w.z = fmaf(w.z, sc.z, bb.z); w.w = fmaf(w.w, sc.w, bb.w);
+        if (act == ACT_RELU) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+        else if (act == ACT_GELU) { w.x = gelu_erf(w.x); w.y = gelu_erf(w.y); w.z = gelu_erf(w.z); w.w = gelu_erf(w.w); }
+        const float4 r1 = q1[it][a][b], r2 = q2[it][a][b];
+        w.x += r1.x; w.y += r1.y; w.z += r1.z; w.w += r1.w;
+        w.x += r2.x; w.y += r2.y; w.z += r2.z; w.w += r2.w;
+        if (post_relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+        if (okp[it][a][b]) *reinterpret_cast<float4*>(P.y + oo[it][a][b]) = w;
+      }
+  }
+  WINO4_STAMP(3);
+}
+
 // 3x3 / stride 1 / pad 1, split-f16 scheme, one fp32 NHWC input, fp32 NHWC output, Winograd weights present
 bool conv_wino_ok(const ConvParams& p) {
   if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nterms != NT_F16X3 || p.nchw_out || p.ups || p.ln || p.splitk > 1) return false;
@@ -318,9 +627,14 @@ bool conv_wino_ok(const ConvParams& p) {
   return true;
 }
 
-void launch_conv_wino(const ConvParams& p, hipStream_t s) {
+void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant) {
   const int tilesN = p.Cout / W_BN, tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(W_NT);
+  if (variant == 1) {  // "wino256x64w4"
+    if (p.stamps) hipLaunchKernelGGL(wino4_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
+    else hipLaunchKernelGGL(wino4_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
+    return;
+  }
   if (p.stamps) hipLaunchKernelGGL(wino_f2x2_kernel<true>, grid, block, 0, s, p);
   else hipLaunchKernelGGL(wino_f2x2_kernel<false>, grid, block, 0, s, p);
 }

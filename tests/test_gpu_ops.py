@@ -719,15 +719,16 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile_name", ["wino256x64", "wino256x64w4"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
-def test_conv2d_winograd_tile(ops, case):
+def test_conv2d_winograd_tile(ops, case, tile_name):
     """Winograd F(2x2, 3x3) tile "wino256x64" (wino.hip: 16 position GEMMs on the split-f16 MFMA, input / output transforms in fp32) against fp64, with the whole
     epilogue (bias, ReLU, two residuals, ReLU after the residuals -- the ResidualConvUnit forms of decode_head.py:242-256) and without; error measured against the
     natural scale of a dot product, sum |x||w|, and held to 4x the direct halo tile's error + an fp32 floor (the transforms add a few fp32 roundings)."""
     name, B, H, W, Cin, Cout = case
     names = ops.conv_tiles()
-    assert "wino256x64" in names
-    tw = names.index("wino256x64")
+    assert tile_name in names
+    tw = names.index(tile_name)
     th = names.index("sbh128x64")
     assert ops.conv2d_bench(1, 16, 16, 64, 64, 3, 1, 1, tile=tw, iters=1) > 0   # the tile really runs such shapes (an unusable tile id would fall back silently)
     x = _rand((B, H, W, Cin), 300)
@@ -741,7 +742,7 @@ def test_conv2d_winograd_tile(ops, case):
     got = ops.conv2d(xd, w, b, pad=1, tile=tw).double().cpu()
     direct = ops.conv2d(xd, w, b, pad=1, tile=th).double().cpu()
     ew, ed = ((got - ref0).abs() / scale).max().item(), ((direct - ref0).abs() / scale).max().item()
-    print(f"[winograd {name}] |err| / sum|x||w|: winograd {ew:.2e}, direct halo tile {ed:.2e}")
+    print(f"[{tile_name} {name}] |err| / sum|x||w|: winograd {ew:.2e}, direct halo tile {ed:.2e}")
     assert ew <= 4 * ed + 2.0 ** -20, (name, ew, ed)
     # full epilogue: y = relu(relu(conv + bias) + res1 + res2)
     ref1 = torch.relu(torch.relu(ref0) + r1.double() + r2.double())
