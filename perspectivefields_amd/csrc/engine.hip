@@ -945,14 +945,6 @@ struct pf_engine {
     p.ups = ups;
     p.ln = w.ln_s ? 1 : 0; p.ln_eps = w.ln_eps;
     p.finish();
-    if (c.dbg && c.dbg->range) {
-      const int q = c.dbg->seq++;
-      for (int g = 0; g < ngroups; ++g) {
-        const std::string nm = fmt("dense%03d%s %dx%d s%d %s M=%d N=%d K=%d", q, ngroups > 1 ? (g ? "[latitude]" : "[gravity]") : "", w.KH, w.KW, w.stride, w.ln_s ? "LN-fused " : "", p.M, p.Cout, w.KH * w.KW * w.CinReal);
-        range_in(c, nm + " x", calls[g].x.f, (size_t)B * (ups ? H / 2 : H) * (ups ? W / 2 : W) * p.C1);
-        if (p.C2 > 0) range_in(c, nm + " x2", calls[g].x2.f, (size_t)B * H * W * p.C2);
-      }
-    }
     if (part) {
       p.splitk = splitk;
       for (int g = 0; g < ngroups; ++g) p.g[g].partial = part + (size_t)g * splitk * p.M * p.Cout;
@@ -971,6 +963,15 @@ struct pf_engine {
     if (!conv_tile_usable(p, tile)) tile = conv_default_tile(p);
     // Winograd form where it exists and the map is large enough (the tile table knows the direct tiles only); never while tuning (tune_conv times the direct tiles)
     if (wino_min_hw > 0 && wino_tile >= 0 && !(c.tuning && c.tune_scratch) && p.Ho >= wino_min_hw && p.Wo >= wino_min_hw && conv_tile_usable(p, wino_tile)) tile = wino_tile;
+    if (c.dbg && c.dbg->range) {
+      const int q = c.dbg->seq++;
+      for (int g = 0; g < ngroups; ++g) {
+        // "[winograd]": the layer runs as Winograd F(2x2, 3x3) -- its input transform adds four values, so its window ends at 65504 / 4 (PerspectiveFields._window_limit)
+        const std::string nm = fmt("dense%03d%s %dx%d s%d %s%sM=%d N=%d K=%d", q, ngroups > 1 ? (g ? "[latitude]" : "[gravity]") : "", w.KH, w.KW, w.stride, w.ln_s ? "LN-fused " : "", tile == wino_tile && wino_tile >= 0 ? "[winograd] " : "", p.M, p.Cout, w.KH * w.KW * w.CinReal);
+        range_in(c, nm + " x", calls[g].x.f, (size_t)B * (ups ? H / 2 : H) * (ups ? W / 2 : W) * p.C1);
+        if (p.C2 > 0) range_in(c, nm + " x2", calls[g].x2.f, (size_t)B * H * W * p.C2);
+      }
+    }
     ProfScope ps(c.prof, c.s, conv_tile_is_sb(tile) ? PC_IGEMM_SB : PC_IGEMM, 2.0 * ngroups * p.M * (double)w.Cout * w.KH * w.KW * w.CinReal, p.M * ngroups, w.Cout, w.KH * w.KW * w.CinReal, w.KH);
     launch_conv_tile(p, tile, c.s);
   }

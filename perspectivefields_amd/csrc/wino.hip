@@ -22,6 +22,7 @@
 //   Epilogue: per cout sub-tile the 16 position accumulators go through LDS ([pos][tile][32 ch] fp32, 128 KB); thread = (tile, 4 channels) reads its 16 values,
 //   applies A^T . A, the weight scale, bias / activation / residuals (the same order as epilogue_nhwc) and stores 4 pixels x 16 bytes.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "igemm_common.h"
@@ -339,188 +340,10 @@ __device__ __forceinline__ void split2_f16_nc(const wf2 v, unsigned& h, unsigned
   asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v.y), "v"(h));
 }
 
+// Epilogue of the 4-wave forms: wave w holds row xi = w of the transformed output (acc[nu][cout sub-tile][tile sub-tile]).
 template <bool STAMP>
-__global__ __launch_bounds__(W4_NT, 1) void wino4_f2x2_kernel(const ConvParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char wsm[W_SMEM];
-  unsigned char* const Ab = wsm;
-  unsigned char* const Raw = wsm + 2 * A_BUF;
-
+__device__ __forceinline__ void wino4_epilogue(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[4][2][2], unsigned char* wsm, int bimg, int oy0, int ox0, int n0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
-  const int tilesN = p.Cout / W_BN;
-  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
-  const int nblk1 = p.B * tilesY * tilesX * tilesN;
-  int t = xcd_tile_index(nblk1 * p.groups);
-  const bool g1 = t >= nblk1;
-  if (g1) t -= nblk1;
-  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
-  const int nt = t % tilesN;
-  int mt = t / tilesN;
-  const int bx = mt % tilesX; mt /= tilesX;
-  const int by = mt % tilesY;
-  const int bimg = mt / tilesY;
-  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
-  const int nC = p.Cin / W_KC;
-
-  // raw halo: element e = tid + 256 i -> (pixel tid / 4 + 64 i, float4 tid % 4): one voffset per element (out-of-image pixels: the out-of-range marker), the chunk
-  // goes into the instruction's SGPR offset; LDS side: one base + immediates
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
-  unsigned g_off[RAW4_F4];
-#pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) {
-    const int pix = (tid >> 2) + 64 * i, c4 = tid & 3;
-    const int hy = pix / W_HX, hx = pix - hy * W_HX;
-    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
-  }
-  unsigned char* const s_base = Raw + (tid >> 2) * RAW_PITCH + (tid & 3) * 16;
-  const bool s_last = tid < 4 * (W_NPIX - 64 * (RAW4_F4 - 1));  // the last round covers pixels 320 .. 323 only
-  u32x4 ra[RAW4_F4];
-  auto load_raw = [&](int c) {
-    const int soff = (c < nC ? c : nC - 1) * (W_KC * 4);  // past the end: a harmless reload of the last chunk (never consumed)
-#pragma unroll
-    for (int i = 0; i < RAW4_F4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], soff, 0);
-  };
-  auto store_raw = [&]() {
-#pragma unroll
-    for (int i = 0; i < RAW4_F4; ++i)
-      if (i + 1 < RAW4_F4 || s_last) *reinterpret_cast<u32x4*>(s_base + i * (64 * RAW_PITCH)) = ra[i];
-  };
-  auto raw_soff = [&](int c) { return (c < nC ? c : nC - 1) * (W_KC * 4); };
-
-  // transform: thread -> (tile tt = 16 wave + lane / 4, channel quad cg = lane & 3), all 16 positions
-  const int cg = lane & 3, tt = wave * 16 + (lane >> 2), tty = tt >> 3, ttx = tt & 7;
-  const unsigned char* const t_src = Raw + ((2 * tty) * W_HX + 2 * ttx) * RAW_PITCH + cg * 16;
-  unsigned char* const t_dst0 = Ab + tt * 32 + (((cg >> 1) ^ ((tt >> 3) & 1)) * 16) + (cg & 1) * 8;
-  WF4 dcol[2][4];  // one pixel column of the 4 x 4 tile (read one sub-step ahead)
-  WF4 rr[4][4];    // B^T d: [xi][column]
-  auto t_load_col = [&](int j) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dcol[j & 1][i] = *reinterpret_cast<const WF4*>(t_src + (i * W_HX + j) * RAW_PITCH);
-  };
-  auto w_add = [](const WF4& a, const WF4& b) { WF4 r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return r; };
-  auto w_sub = [](const WF4& a, const WF4& b) { WF4 r; r.lo = a.lo - b.lo; r.hi = a.hi - b.hi; return r; };
-  auto t_emit = [&](int buf, int xi, int nu) {
-    const WF4(&r)[4] = rr[xi];
-    const WF4 o = nu == 0 ? w_sub(r[0], r[2]) : (nu == 1 ? w_add(r[1], r[2]) : (nu == 2 ? w_sub(r[2], r[1]) : w_sub(r[1], r[3])));
-    uint2 h, l;
-    split2_f16_nc(o.lo, h.x, l.x);
-    split2_f16_nc(o.hi, h.y, l.y);
-    unsigned char* const dst = t_dst0 + buf * A_BUF + (xi * 4 + nu) * A_POS;
-    *reinterpret_cast<uint2*>(dst) = h;
-    *reinterpret_cast<uint2*>(dst + A_PLANE) = l;
-  };
-
-  // multiply: positions 4 wave + q; weight fragments through a buffer resource: lane offset in a VGPR, (chunk, position) in the SGPR offset, fragment in the immediate
-  const int w_frags = tilesN * nC * 16;  // (chunk, position) slices of 4 KB
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_wino), 0, w_frags * 4096, 0x00020000);
-  const int w_s0 = (nt * nC * 16 + 4 * wave) * 4096;
-  u32x4 bw[4][2][2];  // [q][cout sub-tile][plane]
-  auto load_w = [&](int c, int q) {
-    const int cc = c < nC ? c : nC - 1;
-    const int soff = w_s0 + (cc * 16 + q) * 4096;
-#pragma unroll
-    for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) bw[q][ns][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + (ns * 2 + pl) * 1024, soff, 0);
-  };
-  auto load_w1 = [&](int c, int q, int piece) {  // one of the four fragments of (chunk c, position q)
-    const int cc = c < nC ? c : nC - 1;
-    bw[q][piece >> 1][piece & 1] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + piece * 1024, w_s0 + (cc * 16 + q) * 4096, 0);
-  };
-  f32x16 acc[4][2][2];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][b][m][e] = 0.f;
-  const unsigned char* const a_frag0 = Ab + (4 * wave) * A_POS + l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16);
-  u32x4 av[2][2][2];  // [q & 1][tile sub-tile][plane]
-  auto load_frag = [&](int buf, int q) {
-    const unsigned char* src = a_frag0 + buf * A_BUF + q * A_POS;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) av[q & 1][m][pl] = *reinterpret_cast<const u32x4*>(src + pl * A_PLANE + m * (32 * 32));
-  };
-  auto mma_one = [&](int q, int i) {  // MFMA i = 0..11 of position q: product t3 = i / 4 (wh al, wl ah, wh ah), accumulator (i % 4): consecutive MFMAs are independent
-    const int t3 = i >> 2, ns = (i >> 1) & 1, m = i & 1;
-    const int tw = t3 == 1 ? 1 : 0, tv = t3 == 0 ? 1 : 0;
-    acc[q][ns][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, bw[q][ns][tw]), __builtin_bit_cast(wf16x8, av[q & 1][m][tv]), acc[q][ns][m], 0, 0, 0);
-  };
-  auto t_rows_a = [&](int j) { const WF4(&d)[4] = dcol[j & 1]; rr[0][j] = w_sub(d[0], d[2]); rr[1][j] = w_add(d[1], d[2]); };
-  auto t_rows_b = [&](int j) { const WF4(&d)[4] = dcol[j & 1]; rr[2][j] = w_sub(d[2], d[1]); rr[3][j] = w_sub(d[1], d[3]); };
-
-  // ---- prologue: raw(0) -> LDS -> V(0) -> A[0]; raw(1) -> LDS; raw(2) in registers; weights of chunk 0; fragments of (0, position 0)
-  // The order of the LAST vector-memory requests in front of the loop must be the steady state's (raw halo first, then the four weight requests): hipcc's s_waitcnt
-  // insertion merges the loop's two entry states, and with the weights requested first it made every chunk's halo store wait for vmcnt(0) -- i.e. for the weight
-  // loads issued a moment earlier: 600 of a chunk's 3 700 cycles (profiles/r05_winograd.md)
-  load_raw(0);
-  store_raw();
-  load_raw(1);
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { t_load_col(j); t_rows_a(j); t_rows_b(j); }
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) t_emit(0, xi, nu);
-  __syncthreads();
-  store_raw();
-  load_raw(2);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) load_w(0, q);
-  __syncthreads();
-  load_frag(0, 0);
-  t_load_col(0);
-  WINO4_STAMP(0);
-
-#pragma unroll 1
-  for (int c = 0; c < nC; ++c) {
-    const int buf = c & 1;
-    if (c < 16) WINO4_STAMP(8 + 4 * c);
-    // entering: av[0] = fragments of (c, position 0) and dcol[0] = pixel column 0 of raw(c + 1) are in flight
-#pragma unroll
-    for (int k = 0; k < 24; ++k) {
-      const int q = k / 6, i0 = 2 * (k % 6);
-      // ---- chores of this sub-step (memory instructions, placed by hand -- nothing crosses the sched_barrier below -- and at most two per sub-step: six LDS stores +
-      //      six buffer loads in ONE sub-step cost 600 cycles of issue time that no MFMA covered, profiles/r05_winograd.md)
-      if (k < 3) t_load_col(k + 1);                                   // next pixel column of raw(c + 1)
-      if (k % 6 == 2 && q < 3) load_frag(buf, q + 1);                 // next position's fragments
-      if (k == 4) {                                                  // every wave has read raw(c + 1): the halo of chunk c + 2 may overwrite it
-        __syncthreads();
-        if (c < 16) WINO4_STAMP(9 + 4 * c);
-      }
-      if (k >= 5 && k < 5 + RAW4_F4) {                                // raw(c + 2) -> LDS and the request for raw(c + 3), one element per sub-step
-        const int i = k - 5;
-        if (i + 1 < RAW4_F4 || s_last) *reinterpret_cast<u32x4*>(s_base + i * (64 * RAW_PITCH)) = ra[i];
-        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], raw_soff(c + 3), 0);
-      }
-      // weights, one 16-byte request per sub-step: (c, position 3) in k = 0..3 (its registers were last read in k = 23 of the previous chunk), (c + 1, position q - 1)
-      // in k = 6q .. 6q + 3
-      if (k < 4) load_w1(c, 3, k);
-      else if (k >= 6 && (k % 6) < 4) load_w1(c + 1, q - 1, k % 6);
-      // ---- two MFMAs and one piece of the transform
-      mma_one(q, i0);
-      if (k < 4) t_rows_a(k);
-      else if (k < 20) t_emit(buf ^ 1, (k - 4) >> 2, (k - 4) & 3);
-      mma_one(q, i0 + 1);
-      if (k < 4) t_rows_b(k);
-      SGB(0x008, 1); SGB(0x002, 5); SGB(0x008, 1); SGB(0x002, 5); SGB(0x200, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (c == 2) WINO4_STAMP(80 + k);   // STAMP build: every sub-step of one chunk
-    }
-    if (c < 16) WINO4_STAMP(10 + 4 * c);
-    __syncthreads();                       // V(c + 1) complete in A[buf ^ 1], raw(c + 2) in LDS, A[buf] free
-    if (c < 16) WINO4_STAMP(11 + 4 * c);
-    load_frag(buf ^ 1, 0);
-    t_load_col(0);
-  }
-  WINO4_STAMP(1);
-
   // item = (tile, channel quad): 64 x 16 = 1024 items, 4 per thread; item = tid + 256 it -> the SAME channel quad (tid & 15) for all four: scale / bias once.
   // Every global operand (scale, bias, the residuals of all 16 output pixels) is requested BEFORE the LDS reads and the arithmetic: one load latency per block, not one
   // per item (the first form of this loop spent 12 000 cycles here -- profiles/r05_winograd.md)
@@ -616,6 +439,406 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4_f2x2_kernel(const ConvParams p
   WINO4_STAMP(3);
 }
 
+// Ablation forms (tuning builds only, PF_WINO_ABL=<mask> at run time; results WRONG by construction -- they time the kernel with one cost removed): 1 = no split
+// arithmetic in the transform (raw bits stored), 2 = no LDS stores of the transform, 4 = no transform output at all, 8 = no MFMAs, 16 = no weight requests in the loop,
+// 32 = no mid-chunk barrier, 64 = no raw-halo traffic in the loop.  The product build has no such parameter: ABL is the constant 0.
+#ifdef PF_TUNING_BUILD
+#define WINO4_ABL_PARAM , int ABL = 0
+#else
+#define WINO4_ABL_PARAM
+static constexpr int ABL = 0;
+#endif
+template <bool STAMP WINO4_ABL_PARAM>
+__global__ __launch_bounds__(W4_NT, 1) void wino4_f2x2_kernel(const ConvParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char wsm[W_SMEM];
+  unsigned char* const Ab = wsm;
+  unsigned char* const Raw = wsm + 2 * A_BUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+  const int tilesN = p.Cout / W_BN;
+  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
+  const int nblk1 = p.B * tilesY * tilesX * tilesN;
+  int t = xcd_tile_index(nblk1 * p.groups);
+  const bool g1 = t >= nblk1;
+  if (g1) t -= nblk1;
+  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
+  const int nt = t % tilesN;
+  int mt = t / tilesN;
+  const int bx = mt % tilesX; mt /= tilesX;
+  const int by = mt % tilesY;
+  const int bimg = mt / tilesY;
+  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
+  const int nC = p.Cin / W_KC;
+
+  // raw halo: element e = tid + 256 i -> (pixel tid / 4 + 64 i, float4 tid % 4): one voffset per element (out-of-image pixels: the out-of-range marker), the chunk
+  // goes into the instruction's SGPR offset; LDS side: one base + immediates
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
+  unsigned g_off[RAW4_F4];
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) {
+    const int pix = (tid >> 2) + 64 * i, c4 = tid & 3;
+    const int hy = pix / W_HX, hx = pix - hy * W_HX;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
+  }
+  unsigned char* const s_base = Raw + (tid >> 2) * RAW_PITCH + (tid & 3) * 16;
+  const bool s_last = tid < 4 * (W_NPIX - 64 * (RAW4_F4 - 1));  // the last round covers pixels 320 .. 323 only
+  u32x4 ra[RAW4_F4];
+  auto load_raw = [&](int c) {
+    const int soff = (c < nC ? c : nC - 1) * (W_KC * 4);  // past the end: a harmless reload of the last chunk (never consumed)
+#pragma unroll
+    for (int i = 0; i < RAW4_F4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], soff, 0);
+  };
+  auto store_raw = [&]() {
+#pragma unroll
+    for (int i = 0; i < RAW4_F4; ++i)
+      if (i + 1 < RAW4_F4 || s_last) *reinterpret_cast<u32x4*>(s_base + i * (64 * RAW_PITCH)) = ra[i];
+  };
+  auto raw_soff = [&](int c) { return (c < nC ? c : nC - 1) * (W_KC * 4); };
+
+  // transform: thread -> (tile tt = 16 wave + lane / 4, channel quad cg = lane & 3), all 16 positions
+  const int cg = lane & 3, tt = wave * 16 + (lane >> 2), tty = tt >> 3, ttx = tt & 7;
+  const unsigned char* const t_src = Raw + ((2 * tty) * W_HX + 2 * ttx) * RAW_PITCH + cg * 16;
+  unsigned char* const t_dst0 = Ab + tt * 32 + (((cg >> 1) ^ ((tt >> 3) & 1)) * 16) + (cg & 1) * 8;
+  WF4 dcol[2][4];  // one pixel column of the 4 x 4 tile (read one sub-step ahead)
+  WF4 rr[4][4];    // B^T d: [xi][column]
+  auto t_load_col = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dcol[j & 1][i] = *reinterpret_cast<const WF4*>(t_src + (i * W_HX + j) * RAW_PITCH);
+  };
+  auto w_add = [](const WF4& a, const WF4& b) { WF4 r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return r; };
+  auto w_sub = [](const WF4& a, const WF4& b) { WF4 r; r.lo = a.lo - b.lo; r.hi = a.hi - b.hi; return r; };
+  auto t_emit = [&](int buf, int xi, int nu) {
+    const WF4(&r)[4] = rr[xi];
+    const WF4 o = nu == 0 ? w_sub(r[0], r[2]) : (nu == 1 ? w_add(r[1], r[2]) : (nu == 2 ? w_sub(r[2], r[1]) : w_sub(r[1], r[3])));
+    if constexpr ((ABL & 4) != 0) return;
+    uint2 h, l;
+    if constexpr ((ABL & 1) != 0) {
+      h = make_uint2(__builtin_bit_cast(unsigned, o.lo.x), __builtin_bit_cast(unsigned, o.lo.y));
+      l = make_uint2(__builtin_bit_cast(unsigned, o.hi.x), __builtin_bit_cast(unsigned, o.hi.y));
+    } else {
+      split2_f16_nc(o.lo, h.x, l.x);
+      split2_f16_nc(o.hi, h.y, l.y);
+    }
+    unsigned char* const dst = t_dst0 + buf * A_BUF + (xi * 4 + nu) * A_POS;
+    if constexpr ((ABL & 2) != 0) {
+      asm volatile("" ::"v"(h.x), "v"(h.y), "v"(l.x), "v"(l.y));  // the values stay computed
+    } else {
+      *reinterpret_cast<uint2*>(dst) = h;
+      *reinterpret_cast<uint2*>(dst + A_PLANE) = l;
+    }
+  };
+
+  // multiply: positions 4 wave + q; weight fragments through a buffer resource: lane offset in a VGPR, (chunk, position) in the SGPR offset, fragment in the immediate
+  const int w_frags = tilesN * nC * 16;  // (chunk, position) slices of 4 KB
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_wino), 0, w_frags * 4096, 0x00020000);
+  const int w_s0 = (nt * nC * 16 + 4 * wave) * 4096;
+  u32x4 bw[4][2][2];  // [q][cout sub-tile][plane]
+  auto load_w = [&](int c, int q) {
+    const int cc = c < nC ? c : nC - 1;
+    const int soff = w_s0 + (cc * 16 + q) * 4096;
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bw[q][ns][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + (ns * 2 + pl) * 1024, soff, 0);
+  };
+  auto load_w1 = [&](int c, int q, int piece) {  // one of the four fragments of (chunk c, position q)
+    const int cc = c < nC ? c : nC - 1;
+    bw[q][piece >> 1][piece & 1] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + piece * 1024, w_s0 + (cc * 16 + q) * 4096, 0);
+  };
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][b][m][e] = 0.f;
+  const unsigned char* const a_frag0 = Ab + (4 * wave) * A_POS + l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16);
+  u32x4 av[2][2][2];  // [q & 1][tile sub-tile][plane]
+  auto load_frag = [&](int buf, int q) {
+    const unsigned char* src = a_frag0 + buf * A_BUF + q * A_POS;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) av[q & 1][m][pl] = *reinterpret_cast<const u32x4*>(src + pl * A_PLANE + m * (32 * 32));
+  };
+  auto mma_one = [&](int q, int i) {  // MFMA i = 0..11 of position q: product t3 = i / 4 (wh al, wl ah, wh ah), accumulator (i % 4): consecutive MFMAs are independent
+    const int t3 = i >> 2, ns = (i >> 1) & 1, m = i & 1;
+    const int tw = t3 == 1 ? 1 : 0, tv = t3 == 0 ? 1 : 0;
+    if constexpr ((ABL & 8) != 0) { asm volatile("" ::"v"(bw[q][ns][tw]), "v"(av[q & 1][m][tv])); return; }
+    acc[q][ns][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, bw[q][ns][tw]), __builtin_bit_cast(wf16x8, av[q & 1][m][tv]), acc[q][ns][m], 0, 0, 0);
+  };
+  auto t_rows_a = [&](int j) { const WF4(&d)[4] = dcol[j & 1]; rr[0][j] = w_sub(d[0], d[2]); rr[1][j] = w_add(d[1], d[2]); };
+  auto t_rows_b = [&](int j) { const WF4(&d)[4] = dcol[j & 1]; rr[2][j] = w_sub(d[2], d[1]); rr[3][j] = w_sub(d[1], d[3]); };
+
+  // ---- prologue: raw(0) -> LDS -> V(0) -> A[0]; raw(1) -> LDS; raw(2) in registers; weights of chunk 0; fragments of (0, position 0)
+  // The order of the LAST vector-memory requests in front of the loop must be the steady state's (raw halo first, then the four weight requests): hipcc's s_waitcnt
+  // insertion merges the loop's two entry states, and with the weights requested first it made every chunk's halo store wait for vmcnt(0) -- i.e. for the weight
+  // loads issued a moment earlier: 600 of a chunk's 3 700 cycles (profiles/r05_winograd.md)
+  load_raw(0);
+  store_raw();
+  load_raw(1);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { t_load_col(j); t_rows_a(j); t_rows_b(j); }
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) t_emit(0, xi, nu);
+  __syncthreads();
+  store_raw();
+  load_raw(2);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) load_w(0, q);
+  __syncthreads();
+  load_frag(0, 0);
+  t_load_col(0);
+  WINO4_STAMP(0);
+
+#pragma unroll 1
+  for (int c = 0; c < nC; ++c) {
+    const int buf = c & 1;
+    if (c < 16) WINO4_STAMP(8 + 4 * c);
+    // entering: av[0] = fragments of (c, position 0) and dcol[0] = pixel column 0 of raw(c + 1) are in flight
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      const int q = k / 6, i0 = 2 * (k % 6);
+      // ---- chores of this sub-step (memory instructions, placed by hand -- nothing crosses the sched_barrier below -- and at most two per sub-step: six LDS stores +
+      //      six buffer loads in ONE sub-step cost 600 cycles of issue time that no MFMA covered, profiles/r05_winograd.md)
+      if (k < 3) t_load_col(k + 1);                                   // next pixel column of raw(c + 1)
+      if (k % 6 == 2 && q < 3) load_frag(buf, q + 1);                 // next position's fragments
+      if (k == 4) {                                                  // every wave has read raw(c + 1): the halo of chunk c + 2 may overwrite it
+        if constexpr ((ABL & 32) == 0) __syncthreads();
+        if (c < 16) WINO4_STAMP(9 + 4 * c);
+      }
+      if ((ABL & 64) == 0 && k >= 5 && k < 5 + RAW4_F4) {            // raw(c + 2) -> LDS and the request for raw(c + 3), one element per sub-step
+        const int i = k - 5;
+        if (i + 1 < RAW4_F4 || s_last) *reinterpret_cast<u32x4*>(s_base + i * (64 * RAW_PITCH)) = ra[i];
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], raw_soff(c + 3), 0);
+      }
+      // weights, one 16-byte request per sub-step: (c, position 3) in k = 0..3 (its registers were last read in k = 23 of the previous chunk), (c + 1, position q - 1)
+      // in k = 6q .. 6q + 3
+      if constexpr ((ABL & 16) == 0) {
+        if (k < 4) load_w1(c, 3, k);
+        else if (k >= 6 && (k % 6) < 4) load_w1(c + 1, q - 1, k % 6);
+      }
+      // ---- two MFMAs and one piece of the transform
+      mma_one(q, i0);
+      if (k < 4) t_rows_a(k);
+      else if (k < 20) t_emit(buf ^ 1, (k - 4) >> 2, (k - 4) & 3);
+      mma_one(q, i0 + 1);
+      if (k < 4) t_rows_b(k);
+      SGB(0x008, 1); SGB(0x002, 5); SGB(0x008, 1); SGB(0x002, 5); SGB(0x200, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c == 2) WINO4_STAMP(80 + k);   // STAMP build: every sub-step of one chunk
+    }
+    if (c < 16) WINO4_STAMP(10 + 4 * c);
+    __syncthreads();                       // V(c + 1) complete in A[buf ^ 1], raw(c + 2) in LDS, A[buf] free
+    if (c < 16) WINO4_STAMP(11 + 4 * c);
+    load_frag(buf ^ 1, 0);
+    t_load_col(0);
+  }
+  WINO4_STAMP(1);
+
+  wino4_epilogue<STAMP>(p, P, acc, wsm, bimg, oy0, ox0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// "wino256x64c": the 4-wave form WITHOUT the transformed operand in LDS.  The ablation of wino256x64w4 (profiles/r05_winograd.md) put its largest single cost on the
+// LDS stores of V (23 % of the launch: 16 stores of 16 bytes per thread and chunk, in a stream that has no second wave to cover them).  Here wave w (row xi = w of the
+// transformed tile) computes the MFMA B-operand fragments it needs ITSELF, in fragment layout: lane = (tile column l & 31, channel half l >> 5) reads the 2 x 4 input
+// pixels its row needs (8 channels each: 16 ds_read_b128 per tile sub-tile) from the raw halo tile, forms the row combination (one packed FMA with a wave-uniform sign),
+// the four column combinations and the fp16 split -- 8 channels x 4 positions = the four fragments of (tile sub-tile m, nu = 0..3).  No V stores, no fragment reads,
+// no second barrier; the VALU work is the same (every V element is computed exactly once, by the wave that multiplies it).
+//   raw halo tile: 18 rows x (18 pixels x 64 B + 32 B pad); the four 16-byte pieces of a pixel are stored XOR-swizzled by ((column >> 1) & 3): conflict-free
+//   ds_read_b128 for the stride-2 tile origins (brute-force search, tests/test_host_logic.py); three buffers (chunk c, c + 1 being read, c + 2 being filled): ONE barrier per chunk.
+//   software pipeline over the 8 fragments (m, nu) of a chunk: the MFMAs of fragment f run two fragments behind the transform (ring of four fragment registers); a
+//   fragment = 6 MFMAs = 3 sub-steps of {MFMA, VALU, MFMA, VALU}; the transform pieces, the LDS reads (8 per sub-step, one fragment ahead of their use), the weight
+//   requests (one per sub-step) and the raw-halo staging (one element per sub-step) are placed by hand; sched_barrier between the sub-steps.
+namespace {
+constexpr int RC_ROW = 18 * 64 + 32;          // 1184 bytes per halo row
+constexpr int RC_BYTES = W_HY * RC_ROW;       // 21312
+constexpr int WC_SMEM = 16 * M_POS;           // the epilogue's exchange (128 KB) is the largest user; the three raw tiles take 63 936 bytes of it
+static_assert(3 * RC_BYTES <= WC_SMEM, "raw tiles fit");
+struct V8 { wf2 c[4]; };                      // eight channels
+}  // namespace
+
+template <bool STAMP>
+__global__ __launch_bounds__(W4_NT, 1) void wino4c_f2x2_kernel(const ConvParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char wsm[WC_SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+  const int tilesN = p.Cout / W_BN;
+  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
+  const int nblk1 = p.B * tilesY * tilesX * tilesN;
+  int t = xcd_tile_index(nblk1 * p.groups);
+  const bool g1 = t >= nblk1;
+  if (g1) t -= nblk1;
+  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
+  const int nt = t % tilesN;
+  int mt = t / tilesN;
+  const int bx = mt % tilesX; mt /= tilesX;
+  const int by = mt % tilesY;
+  const int bimg = mt / tilesY;
+  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
+  const int nC = p.Cin / W_KC;
+
+  // ---- raw halo staging: element e = tid + 256 i -> (pixel tid / 4 + 64 i, logical piece tid % 4); LDS offset with the piece swizzle
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
+  unsigned g_off[RAW4_F4];
+  int s_off[RAW4_F4];
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) {
+    const int pix = (tid >> 2) + 64 * i, c4 = tid & 3;
+    const int hy = pix / W_HX, hx = pix - hy * W_HX;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
+    s_off[i] = hy * RC_ROW + hx * 64 + ((c4 ^ ((hx >> 1) & 3)) * 16);
+  }
+  const bool s_last = tid < 4 * (W_NPIX - 64 * (RAW4_F4 - 1));
+  auto raw_soff = [&](int c) { return (c < nC ? c : nC - 1) * (W_KC * 4); };
+  u32x4 ra[RAW4_F4];
+  auto raw_load1 = [&](int i, int c) { ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], raw_soff(c), 0); };
+  auto raw_store1 = [&](int i, int c) {
+    if (i + 1 < RAW4_F4 || s_last) *reinterpret_cast<u32x4*>(wsm + (c % 3) * RC_BYTES + s_off[i]) = ra[i];
+  };
+
+  // ---- transform operands: lane -> tile column l31 of sub-tile m (tile row ty = l31 / 8 + 4 m, tx = l31 % 8), channels 8 hi .. 8 hi + 7 = logical pieces 2 hi, 2 hi + 1
+  // row pair of this wave's xi: xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3  ->  t = xA + sgn xB
+  const int rA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), rB = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+  const float sgn_f = wave == 1 ? 1.f : -1.f;
+  const wf2 sgn = {sgn_f, sgn_f};
+  const int ty0 = l31 >> 3, tx0 = l31 & 7;
+  const int t_base = (2 * ty0) * RC_ROW + (2 * tx0) * 64;
+  // byte offsets inside a raw tile of this lane's two pieces for pixel columns {0, 1} (swizzle tx & 3) and {2, 3} (swizzle (tx + 1) & 3)
+  int t_pc[2][2];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) t_pc[jp][hf] = t_base + jp * 128 + (((2 * hi + hf) ^ ((tx0 + jp) & 3)) * 16);
+  V8 xa[4], xb[4];  // the two pixel rows (4 columns x 8 channels each) of one tile sub-tile
+  auto t_read = [&](int c, int m, int part) {  // part 0: row A, part 1: row B (8 ds_read_b128 each)
+    const unsigned char* base = wsm + (c % 3) * RC_BYTES + m * (8 * RC_ROW) + (part ? rB : rA) * RC_ROW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const WF4 v = *reinterpret_cast<const WF4*>(base + t_pc[j >> 1][hf] + (j & 1) * 64);
+        if (part) { xb[j].c[2 * hf] = v.lo; xb[j].c[2 * hf + 1] = v.hi; }
+        else      { xa[j].c[2 * hf] = v.lo; xa[j].c[2 * hf + 1] = v.hi; }
+      }
+  };
+  V8 tr[4];  // row combination, four pixel columns
+  auto t_rows = [&](int j) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tr[j].c[e] = __builtin_elementwise_fma(sgn, xb[j].c[e], xa[j].c[e]);
+  };
+  u32x4 vf[4][2];  // ring of four fragments: [slot][plane hi / lo]
+  V8 vo;           // one column combination (between its two pieces)
+  auto t_cols = [&](int nu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      vo.c[e] = nu == 0 ? tr[0].c[e] - tr[2].c[e] : (nu == 1 ? tr[1].c[e] + tr[2].c[e] : (nu == 2 ? tr[2].c[e] - tr[1].c[e] : tr[1].c[e] - tr[3].c[e]));
+  };
+  auto t_split = [&](int slot) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2_f16_nc(vo.c[e], h[e], l[e]);
+    vf[slot][0] = u32x4{h[0], h[1], h[2], h[3]};
+    vf[slot][1] = u32x4{l[0], l[1], l[2], l[3]};
+  };
+
+  // ---- weights: fragments of positions 4 wave + nu through a buffer resource (as in wino256x64w4)
+  const int w_frags = tilesN * nC * 16;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_wino), 0, w_frags * 4096, 0x00020000);
+  const int w_s0 = (nt * nC * 16 + 4 * wave) * 4096;
+  u32x4 bw[4][2][2];  // [nu][cout sub-tile][plane]
+  auto load_w1 = [&](int c, int nu, int piece) {
+    const int cc = c < nC ? c : nC - 1;
+    bw[nu][piece >> 1][piece & 1] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + piece * 1024, w_s0 + (cc * 16 + nu) * 4096, 0);
+  };
+  f32x16 acc[4][2][2];  // [nu][cout sub-tile][tile sub-tile]
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][b][m][e] = 0.f;
+  auto mma_one = [&](int f, int i) {  // MFMA i = 0..5 of fragment f = 4 m + nu: product i / 2 (wh vl, wl vh, wh vh), cout sub-tile i % 2
+    const int m = f >> 2, nu = f & 3, t3 = i >> 1, ns = i & 1;
+    const int tw = t3 == 1 ? 1 : 0, tv = t3 == 0 ? 1 : 0;
+    acc[nu][ns][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, bw[nu][ns][tw]), __builtin_bit_cast(wf16x8, vf[f & 3][tv]), acc[nu][ns][m], 0, 0, 0);
+  };
+
+  // ---- prologue: raw(0), raw(1) -> LDS; raw(2) requested; weights of chunk 0; fragments 0 and 1 of chunk 0
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 0);
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_store1(i, 0);
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 1);
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_store1(i, 1);
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 2);
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) load_w1(0, nu, pc);
+  __syncthreads();
+  t_read(0, 0, 0); t_read(0, 0, 1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t_rows(j);
+  t_cols(0); t_split(0);
+  t_cols(1); t_split(1);
+  WINO4_STAMP(0);
+
+#pragma unroll 1
+  for (int c = 0; c < nC; ++c) {
+    if (c < 16) WINO4_STAMP(8 + 2 * c);
+    // entering: fragments 0, 1 of chunk c are in vf[0], vf[1]; tr = row combinations of (chunk c, m = 0); raw(c), raw(c + 1) in LDS; ra = raw(c + 2) requested
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      const int f = k / 3, ks = k % 3;     // MFMAs of fragment f
+      const int g = f + 2;                 // the transform works on fragment g (g >= 8: fragments 0, 1 of chunk c + 1)
+      const int gc = g < 8 ? c : c + 1, gf = g & 7, gm = gf >> 2, gnu = gf & 3;
+      // ---- chores (memory instructions: placed by hand, at most ~8 LDS reads + 1 store + 1-2 requests per sub-step)
+      // raw(c + 2) -> LDS, then raw(c + 3) requested: element i in sub-steps 2 i (store) and 2 i + 1 (request), i = 0..5
+      if (k < 2 * RAW4_F4) { if ((k & 1) == 0) raw_store1(k >> 1, c + 2); else raw_load1(k >> 1, c + 3); }
+      // pixel rows of the NEXT tile sub-tile, one fragment ahead of the row combination: during the nu = 3 fragment (gnu == 3): row A in its second sub-step, row B in its third
+      if (gnu == 3 && ks == 1) t_read(gm == 0 ? gc : gc + 1, gm ^ 1, 0);
+      if (gnu == 3 && ks == 2) t_read(gm == 0 ? gc : gc + 1, gm ^ 1, 1);
+      // weights of chunk c + 1 for position nu: requested after its last MFMAs of this chunk (fragment 4 + nu), one 16-byte piece per sub-step
+      if (f >= 5 && f - 5 < 3) { if (ks < 2) { load_w1(c + 1, f - 5, 2 * ks); load_w1(c + 1, f - 5, 2 * ks + 1); } }
+      if (f == 0 && ks < 2) { load_w1(c, 3, 2 * ks); load_w1(c, 3, 2 * ks + 1); }  // position 3: last read in the previous chunk's fragment 7
+      // ---- two MFMAs and the transform's piece
+      mma_one(f, 2 * ks);
+      if (gnu == 0) {              // rows (16 packed FMAs) + first column combination + split: 32 VALU instructions over three sub-steps
+        if (ks == 0) { t_rows(0); t_rows(1); }
+        if (ks == 1) { t_rows(2); t_rows(3); t_cols(0); }
+        if (ks == 2) t_split(g & 3);
+      } else {
+        if (ks == 0) t_cols(gnu);
+        if (ks == 1) t_split(g & 3);
+      }
+      mma_one(f, 2 * ks + 1);
+      SGB(0x008, 1); SGB(0x002, 6); SGB(0x008, 1); SGB(0x002, 6);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c == 2) WINO4_STAMP(80 + k);
+    }
+    if (c < 16) WINO4_STAMP(9 + 2 * c);
+    __syncthreads();   // raw(c + 2) complete in LDS; raw(c) free
+  }
+  WINO4_STAMP(1);
+  wino4_epilogue<STAMP>(p, P, acc, wsm, bimg, oy0, ox0, n0);
+}
+
 // 3x3 / stride 1 / pad 1, split-f16 scheme, one fp32 NHWC input, fp32 NHWC output, Winograd weights present
 bool conv_wino_ok(const ConvParams& p) {
   if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nterms != NT_F16X3 || p.nchw_out || p.ups || p.ln || p.splitk > 1) return false;
@@ -630,7 +853,27 @@ bool conv_wino_ok(const ConvParams& p) {
 void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant) {
   const int tilesN = p.Cout / W_BN, tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(W_NT);
+  if (variant == 2) {  // "wino256x64c"
+    if (p.stamps) hipLaunchKernelGGL(wino4c_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
+    else hipLaunchKernelGGL(wino4c_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
+    return;
+  }
   if (variant == 1) {  // "wino256x64w4"
+#ifdef PF_TUNING_BUILD
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("PF_WINO_ABL"); abl = e ? atoi(e) : 0; }
+    switch (abl) {
+      case 1: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 1>), grid, dim3(W4_NT), 0, s, p); return;
+      case 2: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 2>), grid, dim3(W4_NT), 0, s, p); return;
+      case 4: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 4>), grid, dim3(W4_NT), 0, s, p); return;
+      case 8: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 8>), grid, dim3(W4_NT), 0, s, p); return;
+      case 16: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 16>), grid, dim3(W4_NT), 0, s, p); return;
+      case 32: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 32>), grid, dim3(W4_NT), 0, s, p); return;
+      case 64: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 64>), grid, dim3(W4_NT), 0, s, p); return;
+      case 84: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 84>), grid, dim3(W4_NT), 0, s, p); return;   // 4 + 16 + 64: MFMAs, fragment reads and barriers only
+      default: break;
+    }
+#endif
     if (p.stamps) hipLaunchKernelGGL(wino4_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
     else hipLaunchKernelGGL(wino4_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
     return;

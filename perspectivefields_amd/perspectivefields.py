@@ -74,8 +74,10 @@ def _resolve_weights(version: str, weights) -> Dict[str, np.ndarray]:
 
 def _window_limit(r) -> float:
     """upper end of the split-f16 window for one range record: 65504, except the attention operands, which carry extra powers of two inside the kernel
-    (attn.hip: q x 8, k / v x 16) -- their window ends at 8188 / 4094"""
+    (attn.hip: q x 8, k / v x 16) -- their window ends at 8188 / 4094 -- and the inputs of the Winograd convolutions (16376)"""
     name = r["name"]
+    if "[winograd]" in name:   # the input transform of the Winograd convs adds four values (wino.hip) and does not clamp
+        return 65504.0 / 4.0
     if name.startswith("attention") and name.endswith(" q"):
         return 8188.0
     if name.startswith("attention") and name.endswith(" kv"):

@@ -719,7 +719,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile_name", ["wino256x64", "wino256x64w4"])
+@pytest.mark.parametrize("tile_name", ["wino256x64", "wino256x64w4", "wino256x64c"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
 def test_conv2d_winograd_tile(ops, case, tile_name):
     """Winograd F(2x2, 3x3) tile "wino256x64" (wino.hip: 16 position GEMMs on the split-f16 MFMA, input / output transforms in fp32) against fp64, with the whole
@@ -730,7 +730,8 @@ def test_conv2d_winograd_tile(ops, case, tile_name):
     assert tile_name in names
     tw = names.index(tile_name)
     th = names.index("sbh128x64")
-    assert ops.conv2d_bench(1, 16, 16, 64, 64, 3, 1, 1, tile=tw, iters=1) > 0   # the tile really runs such shapes (an unusable tile id would fall back silently)
+    assert ops.conv2d_bench(B, H, W, Cin, Cout, 3, 1, 1, tile=tw, iters=1) > 0   # the tile really runs this shape (an unusable tile id would fall back silently) ...
+    # ... and splitk=False below: with the engine's split-K rule on (deep K, few blocks) pf_op_conv2d would hand the small shapes to the linear tiles instead
     x = _rand((B, H, W, Cin), 300)
     w = _rand((Cout, Cin, 3, 3), 301, 1.0 / math.sqrt(Cin * 9))
     b = _rand((Cout,), 302, 0.1)
@@ -739,15 +740,15 @@ def test_conv2d_winograd_tile(ops, case, tile_name):
     ref0 = _ref_conv(x, w, b, 1, 1)
     scale = _ref_conv(x.abs(), w.abs(), None, 1, 1)
     xd = x.cuda()
-    got = ops.conv2d(xd, w, b, pad=1, tile=tw).double().cpu()
+    got = ops.conv2d(xd, w, b, pad=1, tile=tw, splitk=False).double().cpu()
     direct = ops.conv2d(xd, w, b, pad=1, tile=th).double().cpu()
     ew, ed = ((got - ref0).abs() / scale).max().item(), ((direct - ref0).abs() / scale).max().item()
     print(f"[{tile_name} {name}] |err| / sum|x||w|: winograd {ew:.2e}, direct halo tile {ed:.2e}")
     assert ew <= 4 * ed + 2.0 ** -20, (name, ew, ed)
     # full epilogue: y = relu(relu(conv + bias) + res1 + res2)
     ref1 = torch.relu(torch.relu(ref0) + r1.double() + r2.double())
-    got1 = ops.conv2d(xd, w, b, pad=1, act=1, res1=r1.cuda(), res2=r2.cuda(), post_relu=True, tile=tw).double().cpu()
+    got1 = ops.conv2d(xd, w, b, pad=1, act=1, res1=r1.cuda(), res2=r2.cuda(), post_relu=True, tile=tw, splitk=False).double().cpu()
     assert ((got1 - ref1).abs() / (scale + 1.0)).max().item() <= 4 * ed + 2.0 ** -20, name
     # no bias
-    got2 = ops.conv2d(xd, w, None, pad=1, tile=tw).double().cpu()
+    got2 = ops.conv2d(xd, w, None, pad=1, tile=tw, splitk=False).double().cpu()
     assert ((got2 - _ref_conv(x, w, None, 1, 1)).abs() / scale).max().item() <= 4 * ed + 2.0 ** -20, name
