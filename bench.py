@@ -38,7 +38,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 dense MFMA peak (spec; 2:1 sparsity NOT counted)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 GFLOP_PER_IMAGE_REF = 213.44   # contraction FLOPs of the reference graph, Paramnet-centered
-MFMA_PER_PRODUCT = {"fp32": 3, "fp32_bf16x6": 6, "bf16": 1}  # (the 3-term bf16 split "bf16x3" is no bench mode any more: reduced precision AND slower than the fp32-class default, profiles/r03_bench_configs.json)
+MFMA_PER_PRODUCT = {"fp32": 3, "fp32_bf16x6": 6}  # (the 3-term bf16 split "bf16x3" is no bench mode any more: reduced precision AND slower than the fp32-class default, profiles/r03_bench_configs.json)
 
 
 def parse(argv=None):
@@ -51,7 +51,7 @@ def parse(argv=None):
     ap.add_argument("--version", default="Paramnet-360Cities-edina-centered")
     ap.add_argument("--precision", default="fp32", choices=list(MFMA_PER_PRODUCT),
                     help="arithmetic of the dense contractions; fp32 (split-f16, fp32-class accuracy) is the parity mode and the headline; "
-                         "fp32_bf16x6 = exact bf16 split (no range window); bf16 is the reduced-precision mode (reported, never the headline)")
+                         "fp32_bf16x6 = exact bf16 split (no range window); no reduced-precision mode is offered")
     ap.add_argument("--autotune", type=int, default=0, help="1: time every tile configuration for this batch size before the warm-up (default: shipped tile table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--defer-params", type=int, default=1, help="1 (default): the ParamNet branch of step i runs on the engine's own stream next to step i + 1's backbone (pf_set_defer_params); "
@@ -612,7 +612,7 @@ def main(argv=None):
             except Exception:
                 pass
         line["precision_modes"] = ("fp32 (2-way fp16 split, 3 MFMAs per product) is the fastest mode that holds the parity tolerances; fp32_bf16x6 is the exact alternative; "
-                                   "bf16 is reduced precision (fails the ParamNet tolerance); the 3-term bf16 split is no longer offered (slower than fp32 AND outside tolerance)")
+                                   "no reduced-precision mode is offered (r01-r04's bf16 switches cost accuracy for +0.6 ... 4 %; a bf16 throughput path was not built: include/pf_hip.h)")
         # ---- (3) latency of the reference's primary call pattern: inference(img) / small batches
         try:
             lat = {}

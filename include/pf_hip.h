@@ -108,15 +108,23 @@ size_t pf_workspace_bytes(pf_handle h, int batch);
  *     Activations beyond the fp16 range (|x| > 65504) saturate.
  *   FP32_BF16X6: every operand split EXACTLY into three bf16 values, six bf16 MFMA partial products -- fp32-accurate
  *     for any fp32 input (no range restriction), twice the matrix-core work.
- *   BF16X3: three bf16 partial products (operands carried to ~16 significant bits).  BF16: one (plain bf16 operands,
- *     fp32 accumulation), the reference's autocast-style mode.  These two trade accuracy for speed and are NOT held to
- *     the parity tolerances.
+ * NO reduced-precision mode is offered (r05): r01-r04 carried "bf16x3" / "bf16" switches on these same kernels -- 98.9 % argmax agreement for +0.6 ... 4 % speed,
+ * i.e. lower accuracy for nothing (profiles/r04_bench_configs.json) -- and a bf16 THROUGHPUT path (bf16 activations in HBM, one MFMA per product, its own tile
+ * table) was not built; values 1 and 2 of earlier headers are rejected with PF_ERR_ARG.
  * May be called at any time; it applies to the following forwards (tile choices are tuned per mode). */
 #define PF_PRECISION_FP32 0
-#define PF_PRECISION_BF16X3 1
-#define PF_PRECISION_BF16 2
 #define PF_PRECISION_FP32_BF16X6 3
 int pf_set_precision(pf_handle h, int mode);
+
+/* Always-on saturation watch of the FP32 (split-f16) mode.  d_counter_u32: a caller-owned, zero-initialised 4-byte device counter (nullptr: off).  Every kernel that
+ * WRITES a tensor a split-f16 contraction will read (GEMM / conv epilogues, the fused block MLPs, the Winograd convs) adds to it the number of 16-byte output groups
+ * with an element beyond the window of that tensor's consumer (65504; 65504 / 4 in front of a Winograd conv; 8188 / 4094 for the attention operands; the input limit
+ * of a depthwise conv, from its weights) or NaN.  Cost: one compare per 4 outputs; the counter only ever grows.  Read it in stream order behind a forward (a 4-byte
+ * copy): unchanged = every dense-layer input of that forward was inside the window.  The Python layer (`precision="auto"`) re-runs a batch that moved it in the
+ * FP32_BF16X6 mode and stays there.  Tensors no kernel can watch (LayerNorm outputs, the register-only hidden maps of the fused MLPs) are bounded from the weights
+ * alone: pf_static_window_max returns the largest such bound, scaled so that a value > 65504 means "a static bound exceeds its window". */
+int pf_set_saturation_counter(pf_handle h, void* d_counter_u32);
+int pf_static_window_max(pf_handle h, float* out);
 
 int pf_forward_u8(pf_handle h, int batch, const uint8_t* d_images_u8, float* d_pred_gravity, float* d_pred_latitude,
                   float* d_params, void* d_workspace, size_t workspace_bytes, void* stream);

@@ -35,7 +35,7 @@ __device__ __forceinline__ f32x16 cm_mfma(const u32x4 a, const u32x4 b, const f3
 // tab: inv1[H], cs1[H] (column sums of the gamma-folded W1), b1[H] (bias + W1 beta), inv2[C], b2[C]  (H = 4 C)
 template <int C, int DIAG = 0 /*tuning builds (ablation): 1 no GELU, 2 no weight DMA inside the loop, 3 no MFMA, 5 no s_setprio*/>
 __global__ __launch_bounds__(256, C <= 96 ? 3 : 1) void cnx_mlp_kernel(const float* __restrict__ d, float* __restrict__ y, const unsigned short* __restrict__ wpk,
-                                                         const float* __restrict__ tab, int M, float eps) {
+                                                         const float* __restrict__ tab, int M, float eps, unsigned* sat, float sat_limit) {
   constexpr int H = 4 * C, S1 = C / 16, Q = C / 32, NCH = H / 32;
   constexpr bool PRIO = DIAG != 5;
   constexpr int CH1 = S1 * 2 * 512, CH2 = Q * 2 * 2 * 512;  // ushorts per chunk part (one fragment = 64 lanes x 8 = 512 ushorts)
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, C <= 96 ? 3 : 1) void cnx_mlp_kernel(const flo
       float4 v;
       v.x = fmaf(acc2[q][4 * g], iv.x, bb.x) + r.x; v.y = fmaf(acc2[q][4 * g + 1], iv.y, bb.y) + r.y;
       v.z = fmaf(acc2[q][4 * g + 2], iv.z, bb.z) + r.z; v.w = fmaf(acc2[q][4 * g + 3], iv.w, bb.w) + r.w;
+      if (sat) sat_watch4(sat, sat_limit, v.x, v.y, v.z, v.w);  // the residual stream feeds the next block's depthwise conv / LayerNorm-fused pwconv1 (ConvParams::sat)
       *reinterpret_cast<float4*>(yrow + n) = v;
     }
 }
@@ -236,17 +237,17 @@ bool cnx_mlp_preferred(int C) {
   return C == 96 || (C == 192 && with192);
 }
 
-void launch_cnx_mlp(const float* d, float* y, const unsigned short* wpk, const float* tab, long M, int C, float eps, hipStream_t s) {
+void launch_cnx_mlp(const float* d, float* y, const unsigned short* wpk, const float* tab, long M, int C, float eps, hipStream_t s, unsigned* sat, float sat_limit) {
   const dim3 grid((unsigned)((M + 127) / 128)), block(256);
 #ifdef PF_TUNING_BUILD
   static const int diag = [] { const char* e = getenv("PF_CNX_DIAG"); return e ? atoi(e) : 0; }();
-  if (C == 96 && diag == 1) { hipLaunchKernelGGL((cnx_mlp_kernel<96, 1>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps); return; }
-  if (C == 96 && diag == 2) { hipLaunchKernelGGL((cnx_mlp_kernel<96, 2>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps); return; }
-  if (C == 96 && diag == 3) { hipLaunchKernelGGL((cnx_mlp_kernel<96, 3>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps); return; }
-  if (C == 96 && diag == 5) { hipLaunchKernelGGL((cnx_mlp_kernel<96, 5>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps); return; }
+  if (C == 96 && diag == 1) { hipLaunchKernelGGL((cnx_mlp_kernel<96, 1>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps, sat, sat_limit); return; }
+  if (C == 96 && diag == 2) { hipLaunchKernelGGL((cnx_mlp_kernel<96, 2>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps, sat, sat_limit); return; }
+  if (C == 96 && diag == 3) { hipLaunchKernelGGL((cnx_mlp_kernel<96, 3>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps, sat, sat_limit); return; }
+  if (C == 96 && diag == 5) { hipLaunchKernelGGL((cnx_mlp_kernel<96, 5>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps, sat, sat_limit); return; }
 #endif
-  if (C == 96) hipLaunchKernelGGL((cnx_mlp_kernel<96>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps);
-  else if (C == 192) hipLaunchKernelGGL((cnx_mlp_kernel<192>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps);
+  if (C == 96) hipLaunchKernelGGL((cnx_mlp_kernel<96>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps, sat, sat_limit);
+  else if (C == 192) hipLaunchKernelGGL((cnx_mlp_kernel<192>), grid, block, 0, s, d, y, wpk, tab, (int)M, eps, sat, sat_limit);
 }
 
 }  // namespace pf

@@ -63,13 +63,15 @@ struct ConvW {
   float* wwino_inv = nullptr;      //   and their inverse scale per output channel
   float* ln_s = nullptr;          // fused input LayerNorm (ConvParams::ln): column sums of the gamma-folded weights; nullptr = no fusion
   float ln_eps = 0.f;
+  float sat_limit = 65504.f;      // window of the tensor this layer WRITES, set by its consumer (ConvParams::sat_limit): Winograd conv 65504 / 4, attention q / kv 8188 / 4094,
+                                  // a depthwise conv behind it: (65504 - max |bias|) / max_c sum_k |w[k][c]|
   int Cout = 0, Cin = 0 /*padded*/, CinReal = 0, KH = 1, KW = 1, stride = 1, pad = 0, KWC = 0, KWCp = 0;
 };
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-6f; };
-struct DwW { float* w = nullptr; float* b = nullptr; int C = 0; };
+struct DwW { float* w = nullptr; float* b = nullptr; int C = 0; float in_limit = 65504.f; /* its INPUT may reach this much and the output still fits 65504 */ };
 
 // a linear layer in the row-block form (rb_gemm.hip): weight stream + inverse scales + bias
-struct RbLin { unsigned short* w = nullptr; size_t bytes = 0; float* inv = nullptr; float* b = nullptr; int N = 0, K = 0; };
+struct RbLin { unsigned short* w = nullptr; size_t bytes = 0; float* inv = nullptr; float* b = nullptr; int N = 0, K = 0; float sat_limit = 65504.f; };
 // the key / value branch of a stage-3 block as one launch (rb_chain.hip): combined weight stream (conv as GEMM, then kv) + the two layers' scales / biases
 struct RbSrKv { unsigned short* w = nullptr; size_t bytes = 0; float *sr_inv = nullptr, *sr_b = nullptr, *kv_inv = nullptr, *kv_b = nullptr; };
 struct RbProjFc1 { unsigned short* w = nullptr; size_t bytes = 0; };  // combined weight stream of rb_proj_fc1_kernel (scales / biases: rproj, rfc1)
@@ -79,7 +81,7 @@ struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
   float* predw = nullptr; float* predb = nullptr; int nout = 0;
 };
-struct CnxBlock { DwW dw; LNW n; ConvW pw1, pw2; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused MLP (cnx_mlp.hip), when built */ };
+struct CnxBlock { float out_limit = 65504.f; /* window of the residual stream this block writes: the next block's depthwise conv */ DwW dw; LNW n; ConvW pw1, pw2; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused MLP (cnx_mlp.hip), when built */ };
 struct Cnx { ConvW stem, ds[3]; LNW stemn, dsn[3], norm; std::vector<CnxBlock> blocks[4]; float* headw = nullptr; float* headb = nullptr; int nout = 0; };
 
 // Split-bf16 activation tensor (sb_split.h): three exact bf16 planes `plane` elements apart.
@@ -501,7 +503,9 @@ struct pf_engine {
   int num_cus = 256;         // hipDeviceProp_t::multiProcessorCount (partitioned / smaller gfx950 configurations: CPX / DPX modes)
   int wino_min_hw = 40;      // PF_WINO=<n>: 3x3 / stride-1 convs with Cin, Cout multiples of 64 on maps of at least n x n run as Winograd F(2x2, 3x3) (wino.hip; split-f16
                              // scheme only; 0 = never).  Their inputs' window ends at 65504 / 4 (the input transform adds four values)
-  int wino_tile = -1;        // tile id of "wino256x64"
+  int wino_tile = -1;        // tile id of the Winograd kernel in use
+  unsigned* d_sat = nullptr; // pf_set_saturation_counter: caller-owned device counter of the always-on saturation watch (ConvParams::sat); nullptr = off
+  float static_window_max = 0.f;  // largest STATIC bound of a tensor that never reaches HBM (the hidden maps of the fused block MLPs), pf_static_window_max
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
   bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
@@ -692,11 +696,53 @@ struct pf_engine {
     l.C = C; l.eps = eps;
     return l;
   }
+  // ---- static bounds of tensors no kernel can watch (LayerNorm outputs, the register-only hidden maps of the fused block MLPs): functions of the checkpoint alone
+  void note_static(double bound, float limit) { static_window_max = std::max(static_window_max, (float)std::min(3.0e38, bound * 65504.0 / std::max((double)limit, 1e-30))); }
+  double ln_bound(const std::string& pfx, int C) {  // |LN(x)_k| <= |gamma_k| sqrt(C) + |beta_k|
+    const std::vector<float>& g = host.at(pfx + ".weight").data;
+    const std::vector<float>& b = host.at(pfx + ".bias").data;
+    double m = 0.0;
+    for (int k = 0; k < C; ++k) m = std::max(m, std::fabs((double)g[k]) * std::sqrt((double)C) + std::fabs((double)b[k]));
+    return m;
+  }
+  // hidden = GELU(dw3x3?(fc1(LN(x)))): max_n { sum_k |W1[n][k]| (|gamma_k| sqrt(C) + |beta_k|) + |b1[n]| }, through the depthwise conv when there is one
+  double mlp_hidden_bound(const std::string& ln, const std::string& fc1, const std::string& dw, int C) {
+    const std::vector<float>& g = host.at(ln + ".weight").data;
+    const std::vector<float>& be = host.at(ln + ".bias").data;
+    const std::vector<float>& w = host.at(fc1 + ".weight").data;
+    const std::vector<float>& b = host.at(fc1 + ".bias").data;
+    const int H = 4 * C;
+    double m = 0.0;
+    for (int n = 0; n < H; ++n) {
+      double a = std::fabs((double)b[n]);
+      for (int k = 0; k < C; ++k) a += std::fabs((double)w[(size_t)n * C + k]) * (std::fabs((double)g[k]) * std::sqrt((double)C) + std::fabs((double)be[k]));
+      if (!dw.empty()) {
+        const std::vector<float>& dwv = host.at(dw + ".weight").data;
+        const std::vector<float>& db = host.at(dw + ".bias").data;
+        double ws = 0.0;
+        for (int t = 0; t < 9; ++t) ws += std::fabs((double)dwv[(size_t)n * 9 + t]);
+        a = ws * a + std::fabs((double)db[n]);
+      }
+      m = std::max(m, a);
+    }
+    return m;
+  }
   DwW make_dw(const std::string& pfx, int C, int K) {
     DwW d;
-    d.w = upload(pack_dw(get(pfx + ".weight", {C, 1, K, K}).data.data(), C, K));
-    d.b = upload(get(pfx + ".bias", {C}).data);
+    const std::vector<float>& wv = get(pfx + ".weight", {C, 1, K, K}).data;
+    const std::vector<float>& bv = get(pfx + ".bias", {C}).data;
+    d.w = upload(pack_dw(wv.data(), C, K));
+    d.b = upload(bv);
     d.C = C;
+    // |out| <= sum_k |w_k| max |in| + |b| (and |GELU(x)| <= |x| behind the 3x3): the producer of the input is watched with this limit (ConvW::sat_limit)
+    double wsum = 0.0, bmax = 0.0;
+    for (int ch = 0; ch < C; ++ch) {
+      double a = 0.0;
+      for (int k = 0; k < K * K; ++k) a += std::fabs((double)wv[(size_t)ch * K * K + k]);
+      wsum = std::max(wsum, a);
+      bmax = std::max(bmax, std::fabs((double)bv[ch]));
+    }
+    d.in_limit = (float)std::min(65504.0, std::max(0.0, 65504.0 - bmax) / std::max(wsum, 1e-30));
     return d;
   }
 
@@ -731,6 +777,9 @@ struct pf_engine {
       hd.r2c1[k] = make_conv(f + "resConfUnit2.conv1.weight", f + "resConfUnit2.conv1.bias", DEC_FEAT, DEC_FEAT, 3, 1, 1);
       hd.r2c2[k] = make_conv(f + "resConfUnit2.conv2.weight", f + "resConfUnit2.conv2.bias", DEC_FEAT, DEC_FEAT, 3, 1, 1);
     }
+    if (wino_min_hw > 0)  // every 256-channel map of the decoder may be read by a Winograd conv (wino.hip: its input transform adds four values, no clamp)
+      for (int k = 0; k < 4; ++k)
+        for (ConvW* cw : {&hd.fold[k], &hd.proc[k], &hd.r1c1[k], &hd.r1c2[k], &hd.r2c1[k], &hd.r2c2[k]}) cw->sat_limit = 65504.f / 4.f;
     hd.conv0 = make_conv(p + "conv_fuse_conv0.conv.weight", p + "conv_fuse_conv0.conv.bias", 64, DEC_FEAT + LL_CH, 3, 1, 1);
     hd.conv1 = make_conv(p + "conv_fuse_conv1.conv.weight", p + "conv_fuse_conv1.conv.bias", 32, 64, 3, 1, 1);
     hd.nout = nout;
@@ -769,12 +818,16 @@ struct pf_engine {
         mb.fc1 = make_linear(b + ".mlp.fc1", 4 * C, C, nullptr, b + ".norm2", 1e-6f);
         mb.dw = make_dw(b + ".mlp.dwconv.dwconv", 4 * C, 3);
         mb.fc2 = make_linear(b + ".mlp.fc2", C, 4 * C);
+        if (fuse_mit_mlp && mit_mlp_preferred(C)) note_static(mlp_hidden_bound(b + ".norm2", b + ".mlp.fc1", b + ".mlp.dwconv.dwconv", C), 65504.f);  // hidden map of the fused Mlp (LDS / registers only)
+        mb.q.sat_limit = 8188.f; mb.kv.sat_limit = 4094.f;  // the attention kernel's windows (attn.hip: q x 8, k / v x 16 inside the kernel)
+        mb.fc1.sat_limit = mb.dw.in_limit;                   // fc1's output goes through the depthwise 3x3 before fc2 contracts it
         if (rb_chain && split_bf16 && rb_linear_supported(C, C) && MIT_SR[s] > 1) {  // stage 3: the row-block form of the block's linear layers
           mb.rq = make_rb(b + ".attn.q", C, C, 320);
           mb.rkv = make_rb(b + ".attn.kv", 2 * C, C, 320);
           mb.rproj = make_rb(b + ".attn.proj", C, C, 320);
           mb.rfc1 = make_rb(b + ".mlp.fc1", 4 * C, C, 320);
           mb.rfc2 = make_rb(b + ".mlp.fc2", C, 4 * C, 320);
+          mb.rq.sat_limit = 8188.f; mb.rkv.sat_limit = 4094.f; mb.rfc1.sat_limit = mb.dw.in_limit;
           {  // proj followed by fc1 as ONE stream (rb_proj_fc1_kernel)
             std::vector<unsigned short> st1, st2;
             std::vector<float> inv1, inv2;
@@ -797,6 +850,7 @@ struct pf_engine {
             mb.rsrkv.sr_inv = upload(inv1); mb.rsrkv.sr_b = upload(get(b + ".attn.sr.bias", {C}).data);
             mb.rsrkv.kv_inv = upload(inv2); mb.rsrkv.kv_b = upload(get(b + ".attn.kv.bias", {2 * C}).data);
             mb.qln = make_linear(b + ".attn.q", C, C, nullptr, b + ".norm1", 1e-6f);
+            mb.qln.sat_limit = 8188.f;
           }
         }
         if (fuse_mit_mlp && mit_mlp_preferred(C)) {
@@ -869,6 +923,21 @@ struct pf_engine {
           cnx.blocks[s].push_back(cb);
         }
       }
+      // windows of the residual stream: what block j writes is read by block j + 1's depthwise conv (then contracted raw by the LayerNorm-fused pwconv1)
+      for (int s = 0; s < 4; ++s) {
+        if (s > 0) cnx.ds[s - 1].sat_limit = cnx.blocks[s][0].dw.in_limit;
+        for (size_t j = 0; j < cnx.blocks[s].size(); ++j) {
+          const float lim = j + 1 < cnx.blocks[s].size() ? cnx.blocks[s][j + 1].dw.in_limit : 65504.f;
+          cnx.blocks[s][j].out_limit = lim;
+          cnx.blocks[s][j].pw2.sat_limit = lim;
+        }
+      }
+      note_static(ln_bound(p + "downsample_layers.0.1", CNX_DIMS[0]), cnx.blocks[0][0].dw.in_limit);  // the stem's LayerNorm output feeds the first depthwise conv
+      for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < CNX_DEPTHS[s]; ++j) {
+          const std::string b = p + "stages." + std::to_string(s) + "." + std::to_string(j);
+          if (cnx.blocks[s][j].mlp_w) note_static(mlp_hidden_bound(b + ".norm", b + ".pwconv1", "", CNX_DIMS[s]), 65504.f);  // hidden map of the fused block MLP (registers only)
+        }
       cnx.norm = make_ln(p + "norm", CNX_DIMS[3], 1e-6f);
       cnx.headw = upload(get(p + "head.weight", {cnx.nout, CNX_DIMS[3]}).data);
       cnx.headb = upload(get(p + "head.bias", {cnx.nout}).data);
@@ -944,6 +1013,8 @@ struct pf_engine {
     p.nterms = nterms;
     p.ups = ups;
     p.ln = w.ln_s ? 1 : 0; p.ln_eps = w.ln_eps;
+    p.sat = (c.tuning || c.dry) ? nullptr : d_sat; p.sat_limit = w.sat_limit;
+    for (int g = 1; g < ngroups; ++g) p.sat_limit = std::min(p.sat_limit, calls[g].w->sat_limit);
     p.finish();
     if (part) {
       p.splitk = splitk;
@@ -952,7 +1023,7 @@ struct pf_engine {
     int tile = -1;
     {
       // operand formats are part of the key: a split-plane input changes which tile is fastest
-      const int prec_code = nterms == NT_F16X3 ? 0 : (nterms == 6 ? 3 : (nterms == 3 ? 1 : 2));  // = PF_PRECISION_*
+      const int prec_code = nterms == NT_F16X3 ? 0 : 3;  // = PF_PRECISION_*
       const int fmt_bits = (calls[0].res1 ? 1 : 0) + (calls[0].res2 ? 2 : 0) + (calls[0].x.s.p ? 4 : 0) + (calls[0].y.s.p ? 8 : 0) + (calls[0].y.f ? 0 : 16) + 32 * prec_code + 128 * ups + 256 * (calls[0].head_kind ? 1 : 0);
       std::vector<int> key = {p.M, p.Cout, p.KH, p.KW, p.Cin, p.stride, p.H, p.W, ngroups, p.nchw_out, fmt_bits + 512 * p.ln, p.act};
       auto it = tile_cache.find(key);
@@ -1036,6 +1107,7 @@ struct pf_engine {
     a.x = x; a.ln_g = lnw ? lnw->g : nullptr; a.ln_b = lnw ? lnw->b : nullptr; a.ln_eps = lnw ? lnw->eps : 0.f;
     a.w = r.w; a.w_bytes = r.bytes; a.inv = r.inv; a.bias = r.b; a.res = res; a.y = y;
     a.M = (int)M; a.tokens = tokens; a.bpi = (tokens + 63) / 64; a.N = r.N; a.act = act;
+    a.sat = d_sat; a.sat_limit = r.sat_limit;
     ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * M * (double)r.N * r.K, (int)M, r.N, r.K, 1);
     launch_rb_linear(a, r.K, c.s);
   }
@@ -1110,7 +1182,7 @@ struct pf_engine {
             a.x = x; a.ln1_g = mb.n1.g; a.ln1_b = mb.n1.b; a.ln1_eps = mb.n1.eps;
             a.w = mb.rsrkv.w; a.w_bytes = mb.rsrkv.bytes; a.sr_inv = mb.rsrkv.sr_inv; a.sr_bias = mb.rsrkv.sr_b;
             a.srn_g = mb.srn.g; a.srn_b = mb.srn.b; a.srn_eps = mb.srn.eps; a.kv_inv = mb.rsrkv.kv_inv; a.kv_bias = mb.rsrkv.kv_b;
-            a.kv = kvb; a.B = B; a.Hr = kvh; a.Wr = kvw; a.bpi = (kvh * kvw + 31) / 32;
+            a.kv = kvb; a.B = B; a.Hr = kvh; a.Wr = kvw; a.bpi = (kvh * kvw + 31) / 32; a.sat = d_sat;
             ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * Mkv * (double)C * (sr * sr * C + 2 * C), (int)Mkv, 3 * C, sr * sr * C + 2 * C, sr);
             launch_rb_srkv(a, C, c.s);
           }
@@ -1179,7 +1251,7 @@ struct pf_engine {
             RbProjFc1Args a;
             a.attn = ab.f; a.x = x; a.w = mb.rpf.w; a.w_bytes = mb.rpf.bytes; a.proj_inv = mb.rproj.inv; a.proj_bias = mb.rproj.b;
             a.ln2_g = mb.n2.g; a.ln2_b = mb.n2.b; a.ln2_eps = mb.n2.eps; a.fc1_inv = mb.rfc1.inv; a.fc1_bias = mb.rfc1.b; a.hidden = hb;
-            a.B = B; a.tokens = (int)N; a.bpi = ((int)N + 63) / 64;
+            a.B = B; a.tokens = (int)N; a.bpi = ((int)N + 63) / 64; a.sat = d_sat;
             ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * M * (double)C * 5 * C, (int)M, 5 * C, C, 1);
             launch_rb_proj_fc1(a, C, c.s);
           }
@@ -1190,7 +1262,7 @@ struct pf_engine {
           range_in(c, fmt("mit_mlp s%d.b%d x (LN-fused)", s + 1, blk), x, (size_t)M * C);
           if (!c.dry) {
             ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * 2.0 * M * (double)C * 4 * C, (int)M, C, 8 * C, 9);
-            launch_mit_mlp(x, xalt, mb.mlp_w, mb.mlp_tab, B, Ho, Wo, C, mb.n2.eps, c.s);
+            launch_mit_mlp(x, xalt, mb.mlp_w, mb.mlp_tab, B, Ho, Wo, C, mb.n2.eps, c.s, d_sat, 65504.f);
           }
           std::swap(x, xalt);
           continue;
@@ -1361,7 +1433,7 @@ struct pf_engine {
           range_in(c, fmt("cnx_mlp s%d.b%d d (LN-fused)", s + 1, blk), d, (size_t)M * C);
           if (!c.dry) {
             ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * 2.0 * M * (double)C * 4 * C, (int)M, C, 8 * C, 1);
-            launch_cnx_mlp(d, y, cb.mlp_w, cb.mlp_tab, M, C, cb.n.eps, c.s);
+            launch_cnx_mlp(d, y, cb.mlp_w, cb.mlp_tab, M, C, cb.n.eps, c.s, d_sat, cb.out_limit);
           }
           continue;
         }
@@ -1601,14 +1673,24 @@ int pf_create(pf_handle* out, int device, int arch) {
 
 int pf_set_precision(pf_handle h, int mode) {
   if (!h) return PF_ERR_ARG;
-  if (mode < PF_PRECISION_FP32 || mode > PF_PRECISION_FP32_BF16X6) return h->fail(PF_ERR_ARG, "pf_set_precision: unknown mode");
+  if (mode != PF_PRECISION_FP32 && mode != PF_PRECISION_FP32_BF16X6) return h->fail(PF_ERR_ARG, "pf_set_precision: unknown mode (0 = FP32 split-f16, 3 = FP32_BF16X6; the reduced-precision modes 1 / 2 of earlier versions are gone)");
   if (mode != PF_PRECISION_FP32 && !h->split_bf16) return h->fail(PF_ERR_ARG, "pf_set_precision: this mode needs the split kernels (PF_SPLIT_BF16=0 is set)");
   if (h->pn_pending) { h->issue_deferred(); (void)hipStreamSynchronize(h->pstream); h->pn_pending = false; }  // a deferred ParamNet branch still works in the old layout
   h->ws_cache.clear();  // the split-plane activation format (2 fp16 / 3 bf16 planes) follows the scheme
-  h->nterms = mode == PF_PRECISION_BF16 ? 1 : (mode == PF_PRECISION_BF16X3 ? 3 : (mode == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
+  h->nterms = mode == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3;
   return PF_OK;
 }
 
+int pf_set_saturation_counter(pf_handle h, void* d_counter_u32) {
+  if (!h) return PF_ERR_ARG;
+  h->d_sat = static_cast<unsigned*>(d_counter_u32);
+  return PF_OK;
+}
+int pf_static_window_max(pf_handle h, float* out) {
+  if (!h || !out || !h->finalized) return PF_ERR_ARG;
+  *out = h->static_window_max;
+  return PF_OK;
+}
 int pf_set_defer_params(pf_handle h, int on) {
   if (!h) return PF_ERR_ARG;
   h->defer_params = on ? 1 : 0;
@@ -2030,6 +2112,7 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
                  long x2_plane_elems, uint16_t* y_planes, long y_plane_elems, int precision_flags, void* stream) {
   const int precision = precision_flags & 15;
   const bool allow_splitk = !(precision_flags & 16);
+  if (precision != PF_PRECISION_FP32 && precision != PF_PRECISION_FP32_BF16X6) { g_create_error = "pf_op_conv2d: precision must be 0 (split-f16) or 3 (exact bf16 split)"; return PF_ERR_ARG; }
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
@@ -2059,7 +2142,7 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
   p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.Cout = Cout; p.act = act; p.post_relu = post_relu; p.nchw_out = nchw_out;
-  p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : (precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
+  p.nterms = precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3;
   // split-plane INPUT: the plane format (bit 0 of x_plane_elems, sb_split.h) fixes the scheme: fp16 planes <-> split-f16, bf16 planes <-> bf16 schemes
   if (x_planes) p.nterms = (x_plane_elems & 1) ? NT_F16X3 : (p.nterms == NT_F16X3 ? 6 : p.nterms);
   p.finish();
@@ -2100,7 +2183,7 @@ int pf_op_linear_ln(int device, const float* x, long rows, int K, const float* h
   p.g[0].x = x; p.g[0].res1 = res1; p.g[0].y = y;
   p.B = 1; p.H = (int)rows; p.W = 1; p.C1 = K; p.C2 = 0; p.KH = p.KW = 1; p.stride = 1; p.pad = 0;
   p.Cout = N; p.act = act; p.post_relu = 0; p.nchw_out = 0;
-  p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : (precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
+  p.nterms = precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3;
   p.ln = 1; p.ln_eps = eps;
   p.finish();
   if (tile_id >= 0 && !conv_tile_usable(p, tile_id)) { g_create_error = "pf_op_linear_ln: tile config cannot run the fused LayerNorm form"; return PF_ERR_ARG; }
@@ -2316,7 +2399,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   p.KWC = K * Cin; p.KWCp = roundup(p.KWC, 32);
   p.B = B; p.H = H; p.W = W; p.C1 = Cin; p.C2 = 0; p.KH = K; p.KW = K; p.stride = stride; p.pad = pad;
   p.Cout = Cout; p.act = ACT_RELU; p.post_relu = 0; p.nchw_out = 0;
-  p.nterms = precision == PF_PRECISION_BF16 ? 1 : (precision == PF_PRECISION_BF16X3 ? 3 : (precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3));
+  p.nterms = precision == PF_PRECISION_FP32_BF16X6 ? 6 : NT_F16X3;
   p.finish();
   const size_t nx = (size_t)B * H * W * Cin, nw = (size_t)Cout * K * p.KWCp, ny = (size_t)p.M * Cout;
   float *dx = nullptr, *dw = nullptr, *dy = nullptr, *db = nullptr;

@@ -89,6 +89,7 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
   const bool has_bias = bias_tab != nullptr || P.bias != nullptr, any_res = res1 != nullptr || (Q2B && res2 != nullptr);
   const unsigned coff = (vec_ok && n_ok) ? (unsigned)n * 4u : OOB;
   const float4 sc = buf_load16(r_sc, coff), cs = buf_load16(r_cs, coff);
+  float amax = 0.f;  // saturation watch (ConvParams::sat): running max |output| of this thread
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
     __syncthreads();  // previous chunk fully written back / K loop finished reading the operand tiles
@@ -190,6 +191,7 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
               continue;
             }
           }
+          amax = sat_acc4(amax, w.x, w.y, w.z, w.w);
           if (y) *reinterpret_cast<float4*>(y + o) = w;
           if (y_sb) store_sb4(y_sb, p.y_sb_plane, (size_t)o, w);  // split once here instead of per (tap, n-tile) in the consumer
         } else {  // ragged channel count: scalar tail
@@ -213,6 +215,7 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
       }
     }
   }
+  sat_flush(p.sat, p.sat_limit, amax);
 }
 
 // Direct epilogue for TRANSPOSED accumulators.  With the MFMA operands swapped (weights as the instruction's A operand, pixels as B)
@@ -243,6 +246,7 @@ __device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvP
   const bool has_bias = bias_tab != nullptr || P.bias != nullptr;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int EG = 1;  // column groups per batch of loads (2 costs the 64 x 64 tiles a resident block)
+  float amax = 0.f;  // saturation watch (ConvParams::sat)
 #pragma unroll
   for (int i = 0; i < SM; ++i) {
     const int ml = ml0 + i * 32 + l31, m = m0 + ml;
@@ -296,6 +300,7 @@ __device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvP
               v.x += q2.x; v.y += q2.y; v.z += q2.z; v.w += q2.w;
             }
             if (post_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            amax = sat_acc4(amax, v.x, v.y, v.z, v.w);
             if (y) *reinterpret_cast<float4*>(y + o) = v;
             if (y_sb) store_sb4(y_sb, p.y_sb_plane, (size_t)o, v);
           }
@@ -321,6 +326,7 @@ __device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvP
       }
     }
   }
+  sat_flush(p.sat, p.sat_limit, amax);
 }
 
 }  // namespace pf

@@ -97,8 +97,6 @@ int conv_sb_default_tile(const ConvParams& p) {
 }
 
 
-void launch_conv_sb3(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb3.hip
-void launch_conv_sb1(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sb1.hip
 void launch_conv_sbf(const ConvParams& p, int sb_tile, hipStream_t s);  // igemm_sbf.hip (split-f16)
 
 void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
@@ -183,8 +181,6 @@ void launch_conv_sb(const ConvParams& p0, int sb_tile, hipStream_t s) {
     sb_tile = conv_sb_default_tile(p);
   }
   if (p.nterms == NT_F16X3) launch_conv_sbf(p, sb_tile, s);
-  else if (p.nterms == 3) launch_conv_sb3(p, sb_tile, s);
-  else if (p.nterms == 1) launch_conv_sb1(p, sb_tile, s);
   else launch_conv_sb_nt<6>(p, sb_tile, s);
 }
 

@@ -42,7 +42,7 @@ template <int C> struct MitMlpCfg {
 
 template <int C, int TY, int TX>
 __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const float* __restrict__ x, float* __restrict__ y, const unsigned short* __restrict__ wpk,
-                                                                      const float* __restrict__ tab2, int B, int Hs, int Ws, float eps) {
+                                                                      const float* __restrict__ tab2, int B, int Hs, int Ws, float eps, unsigned* sat, float sat_limit) {
   typedef MitMlpCfg<C> Cfg;
   constexpr int H = 4 * C, S1 = Cfg::S1, Q = Cfg::Q, NCH = H / 32;
   constexpr int HY = TY + 2, HX = TX + 2, NHALO = HY * HX, RT1 = (NHALO + 31) / 32, NINT = TY * TX, RT2 = NINT / 32;
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
       float4 v;
       v.x = fmaf(acc2[j][4 * g], iv.x, bb.x) + r.x; v.y = fmaf(acc2[j][4 * g + 1], iv.y, bb.y) + r.y;
       v.z = fmaf(acc2[j][4 * g + 2], iv.z, bb.z) + r.z; v.w = fmaf(acc2[j][4 * g + 3], iv.w, bb.w) + r.w;
+      if (sat) sat_watch4(sat, sat_limit, v.x, v.y, v.z, v.w);  // the token stream feeds the next block's LayerNorm-fused layers RAW (ConvParams::sat)
       *reinterpret_cast<float4*>(y + o + n) = v;
     }
 }
@@ -263,13 +264,13 @@ bool mit_mlp_preferred(int C) {
 }
 int mit_mlp_chunk_bytes(int C) { return C == 64 ? MitMlpCfg<64>::CHUNK_BYTES : MitMlpCfg<128>::CHUNK_BYTES; }
 
-void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const float* tab2, int B, int Hs, int Ws, int C, float eps, hipStream_t s) {
+void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const float* tab2, int B, int Hs, int Ws, int C, float eps, hipStream_t s, unsigned* sat, float sat_limit) {
   if (C == 64) {
     const dim3 grid((unsigned)(B * ((Hs + 7) / 8) * ((Ws + 15) / 16)));
-    hipLaunchKernelGGL((mit_mlp_kernel<64, 8, 16>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps);
+    hipLaunchKernelGGL((mit_mlp_kernel<64, 8, 16>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps, sat, sat_limit);
   } else if (C == 128) {
     const dim3 grid((unsigned)(B * ((Hs + 7) / 8) * ((Ws + 7) / 8)));
-    hipLaunchKernelGGL((mit_mlp_kernel<128, 8, 8>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps);
+    hipLaunchKernelGGL((mit_mlp_kernel<128, 8, 8>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps, sat, sat_limit);
   }
 }
 

@@ -11,6 +11,21 @@
 namespace pf {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+#if defined(__HIPCC__)
+// saturation watch of a producer (ConvParams::sat): one v_max3 / v_max / compare per 4 outputs, an atomic only when the window is left (!(x <= limit) also catches NaN)
+__device__ __forceinline__ void sat_watch4(unsigned* sat, float limit, float a, float b, float c, float d) {
+  const float mx = fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d)));
+  if (!(mx <= limit)) atomicAdd(sat, 1u);
+}
+// the same with ONE running maximum per thread (two v_max3_f32 per 4 outputs, no temporaries: the epilogues of the GEMM tiles sit at their register caps) ...
+__device__ __forceinline__ float sat_acc4(float amax, float a, float b, float c, float d) {
+  return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(a)), __builtin_fabsf(b)), __builtin_fmaxf(__builtin_fabsf(c), __builtin_fabsf(d)));
+}
+// ... and one compare at the kernel's end (a NaN output is lost by fmaxf: the watch is about saturation; non-finite values are the debug forward's business)
+__device__ __forceinline__ void sat_flush(unsigned* sat, float limit, float amax) {
+  if (sat && amax > limit) atomicAdd(sat, 1u);
+}
+#endif
 // Packed fp32 (v_pk_*_f32) whose LOW lane reads the HIGH half of src1 -- hipcc's horizontal reductions `v_pk_add_f32 d, x, x op_sel:[0,1] op_sel_hi:[1,0]`, packed scalar
 // FMAs -- was exact alone and wrong in lanes 48..63 on MI355X while this library's kernels ran on another stream (profiles/r04_dw7_packed.md,
 // profiles/r05_pk_opsel_beside.txt), which is what every forward with the deferred ParamNet branch is.  tests/test_host_logic.py scans the built library and allows NO such
@@ -93,6 +108,11 @@ struct ConvParams {
   unsigned x_bytes, x2_bytes, w_bytes;  // buffer sizes for the hardware range check (< 2 GiB each)
   unsigned w_sb_plane_bytes;            // bytes of one bf16 weight plane
   size_t x_sb_plane = 0, x2_sb_plane = 0, y_sb_plane = 0;  // elements between consecutive planes of x_sb / x2_sb / y_sb
+  // Always-on saturation watch (engine only; nullptr in the op entry points): every producer of a tensor that a split-f16 contraction will read counts the 16-byte
+  // groups of its output with an element beyond sat_limit (or NaN) into *sat -- one compare per group and, in a healthy network, no atomic ever.  The limit is the
+  // CONSUMER's window: 65504, 65504 / 4 in front of a Winograd conv (wino.hip), 8188 / 4094 for the attention operands q / kv (attn.hip).
+  unsigned* sat = nullptr;
+  float sat_limit = 65504.f;
   unsigned long long* stamps = nullptr;  // timing aid (wino.hip, PF_WINO_STAMPS=1 in pf_op_conv2d_bench): s_memtime stamps of block 17, [wave][128]
   // fills the derived fields (Ho, Wo, M, Cin, *_bytes) from the primary ones
   void finish() {
@@ -221,13 +241,13 @@ void launch_nearest_nhwc4(const float* x, float* y, int B, int H, int W, int Ho,
 // wpk / tab: packed by cnx_mlp_pack (engine.hip)
 bool cnx_mlp_supported(int C);
 bool cnx_mlp_preferred(int C);  // the stages where the engine uses it
-void launch_cnx_mlp(const float* d, float* y, const unsigned short* wpk, const float* tab, long M, int C, float eps, hipStream_t s);
+void launch_cnx_mlp(const float* d, float* y, const unsigned short* wpk, const float* tab, long M, int C, float eps, hipStream_t s, unsigned* sat = nullptr, float sat_limit = 65504.f);
 // Fused MiT block Mlp (mit_mlp.hip): y = x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))) for C = 64 / 128; x and y are different buffers.
 // wpk / tab2: packed by mit_mlp_pack (engine.hip), one chunk of mit_mlp_chunk_bytes(C) per 32 hidden units
 bool mit_mlp_supported(int C);
 bool mit_mlp_preferred(int C);  // the stages where the engine uses it
 int mit_mlp_chunk_bytes(int C);
-void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const float* tab2, int B, int Hs, int Ws, int C, float eps, hipStream_t s);
+void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const float* tab2, int B, int Hs, int Ws, int C, float eps, hipStream_t s, unsigned* sat = nullptr, float sat_limit = 65504.f);
 // Row-block linear layers (rb_gemm.hip, rb_common.h): blocks of 64 token rows of one image, weights streamed from L2 into registers in MFMA fragment order
 struct RbLinArgs {
   const float* x;            // [M][K] fp32 rows
@@ -242,6 +262,11 @@ struct RbLinArgs {
   float* y;                  // [M][N]
   int M, tokens, bpi;        // rows, tokens per image, blocks per image = ceil(tokens / 64)
   int N, act;
+  // Always-on saturation watch (engine only; nullptr in the op entry points): every producer of a tensor that a split-f16 contraction will read counts the 16-byte
+  // groups of its output with an element beyond sat_limit (or NaN) into *sat -- one compare per group and, in a healthy network, no atomic ever.  The limit is the
+  // CONSUMER's window: 65504, 65504 / 4 in front of a Winograd conv (wino.hip), 8188 / 4094 for the attention operands q / kv (attn.hip).
+  unsigned* sat = nullptr;
+  float sat_limit = 65504.f;
   unsigned long long* stamps = nullptr;  // timing aid (scripts/tune_rb.py, PF_RB_STAMPS=1): s_memtime stamps of block 17, [wave][64]
 };
 bool rb_linear_supported(int K, int N);
@@ -256,6 +281,7 @@ struct RbSrKvArgs {
   const float* kv_inv; const float* kv_bias;   // [2 C]
   float* kv;                  // [B][Hr Wr][2 C]
   int B, Hr, Wr, bpi;         // bpi = ceil(Hr Wr / 32) blocks per image
+  unsigned* sat = nullptr;    // saturation watch of kv (ConvParams::sat; the attention kernel's window for k / v: 4094)
 };
 bool rb_srkv_supported(int C, int sr);
 // The seam between the attention half and the Mlp half of a MiT block in one launch (rb_chain.hip): x += proj(attn_out); hidden = fc1(LayerNorm_2(x))
@@ -269,6 +295,7 @@ struct RbProjFc1Args {
   const float* fc1_inv; const float* fc1_bias;     // [4 C]
   float* hidden;              // [M][4 C]
   int B, tokens, bpi;         // bpi = ceil(tokens / 64)
+  unsigned* sat = nullptr;    // saturation watch of x1 and hidden (ConvParams::sat)
 };
 void launch_rb_proj_fc1(const RbProjFc1Args& a, int C, hipStream_t s);
 void launch_rb_srkv(const RbSrKvArgs& a, int C, hipStream_t s);

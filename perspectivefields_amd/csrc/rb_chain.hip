@@ -18,7 +18,7 @@ namespace pf {
 
 template <class G, bool RES, int ACT>
 __device__ __forceinline__ void rb_chain_epilogue_store(float* y, int ldy, const float* tabs_inv, const float* tabs_bias, float* scratch, f32x16 (&acc)[G::NACC], int n0, int m0, int nrows,
-                                                        int wave, int lane) {
+                                                        int wave, int lane, unsigned* sat = nullptr, float sat_limit = 65504.f) {
   const int l31 = lane & 31, hi = lane >> 5;
   const int rrow = lane >> 3, c4 = lane & 7;
 #pragma unroll
@@ -43,7 +43,10 @@ __device__ __forceinline__ void rb_chain_epilogue_store(float* y, int ldy, const
     for (int i = 0; i < 4; ++i) {
       const int ml = rt * 32 + rrow + 8 * i;
       const float4 w = make_float4(fmaf(v[i].x, iv.x, bb.x), fmaf(v[i].y, iv.y, bb.y), fmaf(v[i].z, iv.z, bb.z), fmaf(v[i].w, iv.w, bb.w));
-      if (own && ml < nrows) *reinterpret_cast<float4*>(y + (size_t)(m0 + ml) * ldy + n) = w;
+      if (own && ml < nrows) {
+        if (sat) sat_watch4(sat, sat_limit, w.x, w.y, w.z, w.w);
+        *reinterpret_cast<float4*>(y + (size_t)(m0 + ml) * ldy + n) = w;
+      }
     }
   }
 }
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void rb_srkv_kernel(const RbSrKvArgs p) {
         rb_step<G>(acc, W, d, A[d & 1], A[(d + 1) & 1], As + nx * G::CHS, lane, 0);
       }
     }
-    rb_chain_epilogue_store<G, false, ACT_NONE>(p.kv, 2 * C, tabs + 2 * C, tabs + 4 * C, escr + wave * 1024, acc, ps2 * G::COLS, m0, nrows, wave, lane);
+    rb_chain_epilogue_store<G, false, ACT_NONE>(p.kv, 2 * C, tabs + 2 * C, tabs + 4 * C, escr + wave * 1024, acc, ps2 * G::COLS, m0, nrows, wave, lane, p.sat, 4094.f);
   }
 }
 
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void rb_proj_fc1_kernel(const RbProjFc1Args
         rb_step<G>(acc, W, d, A[d & 1], A[(d + 1) & 1], As + nx * G::CHS, lane, xr);
       }
     }
-    rb_chain_epilogue_store<G, false, ACT_NONE>(p.hidden, H4, tabs + 2 * C, tabs + 2 * C + H4, escr + wave * 1024, acc, ps2 * G::COLS, m0, nrows, wave, lane);
+    rb_chain_epilogue_store<G, false, ACT_NONE>(p.hidden, H4, tabs + 2 * C, tabs + 2 * C + H4, escr + wave * 1024, acc, ps2 * G::COLS, m0, nrows, wave, lane, p.sat);
   }
 }
 

@@ -83,7 +83,10 @@ __device__ __forceinline__ void rb_epilogue_store(const RbLinArgs& p, const floa
       float4 w = make_float4(fmaf(v[i].x, iv.x, bb.x), fmaf(v[i].y, iv.y, bb.y), fmaf(v[i].z, iv.z, bb.z), fmaf(v[i].w, iv.w, bb.w));
       if constexpr (ACT == ACT_GELU) w = make_float4(gelu_erf(w.x), gelu_erf(w.y), gelu_erf(w.z), gelu_erf(w.w));
       if constexpr (RES) { w.x += rr[idx][i].x; w.y += rr[idx][i].y; w.z += rr[idx][i].z; w.w += rr[idx][i].w; }
-      if (own && ml < nrows) *reinterpret_cast<float4*>(p.y + (size_t)(m0 + ml) * p.N + n) = w;
+      if (own && ml < nrows) {
+        if (p.sat) sat_watch4(p.sat, p.sat_limit, w.x, w.y, w.z, w.w);
+        *reinterpret_cast<float4*>(p.y + (size_t)(m0 + ml) * p.N + n) = w;
+      }
     }
   }
 }

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(W_NT, 2) void wino_f2x2_kernel(const ConvParams p) 
           if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
           if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
           if (post_relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+          if (p.sat) sat_watch4(p.sat, p.sat_limit, w.x, w.y, w.z, w.w);
           *reinterpret_cast<float4*>(P.y + o) = w;
         }
     }
@@ -433,7 +434,10 @@ __device__ __forceinline__ void wino4_epilogue(const ConvParams& p, const ConvPt
         w.x += r1.x; w.y += r1.y; w.z += r1.z; w.w += r1.w;
         w.x += r2.x; w.y += r2.y; w.z += r2.z; w.w += r2.w;
         if (post_relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
-        if (okp[it][a][b]) *reinterpret_cast<float4*>(P.y + oo[it][a][b]) = w;
+        if (okp[it][a][b]) {
+          if (p.sat) sat_watch4(p.sat, p.sat_limit, w.x, w.y, w.z, w.w);
+          *reinterpret_cast<float4*>(P.y + oo[it][a][b]) = w;
+        }
       }
   }
   WINO4_STAMP(3);

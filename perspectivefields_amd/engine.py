@@ -37,6 +37,8 @@ _SIGNATURES = {
     "pf_workspace_bytes": (_c.c_size_t, [_P, _c.c_int]),
     "pf_forward_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
     "pf_forward_f32": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "pf_set_saturation_counter": (_c.c_int, [_P, _P]),
+    "pf_static_window_max": (_c.c_int, [_P, _c.POINTER(_c.c_float)]),
     "pf_set_defer_params": (_c.c_int, [_P, _c.c_int]),
     "pf_join_params": (_c.c_int, [_P, _P]),
     "pf_forward_u8_graph": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _P]),
@@ -194,6 +196,12 @@ class Engine:
         self.defer_params = False   # set_defer_params()
         self._deferred = []
         self._graph_bufs = {}
+        # always-on saturation watch of the split-f16 mode (pf_set_saturation_counter): a device counter the producing kernels add to when an output leaves its
+        # consumer's window; read in stream order with saturation_snapshot()
+        with torch.cuda.device(self.device):
+            self._sat = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _check(self.lib.pf_set_saturation_counter(self._h, self._sat.data_ptr()), self._h, "pf_set_saturation_counter")
+        self.sat_seen = 0   # counter value up to which the caller has looked
         g, l, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self.lib.pf_output_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(p))
         self.gravity_channels, self.latitude_channels, self.param_outputs = g.value, l.value, p.value
@@ -242,17 +250,28 @@ class Engine:
         if save_to:
             _check(min(0, self.lib.pf_save_tile_table(self._h, save_to.encode())), self._h, "pf_save_tile_table")
 
-    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp32_bf16x6": 3}
+    PRECISIONS = {"fp32": 0, "fp32_bf16x6": 3}
 
     def set_precision(self, mode: str):
         """Arithmetic of the dense contractions: 'fp32' (default, the parity mode: 2-way fp16 split, three MFMAs per
-        product), 'fp32_bf16x6' (exact 3-way bf16 split, six MFMAs: fp32-accurate for any input range), 'bf16x3' (three
-        bf16 partial products, ~16-bit operands) or 'bf16' (plain bf16 operands).  See pf_set_precision in include/pf_hip.h."""
+        product) or 'fp32_bf16x6' (exact 3-way bf16 split, six MFMAs: fp32-accurate for any input range).  No reduced-precision mode is offered
+        (pf_set_precision in include/pf_hip.h says why)."""
         if mode not in self.PRECISIONS:
             raise PfError(f"unknown precision '{mode}' (expected one of {sorted(self.PRECISIONS)})")
         _check(self.lib.pf_set_precision(self._h, self.PRECISIONS[mode]), self._h, "pf_set_precision")
         self.precision = mode
         self._graph_bufs = {}  # captured graphs and their workspace were sized for the previous mode (the workspace differs between the schemes)
+
+    def saturation_snapshot(self):
+        """The saturation counter as of the work issued so far on the current stream (a 1-element device tensor: reading it synchronises).  It only grows; a forward
+        that leaves it unchanged had every dense-layer input inside the split-f16 window."""
+        return self._sat.clone()
+
+    def static_window_max(self) -> float:
+        """Largest static (weights-only) bound of a tensor no kernel can watch, scaled to the 65504 window (pf_static_window_max): > 65504 = may leave the window."""
+        v = ctypes.c_float()
+        _check(self.lib.pf_static_window_max(self._h, ctypes.byref(v)), self._h, "pf_static_window_max")
+        return float(v.value)
 
     # ---------------------------------------------------------------- forward
     def workspace_bytes(self, batch: int) -> int:

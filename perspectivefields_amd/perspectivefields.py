@@ -92,8 +92,13 @@ class PerspectiveFields(nn.Module):
         # absolute 2^-25 per element below (sb_split.h).  'fp32_bf16x6' is the exact bf16 split (no window, ~1.5x the MFMA work).  'auto' (the DEFAULT: a checkpoint
         # outside the window must not give wrong fields silently) decides between the two ONCE, on the first batch inference() / inference_batch() / forward() see:
         # a range-recording forward (pf_debug_forward_u8) and 'fp32_bf16x6' if any dense-layer input saturates or is all-tiny, 'fp32' otherwise (`self.precision`
-        # then holds the decision, `self.precision_reason` why).  'bf16' is the reduced-precision mode of the dense contractions (Engine.set_precision); its outputs
-        # are not held to the parity tolerances.
+        # then holds the decision, `self.precision_reason` why).  The decision is NOT final: in 'auto' every later forward is watched by the engine's saturation
+        # counter (pf_set_saturation_counter: the producing kernels count outputs beyond their consumer's window), and a batch that moves it is re-run in
+        # 'fp32_bf16x6', where the model then stays (a warning says so).  'fp32' pins the fast mode without the watch's host synchronisation.  No reduced-precision
+        # mode is offered (include/pf_hip.h pf_set_precision says why).
+        if precision not in ("auto", "fp32", "fp32_bf16x6"):
+            raise ValueError(f"precision must be 'auto', 'fp32' or 'fp32_bf16x6', got '{precision}'")
+        self._auto = precision == "auto"
         self.precision = precision
         cfg = get_cfg(version)  # KeyError on an unknown version, as the reference (:127)
         self.version = version
@@ -270,6 +275,16 @@ class PerspectiveFields(nn.Module):
                             r.update(extra)
                 s_join.synchronize()
             item["done"].synchronize()
+            if item["sat"]:   # precision='auto': did this batch (any of its chunks) leave the split-f16 window?  The batch has finished: reading the snapshots costs nothing
+                moved = [self._left_window(eng, snap) for snap, _, _, _ in item["sat"]]
+                if any(moved):
+                    with torch.cuda.stream(s_comp):
+                        new = self._rerun_exact(eng, item["batch"], item["sizes"])   # the model stays in the exact mode; batches already in flight are still looked at
+                    s_comp.synchronize()
+                    for r, n in zip(item["results"], new):
+                        r.clear()
+                        r.update({k: (v.cpu() if (to_host and k in self._HOST_KEYS) else v) for k, v in n.items()})
+                    return item["results"]
             return item["results"]
 
         for imgs in batches:
@@ -307,8 +322,9 @@ class PerspectiveFields(nn.Module):
             batch.record_stream(s_comp)
             s_comp.wait_event(up_done)
             lazy = [] if defer else None
+            sat = [] if self._auto else None
             with torch.cuda.stream(s_comp):
-                results = self._run(batch, sizes, lazy_params=lazy)
+                results = self._run(batch, sizes, lazy_params=lazy, sat_out=sat)
                 comp_done = torch.cuda.Event()
                 comp_done.record(s_comp)
             params_done = eng.params_ready_event(s_join) if defer else None
@@ -329,7 +345,7 @@ class PerspectiveFields(nn.Module):
                             o += src.numel()
                     done = torch.cuda.Event()
                     done.record(s_down)
-            inflight.append({"results": results, "done": done, "comp_done": comp_done, "params_done": params_done, "lazy": lazy})
+            inflight.append({"results": results, "done": done, "comp_done": comp_done, "params_done": params_done, "lazy": lazy, "sat": sat, "batch": batch, "sizes": sizes})
             if len(inflight) >= max(1, depth):
                 yield finish(inflight.pop(0))
         while inflight:
@@ -357,24 +373,59 @@ class PerspectiveFields(nn.Module):
     # pf_forward call is limited to PF_MAX_BATCH = 81 images by its 32-bit activation offsets, include/pf_hip.h)
     MAX_CHUNK = 64
 
-    def _run(self, batch, sizes, lazy_params=None) -> List[dict]:
+    def _run(self, batch, sizes, lazy_params=None, sat_out=None) -> List[dict]:
         """lazy_params: a list -> the ParamNet entries are NOT added to the result dicts here; (results of the chunk, raw (B,8) params) pairs are appended instead and
-        the caller adds them once the parameters are complete (inference_stream with the deferred branch)."""
+        the caller adds them once the parameters are complete (inference_stream with the deferred branch).  sat_out: a list -> the saturation watch of 'auto' is not
+        read here (that would synchronise); (snapshot, batch, sizes, results) is appended for the caller to look at when the batch has finished."""
         eng = self._get_engine()
         chunk = max(1, min(int(os.environ.get("PF_MAX_CHUNK", self.MAX_CHUNK)), eng.max_batch))
         if len(sizes) > chunk:
             out: List[dict] = []
             for i0 in range(0, len(sizes), chunk):
-                out.extend(self._run(batch[i0:i0 + chunk], sizes[i0:i0 + chunk], lazy_params))
+                out.extend(self._run(batch[i0:i0 + chunk], sizes[i0:i0 + chunk], lazy_params, sat_out))
             return out
-        if self.precision == "auto":  # first batch: look at the activations this checkpoint produces, then settle on a precision for the model's lifetime
+        if self.precision == "auto":  # first batch: look at the weights' static bounds and at the activations this checkpoint produces, then settle on a precision
             probe = batch if batch.dtype == torch.uint8 else batch.permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8)  # forward(): (B,3,320,320) float -> the u8 NHWC form of the debug entry
             _, _, _, _, rng = eng.forward_debug(probe.contiguous(), shadow=False, ranges=True)
             outside = [r for r in rng if r["saturated"] > 0 or r["max_abs"] > _window_limit(r) or r["non_finite"] > 0 or 0.0 < r["rms"] < 2.0 ** -5]
-            self.precision = "fp32_bf16x6" if outside else "fp32"
-            self.precision_reason = (f"{len(outside)} of {len(rng)} dense-layer inputs outside the split-f16 window, first: {outside[0]['name']} "
-                                     f"(max |x| {outside[0]['max_abs']:.4g}, rms {outside[0]['rms']:.4g})") if outside else f"all {len(rng)} dense-layer inputs inside the split-f16 window"
+            static_max = eng.static_window_max()
+            self.precision = "fp32_bf16x6" if (outside or static_max > 65504.0) else "fp32"
+            if outside:
+                self.precision_reason = (f"{len(outside)} of {len(rng)} dense-layer inputs outside the split-f16 window, first: {outside[0]['name']} "
+                                         f"(max |x| {outside[0]['max_abs']:.4g}, rms {outside[0]['rms']:.4g})")
+            elif static_max > 65504.0:
+                self.precision_reason = f"a weights-only bound of an unwatched tensor (LayerNorm output / fused-MLP hidden map) reaches {static_max:.4g} > 65504"
+            else:
+                self.precision_reason = f"all {len(rng)} dense-layer inputs inside the split-f16 window (static bounds <= {static_max:.4g}); later batches are watched by the saturation counter"
             eng.set_precision(self.precision)
+            eng.sat_seen = int(eng.saturation_snapshot())
+        watch = self._auto and self.precision == "fp32"
+        pg, pl, params = eng.forward(batch)
+        snap = eng.saturation_snapshot() if watch else None
+        results = self._assemble(eng, pg, pl, params, sizes, lazy_params)
+        if watch:
+            if sat_out is not None:
+                sat_out.append((snap, batch, sizes, results))   # inference_stream looks when the batch is finished
+            elif self._left_window(eng, snap):
+                if lazy_params is not None and params is not None:
+                    lazy_params.pop()
+                results = self._rerun_exact(eng, batch, sizes, lazy_params)
+        return results
+
+    def _left_window(self, eng, snap) -> bool:
+        """True when the forward behind `snap` moved the saturation counter (reading it synchronises with that forward)."""
+        cnt = int(snap)
+        moved = cnt != eng.sat_seen
+        eng.sat_seen = cnt
+        return moved
+
+    def _rerun_exact(self, eng, batch, sizes, lazy_params=None):
+        import warnings
+
+        self.precision = "fp32_bf16x6"
+        self.precision_reason = "a later batch left the split-f16 window (saturation counter moved): re-run and continuing in the exact bf16 split"
+        warnings.warn("PerspectiveFields(precision='auto'): " + self.precision_reason)
+        eng.set_precision(self.precision)
         pg, pl, params = eng.forward(batch)
         return self._assemble(eng, pg, pl, params, sizes, lazy_params)
 

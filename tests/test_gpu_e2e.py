@@ -241,22 +241,19 @@ def test_split_plane_activations_agree_with_fp32_activations(monkeypatch):
         assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
 
 
-@pytest.mark.parametrize("precision,tol_cos,tol_lat,tol_par", [("bf16x3", 1e-4, 2e-2, 5e-2), ("bf16", 2.0, 90.0, 90.0)])
-def test_reduced_precision_modes_run_and_report(precision, tol_cos, tol_lat, tol_par):
-    """Optional reduced-precision modes of the dense contractions (pf_set_precision).  They are NOT parity modes; this
-    test pins that they run end to end and stay finite / bounded, and prints how far they drift from the fp32 (parity)
-    mode.  (Seeded random weights amplify rounding far more than a trained checkpoint: the bf16 row is a smoke bound.)"""
+def test_no_reduced_precision_mode_is_offered():
+    """r05: the 'bf16' / 'bf16x3' switches of r01-r04 are gone from the public surface (98.9 % argmax agreement for +0.6 ... 4 % speed: lower accuracy for nothing);
+    the class, the engine binding and the C ABI refuse them loudly."""
     from perspectivefields_amd import PerspectiveFields
+    from perspectivefields_amd.engine import PfError
 
-    imgs = [synthetic_image(72, 96, seed=95 + i) for i in range(3)]
-    base = model("centered").inference_batch(imgs)
-    alt = PerspectiveFields(CASES["centered"], weights="synthetic:0", precision=precision).eval().cuda().inference_batch(imgs)
-    for i, (a, b) in enumerate(zip(base, alt)):
-        c = one_minus_cos(a["pred_gravity"].cpu().numpy(), b["pred_gravity"].cpu().numpy()).max()
-        e = l1(a["pred_latitude_original"].cpu().numpy(), b["pred_latitude_original"].cpu().numpy())
-        d = max(abs(float(a[k]) - float(b[k])) for k in ("pred_roll", "pred_pitch", "pred_vfov"))
-        print(f"[{precision} vs fp32 img{i}] max 1-cos {c:.2e}  latitude L1 {e:.2e} deg  roll/pitch/vfov |d| {d:.2e} deg")
-        assert np.isfinite(c) and c <= tol_cos and e <= tol_lat and d <= tol_par
+    for mode in ("bf16", "bf16x3"):
+        with pytest.raises(ValueError):
+            PerspectiveFields(CASES["centered"], weights="synthetic:0", precision=mode)
+        with pytest.raises(PfError):
+            model("centered")._get_engine().set_precision(mode)
+    eng = model("centered")._get_engine()
+    assert eng.lib.pf_set_precision(eng._h, 1) != 0 and eng.lib.pf_set_precision(eng._h, 2) != 0
 
 
 def test_fields_from_params_vs_oracle(golden_dir):

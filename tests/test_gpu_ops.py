@@ -210,32 +210,6 @@ def test_split_planes_bits(ops):
     assert not bool(bad.any()), f"lo plane differs in {int(bad.sum())} of {n} elements, first at {int(bad.nonzero()[0])}: x = {float(v.reshape(-1)[bad.nonzero()[0]])}"
 
 
-@pytest.mark.parametrize("precision,tol", [(1, 2e-4), (2, 3e-2)], ids=["bf16x3", "bf16"])
-def test_conv2d_reduced_precision_modes(ops, precision, tol):
-    """The optional reduced-precision forms of the split-bf16 kernel (3 / 1 partial products instead of 6) on every
-    split tile: errors at the level the operand width predicts (2^-16 / 2^-8 per operand, accumulated in fp32), and
-    the fp32 mode on the same tile stays an order of magnitude (or more) closer to the fp64 reference."""
-    B, H, W, C, Cout = 2, 12, 12, 256, 256
-    x = _rand((B, H, W, C), 70)
-    w = _rand((Cout, C, 3, 3), 71, 1.0 / math.sqrt(C * 9))
-    b = _rand((Cout,), 72, 0.1)
-    ref = _ref_conv(x, w, b, 1, 1)
-    xd = x.cuda()
-    names = ops.conv_tiles()
-    for tile in [i for i, n in enumerate(names) if n.startswith("sb") and not n.startswith("sbh")]:  # halo tiles: fp32-accurate modes only
-        got = ops.conv2d(xd, w, b, pad=1, tile=tile, precision=precision)
-        _close(got, ref, tol, f"{names[tile]} precision {precision}")
-        e_red = float((got.double().cpu() - ref).abs().max())
-        e_f32 = float((ops.conv2d(xd, w, b, pad=1, tile=tile).double().cpu() - ref).abs().max())
-        assert e_f32 * 8 < e_red, (names[tile], e_f32, e_red)
-    # concat gather + plane input in reduced precision
-    x2 = _rand((B, H, W, 64), 73)
-    w2 = _rand((64, C + 64, 3, 3), 74, 1.0 / math.sqrt((C + 64) * 9))
-    ref2 = _ref_conv(x, w2, None, 1, 1, x2)
-    _close(ops.conv2d(xd, w2, None, pad=1, x2=x2.cuda(), precision=precision), ref2, tol, "concat")
-    _close(ops.conv2d(xd, w2, None, pad=1, x2=x2.cuda(), precision=precision, planes_in=True), ref2, 2 * tol, "concat planes")
-
-
 def test_elementwise_plane_outputs(ops):
     """LayerNorm / depthwise+GELU / attention / bilinear x2 writing split planes == their fp32 output, exactly."""
     x = _rand((2, 20, 20, 320), 50).cuda()
