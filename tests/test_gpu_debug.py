@@ -194,8 +194,10 @@ def test_auto_watches_every_later_batch():
     assert check(r1[0], 1, "out-of-window batch, re-run in the exact mode")
     assert check(m.inference_batch([flat])[0], 0, "afterwards, exact mode")
     # the pinned fast mode saturates on the same image: this is what the watch is for
-    pinned = PerspectiveFields(version, weights=sd2, precision="fp32").eval().cuda().inference_batch([noisy])[0]
-    assert not check(pinned, 1, "pinned fp32 (saturating), expected OUTSIDE the tolerances", tol_par=1e-4) or True
+    mp = PerspectiveFields(version, weights=sd2, precision="fp32").eval().cuda()
+    pinned = mp.inference_batch([noisy])[0]
+    check(pinned, 1, "pinned fp32 (saturating): printed for comparison", tol_par=1e-4)
+    assert int(mp._get_engine().saturation_snapshot()) > 0   # the counter moves in the pinned mode, too: a caller of the C ABI can read it
     # the pipelined path: in-window batches first, then the one that leaves the window, then another one that was already in flight
     m2 = PerspectiveFields(version, weights=sd2, precision="auto").eval().cuda()
     with warnings.catch_warnings(record=True):
