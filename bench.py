@@ -80,38 +80,49 @@ def pmc_traffic():
 
 
 def cpu_baseline(version, size, budget_s=12.0, max_images=12):
-    """The oracle (CPU port of the reference algorithm) timed on this host's cores on a bounded sample
-    of the same workload.  The unmodified reference cannot travel to the GPU box (kind = "port")."""
-    from oracle import pf_oracle
+    """The reference's CPU path timed on this host's cores on a bounded sample of the same workload.  kind = "reference": the UNMODIFIED reference
+    (/root/reference through oracle/ref_shim.py: stubs for its import-only dependencies) whenever that tree exists -- the build container; kind = "port": the oracle
+    (oracle/pf_oracle.py, pinned to the reference by tests/test_oracle_vs_reference.py and the goldens) on the GPU box, where the reference cannot travel."""
+    from oracle import pf_oracle, ref_shim
     from perspectivefields_amd.config import arch_of, get_cfg
     from perspectivefields_amd.synth import synthetic_image, synthetic_state_dict, to_torch
 
     sd = to_torch(synthetic_state_dict(version, 0))
     arch = arch_of(get_cfg(version))
     ncpu = os.cpu_count() or 1
+    kind = "port"
+    run = lambda imgs: pf_oracle.inference_batch(sd, arch, imgs)
+    what = "oracle/pf_oracle.py inference_batch"
+    if ref_shim.reference_available():
+        try:
+            ref_model = ref_shim.build_reference(version, sd)
+            run = lambda imgs: ref_model.inference_batch(imgs)
+            kind, what = "reference", "the unmodified reference's PerspectiveFields.inference_batch (CPU, through oracle/ref_shim.py)"
+        except Exception:  # the shim failing must not hide the measurement: fall back to the port
+            pass
     with torch.no_grad():
         # torch's intra-op pool does not scale to hundreds of threads on these small maps: pick the
         # fastest of a few thread counts on one image each (reported as `cores`)
         best, threads = None, 1
         for t in sorted({min(ncpu, c) for c in (16, 32, 64)}):
             torch.set_num_threads(t)
-            pf_oracle.inference_batch(sd, arch, [synthetic_image(size, size, 899)])  # warm-up at this setting
+            run([synthetic_image(size, size, 899)])  # warm-up at this setting
             t1 = time.perf_counter()
-            pf_oracle.inference_batch(sd, arch, [synthetic_image(size, size, 900)])
+            run([synthetic_image(size, size, 900)])
             d = time.perf_counter() - t1
             if best is None or d < best:
                 best, threads = d, t
         torch.set_num_threads(threads)
         n, t0 = 0, time.perf_counter()
         while n < max_images and time.perf_counter() - t0 < budget_s:
-            pf_oracle.inference_batch(sd, arch, [synthetic_image(size, size, 901 + n + i) for i in range(2)])
+            run([synthetic_image(size, size, 901 + n + i) for i in range(2)])
             n += 2
         dt = time.perf_counter() - t0
     return {
         "value": round(n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "host_logical_cpus": ncpu,
         "cores_note": f"`cores` = torch intra-op threads actually used (the fastest of 16 / 32 / 64 on one image each); the box has {ncpu} logical CPUs",
-        "kind": "port",
-        "sample": f"{n} synthetic {size}x{size} images through oracle/pf_oracle.py inference_batch (PIL resize + fp32 forward + post-process), batches of 2, {dt:.1f} s",
+        "kind": kind,
+        "sample": f"{n} synthetic {size}x{size} images through {what} (PIL resize + fp32 forward + post-process), batches of 2, {dt:.1f} s",
     }
 
 
@@ -643,6 +654,65 @@ def main(argv=None):
             line["latency_ms"] = lat
         except Exception as e:
             line["latency_ms"] = {"error": repr(e)}
+    if not dry and not args.no_extras and world == 1 and not mixed:
+        # ---- (4) the host edge, one process: host numpy 640x640 images -> pinned staging -> H2D -> bit-exact device resize -> forward -> post-process -> pinned D2H of the
+        #      four field tensors, through PerspectiveFields.inference_stream (three streams, deferred ParamNet branch); what a caller that starts from decoded images gets
+        try:
+            nb = 12
+            host_batches = [[imgs[(j + i) % len(imgs)] for i in range(B)] for j in range(nb)]
+            model.device_resize = True
+            try:
+                list(model.inference_stream(host_batches[:2], to_host=True, depth=2))  # warm-up (allocator, pinned buffers)
+                sync()
+                t1 = time.perf_counter()
+                nimg = 0
+                for res in model.inference_stream(host_batches, to_host=True, depth=2):
+                    nimg += len(res)
+                sync()
+                d_e2e = time.perf_counter() - t1
+                # the same without the D2H of the fields (results stay on the device)
+                t1 = time.perf_counter()
+                for res in model.inference_stream(host_batches, to_host=False, depth=2):
+                    pass
+                sync()
+                d_dev = time.perf_counter() - t1
+            finally:
+                model.device_resize = False
+            mb_in, mb_out = B * S * S * 3 / 1e6, B * 3 * S * S * 4 / 1e6 + B * 3 * 320 * 320 * 4 / 1e6
+            line["e2e_host_stream"] = {
+                "value": round(nimg / d_e2e, 2), "unit": "images/sec", "n_gpus": 1, "batches": nb, "batch": B, "ms_per_batch": round(1000.0 * d_e2e / nb, 3),
+                "fields_left_on_device": {"value": round(nb * B / d_dev, 2), "ms_per_batch": round(1000.0 * d_dev / nb, 3)},
+                "pcie_mb_per_batch": {"h2d": round(mb_in, 1), "d2h": round(mb_out, 1)},
+                "workload": f"{nb} batches of {B} host numpy {S}x{S} uint8 images, ONE process / one Python thread: np.copyto into pinned staging, one H2D per batch, device resize, "
+                            "forward, post-process, async D2H of pred_gravity(_original) / pred_latitude(_original) into pinned host tensors (PerspectiveFields.inference_stream, depth 2)",
+                "note": "`value` of the headline excludes this edge by the bench contract (inputs resident in HBM); this is the PCIe- and host-inclusive rate",
+            }
+        except Exception as e:
+            line["e2e_host_stream"] = {"error": repr(e)}
+        # ---- (5) BASELINE configs[1]: batch 8, 640x640, PersNet-360Cities (73 / 180-way logits + argmax decode), 320x320 uint8 inputs resident in HBM
+        try:
+            m1 = PerspectiveFields("PersNet-360Cities", weights="synthetic:0", precision=precision).eval().to(dev)
+            e1 = m1._get_engine()
+            x1 = torch.from_numpy(np.stack([m1.aug.apply_image(imgs[i % len(imgs)]) for i in range(8)])).to(dev)
+            sz1 = [(S, S)] * 8
+            for _ in range(3):
+                pg1, pl1, _p = e1.forward(x1)
+                e1.postprocess_batch(pg1, pl1, sz1)
+            sync()
+            n1 = 20
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                pg1, pl1, _p = e1.forward(x1)
+                e1.postprocess_batch(pg1, pl1, sz1)
+            sync()
+            d1c = time.perf_counter() - t1
+            line["configs_1"] = {"value": round(8 * n1 / d1c, 2), "unit": "images/sec", "n_gpus": 1, "steps": n1, "ms_per_step": round(1000.0 * d1c / n1, 3),
+                                 "workload": f"batch 8, {S}x{S}, PersNet-360Cities: backbone + decoders + 73 / 180-way classification heads (NCHW logits) + argmax decode + post-process",
+                                 "dtype": line.get("dtype"), "note": "BASELINE names this config 'bf16': no reduced-precision mode is offered (include/pf_hip.h pf_set_precision); "
+                                 "this is the fp32-class parity mode"}
+            del m1, e1
+        except Exception as e:
+            line["configs_1"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline and not dry:
         try:
             line["cpu_baseline"] = cpu_baseline(args.version, S)

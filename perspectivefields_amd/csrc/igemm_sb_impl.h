@@ -419,6 +419,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN == 128 * 128
   if (S > 1) {  // raw partial sums; scale, bias, activation and residual are applied by splitk_reduce_kernel
     ConvParams pp = p;
     pp.act = ACT_NONE; pp.post_relu = 0;
+    pp.sat = nullptr;  // raw partial accumulators (weights still scaled): nothing to watch here
     ConvPtrs Q;
     Q.y = P.partial + (size_t)sidx * p.M * p.ldy;
     if constexpr (DIRECT) epilogue_direct<SM, SN>(pp, Q, acc, m0, wm0, n0 + wn0, nullptr, nullptr);

@@ -32,18 +32,34 @@ from .synth import synthetic_state_dict
 
 
 class ResizeTransform:
-    """uint8 HxWx3 -> 320x320x3 with PIL's antialiased BILINEAR, aspect ratio not kept
-    (reference: ResizeTransform.apply_image, perspectivefields.py:34-46)."""
+    """HxW(xC) image -> new_h x new_w, aspect ratio not kept (reference: ResizeTransform.apply_image, perspectivefields.py:34-66): uint8 through PIL's antialiased
+    BILINEAR (single-channel HxWx1 as mode "L"); any other dtype through torch's F.interpolate (no antialiasing, align_corners=False), as the reference does because
+    "PIL only supports uint8".  Host-side preprocessing, as in the reference; inference()/inference_batch() can run the uint8 form on the GPU instead (device_resize)."""
+
+    _PIL_TO_INTERPOLATE = {Image.NEAREST: "nearest", Image.BILINEAR: "bilinear", Image.BICUBIC: "bicubic"}
 
     def __init__(self, new_h: int, new_w: int, interp=None):
         self.new_h, self.new_w = new_h, new_w
         self.interp = Image.BILINEAR if interp is None else interp
 
     def apply_image(self, img: np.ndarray, interp=None) -> np.ndarray:
-        if img.dtype != np.uint8:
-            raise TypeError("PerspectiveFields expects uint8 BGR images (as cv2.imread returns)")
+        assert len(img.shape) <= 4
         method = interp if interp is not None else self.interp
-        return np.asarray(Image.fromarray(img).resize((self.new_w, self.new_h), method))
+        if img.dtype == np.uint8:
+            if len(img.shape) > 2 and img.shape[2] == 1:
+                out = np.asarray(Image.fromarray(img[:, :, 0], mode="L").resize((self.new_w, self.new_h), method))
+                return np.expand_dims(out, -1)
+            return np.asarray(Image.fromarray(img).resize((self.new_w, self.new_h), method))
+        if any(x < 0 for x in img.strides):
+            img = np.ascontiguousarray(img)
+        t = torch.from_numpy(img)
+        shape = list(t.shape)
+        shape_4d = shape[:2] + [1] * (4 - len(shape)) + shape[2:]
+        t = t.view(shape_4d).permute(2, 3, 0, 1)  # hw(c) -> nchw
+        mode = self._PIL_TO_INTERPOLATE[method]
+        t = torch.nn.functional.interpolate(t, (self.new_h, self.new_w), mode=mode, align_corners=None if mode == "nearest" else False)
+        shape[:2] = (self.new_h, self.new_w)
+        return t.permute(2, 3, 0, 1).reshape(shape).numpy()  # nchw -> hw(c)
 
 
 def _resolve_weights(version: str, weights) -> Dict[str, np.ndarray]:
@@ -173,13 +189,21 @@ class PerspectiveFields(nn.Module):
 
     @torch.no_grad()
     def inference_batch(self, img_bgr_list: List[np.ndarray]) -> List[dict]:
+        """uint8 HxWx3 images (as cv2.imread returns) take the PIL path -- bit-identical bytes on the host or on the GPU; any other dtype (float images, 0..255) follows
+        the reference's other branch (perspectivefields.py:48-66): F.interpolate on the host, then the float entry point of the engine (pf_forward_f32)."""
+        if any(im.dtype != np.uint8 for im in img_bgr_list):
+            sizes, chw = [], []
+            for img_bgr in img_bgr_list:
+                original = img_bgr[:, :, ::-1] if self.input_format == "RGB" else img_bgr
+                sizes.append(tuple(int(v) for v in original.shape[:2]))
+                r = self.aug.apply_image(np.ascontiguousarray(original))
+                chw.append(torch.as_tensor(np.ascontiguousarray(r.astype("float32").transpose(2, 0, 1))))   # as the reference: image.astype("float32").transpose(2, 0, 1)
+            return self._run(torch.stack(chw).to(self.device), sizes)
         sizes, resized = [], []
         for img_bgr in img_bgr_list:
             original = img_bgr  # never mutated: apply_image returns a new array (reference copies, :196,211)
             if self.input_format == "RGB":
                 original = original[:, :, ::-1]
-            if original.dtype != np.uint8:
-                raise TypeError("PerspectiveFields expects uint8 BGR images (as cv2.imread returns)")
             sizes.append(tuple(int(v) for v in original.shape[:2]))
             resized.append(np.ascontiguousarray(original) if self.device_resize else self.aug.apply_image(np.ascontiguousarray(original)))
         if self.device_resize:

@@ -534,3 +534,22 @@ def test_row_block_forms_of_mit_stage3_agree(monkeypatch, mask):
         d = max(abs(float(a[k2]) - float(b[k2])) for k2 in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"))
         print(f"[PF_RB_CHAIN={mask} vs default img{i}] 1-cos {c:.2e} latL1 {e:.2e} param {d:.2e}")
         assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
+
+
+def test_float_images_follow_the_reference_other_branch():
+    """inference() on a float image (the reference's non-uint8 branch, perspectivefields.py:48-66: F.interpolate on the host, no antialiasing, then the float network
+    input): against the oracle fed with the same resized float image."""
+    tag = "centered"
+    m = model(tag)
+    img = synthetic_image(150, 210, seed=77).astype(np.float32) + np.float32(0.25)
+    r = m.inference(img)
+    resized = m.aug.apply_image(img)
+    assert resized.dtype == np.float32 and resized.shape == (320, 320, 3)
+    arch = arch_of(get_cfg(CASES[tag]))
+    with torch.no_grad():
+        o = pf_oracle.forward(to_torch(synthetic_state_dict(CASES[tag], 0)), arch, resized[None], [(150, 210)])[0]
+    assert_fields_close(r["pred_gravity"].cpu().numpy(), o["pred_gravity"].numpy(), r["pred_latitude"].cpu().numpy(), o["pred_latitude"].numpy(), "float image 320")
+    assert_fields_close(r["pred_gravity_original"].cpu().numpy(), o["pred_gravity_original"].numpy(),
+                        r["pred_latitude_original"].cpu().numpy(), o["pred_latitude_original"].numpy(), "float image original size")
+    for k in ("pred_roll", "pred_pitch", "pred_vfov", "pred_rel_focal"):
+        assert abs(float(r[k]) - float(o[k])) <= TOL_PARAM, (k, float(r[k]), float(o[k]))

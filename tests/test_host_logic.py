@@ -531,3 +531,37 @@ def test_unscaled_low_plane_representation():
     assert np.max(np.abs(got - ref) / scale) <= 3 * 2.0 ** -22
 
 
+
+
+def test_resize_transform_all_dtypes():
+    """ResizeTransform.apply_image (reference perspectivefields.py:34-66): uint8 through PIL (3-channel and single-channel "L"), every other dtype through
+    F.interpolate without antialiasing -- byte / bit identical to the unmodified reference where that tree exists, and to the stated formula everywhere."""
+    import sys
+
+    import torch
+    from perspectivefields_amd.perspectivefields import ResizeTransform
+
+    rng = np.random.default_rng(0)
+    cases = [((97, 131, 3), np.float32), ((64, 64, 3), np.float64), ((50, 70, 1), np.uint8), ((50, 70, 3), np.uint8), ((33, 45), np.float32)]
+    ref_rt = None
+    if os.path.isdir("/root/reference/perspective2d"):
+        sys.dont_write_bytecode = True
+        from oracle import ref_shim
+
+        ref_shim.install()
+        import importlib
+
+        ref_rt = importlib.import_module("perspective2d.perspectivefields").ResizeTransform  # ref_shim puts /root/reference first on sys.path: this is the reference's class
+        if not importlib.import_module("perspective2d.perspectivefields").__file__.startswith("/root/reference"):
+            ref_rt = None   # the repo's own alias package was imported earlier in this process: nothing to compare with
+    for shape, dt in cases:
+        img = (rng.random(shape) * 255).astype(dt)
+        got = ResizeTransform(320, 320).apply_image(img)
+        assert got.dtype == img.dtype and got.shape[:2] == (320, 320) and got.shape[2:] == img.shape[2:]
+        if dt != np.uint8:
+            t = torch.from_numpy(img)
+            t4 = t.view(list(t.shape[:2]) + [1] * (4 - t.dim()) + list(t.shape[2:])).permute(2, 3, 0, 1)
+            want = torch.nn.functional.interpolate(t4, (320, 320), mode="bilinear", align_corners=False).permute(2, 3, 0, 1).reshape(got.shape).numpy()
+            assert np.array_equal(got, want)
+        if ref_rt is not None:
+            assert np.array_equal(got, ref_rt(320, 320).apply_image(img)), (shape, dt)
