@@ -505,16 +505,23 @@ def main(argv=None):
             if dom is not None:
                 (M_, N_, K_, KH_), (n_, ms_, work_) = dom
                 ach = work_ / (ms_ * 1e-3) / 1e12
+                # r05: 3x3 / stride-1 convs with 64-multiple channels on maps >= PF_WINO^2 run as Winograd F(2x2, 3x3) (wino.hip): 16 position products per 2x2 outputs
+                # instead of 36 tap products -> 3 * 16 / 36 executed MFMA FLOPs per algorithmic FLOP
+                wino_min = int(os.environ.get("PF_WINO", "40"))
+                is_wino = bool(KH_ == 3 and precision == "fp32" and wino_min > 0 and N_ % 64 == 0 and (K_ // 9) % 64 == 0 and M_ // max(2 * Bl, 1) >= wino_min * wino_min)
+                nt_k = nt * 16.0 / 36.0 if is_wino else float(nt)
                 line["roofline"] = {
                     "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic if KH_ == 3 else None,
-                    "traffic_unit": "HBM bytes per launch of the 3x3 256->256 @80x80 two-head shape (rocprofv3 PMC: (2*FETCH_SIZE + WRITE_SIZE)*1024); NOT measured in this run: read from the committed PMC pass",
+                    "traffic_unit": "HBM bytes per launch of the 3x3 256->256 @80x80 two-head shape (rocprofv3 PMC: (2*FETCH_SIZE + WRITE_SIZE)*1024); NOT measured in this run: read from the newest committed PMC pass",
                     "traffic_source": traffic_src,
-                    "kernel": (f"pf::igemm_sbh_kernel (3x3 halo-tile implicit GEMM, split scheme of --precision {precision}) on the dominant launch shape: GEMM M={M_} N={N_} K={K_} (KH={KH_})" if KH_ == 3 else
+                    "kernel": (f"pf::wino4c_f2x2_kernel (Winograd F(2x2,3x3), tile {os.environ.get('PF_WINO_TILE', 'wino256x64c')}: 16 position GEMMs on the split-f16 MFMA, fused input / output transforms) on the dominant launch shape: conv as GEMM M={M_} N={N_} K={K_} (KH={KH_})" if is_wino else
+                               f"pf::igemm_sbh_kernel (3x3 halo-tile implicit GEMM, split scheme of --precision {precision}) on the dominant launch shape: GEMM M={M_} N={N_} K={K_} (KH={KH_})" if KH_ == 3 else
                                f"pf::igemm_sb_kernel / fused block MLP (linear tile, split scheme of --precision {precision}) on the dominant launch shape: GEMM M={M_} N={N_} K={K_} (KH={KH_})"),
                     "peak_basis": f"achieved = algorithmic FLOPs of the launch (2*M*N*K = {2.0 * M_ * N_ * K_ / 1e9:.1f} GFLOP) / its average HIP-event duration, priced against the DENSE 16-bit MFMA peak; "
-                                  f"the kernel executes {nt} MFMA FLOPs per algorithmic FLOP (executed_mfma_tflops): its ceiling is 2500/{nt} = {2500.0 / nt:.1f} TFLOP/s",
-                    "executed_mfma_tflops": round(ach * nt, 1), "frac_of_scheme_ceiling": round(ach * nt / BF16_MFMA_PEAK_TFLOPS, 4),
+                                  f"the kernel executes {nt_k:.3g} MFMA FLOPs per algorithmic FLOP (executed_mfma_tflops): its ceiling is 2500/{nt_k:.3g} = {2500.0 / nt_k:.1f} TFLOP/s"
+                                  + (" (Winograd: the direct conv's FLOPs stay the numerator -- the figure the r04 halo kernel was priced with -- while 2.25x fewer MFMAs are executed; the kernel is bound by the VALU work of the transforms issued in the same stream, profiles/r05_winograd.md)" if is_wino else ""),
+                    "executed_mfma_tflops": round(ach * nt_k, 1), "frac_of_scheme_ceiling": round(ach * nt_k / BF16_MFMA_PEAK_TFLOPS, 4),
                     "mfma_only_ceiling_tflops": 1900.0,
                     "mfma_only_ceiling_note": "NOT measured in this run: scripts/microbench/valu_mfma_interleave.hip on MI355X (profiles/r03_candidates.md): back-to-back "
                                               "v_mfma_f32_32x32x16_f16 retire one per 42 nominal (2.4 GHz) cycles instead of 32 (the part clocks ~1.8 GHz under MFMA load), and a VALU "

@@ -49,7 +49,7 @@ for k, v in out["kernels"].items():
         # SQ_VALU_MFMA_BUSY_CYCLES: 64 per v_mfma_f32_32x32x2_f32, summed over all SIMDs
         v["mfma_busy_frac"] = p["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / (p["GRBM_GUI_ACTIVE"]["sum"] / 8.0 * 1024)  # GRBM counter is summed over the 8 XCDs; 1024 SIMDs
 # class aggregate matching bench.py's `roofline` object (all split-bf16 implicit-GEMM launches: linear + halo tiles)
-cls = [v["trace"] for k, v in out["kernels"].items() if (k.startswith("pf::igemm_sb") or k.startswith("pf::cnx_mlp")) and "trace" in v]  # igemm_sb_kernel<*>, igemm_sbh_kernel<*>, cnx_mlp_kernel
+cls = [v["trace"] for k, v in out["kernels"].items() if (k.startswith("pf::igemm_sb") or k.startswith("pf::cnx_mlp") or k.startswith("pf::wino")) and "trace" in v]  # igemm_sb_kernel<*>, igemm_sbh_kernel<*>, cnx_mlp_kernel, the Winograd kernels
 if cls:
     n, us = sum(t["calls"] for t in cls), sum(t["total_us"] for t in cls)
     out["split_bf16_igemm_class"] = {"calls": n, "total_us": round(us, 1), "avg_us": round(us / n, 2),
@@ -58,7 +58,7 @@ if cls:
 shapes = {}
 for f in glob.glob(os.path.join(root, "rocprof_trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "igemm_sbh" not in r["Kernel_Name"]: continue
+        if "igemm_sbh" not in r["Kernel_Name"] and "wino" not in r["Kernel_Name"]: continue
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         # launches of one kernel + grid can still differ in K (e.g. 256 -> 256 and the folded 64 -> 256 conv at 80^2): split by duration octave
         k = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]), int(round(math.log2(max(us, 1.0)))))
@@ -68,7 +68,7 @@ for d in glob.glob(os.path.join(root, "rocprof_pmc_*")):
     if not os.path.isdir(d): continue
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "igemm_sbh" not in r["Kernel_Name"]: continue
+            if "igemm_sbh" not in r["Kernel_Name"] and "wino" not in r["Kernel_Name"]: continue
             us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             k = (short(r["Kernel_Name"]), int(r["Grid_Size"]), int(round(math.log2(max(us, 1.0)))))
             e = shapes.setdefault(k, {"calls": 0, "us": 0.0}).setdefault("pmc", {}).setdefault(r["Counter_Name"], [0.0, 0])
@@ -88,7 +88,7 @@ if rows_s and "hbm_bytes_per_launch" in rows_s[0]:
     d0 = rows_s[0]
     json.dump({"kernel": d0["kernel"], "grid": d0["grid"], "calls_in_trace": d0["calls"], "avg_us": d0["avg_us"],
                "hbm_bytes_per_launch": d0["hbm_bytes_per_launch"], "l2_hit_rate": d0.get("l2_hit_rate"), "mfma_busy_frac": d0.get("mfma_busy_frac"),
-               "shape": "dominant launch shape of the forward by total time (3x3 256->256 @80^2, both decoder heads in one grouped launch, B=32)",
+               "shape": "dominant launch shape of the forward by total time (3x3 256->256 @80^2, both decoder heads in one grouped launch, B=32; r05: the Winograd kernel)",
                "algorithmic_bytes_per_launch": {"input": 2 * 32 * 80 * 80 * 256 * 4, "output": 2 * 32 * 80 * 80 * 256 * 4,
                                                 "residual_operands": "0, 1 or 2 x the output size (4 launches per step: none / res1+res2 / none / res1): 0.84 - 1.68 GB, mean 1.15 GB"},
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py (B=32, steady state, shipped tile table), rows of this kernel + grid size only; "
@@ -107,7 +107,7 @@ if "split_bf16_igemm_class" in out:
     md.append(f"split (fp16 / bf16) implicit GEMM as one class (pf::igemm_sb_kernel<*> + pf::igemm_sbh_kernel + pf::cnx_mlp_kernel = bench.py's `split_gemm_class`): "
               f"{c['calls']} calls, {c['total_us']} us, avg {c['avg_us']} us per launch, {c['pct']} % of kernel time")
 md.append("")
-md.append("3x3 halo kernels by launch shape (kernel, grid size):")
+md.append("3x3 halo / Winograd kernels by launch shape (kernel, grid size):")
 md.append("| kernel | grid | calls | avg us | HBM MB/launch | L2 hit | MFMA busy |")
 md.append("|---|---|---|---|---|---|---|")
 for r in rows_s[:12]:
