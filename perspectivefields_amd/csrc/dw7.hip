@@ -137,7 +137,7 @@ __global__ __launch_bounds__(MAXT) void dwconv7x7_lane_kernel(const float* __res
 
 // ---- column-blocked form (default for the larger maps).  The lane kernel above issues 7 dword loads per output and lane:
 // with 4 waves per CU that is 112 texture-address cycles per 98 VALU cycles and row -- the kernel sits on the L1 / TA
-// request rate, which is why it did not react to occupancy, prefetch depth or packed FMAs (DESIGN.md 4.4).  Here a thread
+// request rate, which is why it did not react to occupancy, prefetch depth or packed FMAs (DESIGN.md 4.6).  Here a thread
 // owns NC ADJACENT output columns of one channel: a row costs NC + 6 loads for 49 NC FMAs (2.5 loads per output at NC = 4),
 // the x-overlap lives in registers instead of L1.  Same streaming structure otherwise: lane = channel (32 consecutive
 // channels = one 128-byte piece of a pixel), buffer loads with per-lane fixed offsets + scalar row offset (hardware range

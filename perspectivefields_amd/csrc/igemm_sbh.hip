@@ -49,7 +49,7 @@ template <int H_TY, int H_TX /*output patch*/, int BN, int WM, int WN, int MODE,
                              gravity_head.py:172), interpolated while the halo tile is staged -- the up-sampled tensor never exists in HBM*/,
           bool ASB = false /*the input comes as the two fp16 planes of the split-f16 scheme (ConvPtrs::x_sb, written by the producing conv's epilogue): the halo
                              staging is a plain 16-byte copy per plane -- no split arithmetic in this kernel (VALU instructions are paid in MFMA issue time,
-                             DESIGN.md 4.7), and an element is split once by its producer instead of once per n-tile and halo overlap here.  MODE 0, no UPS.*/
+                             profiles/DESIGN_history_r01_r04.md 4.7), and an element is split once by its producer instead of once per n-tile and halo overlap here.  MODE 0, no UPS.*/
           SBH_ABL_PARAM>
 __global__ __launch_bounds__(WM * WN * 64, ((WM * WN == 8 && BN < 256 && (ABL & 0x8000) == 0) || (SCH == NT_F16X3 && TPG == 1 && !DB && (ABL & 0xa000) == 0 && BN <= 64 && !(H_TY == 16 && BN == 64 && WM * WN == 4))) ? 4 : 2) void igemm_sbh_kernel(const ConvParams p) {  // second argument: min waves per SIMD (the DMA-ring forms of the 4-wave tiles with BN <= 64 stay inside 128 VGPRs: four resident blocks; tuning builds: 0x8000 lifts that)
   constexpr int H_HX = H_TX + 2, H_HY = H_TY + 2;  // halo

@@ -79,7 +79,7 @@ def blocks_per_cu(r):
 
 
 def compare(old_lib, new_lib):
-    """Kernels whose spills or resident blocks per CU differ between two builds (DESIGN.md 4.10: run after every change to a shared device function)."""
+    """Kernels whose spills or resident blocks per CU differ between two builds (DESIGN.md 4.11: run after every change to a shared device function)."""
     a = {r["kernel"]: r for r in kernels(old_lib)}
     out = []
     for r in kernels(new_lib):

@@ -491,7 +491,7 @@ def test_kernel_resources_static():
         assert by[k]["spill"] <= few_spills.get(k, 0) and by[k]["scratch"] <= 6 * few_spills.get(k, 0), by[k]
     # the two-blocks-per-CU 8-wave tiles trade a handful of spilled registers for the second resident block
     assert by["pf::igemm_sb_kernel<256, 128, 4, 2, 0, false, 1, 6, false>"]["vgpr"] <= 128
-    # Resident blocks per CU of the default-path GEMM tiles (r03): a shared epilogue that grew by 16 registers took `sb128x64` from 4 to 3 blocks and
+    # Resident blocks per CU of the default-path GEMM tiles (r03, profiles/DESIGN_history_r01_r04.md 4.10): a shared epilogue that grew by 16 registers took `sb128x64` from 4 to 3 blocks and
     # the B = 64 stage-3 launches (1000 blocks) from one round to two, -2.9 % end to end with no spill to warn about.  512 VGPRs per SIMD lane in granules of 8, 160 KB LDS.
     blocks_per_cu = kr.blocks_per_cu
     floor = {"pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 1, 23, false>": 4, "pf::igemm_sb_kernel<128, 64, 2, 2, 0, false, 2, 23, false>": 3,
