@@ -153,7 +153,7 @@ int conv_splitk_shape(long M, int Cout, int KH, int KWCp, int groups);  // its s
 const char* conv_tile_name(int tile_id);
 // Winograd F(2x2, 3x3) kernel (wino.hip; tile "wino256x64" of the split family)
 bool conv_wino_ok(const ConvParams& p);
-void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant = 0);  // 0: 8 waves ("wino256x64"), 1: 4 waves, transform interleaved with the MFMAs ("wino256x64w4")
+void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant = 0);  // 0: "wino256x64" (8 waves), 1: "wino256x64w4", 2: "wino256x64c", 3: "wino256x64d"
 void wino_pack_weights(const float* packed /*[Cout][3][KWCp], k = (kx, ci)*/, int Cout, int Cin, int KWCp, std::vector<unsigned short>* planes, std::vector<float>* inv_scale);
 
 // rows x C LayerNorm (biased variance), y may alias x

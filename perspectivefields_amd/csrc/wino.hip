@@ -843,6 +843,247 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4c_f2x2_kernel(const ConvParams 
   wino4_epilogue<STAMP>(p, P, acc, wsm, bimg, oy0, ox0, n0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// "wino256x64d": the data flow of wino256x64c with EVERY instruction of the chunk loop placed by hand, one MFMA per slot.  The disassembly of wino256x64c showed what
+// its stamps could not: between two MFMAs the compiler had put anything from 0 to 33 VALU instructions (sched_group_barrier does not classify the inline-asm
+// v_fma_mix as VALU, the exec-masked store of the last halo element split the body into two scheduling regions, ~48 integer address instructions per chunk, and half
+// of the row / column combinations scalarised) -- a VALU cluster longer than the ~32 cycles one MFMA occupies the matrix core delays the next MFMA by the excess, and
+// an empty slot hides nothing.  Here:
+//   * a chunk = 48 slots {one MFMA, <= 4 VALU instructions (<= 23 cycles), <= 2 memory instructions}, sched_barrier(0) after every slot;
+//   * window w (6 slots) multiplies fragment w = (tile sub-tile m, nu) and transforms fragment w + 2: slot 0 the column combination (4 packed), slots 1-4 the fp16
+//     split (v_cvt_pk / v_fma_mixlo / v_fma_mixhi of four channel pairs, skewed so that no instruction depends on its predecessor), slot 5 ONE pixel column of the row
+//     combination (4 packed FMAs) for the tile sub-tile that needs it next -- its 2 x 2 ds_read_b128 are issued in slots 0 and 1 of the same window;
+//   * no address arithmetic in the loop: the chunk loop is unrolled by three (the raw-tile ring), every LDS address is a loop-invariant register + an immediate;
+//   * the last (partial) halo element is stored by every thread, the idle ones into a dump area: no branch in the body.
+// Arithmetic and accumulation order are those of wino256x64c: bit-identical results.
+// DABL (tuning builds, PF_WINO_ABL=<mask>; WRONG results, timing only): 1 = no LDS reads of the pixel columns, 2 = no raw-halo staging, 4 = no weight requests,
+// 8 = no transform arithmetic, 16 = no barrier, 32 = no address updates -- each removed from the chunk loop only; 128 / 256 = halo / weight requests issued as
+// inline asm, i.e. without the compiler's s_waitcnt for their results (issue cost without the waits).
+template <bool STAMP, int DABL = 0>
+__global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char wsm[WC_SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+  const int tilesN = p.Cout / W_BN;
+  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
+  const int nblk1 = p.B * tilesY * tilesX * tilesN;
+  int t = xcd_tile_index(nblk1 * p.groups);
+  const bool g1 = t >= nblk1;
+  if (g1) t -= nblk1;
+  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
+  const int nt = t % tilesN;
+  int mt = t / tilesN;
+  const int bx = mt % tilesX; mt /= tilesX;
+  const int by = mt % tilesY;
+  const int bimg = mt / tilesY;
+  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
+  const int nC = p.Cin / W_KC;
+
+  // ---- raw halo staging: element e = tid + 256 i -> (pixel tid / 4 + 64 i, logical piece tid % 4); st[i]: its LDS address (piece swizzle) in the tile being filled;
+  //      the threads without a sixth element store it (zeros) into a dump area behind the three tiles
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
+  unsigned g_off[RAW4_F4];
+  int st[RAW4_F4];
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) {
+    const int pix = (tid >> 2) + 64 * i, c4 = tid & 3;
+    const int hy = pix / W_HX, hx = pix - hy * W_HX;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
+    st[i] = pix < W_NPIX ? hy * RC_ROW + hx * 64 + ((c4 ^ ((hx >> 1) & 3)) * 16) : 3 * RC_BYTES + tid * 16;
+  }
+  auto raw_soff = [&](int c) { return (c < nC ? c : nC - 1) * (W_KC * 4); };
+  u32x4 ra[RAW4_F4];
+  // DABL 128 / 256: the halo / weight requests as inline asm -- issued, but the compiler inserts no s_waitcnt for their results (timing: issue cost without the waits)
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  auto rsrc_words = [](const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    i32x4_t r = {__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)), __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+    return r;
+  };
+  const i32x4_t rx_w = rsrc_words(P.x, (unsigned)p.x_bytes);
+  auto raw_load1 = [&](int i, int c) {
+    if constexpr ((DABL & 128) != 0) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[i]) : "v"(g_off[i]), "s"(rx_w), "s"(raw_soff(c)));
+    else ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], raw_soff(c), 0);
+  };
+  auto raw_store1 = [&](int i, int imm) { *reinterpret_cast<u32x4*>(wsm + st[i] + imm) = ra[i]; };
+
+  // ---- transform operands: lane -> tile column l31 of sub-tile m (tile row ty = l31 / 8 + 4 m, tx = l31 % 8), channels 8 hi .. 8 hi + 7 = logical pieces 2 hi, 2 hi + 1
+  // row pair of this wave's xi: xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3  ->  t = xA + sgn xB
+  const int rA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), rB = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+  const float sgn_f = wave == 1 ? 1.f : -1.f;
+  wf2 sgn = {sgn_f, sgn_f}, neg = {-1.f, -1.f};
+  asm volatile("" : "+v"(sgn), "+v"(neg));  // register pairs: the packed forms take no scalar pair / no negated operand here
+  const int ty0 = l31 >> 3, tx0 = l31 & 7;
+  const int t_base = (2 * ty0) * RC_ROW + (2 * tx0) * 64;
+  // LDS addresses of this lane's two pieces for pixel columns {0, 1} (swizzle tx & 3) and {2, 3} (swizzle (tx + 1) & 3), rows A and B, sub-tile 0.  Two sets that
+  // walk the ring of raw tiles: X serves the windows that read tile c (0, 1, 3), Y those that read tile c + 1 (2, 4..7); both are advanced by one tile per chunk in
+  // slots where they are idle (one v_add each: 22 address instructions per chunk with the six store addresses)
+  int X[2][2][2], Y[2][2][2];  // [row A / B][column pair][piece]
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int o = t_base + jp * 128 + (((2 * hi + hf) ^ ((tx0 + jp) & 3)) * 16);
+      X[0][jp][hf] = Y[0][jp][hf] = o + rA * RC_ROW;
+      X[1][jp][hf] = Y[1][jp][hf] = o + rB * RC_ROW;
+    }
+  V8 xA, xB;  // ONE pixel column (8 channels) of the two rows: read in slots 0 / 1 of a window, combined in its slot 5
+  auto col_read = [&](const int (&S)[2][2][2], int imm, int j, int part) {  // imm: sub-tile offset (compile time)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const WF4 v = *reinterpret_cast<const WF4*>(wsm + S[part][j >> 1][hf] + (imm + (j & 1) * 64));
+      if (part) { xB.c[2 * hf] = v.lo; xB.c[2 * hf + 1] = v.hi; }
+      else      { xA.c[2 * hf] = v.lo; xA.c[2 * hf + 1] = v.hi; }
+    }
+  };
+  // (the packed instructions are written out: left to itself the compiler scalarised half of these combinations -- 6 instructions per slot instead of 4)
+  auto pk_fma = [](const wf2 a, const wf2 b, const wf2 c) { wf2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; };
+  auto pk_add = [](const wf2 a, const wf2 b) { wf2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
+  V8 tr[4];  // row combination, four pixel columns
+  auto t_rows = [&](int j) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tr[j].c[e] = pk_fma(sgn, xB.c[e], xA.c[e]);
+  };
+  V8 vo;  // one column combination
+  auto t_cols = [&](int nu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      vo.c[e] = nu == 0 ? pk_fma(neg, tr[2].c[e], tr[0].c[e]) : (nu == 1 ? pk_add(tr[1].c[e], tr[2].c[e]) : (nu == 2 ? pk_fma(neg, tr[1].c[e], tr[2].c[e]) : pk_fma(neg, tr[3].c[e], tr[1].c[e])));
+  };
+  unsigned vfh[4][4], vfl[4][4];  // ring of four fragments: [slot][channel pair], planes hi / lo
+  auto s_cvt = [&](int slot, int e) {
+    const sb_h2 hv = {(_Float16)vo.c[e].x, (_Float16)vo.c[e].y};
+    vfh[slot][e] = __builtin_bit_cast(unsigned, hv);
+  };
+  auto s_lo = [&](int slot, int e) { asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(vfl[slot][e]) : "v"(vo.c[e].x), "v"(vfh[slot][e])); };
+  auto s_hi = [&](int slot, int e) { asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(vfl[slot][e]) : "v"(vo.c[e].y), "v"(vfh[slot][e])); };
+
+  // ---- weights: fragments of positions 4 wave + nu through a buffer resource (as in wino256x64c)
+  const int w_frags = tilesN * nC * 16;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_wino), 0, w_frags * 4096, 0x00020000);
+  const int w_s0 = (nt * nC * 16 + 4 * wave) * 4096;
+  u32x4 bw[4][2][2];  // [nu][cout sub-tile][plane]
+  const i32x4_t rw_w = rsrc_words(P.w_wino, (unsigned)(w_frags * 4096));
+  auto load_w1 = [&](int c, int nu, int piece) {
+    const int cc = c < nC ? c : nC - 1;
+    if constexpr ((DABL & 256) != 0) {
+      const int vo_ = lane * 16 + piece * 1024;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(bw[nu][piece >> 1][piece & 1]) : "v"(vo_), "s"(rw_w), "s"(w_s0 + (cc * 16 + nu) * 4096));
+    } else {
+      bw[nu][piece >> 1][piece & 1] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + piece * 1024, w_s0 + (cc * 16 + nu) * 4096, 0);
+    }
+  };
+  f32x16 acc[4][2][2];  // [nu][cout sub-tile][tile sub-tile]
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][b][m][e] = 0.f;
+  auto mma_one = [&](int f, int i) {  // MFMA i = 0..5 of fragment f = 4 m + nu: product i / 2 (wh vl, wl vh, wh vh), cout sub-tile i % 2
+    const int m = f >> 2, nu = f & 3, t3 = i >> 1, ns = i & 1, sl = f & 3;
+    const int tw = t3 == 1 ? 1 : 0;
+    const u32x4 v = t3 == 0 ? u32x4{vfl[sl][0], vfl[sl][1], vfl[sl][2], vfl[sl][3]} : u32x4{vfh[sl][0], vfh[sl][1], vfh[sl][2], vfh[sl][3]};
+    acc[nu][ns][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, bw[nu][ns][tw]), __builtin_bit_cast(wf16x8, v), acc[nu][ns][m], 0, 0, 0);
+  };
+
+  // ---- prologue: raw(0), raw(1) -> LDS; then the requests in the order a chunk of the loop leaves them in (the compiler's s_waitcnt insertion merges the loop's
+  //      entry states): raw(2), then the weights of (chunk 0, positions 0..2)
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 0);
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_store1(i, 0);
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 1);
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_store1(i, RC_BYTES);
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 2);
+#pragma unroll
+  for (int nu = 0; nu < 3; ++nu)
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) load_w1(0, nu, pc);
+#pragma unroll
+  for (int i = 0; i < RAW4_F4; ++i) st[i] += 2 * RC_BYTES;  // the loop's first chunk fills tile 2
+  __syncthreads();
+  // rows of (chunk 0, m = 0); fragments 0 and 1 of chunk 0; pixel column 0 of (chunk 0, m = 1)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { col_read(X, 0, j, 0); col_read(X, 0, j, 1); t_rows(j); }
+#pragma unroll
+  for (int nu = 0; nu < 2; ++nu) {
+    t_cols(nu);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s_cvt(nu, e); s_lo(nu, e); s_hi(nu, e); }
+  }
+  col_read(X, 8 * RC_ROW, 0, 0); col_read(X, 8 * RC_ROW, 0, 1); t_rows(0);
+  WINO4_STAMP(0);
+
+  // entering chunk c: fragments 0, 1 of chunk c in ring slots 0, 1; tr[0] = column 0 of (c, m = 1), tr[1..3] = columns of (c, m = 0); raw(c), raw(c + 1) in LDS;
+  // ra = raw(c + 2) requested; weights of chunk c, positions 0..2 requested; X, Y -> tile c; st -> tile c + 2.
+  // WD_SLOT(K): slot K of the chunk: window w = K / 6 runs the MFMAs of fragment w and the transform of fragment g = w + 2 (g >= 8: fragments 0, 1 of chunk c + 1).
+  // The pixel column a window combines in slot 5 (read in slots 0, 1): nu = 1 -> column 3 of its own sub-tile, nu = 0 / 2 / 3 -> column 0 / 2 / 1 of the NEXT sub-tile;
+  // it lies in tile c for windows 0, 1, 3 (address set X) and in tile c + 1 for the others (Y).
+#define WD_SLOT(K)                                                                                                                                  \
+  {                                                                                                                                                 \
+    constexpr int k = (K), w = k / 6, s = k % 6;                                                                                                    \
+    constexpr int g = w + 2, gf = g & 7, gm = gf >> 2, gnu = gf & 3;                                                                                \
+    constexpr int rj = gnu == 1 ? 3 : (gnu == 0 ? 0 : (gnu == 2 ? 2 : 1));                                                                          \
+    constexpr int rm = gnu == 1 ? gm : (gm ^ 1);                                                                                                    \
+    constexpr bool useX = w == 0 || w == 1 || w == 3;                                                                                               \
+    /* memory instructions of the slot */                                                                                                           \
+    if constexpr (s < 2 && (DABL & 1) == 0) { if constexpr (useX) col_read(X, rm * (8 * RC_ROW), rj, s); else col_read(Y, rm * (8 * RC_ROW), rj, s); } \
+    /* raw(c + 2) -> LDS in slots 2..7 (its requests are a chunk old), then the six requests for raw(c + 3) in slots 10..17: BEHIND the weights of position 3 and as \
+       far ahead of the next weights as the registers allow -- loads return in order, a weight fragment from L2 must not queue behind a halo pixel from HBM */    \
+    if constexpr ((DABL & 2) == 0) {                                                                                                                \
+      if constexpr (w == 0 && s >= 2) raw_store1(s - 2, 0);                                                                                         \
+      if constexpr (w == 1 && (s == 2 || s == 3)) raw_store1(s + 2, 0);                                                                             \
+      if constexpr (w == 1 && s >= 4) raw_load1(s - 4, c + 3);                                                                                      \
+      if constexpr (w == 2 && s >= 2) raw_load1(s, c + 3);                                                                                          \
+    }                                                                                                                                               \
+    /* weights: position 3 of this chunk in window 0 (last read in window 7 of the previous chunk); positions 0..2 of chunk c + 1 in windows 5..7 */ \
+    if constexpr (s >= 2 && w == 0 && (DABL & 4) == 0) load_w1(c, 3, s - 2);                                                                        \
+    if constexpr (s >= 2 && w >= 5 && (DABL & 4) == 0) load_w1(c + 1, w - 5, s - 2);                                                                \
+    /* the MFMA and the transform's piece */                                                                                                        \
+    mma_one(w, s);                                                                                                                                  \
+    if constexpr ((DABL & 8) == 0) {                                                                                                                \
+      if constexpr (s == 0) t_cols(gnu);                                                                                                            \
+      if constexpr (s == 1) { s_cvt(g & 3, 0); s_cvt(g & 3, 1); s_cvt(g & 3, 2); s_lo(g & 3, 0); }                                                  \
+      if constexpr (s == 2) { s_hi(g & 3, 0); s_lo(g & 3, 1); s_lo(g & 3, 2); }                                                                     \
+      if constexpr (s == 3) { s_cvt(g & 3, 3); s_hi(g & 3, 1); s_lo(g & 3, 3); }                                                                    \
+      if constexpr (s == 4) { s_hi(g & 3, 2); s_hi(g & 3, 3); }                                                                                     \
+      if constexpr (s == 5) t_rows(rj);                                                                                                             \
+    }                                                                                                                                               \
+    /* address sets: Y -> tile c + 1 in windows 0, 1 (idle until window 2); X -> tile c + 1 in windows 4, 5 (idle after window 3); the store addresses in window 3 */ \
+    if constexpr ((DABL & 32) == 0) {                                                                                                               \
+      if constexpr (w < 2 && s >= 2) { Y[(s - 2) >> 1][w][(s - 2) & 1] += d0; }                                                                     \
+      if constexpr ((w == 4 || w == 5) && s >= 2) { X[(s - 2) >> 1][w - 4][(s - 2) & 1] += d0; }                                                   \
+      if constexpr (w == 3) st[s] += d2;                                                                                                            \
+    }                                                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                              \
+    if (c == 2) WINO4_STAMP(80 + k);                                                                                                                \
+  }
+#define WD_SLOT6(B) WD_SLOT(B) WD_SLOT((B) + 1) WD_SLOT((B) + 2) WD_SLOT((B) + 3) WD_SLOT((B) + 4) WD_SLOT((B) + 5)
+  int ph = 0;  // c % 3
+#pragma unroll 1
+  for (int c = 0; c < nC; ++c) {
+    const int d0 = ph == 2 ? -2 * RC_BYTES : RC_BYTES;   // tile (c + 1) - tile c
+    const int d2 = ph == 0 ? -2 * RC_BYTES : RC_BYTES;   // tile (c + 3) - tile (c + 2)
+    if (c < 16) WINO4_STAMP(8 + 2 * c);
+    WD_SLOT6(0) WD_SLOT6(6) WD_SLOT6(12) WD_SLOT6(18) WD_SLOT6(24) WD_SLOT6(30) WD_SLOT6(36) WD_SLOT6(42)
+    if (c < 16) WINO4_STAMP(9 + 2 * c);
+    ph = ph == 2 ? 0 : ph + 1;
+    if constexpr ((DABL & 16) == 0) __syncthreads();   // raw(c + 2) complete in LDS; raw(c) free
+  }
+#undef WD_SLOT6
+#undef WD_SLOT
+  WINO4_STAMP(1);
+  wino4_epilogue<STAMP>(p, P, acc, wsm, bimg, oy0, ox0, n0);
+}
+
 // 3x3 / stride 1 / pad 1, split-f16 scheme, one fp32 NHWC input, fp32 NHWC output, Winograd weights present
 bool conv_wino_ok(const ConvParams& p) {
   if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nterms != NT_F16X3 || p.nchw_out || p.ups || p.ln || p.splitk > 1) return false;
@@ -857,6 +1098,32 @@ bool conv_wino_ok(const ConvParams& p) {
 void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant) {
   const int tilesN = p.Cout / W_BN, tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(W_NT);
+  if (variant == 3) {  // "wino256x64d"
+#ifdef PF_TUNING_BUILD
+    static int dabl = -1;
+    if (dabl < 0) { const char* e = getenv("PF_WINO_ABL"); dabl = e ? atoi(e) : 0; }
+    switch (dabl) {
+      case 1: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 1>), grid, dim3(W4_NT), 0, s, p); return;
+      case 2: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 2>), grid, dim3(W4_NT), 0, s, p); return;
+      case 4: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 4>), grid, dim3(W4_NT), 0, s, p); return;
+      case 8: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 8>), grid, dim3(W4_NT), 0, s, p); return;
+      case 16: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 16>), grid, dim3(W4_NT), 0, s, p); return;
+      case 32: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 32>), grid, dim3(W4_NT), 0, s, p); return;
+      case 7: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 7>), grid, dim3(W4_NT), 0, s, p); return;     // MFMAs + transform arithmetic + barrier, no memory instruction
+      case 55: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 55>), grid, dim3(W4_NT), 0, s, p); return;   // 7 + 16 + 32: MFMAs + transform arithmetic only
+      case 63: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 63>), grid, dim3(W4_NT), 0, s, p); return;   // MFMAs only
+      case 15: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 15>), grid, dim3(W4_NT), 0, s, p); return;   // MFMAs + barrier + address updates
+      case 128: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 128>), grid, dim3(W4_NT), 0, s, p); return;  // halo requests issued, never waited for
+      case 256: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 256>), grid, dim3(W4_NT), 0, s, p); return;  // weight requests issued, never waited for
+      case 384: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 384>), grid, dim3(W4_NT), 0, s, p); return;  // both
+      case 6: hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 6>), grid, dim3(W4_NT), 0, s, p); return;      // no halo staging, no weight requests
+      default: break;
+    }
+#endif
+    if (p.stamps) hipLaunchKernelGGL(wino4d_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
+    else hipLaunchKernelGGL(wino4d_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
+    return;
+  }
   if (variant == 2) {  // "wino256x64c"
     if (p.stamps) hipLaunchKernelGGL(wino4c_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
     else hipLaunchKernelGGL(wino4c_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);

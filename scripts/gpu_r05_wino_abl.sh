@@ -1,11 +1,15 @@
 #!/bin/bash
-# Winograd 4-wave kernel with one cost removed (tuning build, PF_WINO_ABL=<mask>; results wrong by construction, timing only): which resource bounds the chunk loop?
+# Winograd 4-wave kernels with one cost removed (tuning build, PF_WINO_ABL=<mask>; results wrong by construction, timing only): which resource bounds the chunk loop?
+# WINO_ABL_TILE=wino256x64w4 (masks of wino4_f2x2_kernel) or wino256x64d (masks of wino4d_f2x2_kernel: 1 no LDS reads, 2 no halo staging, 4 no weight requests,
+# 8 no transform arithmetic, 16 no barrier, 32 no address updates; 7 = no memory instruction, 55 = MFMAs + transform only, 63 = MFMAs only, 15 = MFMAs + barrier)
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp PF_TUNING_BUILD=1
-for abl in 0 1 2 4 8 16 32 64 84; do
+TILE=${WINO_ABL_TILE:-wino256x64d}
+MASKS=${WINO_ABL_MASKS:-"0 1 2 4 8 16 32 7 55 63 15"}
+for abl in $MASKS; do
   PF_WINO_ABL=$abl timeout 100 python -c "
 from perspectivefields_amd import ops
 n = ops.conv_tiles()
-best = min(ops.conv2d_bench(32, 80, 80, 256, 256, 3, 1, 1, tile=n.index('wino256x64w4'), iters=5) for _ in range(3))
-print('PF_WINO_ABL=$abl  rcu80 (one head)  %.3f ms' % best)" 2>&1 | grep PF_WINO_ABL
-done | tee gpurun_out/r05_wino_abl.log
+best = min(ops.conv2d_bench(32, 80, 80, 256, 256, 3, 1, 1, tile=n.index('$TILE'), iters=5) for _ in range(3))
+print('$TILE PF_WINO_ABL=$abl  rcu80 (one head)  %.3f ms' % best)" 2>&1 | grep PF_WINO_ABL
+done | tee gpurun_out/r05_winod_abl.log
