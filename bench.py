@@ -515,7 +515,7 @@ def main(argv=None):
                     "traffic": traffic if KH_ == 3 else None,
                     "traffic_unit": "HBM bytes per launch of the 3x3 256->256 @80x80 two-head shape (rocprofv3 PMC: (2*FETCH_SIZE + WRITE_SIZE)*1024); NOT measured in this run: read from the newest committed PMC pass",
                     "traffic_source": traffic_src,
-                    "kernel": (f"pf::wino4c_f2x2_kernel (Winograd F(2x2,3x3), tile {os.environ.get('PF_WINO_TILE', 'wino256x64c')}: 16 position GEMMs on the split-f16 MFMA, fused input / output transforms) on the dominant launch shape: conv as GEMM M={M_} N={N_} K={K_} (KH={KH_})" if is_wino else
+                    "kernel": (f"pf::wino4d_f2x2_kernel (Winograd F(2x2,3x3), tile {os.environ.get('PF_WINO_TILE', 'wino256x64d')}: 16 position GEMMs on the split-f16 MFMA, fused input / output transforms) on the dominant launch shape: conv as GEMM M={M_} N={N_} K={K_} (KH={KH_})" if is_wino else
                                f"pf::igemm_sbh_kernel (3x3 halo-tile implicit GEMM, split scheme of --precision {precision}) on the dominant launch shape: GEMM M={M_} N={N_} K={K_} (KH={KH_})" if KH_ == 3 else
                                f"pf::igemm_sb_kernel / fused block MLP (linear tile, split scheme of --precision {precision}) on the dominant launch shape: GEMM M={M_} N={N_} K={K_} (KH={KH_})"),
                     "peak_basis": f"achieved = algorithmic FLOPs of the launch (2*M*N*K = {2.0 * M_ * N_ * K_ / 1e9:.1f} GFLOP) / its average HIP-event duration, priced against the DENSE 16-bit MFMA peak; "

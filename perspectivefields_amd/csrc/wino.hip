@@ -1067,251 +1067,6 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams 
   wino4_epilogue<STAMP>(p, P, acc, wsm, bimg, oy0, ox0, n0);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------------------
-// "wino256x64e": wino256x64d with the two tile sub-tiles of a position multiplied TOGETHER.  In wino256x64d the six MFMAs of a fragment alternate between two
-// accumulators -- every MFMA waits for the one before the last (scripts/microbench/slot_overlap.hip: 288 -> 262 cycles per window with four accumulators in
-// rotation) -- and a position's weights are reloaded 13 .. 18 slots before they are needed.  Here a "pair" = 12 slots = the fragments (m = 0, nu), (m = 1, nu):
-//   MFMAs in the order (m0, i), (m1, i), i = 0..5: accumulators [nu][0][0], [nu][0][1], [nu][1][0], [nu][1][1] in rotation (a dependent MFMA is three MFMAs away);
-//   the weights of position nu are live for ONE pair per chunk: requested right after it for the next chunk, 31+ slots ahead of their use;
-//   the transform runs in the same fragment order, two fragments ahead; the rows of BOTH sub-tiles are live (tr[2][4], + 32 registers), every pixel column of chunk
-//   c + 1 is combined during chunk c (window w: column {0, 0, 2, 2, 1, 1, 3, 3}[w] of sub-tile w & 1) -- all LDS reads of a chunk go to ONE raw tile.
-// Arithmetic and per-accumulator order are those of wino256x64c / d: bit-identical results.
-// DABL (tuning builds, PF_WINO_ABL=<mask>; WRONG results, timing only): 1 = no LDS reads of the pixel columns, 2 = no raw-halo staging, 4 = no weight requests,
-// 8 = no transform arithmetic, 16 = no barrier, 32 = no address updates -- each removed from the chunk loop only.  (Mask 1 also makes the
-// transform loop invariant: the compiler hoists it -- read it as "no LDS reads, no transform".)
-template <bool STAMP, int DABL = 0>
-__global__ __launch_bounds__(W4_NT, 1) void wino4e_f2x2_kernel(const ConvParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char wsm[WC_SMEM];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
-  const int tilesN = p.Cout / W_BN;
-  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
-  const int nblk1 = p.B * tilesY * tilesX * tilesN;
-  int t = xcd_tile_index(nblk1 * p.groups);
-  const bool g1 = t >= nblk1;
-  if (g1) t -= nblk1;
-  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
-  const int nt = t % tilesN;
-  int mt = t / tilesN;
-  const int bx = mt % tilesX; mt /= tilesX;
-  const int by = mt % tilesY;
-  const int bimg = mt / tilesY;
-  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
-  const int nC = p.Cin / W_KC;
-
-  // ---- raw halo staging: element e = tid + 256 i -> (pixel tid / 4 + 64 i, logical piece tid % 4); st[i]: its LDS address (piece swizzle) in the tile being filled;
-  //      the threads without a sixth element store it (zeros) into a dump area behind the three tiles
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
-  unsigned g_off[RAW4_F4];
-  int st[RAW4_F4];
-#pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) {
-    const int pix = (tid >> 2) + 64 * i, c4 = tid & 3;
-    const int hy = pix / W_HX, hx = pix - hy * W_HX;
-    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
-    st[i] = pix < W_NPIX ? hy * RC_ROW + hx * 64 + ((c4 ^ ((hx >> 1) & 3)) * 16) : 3 * RC_BYTES + tid * 16;
-  }
-  auto raw_soff = [&](int c) { return (c < nC ? c : nC - 1) * (W_KC * 4); };
-  u32x4 ra[RAW4_F4];
-  bool in_loop = false;  // (ablation forms only)
-  auto raw_load1 = [&](int i, int c) {
-    if constexpr ((DABL & 64) != 0) { if (in_loop) return; }   // no halo requests in the loop: the stores write stale registers
-    ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], raw_soff(c), 0);
-  };
-  auto raw_store1 = [&](int i, int imm) {
-    if constexpr ((DABL & 128) != 0) { if (in_loop) { asm volatile("" ::"v"(ra[i])); return; } }   // no LDS stores in the loop: the requests are still waited for here
-    *reinterpret_cast<u32x4*>(wsm + st[i] + imm) = ra[i];
-  };
-
-  // ---- transform operands: lane -> tile column l31 of sub-tile m (tile row ty = l31 / 8 + 4 m, tx = l31 % 8), channels 8 hi .. 8 hi + 7 = logical pieces 2 hi, 2 hi + 1
-  // row pair of this wave's xi: xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3  ->  t = xA + sgn xB
-  const int rA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), rB = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
-  const float sgn_f = wave == 1 ? 1.f : -1.f;
-  const int ty0 = l31 >> 3, tx0 = l31 & 7;
-  const int t_base = (2 * ty0) * RC_ROW + (2 * tx0) * 64;
-  // LDS addresses of this lane's two pieces for pixel columns {0, 1} (swizzle tx & 3) and {2, 3} (swizzle (tx + 1) & 3), rows A and B, sub-tile 0.  Two sets that
-  // walk the ring of raw tiles: X serves the windows that read tile c (0, 1, 3), Y those that read tile c + 1 (2, 4..7); both are advanced by one tile per chunk in
-  // slots where they are idle (one v_add each: 22 address instructions per chunk with the six store addresses)
-  int X[2][2][2], Y[2][2][2];  // [row A / B][column pair][piece]
-#pragma unroll
-  for (int jp = 0; jp < 2; ++jp)
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const int o = t_base + jp * 128 + (((2 * hi + hf) ^ ((tx0 + jp) & 3)) * 16);
-      X[0][jp][hf] = Y[0][jp][hf] = o + rA * RC_ROW;
-      X[1][jp][hf] = Y[1][jp][hf] = o + rB * RC_ROW;
-    }
-  // The transform is written in SCALAR fp32 instructions (inline asm, so that nothing re-packs them): beside MFMAs a packed-fp32 instruction costs ~20 cycles more than
-  // the two scalar ones it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), and up to five single-issue instructions hide in one MFMA gap.
-  float xA[8], xB[8];  // ONE pixel column (8 channels) of the two rows: read in slot 0 of a window, combined in its slots 3..5
-  auto col_read = [&](const int (&S)[2][2][2], int imm, int j, int part) {  // imm: sub-tile offset (compile time)
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const WF4 v = *reinterpret_cast<const WF4*>(wsm + S[part][j >> 1][hf] + (imm + (j & 1) * 64));
-      float* d = part ? xB : xA;
-      d[4 * hf] = v.lo.x; d[4 * hf + 1] = v.lo.y; d[4 * hf + 2] = v.hi.x; d[4 * hf + 3] = v.hi.y;
-    }
-  };
-  float sgn1 = sgn_f;
-  asm volatile("" : "+v"(sgn1));
-  auto s_fma = [](float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; };
-  auto s_add = [](float a, float b) { float d; asm("v_add_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
-  auto s_sub = [](float a, float b) { float d; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
-  float tr[2][4][8];  // row combination: [tile sub-tile][pixel column][channel]
-  auto t_row1 = [&](int m, int j, int ch) { tr[m][j][ch] = s_fma(sgn1, xB[ch], xA[ch]); };
-  float vo[8];  // one column combination
-  auto t_col1 = [&](int m, int nu, int ch) {
-    vo[ch] = nu == 0 ? s_sub(tr[m][0][ch], tr[m][2][ch]) : (nu == 1 ? s_add(tr[m][1][ch], tr[m][2][ch]) : (nu == 2 ? s_sub(tr[m][2][ch], tr[m][1][ch]) : s_sub(tr[m][1][ch], tr[m][3][ch])));
-  };
-  unsigned vfh[4][4], vfl[4][4];  // ring of four fragments: [slot][channel pair], planes hi / lo
-  auto s_cvt = [&](int slot, int e) {
-    const sb_h2 hv = {(_Float16)vo[2 * e], (_Float16)vo[2 * e + 1]};
-    vfh[slot][e] = __builtin_bit_cast(unsigned, hv);
-  };
-  auto s_lo = [&](int slot, int e) { asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(vfl[slot][e]) : "v"(vo[2 * e]), "v"(vfh[slot][e])); };
-  auto s_hi = [&](int slot, int e) { asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(vfl[slot][e]) : "v"(vo[2 * e + 1]), "v"(vfh[slot][e])); };
-
-  // ---- weights: fragments of positions 4 wave + nu through a buffer resource (as in wino256x64c)
-  const int w_frags = tilesN * nC * 16;
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_wino), 0, w_frags * 4096, 0x00020000);
-  const int w_s0 = (nt * nC * 16 + 4 * wave) * 4096;
-  u32x4 bw[4][2][2];  // [nu][cout sub-tile][plane]
-  auto load_w1 = [&](int c, int nu, int piece) {
-    const int cc = c < nC ? c : nC - 1;
-    bw[nu][piece >> 1][piece & 1] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + piece * 1024, w_s0 + (cc * 16 + nu) * 4096, 0);
-  };
-  f32x16 acc[4][2][2];  // [nu][cout sub-tile][tile sub-tile]
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][b][m][e] = 0.f;
-  auto mma_one = [&](int m, int nu, int sl, int i) {  // MFMA i = 0..5 of fragment (m, nu) in ring slot sl: product i / 2 (wh vl, wl vh, wh vh), cout sub-tile i % 2
-    const int t3 = i >> 1, ns = i & 1;
-    const int tw = t3 == 1 ? 1 : 0;
-    const u32x4 v = t3 == 0 ? u32x4{vfl[sl][0], vfl[sl][1], vfl[sl][2], vfl[sl][3]} : u32x4{vfh[sl][0], vfh[sl][1], vfh[sl][2], vfh[sl][3]};
-    acc[nu][ns][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, bw[nu][ns][tw]), __builtin_bit_cast(wf16x8, v), acc[nu][ns][m], 0, 0, 0);
-  };
-
-  // ---- prologue: raw(0), raw(1) -> LDS; then the requests in the order a chunk of the loop leaves them in (the compiler's s_waitcnt insertion merges the loop's
-  //      entry states): raw(2) elements 0..3, weights (0, position 0), raw(2) elements 4, 5, weights (0, positions 1, 2)
-#pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 0);
-#pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) raw_store1(i, 0);
-#pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 1);
-#pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) raw_store1(i, RC_BYTES);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) raw_load1(i, 2);
-#pragma unroll
-  for (int pc = 0; pc < 4; ++pc) load_w1(0, 0, pc);
-  raw_load1(4, 2); raw_load1(5, 2);
-#pragma unroll
-  for (int nu = 1; nu < 3; ++nu)
-#pragma unroll
-    for (int pc = 0; pc < 4; ++pc) load_w1(0, nu, pc);
-#pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) st[i] += 2 * RC_BYTES;  // the loop's first chunk fills tile 2
-  __syncthreads();
-  // all rows of chunk 0 (tile 0); fragments (m0, nu0), (m1, nu0) of chunk 0 into ring slots 0, 1; then the address sets move on to tile 1
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      col_read(X, m * (8 * RC_ROW), j, 0); col_read(X, m * (8 * RC_ROW), j, 1);
-#pragma unroll
-      for (int ch = 0; ch < 8; ++ch) t_row1(m, j, ch);
-    }
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) t_col1(m, 0, ch);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { s_cvt(m, e); s_lo(m, e); s_hi(m, e); }
-  }
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) X[a][jp][hf] += RC_BYTES;   // Y takes its step in windows 0, 1 of the first chunk
-  WINO4_STAMP(0);
-
-  // entering chunk c: fragments (m0, nu0), (m1, nu0) of chunk c in ring slots 0, 1; tr = the rows of chunk c; raw(c + 1) in LDS (every read of the chunk goes there:
-  // raw(c) is not read again); ra = raw(c + 2) requested; weights of chunk c, positions 0..2 requested; X -> tile c + 1, Y -> tile c; st -> tile c + 2.
-  // Fragment order t = 0..7: (m = t & 1, nu = t >> 1).  WE_SLOT(K): pair P = K / 12 multiplies fragments 2P (even slots), 2P + 1 (odd slots); window w = K / 6
-  // transforms fragment t = w + 2 (t >= 8: fragments 0, 1 of chunk c + 1) and, in slot 5, combines pixel column {0, 0, 2, 2, 1, 1, 3, 3}[w] of sub-tile w & 1 of chunk
-  // c + 1 (read in slots 0, 1 through address set X in windows 0..3, Y in windows 4..7) -- a column is overwritten right after its last reader of chunk c:
-  // column 0 by nu 0 (transformed in windows 6, 7 of the previous chunk), 2 by nu 2 (windows 2, 3), 1 and 3 by nu 3 (windows 4, 5).
-#define WE_SLOT(K)                                                                                                                                  \
-  {                                                                                                                                                 \
-    constexpr int k = (K), w = k / 6, s = k % 6, P = k / 12, q = k % 12;                                                                            \
-    constexpr int t = (w + 2) & 7, tm = t & 1, tnu = t >> 1, ring = (w + 2) & 3;                                                                    \
-    constexpr int rm = w & 1, rj = w < 2 ? 0 : (w < 4 ? 2 : (w < 6 ? 1 : 3));                                                                       \
-    /* memory instructions of the slot */                                                                                                           \
-    if constexpr (s == 0 && (DABL & 1) == 0) {                                                                                                      \
-      if constexpr (w < 4) { col_read(X, rm * (8 * RC_ROW), rj, 0); col_read(X, rm * (8 * RC_ROW), rj, 1); }                                        \
-      else { col_read(Y, rm * (8 * RC_ROW), rj, 0); col_read(Y, rm * (8 * RC_ROW), rj, 1); }                                                        \
-    }                                                                                                                                               \
-    /* raw(c + 2) -> LDS in slots 2..7, then the requests for raw(c + 3) right behind the weights of position 3: loads return in order -- a weight fragment \
-       from L2 must not queue behind a halo pixel from HBM, and the halo requests get the longest run before a younger weight is waited for */            \
-    if constexpr ((DABL & 2) == 0) {                                                                                                                \
-      if constexpr (w == 0 && s >= 2) raw_store1(s - 2, 0);                                                                                         \
-      if constexpr (w == 1 && (s == 2 || s == 3)) raw_store1(s + 2, 0);                                                                             \
-      if constexpr (w == 1 && s >= 4) raw_load1(s - 4, c + 3);                                                                                      \
-      if constexpr (w == 2 && s < 2) raw_load1(s + 2, c + 3);                                                                                       \
-      if constexpr (w == 3 && (s == 2 || s == 3)) raw_load1(s + 2, c + 3);                                                                          \
-    }                                                                                                                                               \
-    /* weights: position 3 of this chunk in window 0 (its pair ended with the previous chunk); position nu of chunk c + 1 in window 2 nu + 2, right after its pair */ \
-    if constexpr (s >= 2 && w == 0 && (DABL & 4) == 0) load_w1(c, 3, s - 2);                                                                        \
-    if constexpr (s >= 2 && (w == 2 || w == 4 || w == 6) && (DABL & 4) == 0) load_w1(c + 1, w / 2 - 1, s - 2);                                      \
-    /* the MFMA and the transform's piece */                                                                                                        \
-    mma_one(q & 1, P, (2 * P + (q & 1)) & 3, q >> 1);                                                                                               \
-    if constexpr ((DABL & 8) == 0) {                                                                                                                \
-      /* 28 instructions per window, 5 5 5 5 4 4 per slot: column combination (8), split (4 cvt_pk, 4 mixlo, 4 mixhi), row combination of one pixel column (8) */ \
-      if constexpr (s == 0) { t_col1(tm, tnu, 0); t_col1(tm, tnu, 1); t_col1(tm, tnu, 2); t_col1(tm, tnu, 3); s_cvt(ring, 0); }                     \
-      if constexpr (s == 1) { t_col1(tm, tnu, 4); t_col1(tm, tnu, 5); t_col1(tm, tnu, 6); t_col1(tm, tnu, 7); s_cvt(ring, 1); }                     \
-      if constexpr (s == 2) { s_cvt(ring, 2); s_cvt(ring, 3); s_lo(ring, 0); s_lo(ring, 1); s_hi(ring, 0); }                                        \
-      if constexpr (s == 3) { s_lo(ring, 2); s_lo(ring, 3); s_hi(ring, 1); s_hi(ring, 2); t_row1(rm, rj, 0); }                                      \
-      if constexpr (s == 4) { s_hi(ring, 3); t_row1(rm, rj, 1); t_row1(rm, rj, 2); t_row1(rm, rj, 3); }                                             \
-      if constexpr (s == 5) { t_row1(rm, rj, 4); t_row1(rm, rj, 5); t_row1(rm, rj, 6); t_row1(rm, rj, 7); }                                         \
-    }                                                                                                                                               \
-    /* address sets: X (idle in windows 4..7) and Y (idle in windows 0..3) move on by one tile; the store addresses in window 2 */                   \
-    if constexpr ((DABL & 32) == 0) {                                                                                                               \
-      if constexpr ((w == 4 || w == 5) && s >= 2) { X[(s - 2) >> 1][w - 4][(s - 2) & 1] += d1; }                                                    \
-      if constexpr ((w == 0 || w == 1) && s >= 2) { Y[(s - 2) >> 1][w][(s - 2) & 1] += d0; }                                                        \
-      if constexpr (w == 2) st[s] += d2;                                                                                                            \
-    }                                                                                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                                                              \
-    if (c == 2) WINO4_STAMP(80 + k);                                                                                                                \
-  }
-#define WE_SLOT6(B) WE_SLOT(B) WE_SLOT((B) + 1) WE_SLOT((B) + 2) WE_SLOT((B) + 3) WE_SLOT((B) + 4) WE_SLOT((B) + 5)
-  int ph = 0;  // c % 3
-  in_loop = true;
-#pragma unroll 1
-  for (int c = 0; c < nC; ++c) {
-    const int d0 = ph == 2 ? -2 * RC_BYTES : RC_BYTES;   // tile (c + 1) - tile c:      Y enters the chunk on tile c (it served tile c in windows 4..7 of the previous chunk)
-    const int d1 = ph == 1 ? -2 * RC_BYTES : RC_BYTES;   // tile (c + 2) - tile (c + 1): X leaves the chunk on tile c + 2
-    const int d2 = ph == 0 ? -2 * RC_BYTES : RC_BYTES;   // tile (c + 3) - tile (c + 2)
-    if (c < 16) WINO4_STAMP(8 + 2 * c);
-    WE_SLOT6(0) WE_SLOT6(6) WE_SLOT6(12) WE_SLOT6(18) WE_SLOT6(24) WE_SLOT6(30) WE_SLOT6(36) WE_SLOT6(42)
-    if (c < 16) WINO4_STAMP(9 + 2 * c);
-    ph = ph == 2 ? 0 : ph + 1;
-    if constexpr ((DABL & 16) == 0) __syncthreads();   // raw(c + 2) complete in LDS; raw(c) free
-  }
-#undef WE_SLOT6
-#undef WE_SLOT
-  WINO4_STAMP(1);
-  wino4_epilogue<STAMP>(p, P, acc, wsm, bimg, oy0, ox0, n0);
-}
-
 // 3x3 / stride 1 / pad 1, split-f16 scheme, one fp32 NHWC input, fp32 NHWC output, Winograd weights present
 bool conv_wino_ok(const ConvParams& p) {
   if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nterms != NT_F16X3 || p.nchw_out || p.ups || p.ln || p.splitk > 1) return false;
@@ -1326,25 +1081,6 @@ bool conv_wino_ok(const ConvParams& p) {
 void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant) {
   const int tilesN = p.Cout / W_BN, tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(W_NT);
-  if (variant == 4) {  // "wino256x64e"
-#ifdef PF_TUNING_BUILD
-    static int eabl = -1;
-    if (eabl < 0) { const char* e = getenv("PF_WINO_ABL"); eabl = e ? atoi(e) : 0; }
-    switch (eabl) {
-      case 2: hipLaunchKernelGGL((wino4e_f2x2_kernel<false, 2>), grid, dim3(W4_NT), 0, s, p); return;
-      case 4: hipLaunchKernelGGL((wino4e_f2x2_kernel<false, 4>), grid, dim3(W4_NT), 0, s, p); return;
-      case 6: hipLaunchKernelGGL((wino4e_f2x2_kernel<false, 6>), grid, dim3(W4_NT), 0, s, p); return;
-      case 8: hipLaunchKernelGGL((wino4e_f2x2_kernel<false, 8>), grid, dim3(W4_NT), 0, s, p); return;
-      case 63: hipLaunchKernelGGL((wino4e_f2x2_kernel<false, 63>), grid, dim3(W4_NT), 0, s, p); return;
-      case 64: hipLaunchKernelGGL((wino4e_f2x2_kernel<false, 64>), grid, dim3(W4_NT), 0, s, p); return;    // no halo requests (LDS stores of stale registers)
-      case 128: hipLaunchKernelGGL((wino4e_f2x2_kernel<false, 128>), grid, dim3(W4_NT), 0, s, p); return;  // no LDS stores (requests issued and waited for)
-      default: break;
-    }
-#endif
-    if (p.stamps) hipLaunchKernelGGL(wino4e_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
-    else hipLaunchKernelGGL(wino4e_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
-    return;
-  }
   if (variant == 3) {  // "wino256x64d"
 #ifdef PF_TUNING_BUILD
     static int dabl = -1;
