@@ -15,7 +15,7 @@ by = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in sorted(glob.glob('gpurun_out/pmc_conv_*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
-        if 'igemm' not in r['Kernel_Name']: continue
+        if 'igemm' not in r['Kernel_Name'] and 'wino' not in r['Kernel_Name']: continue
         k = re.sub(r'^void pf::', '', re.sub(r'\(.*$', '', r['Kernel_Name'])) + ' grid' + r['Grid_Size']
         by[k][r['Counter_Name']].append(float(r['Counter_Value']))
         dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
