@@ -1406,7 +1406,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_WINO")) e->wino_min_hw = atoi(v);
   {
-    const char* wt = getenv("PF_WINO_TILE");  // "wino256x64d" (default: 4 waves, B fragments computed in registers, hand-placed slots), "wino256x64c" (its compiler-scheduled form), "wino256x64w4" (4 waves, V through LDS) or "wino256x64" (8 waves)
+    const char* wt = getenv("PF_WINO_TILE");  // "wino256x64d" (default: 4 waves, B fragments computed in registers, hand-placed slots), or "wino256x64c" (its compiler-scheduled form)
     for (int t = 0; t < conv_num_tiles(); ++t) if (strcmp(conv_tile_name(t), wt ? wt : "wino256x64d") == 0) e->wino_tile = t;
   }
   if (const char* v = getenv("PF_RB_CHAIN")) e->rb_chain = atoi(v);

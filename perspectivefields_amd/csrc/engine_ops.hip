@@ -33,7 +33,7 @@ int pf_op_conv2d(int device, const float* x, const float* x2, int B, int H, int 
     const F16Planes f = split_f16x2(packed, Cout);
     p.g[0].w_h16 = tmp.up_u16(f.planes); p.g[0].w_h16_inv_scale = tmp.up(f.inv_scale);
   }
-  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && C2 == 0 && Cin % 16 == 0 && Cout % 64 == 0 && p.KWCp == p.KWC) {  // Winograd form (tile "wino256x64")
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && C2 == 0 && Cin % 16 == 0 && Cout % 64 == 0 && p.KWCp == p.KWC) {  // Winograd form (tiles "wino256x64d" / "wino256x64c")
     std::vector<unsigned short> planes;
     std::vector<float> inv;
     wino_pack_weights(packed.data(), Cout, Cin, p.KWCp, &planes, &inv);
@@ -330,7 +330,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
     const F16Planes f = split_f16x2(hw, Cout);
     (void)hipMemcpy(dh16, f.planes.data(), nw * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dinv, f.inv_scale.data(), (size_t)Cout * 4, hipMemcpyHostToDevice);
-    if (K == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 && Cout % 64 == 0 && p.KWCp == p.KWC) {  // Winograd form (tile "wino256x64")
+    if (K == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 && Cout % 64 == 0 && p.KWCp == p.KWC) {  // Winograd form (tiles "wino256x64d" / "wino256x64c")
       std::vector<unsigned short> planes;
       std::vector<float> inv;
       wino_pack_weights(hw.data(), Cout, Cin, p.KWCp, &planes, &inv);
@@ -357,7 +357,7 @@ int pf_op_conv2d_bench(int device, int B, int H, int W, int Cin, int Cout, int K
   float t = 0.f;
   (void)hipEventElapsedTime(&t, a, b);
   *ms_out = t / iters;
-  if (getenv("PF_WINO_STAMPS") && strncmp(conv_tile_name(tile_id), "wino", 4) == 0) {  // timing aid: s_memtime stamps of block 17's eight waves of one more launch, to stderr
+  if (getenv("PF_WINO_STAMPS") && strncmp(conv_tile_name(tile_id), "wino", 4) == 0) {  // timing aid: s_memtime stamps of block 17's waves of one more launch, to stderr
     unsigned long long* ds = nullptr;
     if (hipMalloc(&ds, 8 * 128 * 8) == hipSuccess) {
       (void)hipMemset(ds, 0, 8 * 128 * 8);

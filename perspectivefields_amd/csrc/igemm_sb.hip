@@ -42,10 +42,8 @@ static const SbCfg kSb[] = {{128, 128, 1, "sb128x128"}, {64, 64, 1, "sb64x64"}, 
                              {256, 64, 0, "sbhAa"}, {256, 64, 0, "sbhAb"}, {256, 64, 0, "sbhLA0"}, {256, 64, 0, "sbhLA2"}, {256, 64, 0, "sbhLAbf"}, {256, 64, 0, "sbhLAbf0"}, {256, 64, 0, "sbhDMA"}, {256, 64, 0, "sbhREG"},
                              {256, 128, 0, "sbh256x128w8"}, {256, 128, 0, "sbh256x128w8u"}, {256, 64, 0, "sbh256x64"},  // 16 x 16 patch x 128 channels, 8 waves: wave tile 64 x 64 (683 B of LDS fragment reads per MFMA instead of 1024); "u" = no 128-VGPR cap
 #endif
-                             {256, 64, -1, "wino256x64d"},  // Winograd F(2x2, 3x3): wino256x64c with one MFMA + <= 4 VALU instructions per hand-placed slot; LAST BUT THREE
-                             {256, 64, -1, "wino256x64c"},  // Winograd F(2x2, 3x3), 4 waves, B-operand fragments computed in registers (no transformed operand in LDS); LAST BUT TWO
-                             {256, 64, -1, "wino256x64w4"},  // Winograd F(2x2, 3x3), 4 waves, transform interleaved with the MFMAs (wino.hip); the LAST BUT ONE tile
-                             {256, 64, -1, "wino256x64"},  // Winograd F(2x2, 3x3), 16 x 16 output pixels x 64 channels x 16 positions, 8 waves (wino.hip); always the LAST tile
+                             {256, 64, -1, "wino256x64d"},  // Winograd F(2x2, 3x3): wino256x64c with one MFMA + <= 4 VALU instructions per hand-placed slot; the LAST BUT ONE tile
+                             {256, 64, -1, "wino256x64c"},  // Winograd F(2x2, 3x3), 4 waves, B-operand fragments computed in registers (no transformed operand in LDS); always the LAST tile
 };
 #ifdef PF_TUNING_BUILD
 static constexpr int kFirstH = 12 + 16;  // index of the first "sbh" tile (behind the linear tiles' tuning forms)
@@ -104,7 +102,7 @@ void launch_conv_sbh(const ConvParams& p, int h_tile, hipStream_t s);
 
 bool conv_sbh_tile_ok(const ConvParams& p, int h_tile);                  // igemm_sbh.hip
 bool conv_sb_tile_ok(const ConvParams& p, int sb_tile) {
-  if (sb_tile >= conv_sb_num_tiles() - 4) return conv_wino_ok(p);  // "wino256x64d", "wino256x64c", "wino256x64w4", "wino256x64"
+  if (sb_tile >= conv_sb_num_tiles() - 2) return conv_wino_ok(p);  // "wino256x64d", "wino256x64c"
 #ifdef PF_TUNING_BUILD
   if (sb_tile >= 12 && sb_tile < kFirstH)  // tuning forms of the linear tiles: split-f16 scheme, one fp32 input, plain epilogue
     return p.nterms == NT_F16X3 && !p.ln && p.C2 == 0 && !p.g[0].x_sb && p.Cin != 4 && (p.Cin % BK) == 0 && !p.ups && !p.g[0].head_kind;
@@ -173,7 +171,7 @@ void launch_conv_sb(const ConvParams& p0, int sb_tile, hipStream_t s) {
                          reinterpret_cast<const float4*>(q.res1), p.post_relu, reinterpret_cast<float4*>(q.y));
     }
   } } reduce_after{p, s};
-  if (sb_tile >= conv_sb_num_tiles() - 4) {
+  if (sb_tile >= conv_sb_num_tiles() - 2) {
     if (conv_wino_ok(p)) { launch_conv_wino(p, s, conv_sb_num_tiles() - 1 - sb_tile); return; }
     sb_tile = conv_sb_default_tile(p);
   }

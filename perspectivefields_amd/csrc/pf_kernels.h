@@ -151,9 +151,9 @@ void launch_conv_sb(const ConvParams& p, int sb_tile, hipStream_t s);
 int conv_splitk_factor(const ConvParams& p);
 int conv_splitk_shape(long M, int Cout, int KH, int KWCp, int groups);  // its shape-only part
 const char* conv_tile_name(int tile_id);
-// Winograd F(2x2, 3x3) kernel (wino.hip; tile "wino256x64" of the split family)
+// Winograd F(2x2, 3x3) kernel (wino.hip; tiles "wino256x64d" / "wino256x64c" of the split family)
 bool conv_wino_ok(const ConvParams& p);
-void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant = 0);  // 0: "wino256x64" (8 waves), 1: "wino256x64w4", 2: "wino256x64c", 3: "wino256x64d"
+void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant = 0);  // 0: "wino256x64c", 1: "wino256x64d"
 void wino_pack_weights(const float* packed /*[Cout][3][KWCp], k = (kx, ci)*/, int Cout, int Cin, int KWCp, std::vector<unsigned short>* planes, std::vector<float>* inv_scale);
 
 // rows x C LayerNorm (biased variance), y may alias x

@@ -6,21 +6,17 @@
 //
 // U = G g G^T is made once on the host (fp64), scaled per output channel by a power of two and split into two fp16 planes like every split-f16 weight (engine.hip
 // split_f16x2), and stored in MFMA FRAGMENT ORDER so that a wave streams it from L2 straight into registers (no LDS, as rb_gemm.hip does).
-// V = B^T d B is adds only (fp32), then the usual 2-way fp16 split (sb_split.h); |V| <= 4 max|d|, so this kernel's window ends at 65504 / 4 (conv_wino_ok's caller).
+// V = B^T d B is adds only (fp32), then the 2-way fp16 split without its clamp; |V| <= 4 max|d|, so this kernel's window ends at 65504 / 4 (conv_wino_ok's caller).
 //
-// Block = 16 x 16 output pixels of one image (8 x 8 tiles = 64 GEMM columns) x 64 output channels x all 16 positions, 8 waves, one block per CU (LDS):
-//   wave w owns positions 2w, 2w + 1: accumulators [2 pos][2 cout sub-tiles][2 tile sub-tiles] x 16 = 128 registers; M^T = U V^T, i.e. the WEIGHTS are the MFMA's
-//   A operand (rows = output channels) -- four consecutive accumulator registers are then four consecutive channels of one tile: 16-byte LDS / global accesses.
-//   K loop in chunks of 16 input channels (one MFMA k step):
-//     G  global -> registers: the 18 x 18 input halo of chunk c + 2 (3 float4 per thread, out-of-image pixels read as zero through the buffer range check)
-//     S  registers -> raw LDS tile (pixel pitch 96 B: conflict-free ds_read_b128 for the transform's lane map)
-//     T  raw LDS -> V: thread = (tile, half nu_h of the four columns, 4 channels): 12 pixels in, row transform (3 columns), column transform (2 of 4 columns),
-//        split, 16 x ds_write_b64 into the A-operand buffer of chunk c + 1 ([pos][plane][tile][16 ch] fp16, 32-byte rows, 16-byte pieces XOR-swizzled by bit 3
-//        of the tile index: conflict-free fragment reads).  nu_h is WAVE-uniform (no divergent formulas).
-//     M  per position: 4 fragment reads + 4 weight fragments (global, loaded one position ahead) -> 12 MFMAs
-//   T(c + 1) and M(c) sit in the same loop body (two A buffers); two barriers per chunk.
-//   Epilogue: per cout sub-tile the 16 position accumulators go through LDS ([pos][tile][32 ch] fp32, 128 KB); thread = (tile, 4 channels) reads its 16 values,
-//   applies A^T . A, the weight scale, bias / activation / residuals (the same order as epilogue_nhwc) and stores 4 pixels x 16 bytes.
+// Block = 16 x 16 output pixels of one image (8 x 8 tiles = 64 GEMM columns) x 64 output channels x all 16 positions, FOUR waves -- one per SIMD, 512 registers each:
+//   wave w owns row xi = w of the transformed tile (positions 4w .. 4w + 3: 256 accumulator registers); M^T = U V^T, i.e. the WEIGHTS are the MFMA's A operand (rows =
+//   output channels) -- four consecutive accumulator registers are then four consecutive channels of one tile: 16-byte LDS / global accesses in the epilogue.
+//   The B operand (V) never exists in LDS: each wave computes the fragments it multiplies in registers from the raw halo tile (wino4c_f2x2_kernel's comment).
+//   Epilogue (shared): A over nu in registers (4 positions -> 2 values), one 128 KB exchange between the waves through LDS, thread = (tile, 4 channels) applies A over
+//   xi, the weight scale, bias / activation / residuals (the same order as epilogue_nhwc) and stores 4 pixels x 16 bytes.
+// Two kernels: wino256x64c (the transform interleaved with the MFMAs by sched_group_barrier) and wino256x64d (the same data flow, every instruction of the chunk loop
+// placed by hand; the engine's default).  The round's earlier forms -- 8 waves with V through LDS, 4 waves with V through LDS -- and two later ones are in
+// profiles/r05_rejected/ with their measurements in profiles/r05_winograd.md.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -40,16 +36,9 @@ constexpr int W_HY = W_PY + 2, W_HX = W_PX + 2;  // input halo
 constexpr int W_NPIX = W_HY * W_HX;           // 324
 constexpr int W_BN = 64;                      // output channels per block
 constexpr int W_KC = 16;                      // input channels per chunk
-constexpr int W_NT = 512;
-constexpr int RAW_PITCH = 96;                 // bytes per halo pixel (64 used)
-constexpr int RAW_BYTES = W_NPIX * RAW_PITCH; // 31104
-constexpr int A_PLANE = 64 * 32;              // bytes of one (position, plane): 64 tiles x 16 fp16
-constexpr int A_POS = 2 * A_PLANE;
-constexpr int A_BUF = 16 * A_POS;             // 65536
 constexpr int M_POS = 64 * 128;               // epilogue: bytes of one position: 64 tiles x 32 fp32
-constexpr int W_SMEM = 2 * A_BUF + RAW_BYTES; // 162176 <= 163840
-static_assert(16 * M_POS <= 2 * A_BUF, "epilogue staging reuses the operand buffers");
-constexpr int RAW_F4 = (W_NPIX * 4 + W_NT - 1) / W_NT;  // float4 loads per thread per chunk (3)
+constexpr int W4_NT = 256;                    // four waves
+constexpr int RAW4_F4 = (W_NPIX * 4 + W4_NT - 1) / W4_NT;  // 16-byte halo elements per thread and chunk (6; the sixth for 16 threads only)
 
 __device__ __forceinline__ float4 f4add(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(const float4 a, const float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -57,275 +46,6 @@ __device__ __forceinline__ float4 f4sub(const float4 a, const float4 b) { return
 }  // namespace
 
 // s_memtime stamps of block 17's waves (STAMP instantiation only: PF_WINO_STAMPS=1 in pf_op_conv2d_bench; a stamp drains lgkmcnt, i.e. it perturbs the step it sits in)
-#define WINO_STAMP(i) do { if constexpr (STAMP) { if (blockIdx.x == 17 && lane == 0) p.stamps[wave * 128 + (i)] = __builtin_readcyclecounter(); } } while (0)
-
-template <bool STAMP>
-__global__ __launch_bounds__(W_NT, 2) void wino_f2x2_kernel(const ConvParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char wsm[W_SMEM];
-  unsigned char* const Ab = wsm;                  // [2][16 pos][2 planes][64 tiles][32 B]
-  unsigned char* const Raw = wsm + 2 * A_BUF;     // [324 px][96 B]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;  // wave in an SGPR: nuh below selects formulas by scalar branches
-  const int tilesN = p.Cout / W_BN;
-  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
-  const int nblk1 = p.B * tilesY * tilesX * tilesN;
-  int t = xcd_tile_index(nblk1 * p.groups);
-  const bool g1 = t >= nblk1;
-  if (g1) t -= nblk1;
-  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
-  const int nt = t % tilesN;
-  int mt = t / tilesN;
-  const int bx = mt % tilesX; mt /= tilesX;
-  const int by = mt % tilesY;
-  const int bimg = mt / tilesY;
-  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
-  const int nC = p.Cin / W_KC;
-
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
-
-  // ---- G / S: raw halo element e = tid + 512 i -> (pixel e / 4, float4 e % 4 of the 16-channel chunk)
-  unsigned g_off[RAW_F4];
-#pragma unroll
-  for (int i = 0; i < RAW_F4; ++i) {
-    const int e = tid + W_NT * i, pix = e >> 2, c4 = e & 3;
-    const int hy = pix / W_HX, hx = pix - hy * W_HX;
-    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
-  }
-  float4 ra[RAW_F4];
-  auto load_raw = [&](int c) {
-    const bool live = c < nC;
-#pragma unroll
-    for (int i = 0; i < RAW_F4; ++i) ra[i] = buf_load16(rx, (live && g_off[i] != OOB) ? g_off[i] + (unsigned)c * (W_KC * 4) : OOB);
-  };
-  auto store_raw = [&]() {
-#pragma unroll
-    for (int i = 0; i < RAW_F4; ++i) {
-      const int e = tid + W_NT * i, pix = e >> 2, c4 = e & 3;
-      if (pix < W_NPIX) *reinterpret_cast<float4*>(Raw + pix * RAW_PITCH + c4 * 16) = ra[i];
-    }
-  };
-
-  // ---- T: thread -> (tile tt = 16 (wave / 2) + lane / 4, column half nuh = wave & 1, channel quad cg = lane & 3)
-  // The two column halves differ only in WHICH three of the tile's four pixel columns a thread holds and in one sign, so they share one instruction stream:
-  //   nuh = 0: X, Y, Z = columns 0, 1, 2, s = +1:  nu 0 = c0 - c2 = X - Z,  nu 1 = c1 + c2 = Z + s Y
-  //   nuh = 1: X, Y, Z = columns 2, 3, 1, s = -1:  nu 2 = c2 - c1 = X - Z,  nu 3 = c1 - c3 = Z + s Y
-  // (wave-uniform column offsets and sign: no per-element selects, no second copy of the code)
-  const int nuh = wave & 1, cg = lane & 3;
-  const int tt = (wave >> 1) * 16 + (lane >> 2), tty = tt >> 3, ttx = tt & 7;
-  const unsigned char* const t_src = Raw + ((2 * tty) * W_HX + 2 * ttx) * RAW_PITCH + cg * 16;
-  const int t_col[3] = {(nuh ? 2 : 0) * RAW_PITCH, (nuh ? 3 : 1) * RAW_PITCH, (nuh ? 1 : 2) * RAW_PITCH};
-  const float t_sgn = nuh ? -1.f : 1.f;
-  const int t_dst = tt * 32 + (((cg >> 1) ^ ((tt >> 3) & 1)) * 16) + (cg & 1) * 8 + 2 * nuh * A_POS;  // inside one (position, plane); positions xi * 4 + 2 nuh (+ 1)
-  auto transform = [&](int buf) {
-    unsigned char* const dst = Ab + buf * A_BUF + t_dst;
-    auto ld_row = [&](int i, float4 (&d)[3]) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) d[j] = *reinterpret_cast<const float4*>(t_src + i * (W_HX * RAW_PITCH) + t_col[j]);
-    };
-    auto emit = [&](int xi, const float4 (&r)[3]) {  // row xi of B^T d for the columns X, Y, Z -> positions xi * 4 + 2 nuh (+ 1)
-      const float4 o0 = f4sub(r[0], r[2]);
-      const float4 o1 = make_float4(fmaf(t_sgn, r[1].x, r[2].x), fmaf(t_sgn, r[1].y, r[2].y), fmaf(t_sgn, r[1].z, r[2].z), fmaf(t_sgn, r[1].w, r[2].w));  // +-1: exact, one rounding like the add
-      uint2 h0, l0, h1, l1;
-      split4_f16(o0, h0, l0);
-      split4_f16(o1, h1, l1);
-      *reinterpret_cast<uint2*>(dst + (xi * 4) * A_POS) = h0;
-      *reinterpret_cast<uint2*>(dst + (xi * 4) * A_POS + A_PLANE) = l0;
-      *reinterpret_cast<uint2*>(dst + (xi * 4 + 1) * A_POS) = h1;
-      *reinterpret_cast<uint2*>(dst + (xi * 4 + 1) * A_POS + A_PLANE) = l1;
-    };
-    // rows 1 and 2 first (xi = 1: d1 + d2, xi = 2: d2 - d1), then row 0 (xi = 0: d0 - d2), then row 3 (xi = 3: d1 - d3): at most three pixel rows (36 registers) live
-    float4 d1[3], d2[3], dx[3], r[3];
-    ld_row(1, d1);
-    ld_row(2, d2);
-    ld_row(0, dx);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r[j] = f4add(d1[j], d2[j]);
-    emit(1, r);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r[j] = f4sub(d2[j], d1[j]);
-    emit(2, r);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r[j] = f4sub(dx[j], d2[j]);
-    asm volatile("" ::: "memory");  // keep row 3's reads behind row 0's use (register pressure: the block sits at the 256-register limit)
-    ld_row(3, dx);
-    emit(0, r);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r[j] = f4sub(d1[j], dx[j]);
-    emit(3, r);
-  };
-
-  // ---- M: weights in fragment order [n tile][chunk][pos][cout sub-tile][plane][lane][8 fp16]
-  const unsigned short* const wbase = P.w_wino + ((size_t)nt * nC * 16) * 2048 + lane * 8;  // 2048 ushorts = 4 KB per (chunk, pos)
-  u32x4 bw[2][2][2];  // [position slot][cout sub-tile][plane]
-  auto load_w = [&](int c, int slot) {
-    const int cc = c < nC ? c : nC - 1;  // past the end: a harmless reload
-    const unsigned short* src = wbase + ((size_t)cc * 16 + 2 * wave + slot) * 2048;
-#pragma unroll
-    for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) bw[slot][ns][pl] = *reinterpret_cast<const u32x4*>(src + (ns * 2 + pl) * 512);
-  };
-  f32x16 acc[2][2][2];  // [position slot][cout sub-tile][tile sub-tile]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][b][m][e] = 0.f;
-  const int a_frag = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16);  // tile row l31 of a 32-tile sub-tile, this lane's 8 channels (the swizzle bit is the same for rows r and r + 32)
-  auto mma_pos = [&](int buf, int slot) {
-    asm volatile("" ::: "memory");  // one position's fragments at a time
-    const unsigned char* src = Ab + buf * A_BUF + (2 * wave + slot) * A_POS + a_frag;
-    u32x4 av[2][2];  // [tile sub-tile][plane]
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) av[m][pl] = *reinterpret_cast<const u32x4*>(src + pl * A_PLANE + m * (32 * 32));
-    constexpr int TW[3] = {0, 1, 0}, TV[3] = {1, 0, 0};  // wh al, wl ah, wh ah (smallest terms first); consecutive MFMAs are independent
-#pragma unroll
-    for (int t3 = 0; t3 < 3; ++t3)
-#pragma unroll
-      for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-          acc[slot][ns][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, bw[slot][ns][TW[t3]]), __builtin_bit_cast(wf16x8, av[m][TV[t3]]), acc[slot][ns][m], 0, 0, 0);
-  };
-
-  // ---- prologue: raw(0) -> LDS -> V(0); raw(1) -> LDS; raw(2) in registers; weights of (0, slot 0)
-  load_raw(0);
-  store_raw();
-  load_raw(1);
-  __syncthreads();
-  transform(0);
-  __syncthreads();
-  store_raw();
-  load_raw(2);
-  __syncthreads();
-
-  // The two waves of a SIMD (waves w and w + 4: a block's waves go to the SIMDs cyclically) run the chunk's two phases in OPPOSITE order -- one transforms (VALU + LDS)
-  // while the other multiplies (MFMA): with all eight waves in step the matrix cores idled through every transform phase (profiles/r05_winograd.md).
-  const int t_half = (wave >> 2) & 1;  // the half step in which this wave transforms
-  WINO_STAMP(0);
-  // two complete copies of the loop (same number of barriers in each): a branch INSIDE one loop body made hipcc spill > 100 registers, either order alone needs none
-  auto tail = [&](int c) {
-    if (c < 16) WINO_STAMP(10 + 6 * c);
-    __syncthreads();                      // V(c + 1) complete, raw(c + 1) consumed, A buffer `buf` free
-    if (c < 16) WINO_STAMP(11 + 6 * c);
-    store_raw();                          // raw(c + 2)
-    load_raw(c + 3);
-    if (c < 16) WINO_STAMP(12 + 6 * c);
-    __syncthreads();
-    if (c < 16) WINO_STAMP(13 + 6 * c);
-  };
-  if (t_half == 0) {
-#pragma unroll 1
-    for (int c = 0; c < nC; ++c) {
-      const int buf = c & 1;
-      if (c < 16) WINO_STAMP(8 + 6 * c);
-      if (c + 1 < nC) transform(buf ^ 1);  // block-uniform
-      if (c < 16) WINO_STAMP(9 + 6 * c);
-      load_w(c, 0);
-      load_w(c, 1);
-      mma_pos(buf, 0);
-      mma_pos(buf, 1);
-      tail(c);
-    }
-  } else {
-#pragma unroll 1
-    for (int c = 0; c < nC; ++c) {
-      const int buf = c & 1;
-      if (c < 16) WINO_STAMP(8 + 6 * c);
-      load_w(c, 0);
-      load_w(c, 1);
-      mma_pos(buf, 0);
-      mma_pos(buf, 1);
-      if (c < 16) WINO_STAMP(9 + 6 * c);
-      if (c + 1 < nC) transform(buf ^ 1);
-      tail(c);
-    }
-  }
-  WINO_STAMP(1);
-
-  // ---- epilogue: per cout sub-tile, the 16 positions through LDS
-  float* const Ms = reinterpret_cast<float*>(wsm);
-  const int e_c4 = tid & 7, e_tile = tid >> 3, e_ty = e_tile >> 3, e_tx = e_tile & 7;
-  const int act = p.act, post_relu = p.post_relu;
-#pragma unroll
-  for (int ns = 0; ns < 2; ++ns) {
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int tile = m * 32 + l31;
-        unsigned char* dstp = reinterpret_cast<unsigned char*>(Ms) + (2 * wave + slot) * M_POS + tile * 128;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x16& a = acc[slot][ns][m];
-          *reinterpret_cast<float4*>(dstp + (((2 * j + hi) ^ (tile & 7)) * 16)) = make_float4(a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]);
-        }
-      }
-    __syncthreads();
-    {
-      const unsigned char* srcp = reinterpret_cast<const unsigned char*>(Ms) + e_tile * 128 + ((e_c4 ^ (e_tile & 7)) * 16);
-      float4 s0[4], s1[4];  // A^T M: rows 0 / 1, columns nu = 0..3
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        const float4 m0 = *reinterpret_cast<const float4*>(srcp + (0 * 4 + nu) * M_POS), m1 = *reinterpret_cast<const float4*>(srcp + (1 * 4 + nu) * M_POS);
-        const float4 m2 = *reinterpret_cast<const float4*>(srcp + (2 * 4 + nu) * M_POS), m3 = *reinterpret_cast<const float4*>(srcp + (3 * 4 + nu) * M_POS);
-        s0[nu] = f4add(f4add(m0, m1), m2);
-        s1[nu] = f4sub(f4sub(m1, m2), m3);
-      }
-      float4 yv[2][2];
-      yv[0][0] = f4add(f4add(s0[0], s0[1]), s0[2]); yv[0][1] = f4sub(f4sub(s0[1], s0[2]), s0[3]);
-      yv[1][0] = f4add(f4add(s1[0], s1[1]), s1[2]); yv[1][1] = f4sub(f4sub(s1[1], s1[2]), s1[3]);
-      const int n = n0 + ns * 32 + e_c4 * 4;
-      const float4 sc = *reinterpret_cast<const float4*>(P.w_wino_inv + n);
-      float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (P.bias) bb = *reinterpret_cast<const float4*>(P.bias + n);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int oy = oy0 + 2 * e_ty + a, ox = ox0 + 2 * e_tx + b;
-          if (oy >= p.Ho || ox >= p.Wo) continue;
-          const long o = ((long)(bimg * p.Ho + oy) * p.Wo + ox) * p.ldy + n;
-          float4 w = yv[a][b];
-          w.x = fmaf(w.x, sc.x, bb.x); w.y = fmaf(w.y, sc.y, bb.y); w.z = fmaf(w.z, sc.z, bb.z); w.w = fmaf(w.w, sc.w, bb.w);
-          if (act == ACT_RELU) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
-          else if (act == ACT_GELU) { w.x = gelu_erf(w.x); w.y = gelu_erf(w.y); w.z = gelu_erf(w.z); w.w = gelu_erf(w.w); }
-          if (P.res1) { const float4 q = *reinterpret_cast<const float4*>(P.res1 + o); w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
-          if (P.res2) { const float4 q = *reinterpret_cast<const float4*>(P.res2 + o); w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
-          if (post_relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
-          if (p.sat) sat_watch4(p.sat, p.sat_limit, w.x, w.y, w.z, w.w);
-          *reinterpret_cast<float4*>(P.y + o) = w;
-        }
-    }
-    __syncthreads();
-    WINO_STAMP(2 + ns);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------------------------
-// "wino256x64w4": the same block (16 x 16 pixels x 64 channels x 16 positions), FOUR waves -- one per SIMD, 512 registers each: wave w owns row xi = w of the
-// transformed tile (positions 4w .. 4w + 3: 256 accumulator registers), and the transform of chunk c + 1 is INTERLEAVED, instruction by instruction, with the MFMAs of
-// chunk c in the wave's own stream (a wave issues in order: an MFMA occupies the matrix core for 32 cycles but the issue port for 4-8, the ~7 VALU / LDS instructions
-// that follow it in program order run in its shadow).  The stamped timeline of the 8-wave form (profiles/r05_winograd.md) showed why: each of its phases is latency
-// bound (transform 1 950 cycles for 640 cycles of VALU issue, multiply 1 500 for 768 cycles of MFMA), and the second wave of a SIMD cannot cover both.
-//   chunk loop, 24 sub-steps of {MFMA, ~8 VALU, MFMA, ~8 VALU (+ LDS)}, fixed by sched_group_barrier inside and sched_barrier between the sub-steps:
-//     k = 0..3   transform: pixel column k of the 4 x 4 input tile (4 LDS reads issued one sub-step ahead) -> rows of B^T d
-//     k = 4..19  transform: output (xi, nu) = ((k - 4) / 4, (k - 4) % 4): column combination, split, two 8-byte LDS writes into the A buffer of chunk c + 1
-//     weights of (c + 1, position q) are requested right after position q's last MFMA of chunk c (three quarters of a chunk ahead), the fragments of position q + 1
-//     during position q's MFMAs; the raw halo of chunk c + 2 goes to LDS behind a barrier in sub-step 4 (all waves have read chunk c + 1's by then)
-//   Epilogue: A over nu is applied in registers (4 positions -> 2 values), so the exchange between the waves moves 128 KB through LDS once (the 8-wave form: twice).
-namespace {
-constexpr int W4_NT = 256;
-constexpr int RAW4_F4 = (W_NPIX * 4 + W4_NT - 1) / W4_NT;  // 6
-}  // namespace
-
 #define WINO4_STAMP(i) do { if constexpr (STAMP) { if (blockIdx.x == 17 && lane == 0) p.stamps[wave * 128 + (i)] = __builtin_readcyclecounter(); } } while (0)
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
@@ -443,216 +163,10 @@ __device__ __forceinline__ void wino4_epilogue(const ConvParams& p, const ConvPt
   WINO4_STAMP(3);
 }
 
-// Ablation forms (tuning builds only, PF_WINO_ABL=<mask> at run time; results WRONG by construction -- they time the kernel with one cost removed): 1 = no split
-// arithmetic in the transform (raw bits stored), 2 = no LDS stores of the transform, 4 = no transform output at all, 8 = no MFMAs, 16 = no weight requests in the loop,
-// 32 = no mid-chunk barrier, 64 = no raw-halo traffic in the loop.  The product build has no such parameter: ABL is the constant 0.
-#ifdef PF_TUNING_BUILD
-#define WINO4_ABL_PARAM , int ABL = 0
-#else
-#define WINO4_ABL_PARAM
-static constexpr int ABL = 0;
-#endif
-template <bool STAMP WINO4_ABL_PARAM>
-__global__ __launch_bounds__(W4_NT, 1) void wino4_f2x2_kernel(const ConvParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char wsm[W_SMEM];
-  unsigned char* const Ab = wsm;
-  unsigned char* const Raw = wsm + 2 * A_BUF;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
-  const int tilesN = p.Cout / W_BN;
-  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
-  const int nblk1 = p.B * tilesY * tilesX * tilesN;
-  int t = xcd_tile_index(nblk1 * p.groups);
-  const bool g1 = t >= nblk1;
-  if (g1) t -= nblk1;
-  const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
-  const int nt = t % tilesN;
-  int mt = t / tilesN;
-  const int bx = mt % tilesX; mt /= tilesX;
-  const int by = mt % tilesY;
-  const int bimg = mt / tilesY;
-  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
-  const int nC = p.Cin / W_KC;
-
-  // raw halo: element e = tid + 256 i -> (pixel tid / 4 + 64 i, float4 tid % 4): one voffset per element (out-of-image pixels: the out-of-range marker), the chunk
-  // goes into the instruction's SGPR offset; LDS side: one base + immediates
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x), 0, p.x_bytes, 0x00020000);
-  unsigned g_off[RAW4_F4];
-#pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) {
-    const int pix = (tid >> 2) + 64 * i, c4 = tid & 3;
-    const int hy = pix / W_HX, hx = pix - hy * W_HX;
-    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
-  }
-  unsigned char* const s_base = Raw + (tid >> 2) * RAW_PITCH + (tid & 3) * 16;
-  const bool s_last = tid < 4 * (W_NPIX - 64 * (RAW4_F4 - 1));  // the last round covers pixels 320 .. 323 only
-  u32x4 ra[RAW4_F4];
-  auto load_raw = [&](int c) {
-    const int soff = (c < nC ? c : nC - 1) * (W_KC * 4);  // past the end: a harmless reload of the last chunk (never consumed)
-#pragma unroll
-    for (int i = 0; i < RAW4_F4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], soff, 0);
-  };
-  auto store_raw = [&]() {
-#pragma unroll
-    for (int i = 0; i < RAW4_F4; ++i)
-      if (i + 1 < RAW4_F4 || s_last) *reinterpret_cast<u32x4*>(s_base + i * (64 * RAW_PITCH)) = ra[i];
-  };
-  auto raw_soff = [&](int c) { return (c < nC ? c : nC - 1) * (W_KC * 4); };
-
-  // transform: thread -> (tile tt = 16 wave + lane / 4, channel quad cg = lane & 3), all 16 positions
-  const int cg = lane & 3, tt = wave * 16 + (lane >> 2), tty = tt >> 3, ttx = tt & 7;
-  const unsigned char* const t_src = Raw + ((2 * tty) * W_HX + 2 * ttx) * RAW_PITCH + cg * 16;
-  unsigned char* const t_dst0 = Ab + tt * 32 + (((cg >> 1) ^ ((tt >> 3) & 1)) * 16) + (cg & 1) * 8;
-  WF4 dcol[2][4];  // one pixel column of the 4 x 4 tile (read one sub-step ahead)
-  WF4 rr[4][4];    // B^T d: [xi][column]
-  auto t_load_col = [&](int j) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dcol[j & 1][i] = *reinterpret_cast<const WF4*>(t_src + (i * W_HX + j) * RAW_PITCH);
-  };
-  auto w_add = [](const WF4& a, const WF4& b) { WF4 r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return r; };
-  auto w_sub = [](const WF4& a, const WF4& b) { WF4 r; r.lo = a.lo - b.lo; r.hi = a.hi - b.hi; return r; };
-  auto t_emit = [&](int buf, int xi, int nu) {
-    const WF4(&r)[4] = rr[xi];
-    const WF4 o = nu == 0 ? w_sub(r[0], r[2]) : (nu == 1 ? w_add(r[1], r[2]) : (nu == 2 ? w_sub(r[2], r[1]) : w_sub(r[1], r[3])));
-    if constexpr ((ABL & 4) != 0) return;
-    uint2 h, l;
-    if constexpr ((ABL & 1) != 0) {
-      h = make_uint2(__builtin_bit_cast(unsigned, o.lo.x), __builtin_bit_cast(unsigned, o.lo.y));
-      l = make_uint2(__builtin_bit_cast(unsigned, o.hi.x), __builtin_bit_cast(unsigned, o.hi.y));
-    } else {
-      split2_f16_nc(o.lo, h.x, l.x);
-      split2_f16_nc(o.hi, h.y, l.y);
-    }
-    unsigned char* const dst = t_dst0 + buf * A_BUF + (xi * 4 + nu) * A_POS;
-    if constexpr ((ABL & 2) != 0) {
-      asm volatile("" ::"v"(h.x), "v"(h.y), "v"(l.x), "v"(l.y));  // the values stay computed
-    } else {
-      *reinterpret_cast<uint2*>(dst) = h;
-      *reinterpret_cast<uint2*>(dst + A_PLANE) = l;
-    }
-  };
-
-  // multiply: positions 4 wave + q; weight fragments through a buffer resource: lane offset in a VGPR, (chunk, position) in the SGPR offset, fragment in the immediate
-  const int w_frags = tilesN * nC * 16;  // (chunk, position) slices of 4 KB
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_wino), 0, w_frags * 4096, 0x00020000);
-  const int w_s0 = (nt * nC * 16 + 4 * wave) * 4096;
-  u32x4 bw[4][2][2];  // [q][cout sub-tile][plane]
-  auto load_w = [&](int c, int q) {
-    const int cc = c < nC ? c : nC - 1;
-    const int soff = w_s0 + (cc * 16 + q) * 4096;
-#pragma unroll
-    for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) bw[q][ns][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + (ns * 2 + pl) * 1024, soff, 0);
-  };
-  auto load_w1 = [&](int c, int q, int piece) {  // one of the four fragments of (chunk c, position q)
-    const int cc = c < nC ? c : nC - 1;
-    bw[q][piece >> 1][piece & 1] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + piece * 1024, w_s0 + (cc * 16 + q) * 4096, 0);
-  };
-  f32x16 acc[4][2][2];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][b][m][e] = 0.f;
-  const unsigned char* const a_frag0 = Ab + (4 * wave) * A_POS + l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16);
-  u32x4 av[2][2][2];  // [q & 1][tile sub-tile][plane]
-  auto load_frag = [&](int buf, int q) {
-    const unsigned char* src = a_frag0 + buf * A_BUF + q * A_POS;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) av[q & 1][m][pl] = *reinterpret_cast<const u32x4*>(src + pl * A_PLANE + m * (32 * 32));
-  };
-  auto mma_one = [&](int q, int i) {  // MFMA i = 0..11 of position q: product t3 = i / 4 (wh al, wl ah, wh ah), accumulator (i % 4): consecutive MFMAs are independent
-    const int t3 = i >> 2, ns = (i >> 1) & 1, m = i & 1;
-    const int tw = t3 == 1 ? 1 : 0, tv = t3 == 0 ? 1 : 0;
-    if constexpr ((ABL & 8) != 0) { asm volatile("" ::"v"(bw[q][ns][tw]), "v"(av[q & 1][m][tv])); return; }
-    acc[q][ns][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, bw[q][ns][tw]), __builtin_bit_cast(wf16x8, av[q & 1][m][tv]), acc[q][ns][m], 0, 0, 0);
-  };
-  auto t_rows_a = [&](int j) { const WF4(&d)[4] = dcol[j & 1]; rr[0][j] = w_sub(d[0], d[2]); rr[1][j] = w_add(d[1], d[2]); };
-  auto t_rows_b = [&](int j) { const WF4(&d)[4] = dcol[j & 1]; rr[2][j] = w_sub(d[2], d[1]); rr[3][j] = w_sub(d[1], d[3]); };
-
-  // ---- prologue: raw(0) -> LDS -> V(0) -> A[0]; raw(1) -> LDS; raw(2) in registers; weights of chunk 0; fragments of (0, position 0)
-  // The order of the LAST vector-memory requests in front of the loop must be the steady state's (raw halo first, then the four weight requests): hipcc's s_waitcnt
-  // insertion merges the loop's two entry states, and with the weights requested first it made every chunk's halo store wait for vmcnt(0) -- i.e. for the weight
-  // loads issued a moment earlier: 600 of a chunk's 3 700 cycles (profiles/r05_winograd.md)
-  load_raw(0);
-  store_raw();
-  load_raw(1);
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { t_load_col(j); t_rows_a(j); t_rows_b(j); }
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) t_emit(0, xi, nu);
-  __syncthreads();
-  store_raw();
-  load_raw(2);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) load_w(0, q);
-  __syncthreads();
-  load_frag(0, 0);
-  t_load_col(0);
-  WINO4_STAMP(0);
-
-#pragma unroll 1
-  for (int c = 0; c < nC; ++c) {
-    const int buf = c & 1;
-    if (c < 16) WINO4_STAMP(8 + 4 * c);
-    // entering: av[0] = fragments of (c, position 0) and dcol[0] = pixel column 0 of raw(c + 1) are in flight
-#pragma unroll
-    for (int k = 0; k < 24; ++k) {
-      const int q = k / 6, i0 = 2 * (k % 6);
-      // ---- chores of this sub-step (memory instructions, placed by hand -- nothing crosses the sched_barrier below -- and at most two per sub-step: six LDS stores +
-      //      six buffer loads in ONE sub-step cost 600 cycles of issue time that no MFMA covered, profiles/r05_winograd.md)
-      if (k < 3) t_load_col(k + 1);                                   // next pixel column of raw(c + 1)
-      if (k % 6 == 2 && q < 3) load_frag(buf, q + 1);                 // next position's fragments
-      if (k == 4) {                                                  // every wave has read raw(c + 1): the halo of chunk c + 2 may overwrite it
-        if constexpr ((ABL & 32) == 0) __syncthreads();
-        if (c < 16) WINO4_STAMP(9 + 4 * c);
-      }
-      if ((ABL & 64) == 0 && k >= 5 && k < 5 + RAW4_F4) {            // raw(c + 2) -> LDS and the request for raw(c + 3), one element per sub-step
-        const int i = k - 5;
-        if (i + 1 < RAW4_F4 || s_last) *reinterpret_cast<u32x4*>(s_base + i * (64 * RAW_PITCH)) = ra[i];
-        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, g_off[i], raw_soff(c + 3), 0);
-      }
-      // weights, one 16-byte request per sub-step: (c, position 3) in k = 0..3 (its registers were last read in k = 23 of the previous chunk), (c + 1, position q - 1)
-      // in k = 6q .. 6q + 3
-      if constexpr ((ABL & 16) == 0) {
-        if (k < 4) load_w1(c, 3, k);
-        else if (k >= 6 && (k % 6) < 4) load_w1(c + 1, q - 1, k % 6);
-      }
-      // ---- two MFMAs and one piece of the transform
-      mma_one(q, i0);
-      if (k < 4) t_rows_a(k);
-      else if (k < 20) t_emit(buf ^ 1, (k - 4) >> 2, (k - 4) & 3);
-      mma_one(q, i0 + 1);
-      if (k < 4) t_rows_b(k);
-      SGB(0x008, 1); SGB(0x002, 5); SGB(0x008, 1); SGB(0x002, 5); SGB(0x200, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (c == 2) WINO4_STAMP(80 + k);   // STAMP build: every sub-step of one chunk
-    }
-    if (c < 16) WINO4_STAMP(10 + 4 * c);
-    __syncthreads();                       // V(c + 1) complete in A[buf ^ 1], raw(c + 2) in LDS, A[buf] free
-    if (c < 16) WINO4_STAMP(11 + 4 * c);
-    load_frag(buf ^ 1, 0);
-    t_load_col(0);
-  }
-  WINO4_STAMP(1);
-
-  wino4_epilogue<STAMP>(p, P, acc, wsm, bimg, oy0, ox0, n0);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
 // "wino256x64c": the 4-wave form WITHOUT the transformed operand in LDS.  The ablation of wino256x64w4 (profiles/r05_winograd.md) put its largest single cost on the
-// LDS stores of V (23 % of the launch: 16 stores of 16 bytes per thread and chunk, in a stream that has no second wave to cover them).  Here wave w (row xi = w of the
+// LDS stores of V (23 % of the launch: 16 stores of 16 bytes per thread and chunk, in a stream that has no second wave to cover them; that form is archived in
+// profiles/r05_rejected/wino_8wave_w4.hip.txt).  Here wave w (row xi = w of the
 // transformed tile) computes the MFMA B-operand fragments it needs ITSELF, in fragment layout: lane = (tile column l & 31, channel half l >> 5) reads the 2 x 4 input
 // pixels its row needs (8 channels each: 16 ds_read_b128 per tile sub-tile) from the raw halo tile, forms the row combination (one packed FMA with a wave-uniform sign),
 // the four column combinations and the fp16 split -- 8 channels x 4 positions = the four fragments of (tile sub-tile m, nu = 0..3).  No V stores, no fragment reads,
@@ -756,7 +270,7 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4c_f2x2_kernel(const ConvParams 
     vf[slot][1] = u32x4{l[0], l[1], l[2], l[3]};
   };
 
-  // ---- weights: fragments of positions 4 wave + nu through a buffer resource (as in wino256x64w4)
+  // ---- weights: fragments of positions 4 wave + nu through a buffer resource: lane offset in a VGPR, (chunk, position) in the SGPR offset
   const int w_frags = tilesN * nC * 16;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.w_wino), 0, w_frags * 4096, 0x00020000);
   const int w_s0 = (nt * nC * 16 + 4 * wave) * 4096;
@@ -1080,8 +594,8 @@ bool conv_wino_ok(const ConvParams& p) {
 
 void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant) {
   const int tilesN = p.Cout / W_BN, tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
-  const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups), block(W_NT);
-  if (variant == 3) {  // "wino256x64d"
+  const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups);
+  if (variant == 1) {  // "wino256x64d"
 #ifdef PF_TUNING_BUILD
     static int dabl = -1;
     if (dabl < 0) { const char* e = getenv("PF_WINO_ABL"); dabl = e ? atoi(e) : 0; }
@@ -1104,33 +618,9 @@ void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant) {
     else hipLaunchKernelGGL(wino4d_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
     return;
   }
-  if (variant == 2) {  // "wino256x64c"
-    if (p.stamps) hipLaunchKernelGGL(wino4c_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
-    else hipLaunchKernelGGL(wino4c_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
-    return;
-  }
-  if (variant == 1) {  // "wino256x64w4"
-#ifdef PF_TUNING_BUILD
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("PF_WINO_ABL"); abl = e ? atoi(e) : 0; }
-    switch (abl) {
-      case 1: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 1>), grid, dim3(W4_NT), 0, s, p); return;
-      case 2: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 2>), grid, dim3(W4_NT), 0, s, p); return;
-      case 4: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 4>), grid, dim3(W4_NT), 0, s, p); return;
-      case 8: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 8>), grid, dim3(W4_NT), 0, s, p); return;
-      case 16: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 16>), grid, dim3(W4_NT), 0, s, p); return;
-      case 32: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 32>), grid, dim3(W4_NT), 0, s, p); return;
-      case 64: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 64>), grid, dim3(W4_NT), 0, s, p); return;
-      case 84: hipLaunchKernelGGL((wino4_f2x2_kernel<false, 84>), grid, dim3(W4_NT), 0, s, p); return;   // 4 + 16 + 64: MFMAs, fragment reads and barriers only
-      default: break;
-    }
-#endif
-    if (p.stamps) hipLaunchKernelGGL(wino4_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
-    else hipLaunchKernelGGL(wino4_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
-    return;
-  }
-  if (p.stamps) hipLaunchKernelGGL(wino_f2x2_kernel<true>, grid, block, 0, s, p);
-  else hipLaunchKernelGGL(wino_f2x2_kernel<false>, grid, block, 0, s, p);
+  // variant 0: "wino256x64c"
+  if (p.stamps) hipLaunchKernelGGL(wino4c_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
+  else hipLaunchKernelGGL(wino4c_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
 }
 
 // Host side: packed fp32 weights [Cout][3][KWCp] (k = (kx, ci), ci fastest) -> U = G g G^T per (cout, cin) in fp64, scaled per output channel by a power of two

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Winograd 4-wave kernels with one cost removed (tuning build, PF_WINO_ABL=<mask>; results wrong by construction, timing only): which resource bounds the chunk loop?
-# WINO_ABL_TILE=wino256x64w4 (masks of wino4_f2x2_kernel) or wino256x64d (masks of wino4d_f2x2_kernel: 1 no LDS reads, 2 no halo staging, 4 no weight requests,
+# masks of wino4d_f2x2_kernel (the LDS form wino256x64w4 and its masks are archived in profiles/r05_rejected/): 1 no LDS reads, 2 no halo staging, 4 no weight requests,
 # 8 no transform arithmetic, 16 no barrier, 32 no address updates; 6 = 2 + 4, 63 = MFMAs only, 15 = MFMAs + barrier.  Mask 1 also makes the transform loop invariant)
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp PF_TUNING_BUILD=1

@@ -1,4 +1,4 @@
-"""Winograd F(2x2, 3x3) tile "wino256x64" (wino.hip) against the direct halo tiles on the 3x3 / stride-1 shapes of the decoders (pf_op_conv2d_bench, one head, random
+"""Winograd F(2x2, 3x3) tiles (wino.hip) against the direct halo tiles on the 3x3 / stride-1 shapes of the decoders (pf_op_conv2d_bench, one head, random
 data, best of 3 interleaved repeats).  Output: gpurun_out/tune_wino.txt"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ B = int(os.environ.get("TUNE_B", "32"))
 SHAPES = [("rcu80", B, 80, 80, 256, 256), ("rcu40", B, 40, 40, 256, 256), ("rcu20", B, 20, 20, 256, 256), ("rcu10", B, 10, 10, 256, 256),
           ("fold_c1", B, 80, 80, 64, 256), ("fold_c2", B, 40, 40, 128, 256), ("rcu80_2heads", 2 * B, 80, 80, 256, 256)]
 names = ops.conv_tiles()
-cand = [n for n in ("wino256x64d", "wino256x64c", "wino256x64w4", "wino256x64", "sbh256x64w8", "sbh128x128") if n in names]
+cand = [n for n in ("wino256x64d", "wino256x64c", "sbh256x64w8", "sbh128x128") if n in names]
 out = [f"B={B}; ms per launch (best of 3 x 5 launches) and algorithmic TFLOP/s (2 M N 9 Cin)"]
 for name, b, h, w, cin, cout in SHAPES:
     flops = 2.0 * b * h * w * cout * 9 * cin

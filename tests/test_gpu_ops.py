@@ -697,22 +697,21 @@ WINO_CASES = [
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
 def test_winograd_tiles_are_bit_identical(ops, case):
-    """The four Winograd kernels differ in how the work is laid out over waves and instruction slots, not in arithmetic or accumulation order."""
+    """The two Winograd kernels differ in how the instructions are scheduled, not in arithmetic or accumulation order."""
     name, B, H, W, Cin, Cout = case
     names = ops.conv_tiles()
     x = _rand((B, H, W, Cin), 310).cuda()
     w = _rand((Cout, Cin, 3, 3), 311, 1.0 / math.sqrt(Cin * 9))
     b = _rand((Cout,), 312, 0.1)
     r1 = _rand((B, H, W, Cout), 313).cuda()
-    outs = {t: ops.conv2d(x, w, b, pad=1, act=1, res1=r1, post_relu=True, tile=names.index(t), splitk=False) for t in ("wino256x64c", "wino256x64d", "wino256x64w4")}
+    outs = {t: ops.conv2d(x, w, b, pad=1, act=1, res1=r1, post_relu=True, tile=names.index(t), splitk=False) for t in ("wino256x64c", "wino256x64d")}
     assert torch.equal(outs["wino256x64c"], outs["wino256x64d"]), name
-    assert torch.equal(outs["wino256x64c"], outs["wino256x64w4"]), name
 
 
-@pytest.mark.parametrize("tile_name", ["wino256x64", "wino256x64w4", "wino256x64c", "wino256x64d"])
+@pytest.mark.parametrize("tile_name", ["wino256x64c", "wino256x64d"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
 def test_conv2d_winograd_tile(ops, case, tile_name):
-    """Winograd F(2x2, 3x3) tile "wino256x64" (wino.hip: 16 position GEMMs on the split-f16 MFMA, input / output transforms in fp32) against fp64, with the whole
+    """Winograd F(2x2, 3x3) tiles (wino.hip: 16 position GEMMs on the split-f16 MFMA, input / output transforms in fp32) against fp64, with the whole
     epilogue (bias, ReLU, two residuals, ReLU after the residuals -- the ResidualConvUnit forms of decode_head.py:242-256) and without; error measured against the
     natural scale of a dot product, sum |x||w|, and held to 4x the direct halo tile's error + an fp32 floor (the transforms add a few fp32 roundings)."""
     name, B, H, W, Cin, Cout = case
