@@ -367,8 +367,13 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4c_f2x2_kernel(const ConvParams 
 //   * window w (6 slots) multiplies fragment w = (tile sub-tile m, nu) and transforms fragment w + 2: slot 0 the column combination (4 packed), slots 1-4 the fp16
 //     split (v_cvt_pk / v_fma_mixlo / v_fma_mixhi of four channel pairs, skewed so that no instruction depends on its predecessor), slot 5 ONE pixel column of the row
 //     combination (4 packed FMAs) for the tile sub-tile that needs it next -- its 2 x 2 ds_read_b128 are issued in slots 0 and 1 of the same window;
-//   * no address arithmetic in the loop: the chunk loop is unrolled by three (the raw-tile ring), every LDS address is a loop-invariant register + an immediate;
-//   * the last (partial) halo element is stored by every thread, the idle ones into a dump area: no branch in the body.
+//   * 22 address instructions per chunk instead of 48: every LDS address is a register + an immediate; two sets of read addresses and the six store addresses walk
+//     the ring of raw tiles by one v_add each, in slots where they are idle (a body unrolled by three with immediates only made hipcc hoist 66 "register + constant"
+//     addresses out of the loop: 628 spilled dwords; a 48-iteration #pragma unroll exceeds the unroller's budget -- the slots are macro-expanded);
+//   * the last (partial) halo element is stored by every thread, the idle ones into a dump area: no branch in the body;
+//   * the six halo requests sit right behind the weights of position 3 and as far ahead of the next weights as the staging registers allow: loads return in order,
+//     a weight fragment from L2 must not queue behind a halo pixel from HBM.
+// Measured (profiles/r05_winograd.md): -3 ... 5 % per launch, +1.3 ... 2.9 % end to end against wino256x64c; the ablations and the three rearrangements that gained nothing.
 // Arithmetic and accumulation order are those of wino256x64c: bit-identical results.
 // DABL (tuning builds, PF_WINO_ABL=<mask>; WRONG results, timing only): 1 = no LDS reads of the pixel columns, 2 = no raw-halo staging, 4 = no weight requests,
 // 8 = no transform arithmetic, 16 = no barrier, 32 = no address updates -- each removed from the chunk loop only.  (Mask 1 also makes the
