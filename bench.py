@@ -239,7 +239,7 @@ def main(argv=None):
     if not dry:
         torch.cuda.set_device(dev)
 
-    from perspectivefields_amd.dist import gather_params, shard_round_robin_by_bucket
+    from perspectivefields_amd.dist import shard_round_robin_by_bucket
     from perspectivefields_amd.synth import synthetic_image
 
     precision = args.precision
@@ -295,37 +295,27 @@ def main(argv=None):
             dist.barrier()
         sync()
 
-    # Deferred ParamNet branch (--defer-params 1): forward i returns with its camera-parameter tensor still being computed on the engine's stream, next to forward i + 1's
-    # backbone; the tensor is complete in stream order once forward i + 1 has been issued, so the scalars of step i are gathered (N > 1) right after that -- one step
-    # late -- and the last step's after join_params().  Nothing is skipped: K steps' work is inside the timed region.
+    # The step is the PRODUCT's sharded entry point (perspectivefields_amd.dist.ShardedPerspectiveFields.forward_step: device resize for the mixed stream, forward,
+    # post-process, all-gather of the ParamNet rows).  Pipeline (--defer-params 1): forward i returns with its camera-parameter tensor still being computed on the
+    # engine's stream, next to forward i + 1's backbone; the class gathers the rows of step i one step late and drain() joins the last branch and gathers the last
+    # step's rows.  Nothing is skipped: K steps' work is inside the timed region.
+    from perspectivefields_amd.dist import ShardedPerspectiveFields
+
+    spf = ShardedPerspectiveFields(model, engine=eng)
     defer = bool(args.defer_params)  # also in the CPU dry run: the one-step-late gather of the scalars is rank logic the gloo test walks
-    if defer:
-        eng.set_defer_params(True)
-    late = {"params": None}
+    spf.set_pipeline(defer)
+    local = {}   # references only (no GPU work): this rank's rows of the last two steps, for the bit-identity check after the timed region
 
     def step():
-        if orig is not None:
-            eng.resize_batch_into(orig, batch)  # bucketed bit-exact PIL resize on the device (inside the timed region for the mixed stream)
-        pg, pl, params = eng.forward(batch)
-        outs = eng.postprocess_batch(pg, pl, sizes)
-        if defer and params is not None:  # references only (no GPU work): the local scalars of the last two steps, for the check after the timed region
-            late["overlapped"], late["last_local"] = late.get("last_local"), params
-        if defer and params is not None and world > 1:
-            prev, late["params"] = late["params"], params
-            allp = gather_params(prev, counts) if prev is not None else None
-        else:
-            allp = gather_params(params, counts) if (params is not None and world > 1) else params
-        return pg, pl, outs, allp
+        o = spf.forward_step(batch, sizes, counts, originals=orig)
+        if o.params is not None:
+            local["overlapped"], local["last"] = local.get("last"), o.params
+        return o.pred_gravity, o.pred_latitude, o.fields, o.gathered
 
     def drain(out):
-        """the tail of the pipeline: join the last forward's branch and gather its scalars"""
-        if not defer:
-            return out
-        eng.join_params()
-        if late["params"] is not None:
-            out = out[:3] + (gather_params(late["params"], counts),)
-            late["params"] = None
-        return out
+        """the tail of the pipeline: the last step's rows (joined) replace the one-step-late ones"""
+        last = spf.drain()
+        return out if last is None else out[:3] + (last,)
 
     for _ in range(args.warmup):
         step()
@@ -349,10 +339,10 @@ def main(argv=None):
     # step, whose branch ran alone after the join -- the parity check below only sees the last step (round 4: a packed-FMA operand form that was only wrong beside
     # other kernels went through exactly that gap, tests/test_gpu_e2e.py::test_deferred_paramnet_branch_equals_joined_forward caught it)
     deferred_identical = None
-    if defer and not dry and late.get("overlapped") is not None and late.get("last_local") is not None and args.steps >= 2:
-        deferred_identical = bool(torch.equal(late["overlapped"], late["last_local"]))
+    if defer and not dry and local.get("overlapped") is not None and local.get("last") is not None and args.steps >= 2:
+        deferred_identical = bool(torch.equal(local["overlapped"], local["last"]))
     if defer:
-        eng.set_defer_params(False)  # everything after the timed region (extra profiled step, latency figures, parity check) reads its results right away
+        spf.set_pipeline(False)  # everything after the timed region (extra profiled step, latency figures, parity check) reads its results right away
     if use_events:
         eng.profile_end()
     recs = eng.profile_records() if use_events else []

@@ -98,7 +98,8 @@ size_t pf_workspace_bytes(pf_handle h, int batch);
  *   d_pred_latitude: [batch][Cl][320][320] fp32 -- sin(latitude) in [-1,1] (Cl=1) or 180 logits
  *   d_params       : [batch][PF_PARAMS_STRIDE] fp32 or NULL when the arch has no ParamNet:
  *                    CENTERED  : roll, pitch, vfov (deg), rel_focal, raw x0..x3   (param_network.py:62-67)
- *                    UNCENTERED: raw x0..x4 (roll/90, pitch/90, general_vfov/90, rel_cx, rel_cy), 0, 0, 0
+ *                    UNCENTERED: raw x0..x4 (roll/90, pitch/90, general_vfov/90, rel_cx, rel_cy), rel_focal (closed form of utils/utils.py:47-91 general_vfov_to_focal,
+ *                                fp64 on the device), 0, 0   (param_network.py:204-220)
  */
 /* Arithmetic of the dense contractions (everything else is always fp32).
  *   FP32 (default, the parity mode): "split-f16" -- every fp32 activation is split on the fly into two fp16 values
@@ -118,11 +119,21 @@ int pf_set_precision(pf_handle h, int mode);
 
 /* Always-on saturation watch of the FP32 (split-f16) mode.  d_counter_u32: a caller-owned, zero-initialised 4-byte device counter (nullptr: off).  Every kernel that
  * WRITES a tensor a split-f16 contraction will read (GEMM / conv epilogues, the fused block MLPs, the Winograd convs) adds to it the number of 16-byte output groups
- * with an element beyond the window of that tensor's consumer (65504; 65504 / 4 in front of a Winograd conv; 8188 / 4094 for the attention operands; the input limit
- * of a depthwise conv, from its weights) or NaN.  Cost: one compare per 4 outputs; the counter only ever grows.  Read it in stream order behind a forward (a 4-byte
- * copy): unchanged = every dense-layer input of that forward was inside the window.  The Python layer (`precision="auto"`) re-runs a batch that moved it in the
- * FP32_BF16X6 mode and stays there.  Tensors no kernel can watch (LayerNorm outputs, the register-only hidden maps of the fused MLPs) are bounded from the weights
- * alone: pf_static_window_max returns the largest such bound, scaled so that a value > 65504 means "a static bound exceeds its window". */
+ * with an element beyond the window of that tensor's consumer (65504; 65504 / 4 = 16376 in front of a Winograd conv; 8188 / 4094 for the attention operands; the
+ * input limit of a depthwise conv, from its weights).  Cost: one compare per 4 outputs; the counter only ever grows.  Read it in stream order behind a forward (a
+ * 4-byte copy): unchanged = every dense-layer input of that forward was inside the window.
+ *
+ * THE CONTRACT FOR A CALLER THAT PINS PF_PRECISION_FP32 (mandatory reading since r05, when the 256 -> 256 decoder convs became Winograd F(2x2, 3x3)):
+ *   - outside a window the direct tiles SATURATE (the split clamps to +-65504: a finite, wrong result), but the Winograd layers' input transform adds four values
+ *     and splits WITHOUT the clamp: an input in (16376, 65504] may, and one beyond certainly does, turn into +-inf / NaN in that layer's output;
+ *   - both cases move the counter: the producer of such an input is watched with the 16376 limit, and the Winograd / row-block / fused-MLP epilogues also count NaN
+ *     (inf - inf) outputs; the register-capped GEMM tiles count saturation and +-inf only (a NaN reaches them only behind a producer that was already counted);
+ *   - so: a forward that left the counter unchanged is inside every window and its results are fp32-class; a forward that moved it MUST be discarded and re-run
+ *     with PF_PRECISION_FP32_BF16X6 (no window).  There is no third case, and no output of a counted forward is promised to be finite.
+ *   The Python layer does exactly that with `precision="auto"` (the default) and stays in the exact mode afterwards; `precision="fp32"` skips the check -- and the
+ *   host synchronisation it costs -- and leaves the counter to the caller (tests/test_gpu_e2e.py::test_pinned_fp32_window_contract).
+ * Tensors no kernel can watch (LayerNorm outputs, the register-only hidden maps of the fused MLPs) are bounded from the weights alone: pf_static_window_max returns
+ * the largest such bound, scaled so that a value > 65504 means "a static bound exceeds its window". */
 int pf_set_saturation_counter(pf_handle h, void* d_counter_u32);
 int pf_static_window_max(pf_handle h, float* out);
 

@@ -1191,7 +1191,11 @@ void launch_resize_u8(const uint8_t* in, int H, int W, uint8_t* tmp, uint8_t* ou
 
 // Reference: ParamNet.forward eval branch (param_network.py:62-67).  out is [B][8]:
 // mode 0 (centered): roll, pitch, vfov (deg), rel_focal = 1/(2 tan x2), raw x0..x3
-// mode 1 (uncentered): raw x0..x(n-1), zero padded (host applies the factors / fsolve, param_network.py:204-220)
+// mode 1 (uncentered, ParamNetConvNextRegress, param_network.py:204-220): raw x0..x(n-1), zero padded; with the zoo's output order (roll, pitch, general_vfov, rel_cx,
+//   rel_cy: n = 5) out[5] = rel_focal from the general vertical FoV (utils/utils.py:47-91 with h = 1, degree = True).  The reference runs scipy.fsolve from 1.5 on
+//   cos(gvfov) = (p^2 + q^2 - 1) / (2 p q),  p^2 = f^2 + cx^2 + (cy + 1/2)^2,  q^2 = f^2 + cx^2 + (cy - 1/2)^2  and returns |f|.  With u = f^2 + cx^2 + cy^2 + 1/4:
+//   p^2 q^2 = u^2 - cy^2 and p^2 + q^2 - 1 = 2 u - 1, so cos^2 (u^2 - cy^2) = (u - 1/2)^2 is a quadratic in u: solved in closed form in fp64 (the same expression
+//   as perspectivefields.py general_vfov_to_focal, which stays the host path of non-zoo output orders) -- no host round trip on the uncentered models' hot path.
 __global__ void paramnet_scalars_kernel(const float* __restrict__ raw, int nraw, float* __restrict__ out8, int B, int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -1205,6 +1209,13 @@ __global__ void paramnet_scalars_kernel(const float* __restrict__ raw, int nraw,
     o[4] = r[0]; o[5] = r[1]; o[6] = r[2]; o[7] = r[3];
   } else {
     for (int k = 0; k < 8; ++k) o[k] = k < nraw ? r[k] : 0.f;
+    if (nraw == 5) {
+      const double gv = (double)(r[2] * 90.0f), cx = (double)r[3], cy = (double)r[4];  // the factors in fp32, as the reference's x[:, idx] * factor
+      const double c = cos(gv * 0.017453292519943295), s2 = 1.0 - c * c;
+      const double disc = sqrt(fmax(1.0 - 4.0 * s2 * (c * c * cy * cy + 0.25), 0.0));
+      const double u = (c >= 0.0 ? 1.0 + disc : 1.0 - disc) / (2.0 * s2);  // cos > 0 needs u > 1/2: the '+' root; gvfov > 90 deg: the '-' root
+      o[5] = (float)sqrt(fabs(u - cy * cy - 0.25 - cx * cx));
+    }
   }
 }
 void launch_paramnet_scalars(const float* raw, int nraw, float* out8, int B, int mode, hipStream_t s) {

@@ -836,7 +836,7 @@ struct pf_engine {
       const int q = c.dbg->seq++;
       for (int g = 0; g < ngroups; ++g) {
         // "[winograd]": the layer runs as Winograd F(2x2, 3x3) -- its input transform adds four values, so its window ends at 65504 / 4 (PerspectiveFields._window_limit)
-        const std::string nm = fmt("dense%03d%s %dx%d s%d %s%sM=%d N=%d K=%d", q, ngroups > 1 ? (g ? "[latitude]" : "[gravity]") : "", w.KH, w.KW, w.stride, w.ln_s ? "LN-fused " : "", tile == wino_tile && wino_tile >= 0 ? "[winograd] " : "", p.M, p.Cout, w.KH * w.KW * w.CinReal);
+        const std::string nm = fmt("dense%03d%s %dx%d s%d %s%sM=%d N=%d K=%d", q, ngroups > 1 ? (g ? "[latitude]" : "[gravity]") : "", w.KH, w.KW, w.stride, w.ln_s ? "LN-fused " : "", tile >= 0 && strncmp(conv_tile_name(tile), "wino", 4) == 0 ? "[winograd] " : "", p.M, p.Cout, w.KH * w.KW * w.CinReal);
         range_in(c, nm + " x", calls[g].x.f, (size_t)B * (ups ? H / 2 : H) * (ups ? W / 2 : W) * p.C1);
         if (p.C2 > 0) range_in(c, nm + " x2", calls[g].x2.f, (size_t)B * H * W * p.C2);
       }
@@ -862,6 +862,8 @@ struct pf_engine {
     for (int t = 0; t < conv_num_tiles(); ++t) {
       if (!conv_tile_usable(p, t)) continue;
       if (strncmp(conv_tile_name(t), "sbhA", 4) == 0 || strncmp(conv_tile_name(t), "sbhLA", 5) == 0 || strncmp(conv_tile_name(t), "sbhDMA", 6) == 0 || strncmp(conv_tile_name(t), "sbhREG", 6) == 0 || strncmp(conv_tile_name(t), "sbhV", 4) == 0 || strncmp(conv_tile_name(t), "sbA", 3) == 0 || strncmp(conv_tile_name(t), "sbPI_", 5) == 0 || strncmp(conv_tile_name(t), "sbI_", 4) == 0) continue;  // tuning builds: ablation forms (wrong results by construction) are for scripts/tune_conv.py only
+      if (strncmp(conv_tile_name(t), "wino", 4) == 0) continue;  // the Winograd forms are chosen by map size (wino_min_hw), never by the table: a tuned-in Winograd tile on a small map would run with the
+                                                                 // 65504 / 4 window while the range records tag only `wino_tile` as "[winograd]"
       if (conv_tile_bn(t) > 32 && p.Cout <= 32) continue;
       if ((long)conv_tile_bm(t) * conv_tile_bn(t) > 16L * p.M * p.Cout) continue;  // tile far larger than the problem
       launch_conv_tile(p, t, c.s);  // warm-up (instruction cache, L2 state)

@@ -209,6 +209,7 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
             if (res1) x += res1[o + e];
             if (res2) x += res2[o + e];
             if (post_relu) x = fmaxf(x, 0.f);
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(x));  // the ragged tail is watched like the vector path
             y[o + e] = x;
           }
         }
@@ -320,6 +321,7 @@ __device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvP
             if (res1) x += res1[o + e];
             if (res2) x += res2[o + e];
             if (post_relu) x = fmaxf(x, 0.f);
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(x));  // the ragged tail is watched like the vector path
             y[o + e] = x;
           }
         }

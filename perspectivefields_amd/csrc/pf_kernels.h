@@ -12,16 +12,21 @@ namespace pf {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 #if defined(__HIPCC__)
-// saturation watch of a producer (ConvParams::sat): one v_max3 / v_max / compare per 4 outputs, an atomic only when the window is left (!(x <= limit) also catches NaN)
+// saturation watch of a producer (ConvParams::sat): one v_max3 / v_max / compare per 4 outputs, an atomic only when the window is left.  NaN-aware: fmaxf drops a
+// NaN operand, so the sum of the four values is tested too (NaN if any of them is NaN, or inf - inf) -- this is the form of every epilogue that is not at its
+// register cap (Winograd, row-block layers, fused block MLPs): a Winograd layer whose clamp-free split (wino.hip split2_f16_nc) met a value beyond its window
+// produces inf / NaN outputs, and those are counted HERE, at that layer's own output
 __device__ __forceinline__ void sat_watch4(unsigned* sat, float limit, float a, float b, float c, float d) {
   const float mx = fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d)));
-  if (!(mx <= limit)) atomicAdd(sat, 1u);
+  const float s = (a + b) + (c + d);
+  if (!(mx <= limit) || s != s) atomicAdd(sat, 1u);
 }
 // the same with ONE running maximum per thread (two v_max3_f32 per 4 outputs, no temporaries: the epilogues of the GEMM tiles sit at their register caps) ...
 __device__ __forceinline__ float sat_acc4(float amax, float a, float b, float c, float d) {
   return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(a)), __builtin_fabsf(b)), __builtin_fmaxf(__builtin_fabsf(c), __builtin_fabsf(d)));
 }
-// ... and one compare at the kernel's end (a NaN output is lost by fmaxf: the watch is about saturation; non-finite values are the debug forward's business)
+// ... and one compare at the kernel's end.  SATURATION ONLY: a NaN output is dropped by fmaxf (+-inf is counted).  A NaN can only reach these tiles from a producer
+// that was itself counted (an inf beyond every window, or the Winograd epilogue's NaN test above); non-finite values are otherwise the debug forward's business
 __device__ __forceinline__ void sat_flush(unsigned* sat, float limit, float amax) {
   if (sat && amax > limit) atomicAdd(sat, 1u);
 }

@@ -191,6 +191,28 @@ class PerspectiveFields(nn.Module):
     def inference_batch(self, img_bgr_list: List[np.ndarray]) -> List[dict]:
         """uint8 HxWx3 images (as cv2.imread returns) take the PIL path -- bit-identical bytes on the host or on the GPU; any other dtype (float images, 0..255) follows
         the reference's other branch (perspectivefields.py:48-66): F.interpolate on the host, then the float entry point of the engine (pf_forward_f32)."""
+        batch, sizes = self._prepare_batch(img_bgr_list)
+        return self._run(batch, sizes)
+
+    @torch.no_grad()
+    def inference_batch_with_params(self, img_bgr_list: List[np.ndarray]):
+        """inference_batch plus the engine's raw (B, 8) camera-parameter tensor (include/pf_hip.h pf_forward_u8: d_params; None without a ParamNet) -- the per-image
+        rows the multi-GPU path all-gathers (dist.ShardedPerspectiveFields).  An empty list gives ([], an empty (0, 8) tensor or None)."""
+        if len(img_bgr_list) == 0:
+            return [], (torch.zeros((0, 8), dtype=torch.float32, device=self.device) if self.param_on else None)
+        batch, sizes = self._prepare_batch(img_bgr_list)
+        lazy: list = []
+        results = self._run(batch, sizes, lazy_params=lazy)   # joined forwards: the parameters are complete in stream order
+        params = None
+        if lazy:
+            for res, pr in lazy:
+                for r, extra in zip(res, self._param_dicts(pr)):
+                    r.update(extra)
+            params = lazy[0][1] if len(lazy) == 1 else torch.cat([pr for _, pr in lazy])
+        return results, params
+
+    def _prepare_batch(self, img_bgr_list: List[np.ndarray]):
+        """host images -> (network input on the device, [(H, W)]): uint8 (B,320,320,3) through PIL (or the bit-identical device resize), float (B,3,320,320) otherwise"""
         if any(im.dtype != np.uint8 for im in img_bgr_list):
             sizes, chw = [], []
             for img_bgr in img_bgr_list:
@@ -198,7 +220,7 @@ class PerspectiveFields(nn.Module):
                 sizes.append(tuple(int(v) for v in original.shape[:2]))
                 r = self.aug.apply_image(np.ascontiguousarray(original))
                 chw.append(torch.as_tensor(np.ascontiguousarray(r.astype("float32").transpose(2, 0, 1))))   # as the reference: image.astype("float32").transpose(2, 0, 1)
-            return self._run(torch.stack(chw).to(self.device), sizes)
+            return torch.stack(chw).to(self.device), sizes
         sizes, resized = [], []
         for img_bgr in img_bgr_list:
             original = img_bgr  # never mutated: apply_image returns a new array (reference copies, :196,211)
@@ -218,7 +240,7 @@ class PerspectiveFields(nn.Module):
             eng.resize_batch_into(views, batch)
         else:
             batch = torch.from_numpy(np.stack(resized)).to(self.device, non_blocking=False)  # uint8 (B,320,320,3)
-        return self._run(batch, sizes)
+        return batch, sizes
 
     # ------------------------------------------------------------------ debug forward (sanitizer / shadow-compare mode)
     @torch.no_grad()
@@ -252,16 +274,17 @@ class PerspectiveFields(nn.Module):
     _HOST_KEYS = ("pred_gravity", "pred_gravity_original", "pred_latitude", "pred_latitude_original")
 
     @torch.no_grad()
-    def inference_stream(self, batches, to_host: bool = True, depth: int = 2):
-        """Pipelined inference over an iterable of image lists (see _inference_stream); leaves the engine's deferred-ParamNet mode off however the iteration ends."""
+    def inference_stream(self, batches, to_host: bool = True, depth: int = 2, with_params: bool = False):
+        """Pipelined inference over an iterable of image lists (see _inference_stream); leaves the engine's deferred-ParamNet mode off however the iteration ends.
+        with_params: yield (results, raw (B, 8) camera-parameter tensor or None) pairs -- what dist.ShardedPerspectiveFields all-gathers."""
         try:
-            yield from self._inference_stream(batches, to_host, depth)
+            yield from self._inference_stream(batches, to_host, depth, with_params)
         finally:
             eng = self._engine
             if eng is not None and getattr(eng, "defer_params", False):
                 eng.set_defer_params(False)
 
-    def _inference_stream(self, batches, to_host: bool = True, depth: int = 2):
+    def _inference_stream(self, batches, to_host: bool = True, depth: int = 2, with_params: bool = False):
         """Pipelined inference over an iterable of image lists: yields one `inference_batch`-style result list per input
         batch, in order.  Three HIP streams overlap the stages of consecutive batches -- upload (pinned staging buffer,
         async H2D), compute (forward + post-process), download -- because the reference's callers move the fields to the
@@ -284,32 +307,63 @@ class PerspectiveFields(nn.Module):
         defer = self.param_on and depth >= 2
         if defer:
             eng.set_defer_params(True)
-        s_join = torch.cuda.Stream(device=dev) if defer else None  # waits for the deferred branches only (Engine.params_ready_event)
+        keep_params = self.param_on and (defer or with_params)    # the scalar entries are built when a batch is finished, from its raw parameter tensors
+        s_join = torch.cuda.Stream(device=dev) if keep_params else None  # waits for the deferred branches only (Engine.params_ready_event) / for the batch's own compute
+
+        state = {"rerun_before": 0}   # batches with seq < this were issued in the fast mode before a window exit was seen: re-run unconditionally
 
         def finish(item):
             # With the deferred branch the camera parameters of `item` are written on the engine's own stream.  Wait for THAT branch only (an event recorded behind it on
             # s_join right after the forward was issued) -- not for the compute of the batch submitted after it, which would leave the GPU idle while the host prepares
-            # the next batch -- and only then build the scalar entries: for ParamNetConvNextRegress they are arithmetic on `params` (factors, general_vfov -> focal on the
-            # host), which must not be launched before the branch has written them.
+            # the next batch -- and only then build the scalar entries: for ParamNetConvNextRegress they are arithmetic on `params` (factors), which must not be launched
+            # before the branch has written them.
             if defer:
                 item["params_done"].synchronize()
+            item["done"].synchronize()
+            rerun = False
+            if item["sat"] is not None and item["fast"]:
+                # precision='auto': did this batch leave the split-f16 window?  Two looks at the counter, both behind finished work (reading them costs nothing):
+                # the snapshots behind each chunk's forward on the compute stream, and -- deferred branch -- one behind the BRANCH on s_join: the ParamNet kernels of batch
+                # i run after snapshot i was taken (beside batch i + 1's backbone), so without it their increments would be charged to batch i + 1, or to nobody for the
+                # last batch.  The counter is global: an increment seen here may belong to a later batch that is already running -- so once it moves, EVERY batch that
+                # was issued in the fast mode (at most `depth` of them) is re-run in the exact mode when its turn comes, not only this one.
+                snaps = [snap for snap, _, _, _ in item["sat"]] + ([item["sat_branch"]] if item["sat_branch"] is not None else [])
+                moved = [self._left_window(eng, snap) for snap in snaps]
+                if any(moved):
+                    state["rerun_before"] = max(state["rerun_before"], nbatch)
+                rerun = item["seq"] < state["rerun_before"]
+
+            def out(res, lazy):
+                if not with_params:
+                    return res
+                prs = [pr for _, pr in (lazy or [])]
+                return res, (None if not prs else prs[0] if len(prs) == 1 else torch.cat(prs))
+
+            if rerun:
+                lz = [] if keep_params else None
+                with torch.cuda.stream(s_comp):
+                    new = self._rerun_exact(eng, item["batch"], item["sizes"], lz)   # joined forwards: the parameters are complete in stream order
+                    for res, params in (lz or []):
+                        for r, extra in zip(res, self._param_dicts(params)):
+                            r.update(extra)
+                    if with_params and lz:
+                        lz = [(None, torch.cat([pr for _, pr in lz]))]
+                s_comp.synchronize()
+                for r, n in zip(item["results"], new):
+                    r.clear()
+                    r.update({k: (v.cpu() if (to_host and k in self._HOST_KEYS) else v) for k, v in n.items()})
+                return out(item["results"], lz)
+            if keep_params:
                 with torch.cuda.stream(s_join):  # NOT the compute stream: it already holds the next batch's forward
+                    if not defer:
+                        s_join.wait_event(item["comp_done"])
                     for res, params in item["lazy"]:
                         for r, extra in zip(res, self._param_dicts(params)):
                             r.update(extra)
+                    if with_params and len(item["lazy"]) > 1:
+                        item["lazy"] = [(None, torch.cat([pr for _, pr in item["lazy"]]))]
                 s_join.synchronize()
-            item["done"].synchronize()
-            if item["sat"]:   # precision='auto': did this batch (any of its chunks) leave the split-f16 window?  The batch has finished: reading the snapshots costs nothing
-                moved = [self._left_window(eng, snap) for snap, _, _, _ in item["sat"]]
-                if any(moved):
-                    with torch.cuda.stream(s_comp):
-                        new = self._rerun_exact(eng, item["batch"], item["sizes"])   # the model stays in the exact mode; batches already in flight are still looked at
-                    s_comp.synchronize()
-                    for r, n in zip(item["results"], new):
-                        r.clear()
-                        r.update({k: (v.cpu() if (to_host and k in self._HOST_KEYS) else v) for k, v in n.items()})
-                    return item["results"]
-            return item["results"]
+            return out(item["results"], item["lazy"])
 
         for imgs in batches:
             sizes, resized = [], []
@@ -345,13 +399,17 @@ class PerspectiveFields(nn.Module):
             slot["done"] = up_done
             batch.record_stream(s_comp)
             s_comp.wait_event(up_done)
-            lazy = [] if defer else None
+            lazy = [] if keep_params else None
             sat = [] if self._auto else None
             with torch.cuda.stream(s_comp):
                 results = self._run(batch, sizes, lazy_params=lazy, sat_out=sat)
                 comp_done = torch.cuda.Event()
                 comp_done.record(s_comp)
             params_done = eng.params_ready_event(s_join) if defer else None
+            sat_branch = None
+            if defer and sat is not None and sat:   # the counter as of the END of this batch's ParamNet branch (s_join is behind it)
+                with torch.cuda.stream(s_join):
+                    sat_branch = eng.saturation_snapshot()
             done = comp_done
             if to_host:
                 s_down.wait_event(comp_done)
@@ -369,7 +427,8 @@ class PerspectiveFields(nn.Module):
                             o += src.numel()
                     done = torch.cuda.Event()
                     done.record(s_down)
-            inflight.append({"results": results, "done": done, "comp_done": comp_done, "params_done": params_done, "lazy": lazy, "sat": sat, "batch": batch, "sizes": sizes})
+            inflight.append({"results": results, "done": done, "comp_done": comp_done, "params_done": params_done, "lazy": lazy, "sat": sat, "sat_branch": sat_branch,
+                             "batch": batch, "sizes": sizes, "seq": nbatch - 1, "fast": self.precision == "fp32"})
             if len(inflight) >= max(1, depth):
                 yield finish(inflight.pop(0))
         while inflight:
@@ -444,14 +503,29 @@ class PerspectiveFields(nn.Module):
         return moved
 
     def _rerun_exact(self, eng, batch, sizes, lazy_params=None):
+        """Re-run of a batch that left the split-f16 window, in the exact mode (where the model then stays).  Always JOINED forwards: with the deferred ParamNet branch
+        on, the branch is switched off around the re-run (which also puts the current stream behind a pending branch of a later batch), so that the scalar entries built
+        right here read finished parameters; chunked like _run (a stream batch may exceed the engine's per-forward limit)."""
         import warnings
 
-        self.precision = "fp32_bf16x6"
-        self.precision_reason = "a later batch left the split-f16 window (saturation counter moved): re-run and continuing in the exact bf16 split"
-        warnings.warn("PerspectiveFields(precision='auto'): " + self.precision_reason)
-        eng.set_precision(self.precision)
-        pg, pl, params = eng.forward(batch)
-        return self._assemble(eng, pg, pl, params, sizes, lazy_params)
+        if self.precision != "fp32_bf16x6":
+            self.precision = "fp32_bf16x6"
+            self.precision_reason = "a later batch left the split-f16 window (saturation counter moved): re-run and continuing in the exact bf16 split"
+            warnings.warn("PerspectiveFields(precision='auto'): " + self.precision_reason)
+            eng.set_precision(self.precision)
+        deferred = bool(getattr(eng, "defer_params", False))
+        if deferred:
+            eng.set_defer_params(False)
+        try:
+            chunk = max(1, min(int(os.environ.get("PF_MAX_CHUNK", self.MAX_CHUNK)), eng.max_batch))
+            out: List[dict] = []
+            for i0 in range(0, len(sizes), chunk):
+                pg, pl, params = eng.forward(batch[i0:i0 + chunk])
+                out.extend(self._assemble(eng, pg, pl, params, sizes[i0:i0 + chunk], lazy_params))
+        finally:
+            if deferred:
+                eng.set_defer_params(True)
+        return out
 
     def _assemble(self, eng, pg, pl, params, sizes, lazy_params=None) -> List[dict]:
         results = []
@@ -486,19 +560,25 @@ class PerspectiveFields(nn.Module):
                 pred_general_vfov=params[:, 2], pred_rel_cx=zeros, pred_rel_cy=zeros,
             )
             return [{k: v[i] for k, v in cols.items()} for i in range(B)]
-        # ParamNetConvNextRegress: factors per predicted parameter, then rel_focal from general_vfov on the host
+        # ParamNetConvNextRegress: factors per predicted parameter; rel_focal from general_vfov in closed form -- on the device for the zoo's output order (column 5 of the
+        # engine's (B, 8) output, paramnet_scalars_kernel: no host round trip on the hot path), on the host for any other order of PREDICT_PARAMS
         factors = {"roll": 90.0, "pitch": 90.0, "vfov": 90.0, "rel_focal": 1.0, "rel_cx": 1.0, "rel_cy": 1.0, "general_vfov": 90.0}
         cols = OrderedDict()
         for j, key in enumerate(self.arch["predict_params"]):
             cols["pred_" + key] = params[:, j] * factors[key]
         if "pred_rel_focal" not in cols:
-            cols["pred_rel_focal"] = torch.from_numpy(
-                general_vfov_to_focal(
-                    cols["pred_rel_cx"].double().cpu().numpy(), cols["pred_rel_cy"].double().cpu().numpy(),
-                    cols["pred_general_vfov"].double().cpu().numpy(),
-                ).astype(np.float32)
-            )
+            if list(self.arch["predict_params"]) == list(self._DEVICE_FOCAL_ORDER):
+                cols["pred_rel_focal"] = params[:, 5]
+            else:
+                cols["pred_rel_focal"] = torch.from_numpy(
+                    general_vfov_to_focal(
+                        cols["pred_rel_cx"].double().cpu().numpy(), cols["pred_rel_cy"].double().cpu().numpy(),
+                        cols["pred_general_vfov"].double().cpu().numpy(),
+                    ).astype(np.float32)
+                )
         return [{k: v[i] for k, v in cols.items()} for i in range(B)]
+
+    _DEVICE_FOCAL_ORDER = ("roll", "pitch", "general_vfov", "rel_cx", "rel_cy")   # every ParamNetConvNextRegress entry of the zoo (config/paramnet_*_rpfpp.yaml:32-37)
 
 
 def fields_from_params(roll, pitch, rel_focal, rel_cx=0.0, rel_cy=0.0, height=None, width=None, mode="deg", device=None):
