@@ -483,23 +483,39 @@ int pf_op_dwconv7x7_cfg(int device, const float* x, const float* hw, const float
   return rc;
 }
 
+// Yardstick beside the depthwise kernels (variant 100): a plain 16-byte-per-lane grid-stride copy of the same bytes -- what this memory system gives ANY launch that
+// reads n floats and writes n floats (launch + first byte + drain included), the ceiling a stand-alone HBM-bound kernel of that size can be priced against.
+__global__ __launch_bounds__(256) void copy_f4_kernel(const float4* __restrict__ x, float4* __restrict__ y, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) y[i] = x[i];
+}
+// PF_DW7_BENCH_COLD=K (K >= 2): the timed launches cycle through K input / output buffer pairs, so that a launch reads an input nobody has touched for K - 1 launches
+// (K x 2 x bytes > 512 MB: not in the 256 MiB Infinity Cache, nor in L2) -- "cold"; default: ONE pair, re-read and re-written by every launch -- "warm" (L2 / Infinity
+// Cache resident for the 20 - 160 MB maps of the ConvNeXt stages, which is also their state inside the forward: the previous kernel has just written them).
 int pf_op_dwconv7x7_bench(int device, int variant, int nc, int nb, int th, int B, int H, int W, int C, int iters, float* ms_out) {
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
   if (C % 32 != 0 || iters <= 0 || !ms_out) { g_create_error = "pf_op_dwconv7x7_bench: bad argument"; return PF_ERR_ARG; }
   const size_t n = (size_t)B * H * W * C;
-  float *dx = nullptr, *dy = nullptr, *dw = nullptr, *db = nullptr;
-  if (hipMalloc(&dx, n * 4) != hipSuccess || hipMalloc(&dy, n * 4) != hipSuccess || hipMalloc(&dw, (size_t)49 * C * 4) != hipSuccess ||
-      hipMalloc(&db, (size_t)C * 4) != hipSuccess) { g_create_error = "pf_op_dwconv7x7_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
-  launch_fill_random(dx, (long)n, 777u, 1.0f, nullptr);
+  int K = 1;
+  if (const char* e = getenv("PF_DW7_BENCH_COLD")) K = std::max(1, std::min(64, atoi(e)));
+  std::vector<float*> dx(K, nullptr), dy(K, nullptr);
+  float *dw = nullptr, *db = nullptr;
+  bool ok = hipMalloc(&dw, (size_t)49 * C * 4) == hipSuccess && hipMalloc(&db, (size_t)C * 4) == hipSuccess;
+  for (int k = 0; k < K && ok; ++k) ok = hipMalloc(&dx[k], n * 4) == hipSuccess && hipMalloc(&dy[k], n * 4) == hipSuccess;
+  if (!ok) { g_create_error = "pf_op_dwconv7x7_bench: hipMalloc failed"; return PF_ERR_DEVICE; }
+  for (int k = 0; k < K; ++k) launch_fill_random(dx[k], (long)n, 777u + k, 1.0f, nullptr);
   launch_fill_random(dw, (long)49 * C, 778u, 0.15f, nullptr);
   launch_fill_random(db, (long)C, 779u, 0.1f, nullptr);
+  auto launch = [&](int k) {
+    if (variant == 100) hipLaunchKernelGGL(copy_f4_kernel, dim3(256 * 8), dim3(256), 0, nullptr, reinterpret_cast<const float4*>(dx[k]), reinterpret_cast<float4*>(dy[k]), (long)(n / 4));
+    else launch_dwconv7x7_cfg(variant, nc, nb, th, dx[k], dw, db, dy[k], B, H, W, C, nullptr);
+  };
   hipEvent_t a, b;
   (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-  launch_dwconv7x7_cfg(variant, nc, nb, th, dx, dw, db, dy, B, H, W, C, nullptr);
+  for (int k = 0; k < K; ++k) launch(k);
   (void)hipEventRecord(a, nullptr);
-  for (int i = 0; i < iters; ++i) launch_dwconv7x7_cfg(variant, nc, nb, th, dx, dw, db, dy, B, H, W, C, nullptr);
+  for (int i = 0; i < iters; ++i) launch(i % K);
   (void)hipEventRecord(b, nullptr);
   (void)hipEventSynchronize(b);
   float t = 0.f;
@@ -507,7 +523,8 @@ int pf_op_dwconv7x7_bench(int device, int variant, int nc, int nb, int th, int B
   *ms_out = t / iters;
   rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dw); (void)hipFree(db);
+  for (int k = 0; k < K; ++k) { (void)hipFree(dx[k]); (void)hipFree(dy[k]); }
+  (void)hipFree(dw); (void)hipFree(db);
   return rc;
 }
 
