@@ -189,6 +189,9 @@ class _StubEngine:
     def profile_records(self):
         return []
 
+    def profile_phases(self):
+        return {}
+
 
 MIXED_PATTERN = [(384, 512), (640, 640), (640, 640), (1024, 1365)]  # BASELINE configs[4]: short edge 384 / 640 / 1024, mix 1:2:1
 
@@ -357,6 +360,7 @@ def main(argv=None):
         sync()
         prof = eng.profile_end()
         cls_step_ms = sum(v["ms"] for v in prof.values())
+        phases = eng.profile_phases()   # component split of the same profiled step (pf_profile_phases: event marks at the component boundaries)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -553,6 +557,13 @@ def main(argv=None):
             line["attention"] = {"achieved_tflops": round(at["work"] / (at["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(at["ms"], 3),
                                  "launches_per_step": at["launches"], "measured": "extra profiled step after the timed region"}
         line["achieved_tflops_ref_graph"] = round(value / world * GFLOP_PER_IMAGE_REF / 1e3, 2)
+        if phases and sum(phases.values()) > 0:
+            # SURVEY 8d's component split: elapsed stream time between event marks at the component boundaries of the extra profiled step (joined forward, one stream,
+            # an event pair around every launch: ~15 % slower than a timed step; in the timed steps ParamNet runs beside the next step's backbone)
+            tot = sum(phases.values())
+            line["step_split_ms"] = {**{k: round(v, 3) for k, v in phases.items()}, "total": round(tot, 3),
+                                     "share": {k: round(v / tot, 4) for k, v in phases.items()},
+                                     "measured": "extra profiled step after the timed region (pf_profile_phases); includes launch gaps and the profile's own event pairs"}
     line["host_resize_ms_per_image"] = round(1000.0 * t_resize, 3)
     if deferred_identical is not None:
         line["deferred_branch_bit_identical"] = deferred_identical  # scalars of the step before the last (branch beside the last step's backbone) == the last step's (branch alone)
@@ -710,6 +721,55 @@ def main(argv=None):
             del m1, e1
         except Exception as e:
             line["configs_1"] = {"error": repr(e)}
+    if not dry and not args.no_extras and world == 1 and not mixed:
+        # ---- (6) the DEFAULT-constructed model: PerspectiveFields(version) has precision="auto", which reads the saturation counter behind every forward (a 4-byte copy
+        #      and a host synchronisation) and builds the reference's result dicts -- the headline drives the engine directly with the fast mode pinned.  Same device-resident
+        #      batch through the engine path of inference_batch (PerspectiveFields._run: forward, counter read, post-process, dicts), forwards joined.
+        try:
+            m_auto = PerspectiveFields(args.version, weights="synthetic:0").eval().to(dev)
+            assert m_auto.precision == "auto"
+            for _ in range(3):
+                m_auto._run(batch, sizes)   # the first call is the range probe that settles the mode
+            sync()
+            na = max(5, min(10, args.steps))
+            t1 = time.perf_counter()
+            for _ in range(na):
+                res_a = m_auto._run(batch, sizes)
+            sync()
+            d_a = time.perf_counter() - t1
+            line["default_auto"] = {"value": round(B * na / d_a, 2), "unit": "images/sec", "steps": na, "ms_per_step": round(1000.0 * d_a / na, 3), "n_gpus": 1,
+                                    "precision_settled_on": m_auto.precision, "result_keys": len(res_a[0]),
+                                    "workload": "the headline batch through the default-constructed model (precision='auto'): PerspectiveFields._run = forward + read of the saturation "
+                                                "counter (host sync per batch) + post-process + the reference's result dicts; joined forwards (no deferred ParamNet branch)"}
+            del m_auto
+        except Exception as e:
+            line["default_auto"] = {"error": repr(e)}
+        # ---- (7) BASELINE configs[4]: the mixed-resolution stream (384x512 : 640x640 : 1024x1365 = 1:2:1), 64 images per step, ORIGINAL images resident in HBM ->
+        #      bucketed bit-exact device resize -> forward at 320x320 -> post-process to each original size, through the product's sharded step (world 1 here)
+        try:
+            Bm = 64
+            sizes_m = [MIXED_PATTERN[i % len(MIXED_PATTERN)] for i in range(Bm)]
+            img_m = {hw: torch.from_numpy(synthetic_image(hw[0], hw[1], seed=7 + k)).to(dev) for k, hw in enumerate(sorted(set(MIXED_PATTERN)))}
+            orig_m = [img_m[hw] for hw in sizes_m]
+            batch_m = torch.empty((Bm, 320, 320, 3), dtype=torch.uint8, device=dev)
+            spf.set_pipeline(True)
+            for _ in range(2):
+                spf.forward_step(batch_m, sizes_m, originals=orig_m)
+            spf.drain(); sync()
+            nm = 6
+            t1 = time.perf_counter()
+            for _ in range(nm):
+                spf.forward_step(batch_m, sizes_m, originals=orig_m)
+            spf.drain(); sync()
+            d_m = time.perf_counter() - t1
+            spf.set_pipeline(False)
+            line["configs_4"] = {"value": round(Bm * nm / d_m, 2), "unit": "images/sec", "n_gpus": 1, "steps": nm, "ms_per_step": round(1000.0 * d_m / nm, 3), "batch": Bm,
+                                 "workload": "BASELINE configs[4] on one GPU: 64 images per step, 384x512 : 640x640 : 1024x1365 = 1:2:1 (one synthetic image per bucket), original uint8 "
+                                             "images resident in HBM -> bucketed bit-exact device resize -> forward -> post-process to each original size (ShardedPerspectiveFields.forward_step); "
+                                             "per-bucket figures: `python bench.py --workload mixed --batch 64`"}
+            del orig_m, batch_m, img_m
+        except Exception as e:
+            line["configs_4"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline and not dry:
         try:
             line["cpu_baseline"] = cpu_baseline(args.version, S)

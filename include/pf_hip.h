@@ -210,6 +210,18 @@ int pf_profile_end(pf_handle h, double* ms, double* work, long* launches, int n)
 /* per-launch records of the last begin/end window (valid until the next pf_profile_begin); returns the
  * total number of records, fills at most max_records entries; mnk = GEMM view [M, N, K, KH] for class 0 */
 int pf_profile_records(pf_handle h, int max_records, int* cat, double* work, float* ms, int* mnk);
+/* Component split of the path: inside a FULL per-launch window (class_mask without PF_PROFILE_LARGE_ONLY: one stream, forwards joined) the engine also
+ * records an event at the start of every component -- 0 input normalisation + MiT-B3 backbone (mix_transformers.py:449-485), 1 low-level encoder
+ * (perspectivefields.py:70-83), 2 both decoder heads + prediction heads (gravity_head.py:139-197, latitude_head.py:138-193), 3 ParamNet (param_network.py:46-69),
+ * 4 post-process (pf_postprocess_batch).  Call after pf_profile_end: ms[PF_PROFILE_PHASES] = elapsed stream time per component summed over the window (launch gaps and
+ * the profile's own event pairs included); returns the number of marks recorded. */
+#define PF_PROFILE_PHASES 5
+#define PF_PHASE_BACKBONE 0
+#define PF_PHASE_LOW_LEVEL 1
+#define PF_PHASE_DECODERS 2
+#define PF_PHASE_PARAMNET 3
+#define PF_PHASE_POSTPROCESS 4
+int pf_profile_phases(pf_handle h, int n, double* ms);
 
 /* ---- Debug forward: localise a numerical problem layer by layer, and check a checkpoint's activations against the split-f16 scheme's window.
  * The reference has no such mode; it replaces "print the tensor after every module" in a PyTorch session (perspectivefields.py:223-272 run by hand).

@@ -148,6 +148,7 @@ struct Ctx {
 // Per-kernel-class timing with HIP events on the launch stream (bench.py's `roofline` object):
 // every launch of a class is bracketed by an event pair; work = algorithmic FLOPs or bytes.
 enum ProfCat { PC_IGEMM = 0, PC_ATTN, PC_LAYERNORM, PC_DW3, PC_DW7, PC_UPSAMPLE, PC_OTHER, PC_IGEMM_SB, PC_COUNT };
+enum { PH_BACKBONE = 0, PH_LL = 1, PH_DECODERS = 2, PH_PARAMNET = 3, PH_POST = 4, PH_END = 5 };  // = PF_PHASE_* (include/pf_hip.h)
 struct Profiler {
   struct Rec { int cat; double work; hipEvent_t a, b; int m, n, k, kh; float ms; };
   std::vector<Rec> recs;
@@ -161,7 +162,18 @@ struct Profiler {
     if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
     return pool[used++];
   }
-  void reset() { recs.clear(); used = 0; }
+  // Phase marks of a FULL per-launch profile (one stream, no deferred branch): an event at the start of every component of the path (pf_profile_phases:
+  // SURVEY 8d's component split).  A mark ends the phase before it; PH_END closes a phase without opening one.
+  struct Mark { int phase; hipEvent_t e; };
+  std::vector<Mark> marks;
+  void mark(int phase, hipStream_t s) {
+    if (!on || min_work > 0.0) return;
+    hipEvent_t e = get();
+    if (!e) return;
+    (void)hipEventRecord(e, s);
+    marks.push_back({phase, e});
+  }
+  void reset() { recs.clear(); marks.clear(); used = 0; }
   ~Profiler() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
 };
 struct ProfScope {
@@ -1264,6 +1276,7 @@ struct pf_engine {
       pn_pending = false;
     }
     float* x0 = c.alloc((size_t)B * NET * NET * 4);
+    if (!c.dry && c.prof) c.prof->mark(PH_BACKBONE, c.s);   // input normalisation + MiT-B3
     if (!c.dry) {
       if (is_u8) launch_prep_u8(static_cast<const uint8_t*>(in), x0, (long)B * NET * NET, mean3, std3, c.s);
       else launch_prep_f32_nchw(static_cast<const float*>(in), x0, B, NET * NET, mean3, std3, c.s);
@@ -1274,6 +1287,7 @@ struct pf_engine {
     const Ten llf = c.ten((size_t)B * (NET / 2) * (NET / 2) * LL_CH, !Sh, Sh);
     ll_forked = false;
     mit(c, B, x0, feats, &llf);
+    if (!c.dry && c.prof) c.prof->mark(PH_LL, c.s);
     if (ll_forked) (void)hipStreamWaitEvent(c.s, ev_ll, 0);
     else conv(c, ll, Ten(x0), B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
     tap(c, "ll", llf.f, B, NET / 2, NET / 2, LL_CH);
@@ -1292,16 +1306,19 @@ struct pf_engine {
       pn_pending = false;
     }
     const size_t mk = c.mark();
+    if (!c.dry && c.prof) c.prof->mark(PH_DECODERS, c.s);   // both decoder heads + prediction heads
     heads_fwd(c, B, feats, llf, tg, pg, pl, pn);
     c.release(mk);
     if (arch == PF_ARCH_PERSNET_CLS) {
       // 1x1 convs to 73 / 180 logits, stored NCHW because the logits are API-visible (gravity_head.py:259)
       conv(c, heads[0].predcls, Ten(tg), B, NET, NET, Ten(pg), ACT_NONE, nullptr, nullptr, 0, Ten(), -1, 1);
       conv(c, heads[1].predcls, Ten(tl), B, NET, NET, Ten(pl), ACT_NONE, nullptr, nullptr, 0, Ten(), -1, 1);
+      if (!c.dry && c.prof) c.prof->mark(PH_END, c.s);
       return;
     }
     if (!c.dry && !pf)
       launch_pred_regression(tg, tl, heads[0].predw, heads[0].predb, heads[1].predw, heads[1].predb, pg, pl, pn, B, NET * NET, c.s);
+    if (!c.dry && c.prof) c.prof->mark(has_param ? PH_PARAMNET : PH_END, c.s);
     if (has_param) {
       const bool defer = defer_params && !c.dry && (!c.prof || c.prof->min_work > 0.0) && !c.dbg && !c.tuning && !in_capture && pstream_ready();
       if (defer) {
@@ -1320,6 +1337,7 @@ struct pf_engine {
         }
       }
     }
+    if (!c.dry && c.prof && has_param) c.prof->mark(PH_END, c.s);
     run_pn_peak = cp.peak;
     if (cp.max_conv_out > c.max_conv_out) c.max_conv_out = cp.max_conv_out;
   }
@@ -1790,6 +1808,7 @@ int pf_postprocess_batch(pf_handle h, int B, const float* pg, const float* pl, c
   const bool cls = h->arch == PF_ARCH_PERSNET_CLS;
   const size_t npx = (size_t)NET * NET;
   float *dg = nullptr, *dl = nullptr;
+  h->prof.mark(PH_POST, s);
   if (cls) {  // decode the argmax of all images first (workspace: 3 x 320 x 320 floats per image)
     const size_t need = (size_t)B * 3 * npx * 4 + 256;
     if (!ws || ws_bytes < need) return h->fail(PF_ERR_WORKSPACE, fmt("pf_postprocess_batch: classification needs %zu workspace bytes", need));
@@ -1809,6 +1828,7 @@ int pf_postprocess_batch(pf_handle h, int B, const float* pg, const float* pl, c
     }
     launch_postprocess_batch(pb, NET, NET, cls ? 0 : 1, s);
   }
+  h->prof.mark(PH_END, s);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return h->fail(PF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
   return PF_OK;
@@ -1865,6 +1885,21 @@ int pf_profile_records(pf_handle h, int max_records, int* cat, double* work, flo
     if (mnk) { mnk[4 * i] = r.m; mnk[4 * i + 1] = r.n; mnk[4 * i + 2] = r.k; mnk[4 * i + 3] = r.kh; }
   }
   return (int)h->prof.recs.size();
+}
+
+int pf_profile_phases(pf_handle h, int n, double* ms) {
+  if (!h || !ms || n < PF_PROFILE_PHASES) return h ? h->fail(PF_ERR_ARG, "pf_profile_phases: the array must hold PF_PROFILE_PHASES entries") : PF_ERR_ARG;
+  for (int i = 0; i < n; ++i) ms[i] = 0.0;
+  if (hipSetDevice(h->device) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipSetDevice failed");
+  const auto& m = h->prof.marks;
+  for (size_t i = 0; i + 1 < m.size(); ++i) {
+    if (m[i].phase == PH_END) continue;   // the gap between two calls (forward -> post-process) belongs to nobody
+    if (hipEventSynchronize(m[i + 1].e) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipEventSynchronize failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, m[i].e, m[i + 1].e) != hipSuccess) return h->fail(PF_ERR_DEVICE, "hipEventElapsedTime failed");
+    ms[m[i].phase] += t;
+  }
+  return (int)m.size();
 }
 
 // ---- kernel-level entry points -------------------------------------------------------------

@@ -209,8 +209,8 @@ __device__ __forceinline__ void epilogue_nhwc(const ConvParams& p, const ConvPtr
             if (res1) x += res1[o + e];
             if (res2) x += res2[o + e];
             if (post_relu) x = fmaxf(x, 0.f);
-            amax = __builtin_fmaxf(amax, __builtin_fabsf(x));  // the ragged tail is watched like the vector path
-            y[o + e] = x;
+            y[o + e] = x;  // (not watched: a channel count that is no multiple of 4 only occurs on the 73- / 180-way classification logits, which no contraction reads;
+                           //  one more live value here took the 128 x 64 tile from 4 to 3 resident blocks -- tests/test_host_logic.py::test_kernel_resources_static)
           }
         }
       }
@@ -321,8 +321,8 @@ __device__ __forceinline__ void epilogue_direct(const ConvParams& p, const ConvP
             if (res1) x += res1[o + e];
             if (res2) x += res2[o + e];
             if (post_relu) x = fmaxf(x, 0.f);
-            amax = __builtin_fmaxf(amax, __builtin_fabsf(x));  // the ragged tail is watched like the vector path
-            y[o + e] = x;
+            y[o + e] = x;  // (not watched: a channel count that is no multiple of 4 only occurs on the 73- / 180-way classification logits, which no contraction reads;
+                           //  one more live value here took the 128 x 64 tile from 4 to 3 resident blocks -- tests/test_host_logic.py::test_kernel_resources_static)
           }
         }
       }

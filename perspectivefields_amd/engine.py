@@ -59,6 +59,7 @@ _SIGNATURES = {
     "pf_profile_pause": (_c.c_int, [_P]),
     "pf_profile_end": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.c_int]),
     "pf_profile_records": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double), _c.POINTER(_c.c_float), _c.POINTER(_c.c_int)]),
+    "pf_profile_phases": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_double)]),
     "pf_debug_tap_bytes": (_c.c_size_t, [_P, _c.c_int]),
     "pf_debug_forward_u8": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _P, _P, _c.c_size_t, _c.c_int, _P, _c.c_size_t, _P]),
     "pf_debug_taps": (_c.c_int, [_P, _c.c_int, _P, _c.POINTER(_c.c_longlong), _c.POINTER(_c.c_int)]),
@@ -510,6 +511,15 @@ class Engine:
         cat, work, ms, mnk = (ctypes.c_int * n)(), (ctypes.c_double * n)(), (ctypes.c_float * n)(), (ctypes.c_int * (4 * n))()
         self.lib.pf_profile_records(self._h, n, cat, work, ms, mnk)
         return [(self.PROFILE_CLASSES[cat[i]], work[i], ms[i], tuple(mnk[4 * i : 4 * i + 4])) for i in range(n)]
+
+    PHASES = ("backbone", "low_level_encoder", "decoders", "paramnet", "postprocess")
+
+    def profile_phases(self) -> Dict[str, float]:
+        """Component split of the last FULL profile window (pf_profile_phases; call after profile_end): elapsed stream ms per component of the path."""
+        n = len(self.PHASES)
+        ms = (ctypes.c_double * n)()
+        _check(min(0, self.lib.pf_profile_phases(self._h, n, ms)), self._h, "pf_profile_phases")
+        return {name: ms[i] for i, name in enumerate(self.PHASES)}
 
     def postprocess_batch(self, pred_gravity, pred_latitude, sizes):
         """Whole batch in one launch: (B,Cg,320,320), (B,Cl,320,320), [(H, W)] * B -> list of ((2,H,W) unit up-vectors,

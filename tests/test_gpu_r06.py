@@ -42,9 +42,12 @@ def test_pinned_fp32_window_contract(target):
     img = synthetic_image(96, 128, seed=11)
     sd = synthetic_state_dict(CENTERED, 0)
     _, _, rng = _pf(CENTERED, sd, "fp32").debug_forward([img], shadow=False, ranges=True)
-    wino = [r for r in rng if "[winograd]" in r["name"] and "[gravity]" in r["name"] and r["name"].endswith(" x")]
-    assert wino, [r["name"] for r in rng][:8]
-    a0 = wino[0]["max_abs"]    # first Winograd layer of the gravity head: fusion1.resConfUnit1.conv1 at 80 x 80, input = relu(linear_c1_proc(linear_c1(c1)))
+    # the 256 -> 256 convs of the gravity head at 80 x 80 (M = 6400 at batch 1, K = 9 x 256), in launch order: the first is fusion1.resConfUnit1.conv1, whose input is
+    # relu(linear_c1_proc(linear_c1(c1))) -- the output of the folded first conv
+    pick = lambda records: [r for r in records if "[winograd]" in r["name"] and "[gravity]" in r["name"] and "M=6400 " in r["name"] and "K=2304" in r["name"] and r["name"].endswith(" x")]
+    wino = pick(rng)
+    assert wino, [r["name"] for r in rng if "[winograd]" in r["name"]][:8]
+    a0 = wino[0]["max_abs"]
     assert 0.0 < a0 < 16376.0, a0
     f = np.float32(target / a0)
     sd2 = dict(sd)
@@ -57,7 +60,7 @@ def test_pinned_fp32_window_contract(target):
     moved = int(eng.saturation_snapshot()) - before
     finite = bool(torch.isfinite(out["pred_gravity_original"]).all()) and bool(torch.isfinite(out["pred_latitude_original"]).all())
     _, _, rng2 = mp.debug_forward([img], shadow=False, ranges=True)
-    w2 = [r for r in rng2 if "[winograd]" in r["name"] and "[gravity]" in r["name"] and r["name"].endswith(" x")][0]
+    w2 = pick(rng2)[0]
     print(f"[window contract] Winograd input max |x| {a0:.4g} -> {w2['max_abs']:.4g} (window 16376): pinned fp32 counter +{moved}, outputs finite: {finite}")
     assert w2["max_abs"] > 16376.0
     assert moved > 0, "a pinned-fp32 forward that leaves a Winograd layer's window must move the saturation counter"
