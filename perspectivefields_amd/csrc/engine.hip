@@ -249,6 +249,7 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
+  int s3_split = 1;          // PF_S3_SPLIT: MiT stage 3 on two half-batches / two streams (mit(), "the stage-3 split")
   int side_stream_mode = 1;  // 1 (default): the q projection of a MiT block runs on a second stream next to the sr conv + kv GEMM (both consume LayerNorm-1's
                              // output, attention joins them) -- small launches that each fill a fraction of the chip: +0.6 % (3 x A/B on one box, profiles/
                              // r02_negative_results.md); 2: also the low-level encoder conv next to MiT stage 3 (+0.1 %, noise); PF_SIDE_STREAM=0: one stream.
@@ -964,20 +965,20 @@ struct pf_engine {
       float* kvb = c.alloc(Mkv * 2 * C);
       float* hb = c.alloc(M * 4 * C);
       const Ten h2 = c.ten(M * 4 * C, !S, S);
-      int blk = -1;
-      for (MitBlock& mb : st.blocks) {
-        if (blk >= 0) tap(c, fmt("mit.s%d.b%d", s + 1, blk), x, B, Ho, Wo, C);  // the previous block's output (token stream, pre stage norm)
-        ++blk;
+      // One transformer block on `B` images starting at token row 0 of the given buffers (Block.forward, mix_transformers.py:198-202).  gate_B: the batch the
+      // row-block gate is taken for (the whole batch, also when the block is issued for one half of it -- see the stage-3 split below)
+      auto one_block = [&](Ctx& c, MitBlock& mb, int blk, int B, long M, long Mkv, float*& x, float*& xalt, const Ten& xn, float* qb, const Ten& ab, float* srb, const Ten& srn,
+                           float* kvb, float* hb, const Ten& h2, int gate_B, bool may_fork) {
         // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
         // row-block form of the block's linear layers (stage 3 at batch >= ~14): q, kv, proj, fc1, fc2
         // one 64-row block per CU: the form pays only when the last round of blocks nearly fills the 256 CUs (same-box A/Bs, profiles/r04_rb_linear.md: B = 32 -> 224 blocks
         // +1.2 %, B = 64 -> 448 +1.2 %; B = 48 -> 336 -0.4 %, B = 24 -> 168 -0.9 %, B = 16 -> 112 -4.5 %)
-        const long rb_blocks = (long)B * ((N + 63) / 64);
+        const long rb_blocks = (long)gate_B * ((N + 63) / 64);
         const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && rb_blocks >= rb_min_blocks && (rb_blocks % num_cus == 0 || rb_blocks % num_cus >= num_cus * 3 / 4);
         if (sr > 1 && use_rb && (rb_chain & 32) && mb.rsrkv.w && mb.qln.ln_s && fuse_ln) {
           // key / value branch in ONE launch (LayerNorm-1 of the gathered source tokens, 2 x 2 conv, LayerNorm, kv: rb_chain.hip); q with LayerNorm-1 folded into its
           // GEMM beside it: no LayerNorm-1 launch, no split-K conv + reduce, no normalised map in HBM
-          const bool fork = B >= 4 && can_fork(c);
+          const bool fork = B >= 4 && (may_fork && can_fork(c));
           if (fork) {
             (void)hipEventRecord(ev_fork, c.s);
             (void)hipStreamWaitEvent(side, ev_fork, 0);
@@ -999,7 +1000,7 @@ struct pf_engine {
             launch_rb_srkv(a, C, c.s);
           }
         } else if (sr > 1) {
-          const bool fork = B >= 4 && can_fork(c);  // batch 1-3: a launch already under-fills the chip; the event pair would only add latency
+          const bool fork = B >= 4 && (may_fork && can_fork(c));  // batch 1-3: a launch already under-fills the chip; the event pair would only add latency
           if (use_rb && (rb_chain & 1) && fork) {  // q = LN1(x) Wq with the LayerNorm inside the kernel: independent of the LayerNorm launch below
             (void)hipEventRecord(ev_fork, c.s);
             (void)hipStreamWaitEvent(side, ev_fork, 0);
@@ -1031,7 +1032,7 @@ struct pf_engine {
             gemm(c, mb.kv, srn, Mkv, Ten(kvb));
           }
         } else if (mb.q.ln_s && mb.kv.ln_s) {
-          if (B >= 4 && can_fork(c)) {                // norm1 inside both of its consumers; q next to kv
+          if (B >= 4 && (may_fork && can_fork(c))) {                // norm1 inside both of its consumers; q next to kv
             (void)hipEventRecord(ev_fork, c.s);
             (void)hipStreamWaitEvent(side, ev_fork, 0);
             Ctx c2 = c;
@@ -1047,7 +1048,7 @@ struct pf_engine {
           gemm(c, mb.q, xn, M, Ten(qb));
           gemm(c, mb.kv, xn, M, Ten(kvb));
         }
-        if (B >= 4 && (sr > 1 || (mb.q.ln_s && mb.kv.ln_s)) && can_fork(c)) (void)hipStreamWaitEvent(c.s, ev_join, 0);
+        if (B >= 4 && (sr > 1 || (mb.q.ln_s && mb.kv.ln_s)) && (may_fork && can_fork(c))) (void)hipStreamWaitEvent(c.s, ev_join, 0);
         if (c.dbg && c.dbg->range) {
           range_in(c, fmt("attention s%d.b%d q", s + 1, blk), qb, (size_t)M * C);
           range_in(c, fmt("attention s%d.b%d kv", s + 1, blk), kvb, (size_t)Mkv * 2 * C);
@@ -1077,7 +1078,7 @@ struct pf_engine {
             launch_mit_mlp(x, xalt, mb.mlp_w, mb.mlp_tab, B, Ho, Wo, C, mb.n2.eps, c.s, d_sat, 65504.f);
           }
           std::swap(x, xalt);
-          continue;
+          return;
         }
         if (pf_fused) {
         } else if (use_rb && (rb_chain & 8)) {
@@ -1094,6 +1095,39 @@ struct pf_engine {
         }
         if (use_rb && (rb_chain & 16)) rb_linear(c, mb.rfc2, h2.f, M, (int)N, x, nullptr, ACT_NONE, x);
         else gemm(c, mb.fc2, h2, M, Ten(x), ACT_NONE, x);
+            };
+      // PF_S3_SPLIT (stage 3 only, row-block form, batch >= 16 and even): the stage's 18 blocks are chains of ~6 dependent launches of <= 224 blocks each, every one
+      // a single round whose time is a block's latency (prologue, K loop at one wave per SIMD, epilogue) -- the chip idles in every prologue, epilogue and launch gap.
+      // Images are independent, so the batch is cut in two halves that walk the stage on TWO streams (the caller's and `side`, which gives up the q-beside-kv fork
+      // for it: no additional hardware queue): two desynchronised chains of half-size launches fill each other's gaps.  Same kernels, same per-image arithmetic:
+      // bit-identical results (tests/test_gpu_e2e.py::test_stage3_batch_split_is_bit_identical).
+      const long rb_all = (long)B * ((N + 63) / 64);   // the split rides on the row-block form's gate: full rounds of 64-row blocks over the WHOLE batch
+      const bool split = s3_split && s == 2 && sr > 1 && !S && !fused_mlp && B >= 16 && B % 2 == 0 && !c.dry && !c.dbg && !c.tuning && !st.blocks.empty() && rb_chain && nterms == NT_F16X3 &&
+                         st.blocks[0].rq.w && rb_all >= rb_min_blocks && (rb_all % num_cus == 0 || rb_all % num_cus >= num_cus * 3 / 4) && can_fork(c);
+      int blk = -1;
+      if (split) {
+        const int Bh = B / 2;
+        const long Mh = M / 2, Mkvh = Mkv / 2;
+        (void)hipEventRecord(ev_fork, c.s);
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        Ctx c2 = c;
+        c2.s = side;
+        float* x2 = x + Mh * C;
+        float* none = nullptr;
+        for (MitBlock& mb : st.blocks) {
+          ++blk;
+          one_block(c, mb, blk, Bh, Mh, Mkvh, x, none, xn, qb, ab, srb, srn, kvb, hb, h2, B, false);
+          one_block(c2, mb, blk, Bh, Mh, Mkvh, x2, none, Ten(xn.f ? xn.f + Mh * C : nullptr), qb + Mh * C, Ten(ab.f + Mh * C), srb + Mkvh * C, Ten(srn.f ? srn.f + Mkvh * C : nullptr),
+                    kvb + Mkvh * 2 * C, hb + Mh * 4 * C, Ten(h2.f + Mh * 4 * C), B, false);
+        }
+        (void)hipEventRecord(ev_join, side);
+        (void)hipStreamWaitEvent(c.s, ev_join, 0);
+      } else {
+        for (MitBlock& mb : st.blocks) {
+          if (blk >= 0) tap(c, fmt("mit.s%d.b%d", s + 1, blk), x, B, Ho, Wo, C);  // the previous block's output (token stream, pre stage norm)
+          ++blk;
+          one_block(c, mb, blk, B, M, Mkv, x, xalt, xn, qb, ab, srb, srn, kvb, hb, h2, B, true);
+        }
       }
       c.release(mk);
       if (blk >= 0) tap(c, fmt("mit.s%d.b%d", s + 1, blk), x, B, Ho, Wo, C);
@@ -1441,6 +1475,7 @@ int pf_create(pf_handle* out, int device, int arch) {
 #ifdef PF_TUNING_BUILD
 #endif
   if (const char* v = getenv("PF_SIDE_STREAM")) e->side_stream_mode = atoi(v);
+  if (const char* v = getenv("PF_S3_SPLIT")) e->s3_split = atoi(v);
   if (const char* v = getenv("PF_SBA_HEADS")) e->sba_heads = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;

@@ -212,3 +212,26 @@ def test_sharded_product_class_on_one_gpu():
     spf.set_pipeline(False)
     assert o1.gathered is None and torch.equal(o2.gathered, pr) and torch.equal(last, pr)
     assert torch.equal(o2.pred_gravity, pg) and torch.equal(o2.fields[3][1], want[3]["pred_latitude_original"])
+
+
+def test_stage3_batch_split_is_bit_identical(monkeypatch):
+    """PF_S3_SPLIT (engine.hip mit(), "the stage-3 split"): MiT stage 3 (mix_transformers.py:198-202, 18 blocks) walks the batch as two half-batches on two streams.
+    Same kernels on the same images -- every output of a batch-32 forward must be bit-identical to the one-stream walk, with the deferred ParamNet branch beside it too."""
+    from perspectivefields_amd import PerspectiveFields
+
+    x = torch.from_numpy(np.stack([synthetic_image(320, 320, seed=900 + i) for i in range(32)])).cuda()
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PF_S3_SPLIT", mode)
+        m = PerspectiveFields(CENTERED, weights="synthetic:0", precision="fp32").eval().cuda()
+        eng = m._get_engine()
+        pg, pl, pr = eng.forward(x)
+        eng.set_defer_params(True)
+        runs = [eng.forward(x) for _ in range(3)]
+        eng.set_defer_params(False)
+        torch.cuda.synchronize()
+        for g2, l2, p2 in runs:
+            assert torch.equal(g2, pg) and torch.equal(l2, pl) and torch.equal(p2, pr), mode
+        outs[mode] = (pg, pl, pr)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
