@@ -1101,9 +1101,13 @@ struct pf_engine {
       // Images are independent, so the batch is cut in two halves that walk the stage on TWO streams (the caller's and `side`, which gives up the q-beside-kv fork
       // for it: no additional hardware queue): two desynchronised chains of half-size launches fill each other's gaps.  Same kernels, same per-image arithmetic:
       // bit-identical results (tests/test_gpu_e2e.py::test_stage3_batch_split_is_bit_identical).
-      const long rb_all = (long)B * ((N + 63) / 64);   // the split rides on the row-block form's gate: full rounds of 64-row blocks over the WHOLE batch
+      // Measured (same box, profiles/r06_s3_split.md): batch 64 (two halves of 224 blocks, each a full round of its own) +2.2 %; batch 32 (halves of 112 blocks) -0.3 ... -1.8 %:
+      // a half-size launch takes as long as the full one (a launch IS a block's latency), so the split pays only when EACH half still fills the chip -- the gate below
+      // is the row-block form's gate taken for the half batch (PF_S3_SPLIT=2 forces the split whenever the whole batch passes it: the batch-32 A/B).
+      const long rb_all = (long)B * ((N + 63) / 64), rb_half = rb_all / 2;
+      auto rb_gate = [&](long nb) { return nb >= rb_min_blocks && (nb % num_cus == 0 || nb % num_cus >= num_cus * 3 / 4); };
       const bool split = s3_split && s == 2 && sr > 1 && !S && !fused_mlp && B >= 16 && B % 2 == 0 && !c.dry && !c.dbg && !c.tuning && !st.blocks.empty() && rb_chain && nterms == NT_F16X3 &&
-                         st.blocks[0].rq.w && rb_all >= rb_min_blocks && (rb_all % num_cus == 0 || rb_all % num_cus >= num_cus * 3 / 4) && can_fork(c);
+                         st.blocks[0].rq.w && rb_gate(rb_all) && (s3_split >= 2 || rb_gate(rb_half)) && can_fork(c);
       int blk = -1;
       if (split) {
         const int Bh = B / 2;

@@ -62,8 +62,10 @@ __device__ __forceinline__ void split2_f16_nc(const wf2 v, unsigned& h, unsigned
 }
 
 // Epilogue of the 4-wave forms: wave w holds row xi = w of the transformed output (acc[nu][cout sub-tile][tile sub-tile]).
-template <bool STAMP>
-__device__ __forceinline__ void wino4_epilogue(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[4][2][2], unsigned char* wsm, int bimg, int oy0, int ox0, int n0) {
+// (bimg2, oy2, ox2)[h]: HALF (the half-patch form of wino4d): image and output origin of tile rows 4 h .. 4 h + 3; otherwise entry 0 is the square patch's origin
+template <bool STAMP, bool HALF = false>
+__device__ __forceinline__ void wino4_epilogue(const ConvParams& p, const ConvPtrs& P, f32x16 (&acc)[4][2][2], unsigned char* wsm, const int (&bimg2)[2], const int (&oy2)[2],
+                                               const int (&ox2)[2], int n0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   // item = (tile, channel quad): 64 x 16 = 1024 items, 4 per thread; item = tid + 256 it -> the SAME channel quad (tid & 15) for all four: scale / bias once.
   // Every global operand (scale, bias, the residuals of all 16 output pixels) is requested BEFORE the LDS reads and the arithmetic: one load latency per block, not one
@@ -85,9 +87,10 @@ __device__ __forceinline__ void wino4_epilogue(const ConvParams& p, const ConvPt
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int oy = oy0 + 2 * e_ty + a, ox = ox0 + 2 * e_tx + b;
+        const int eh = HALF ? e_ty >> 2 : 0;
+        const int oy = oy2[eh] + 2 * (HALF ? e_ty & 3 : e_ty) + a, ox = ox2[eh] + 2 * e_tx + b;
         okp[it][a][b] = oy < p.Ho && ox < p.Wo;
-        oo[it][a][b] = (unsigned)(((bimg * p.Ho + oy) * p.Wo + ox) * p.ldy + n);
+        oo[it][a][b] = HALF && !okp[it][a][b] ? 0u : (unsigned)(((bimg2[eh] * p.Ho + oy) * p.Wo + ox) * p.ldy + n);
         q1[it][a][b] = zero4; q2[it][a][b] = zero4;
       }
   }
@@ -354,7 +357,8 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4c_f2x2_kernel(const ConvParams 
     __syncthreads();   // raw(c + 2) complete in LDS; raw(c) free
   }
   WINO4_STAMP(1);
-  wino4_epilogue<STAMP>(p, P, acc, wsm, bimg, oy0, ox0, n0);
+  const int bimg2[2] = {bimg, bimg}, oy2[2] = {oy0, oy0}, ox2[2] = {ox0, ox0};
+  wino4_epilogue<STAMP>(p, P, acc, wsm, bimg2, oy2, ox2, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
@@ -378,24 +382,51 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4c_f2x2_kernel(const ConvParams 
 // DABL (tuning builds, PF_WINO_ABL=<mask>; WRONG results, timing only): 1 = no LDS reads of the pixel columns, 2 = no raw-halo staging, 4 = no weight requests,
 // 8 = no transform arithmetic, 16 = no barrier, 32 = no address updates -- each removed from the chunk loop only.  (Mask 1 also makes the
 // transform loop invariant: the compiler hoists it -- read it as "no LDS reads, no transform".)
-template <bool STAMP, int DABL = 0>
+// HALF: the block's 8 x 8 tiles are TWO independent half patches of 8 x 16 output pixels (tile rows 0..3 / 4..7 = tile sub-tiles m = 0 / 1), each with its own
+// (image, row, column) origin and its own 10-row halo in the raw tile (20 rows instead of 18; the column pitch, the piece swizzle and every lane's addresses inside a
+// sub-tile are unchanged: sub-tile 1 merely starts 10 rows down instead of 8).  For maps whose height is no multiple of 16 -- the 40 x 40 maps of the decoders: 3 x 3
+// patches of 16 x 16 cover 48 x 48 (69 % of the blocks' work is inside the image); 5 x 3 half patches cover 40 x 48 (83 %): 240 blocks per head and channel tile at
+// batch 32 instead of 288.  Per-tile arithmetic and accumulation order are untouched: bit-identical to the square form.
+template <bool STAMP, int DABL = 0, bool HALF = false>
 __global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char wsm[WC_SMEM];
+  constexpr int HROWS = HALF ? 20 : W_HY;          // halo rows in a raw tile
+  constexpr int RCB = HROWS * RC_ROW;              // bytes of a raw tile
+  constexpr int MSTEP = (HALF ? 10 : 8) * RC_ROW;  // sub-tile 1 below sub-tile 0
+  constexpr int NPIX = HROWS * W_HX;
+  static_assert(3 * RCB + W4_NT * 16 <= WC_SMEM && (NPIX * 4 + W4_NT - 1) / W4_NT == RAW4_F4, "raw tiles + dump area fit; six halo elements per thread");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   const int tilesN = p.Cout / W_BN;
-  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
-  const int nblk1 = p.B * tilesY * tilesX * tilesN;
+  const int tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = HALF ? (p.Ho + 7) / 8 : (p.Ho + W_PY - 1) / W_PY;   // HALF: half patches per column of patches
+  const int nhalf = p.B * tilesY * tilesX;          // HALF: half patches of one group
+  const int nblk1 = (HALF ? (nhalf + 1) / 2 : nhalf) * tilesN;
   int t = xcd_tile_index(nblk1 * p.groups);
   const bool g1 = t >= nblk1;
   if (g1) t -= nblk1;
   const ConvPtrs& P = g1 ? p.g[1] : p.g[0];
   const int nt = t % tilesN;
-  int mt = t / tilesN;
-  const int bx = mt % tilesX; mt /= tilesX;
-  const int by = mt % tilesY;
-  const int bimg = mt / tilesY;
-  const int oy0 = by * W_PY, ox0 = bx * W_PX, n0 = nt * W_BN;
+  const int n0 = nt * W_BN;
+  int bimg2[2], oy2[2], ox2[2];   // origin of tile rows 0..3 / 4..7
+  if constexpr (HALF) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int hp = 2 * (t / tilesN) + h;
+      const bool live = hp < nhalf;
+      hp = live ? hp : nhalf - 1;
+      const int bx = hp % tilesX, by = (hp / tilesX) % tilesY;
+      bimg2[h] = hp / (tilesX * tilesY);
+      oy2[h] = live ? by * 8 : (1 << 28);    // a dead half (odd count): every pixel outside the image -> zeros in, nothing out
+      ox2[h] = bx * W_PX;
+    }
+  } else {
+    int mt = t / tilesN;
+    const int bx = mt % tilesX; mt /= tilesX;
+    const int by = mt % tilesY;
+    bimg2[0] = bimg2[1] = mt / tilesY;
+    oy2[0] = oy2[1] = by * W_PY;
+    ox2[0] = ox2[1] = bx * W_PX;
+  }
   const int nC = p.Cin / W_KC;
 
   // ---- raw halo staging: element e = tid + 256 i -> (pixel tid / 4 + 64 i, logical piece tid % 4); st[i]: its LDS address (piece swizzle) in the tile being filled;
@@ -407,10 +438,11 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams 
   for (int i = 0; i < RAW4_F4; ++i) {
     const int pix = (tid >> 2) + 64 * i, c4 = tid & 3;
     const int hy = pix / W_HX, hx = pix - hy * W_HX;
-    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-    const bool ok = pix < W_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    g_off[i] = ok ? (unsigned)(((bimg * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
-    st[i] = pix < W_NPIX ? hy * RC_ROW + hx * 64 + ((c4 ^ ((hx >> 1) & 3)) * 16) : 3 * RC_BYTES + tid * 16;
+    const int hh = HALF ? (hy >= 10 ? 1 : 0) : 0;                  // which half's halo this row belongs to
+    const int iy = oy2[hh] - 1 + (HALF ? hy - 10 * hh : hy), ix = ox2[hh] - 1 + hx;
+    const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    g_off[i] = ok ? (unsigned)(((bimg2[hh] * p.H + iy) * p.W + ix) * p.Cin * 4 + c4 * 16) : OOB;
+    st[i] = pix < NPIX ? hy * RC_ROW + hx * 64 + ((c4 ^ ((hx >> 1) & 3)) * 16) : 3 * RCB + tid * 16;
   }
   auto raw_soff = [&](int c) { return (c < nC ? c : nC - 1) * (W_KC * 4); };
   u32x4 ra[RAW4_F4];
@@ -502,7 +534,7 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams 
 #pragma unroll
   for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 1);
 #pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) raw_store1(i, RC_BYTES);
+  for (int i = 0; i < RAW4_F4; ++i) raw_store1(i, RCB);
 #pragma unroll
   for (int i = 0; i < RAW4_F4; ++i) raw_load1(i, 2);
 #pragma unroll
@@ -510,7 +542,7 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams 
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc) load_w1(0, nu, pc);
 #pragma unroll
-  for (int i = 0; i < RAW4_F4; ++i) st[i] += 2 * RC_BYTES;  // the loop's first chunk fills tile 2
+  for (int i = 0; i < RAW4_F4; ++i) st[i] += 2 * RCB;  // the loop's first chunk fills tile 2
   __syncthreads();
   // rows of (chunk 0, m = 0); fragments 0 and 1 of chunk 0; pixel column 0 of (chunk 0, m = 1)
 #pragma unroll
@@ -521,7 +553,7 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams 
 #pragma unroll
     for (int e = 0; e < 4; ++e) { s_cvt(nu, e); s_lo(nu, e); s_hi(nu, e); }
   }
-  col_read(X, 8 * RC_ROW, 0, 0); col_read(X, 8 * RC_ROW, 0, 1); t_rows(0);
+  col_read(X, MSTEP, 0, 0); col_read(X, MSTEP, 0, 1); t_rows(0);
   WINO4_STAMP(0);
 
   // entering chunk c: fragments 0, 1 of chunk c in ring slots 0, 1; tr[0] = column 0 of (c, m = 1), tr[1..3] = columns of (c, m = 0); raw(c), raw(c + 1) in LDS;
@@ -537,7 +569,7 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams 
     constexpr int rm = gnu == 1 ? gm : (gm ^ 1);                                                                                                    \
     constexpr bool useX = w == 0 || w == 1 || w == 3;                                                                                               \
     /* memory instructions of the slot */                                                                                                           \
-    if constexpr (s < 2 && (DABL & 1) == 0) { if constexpr (useX) col_read(X, rm * (8 * RC_ROW), rj, s); else col_read(Y, rm * (8 * RC_ROW), rj, s); } \
+    if constexpr (s < 2 && (DABL & 1) == 0) { if constexpr (useX) col_read(X, rm * MSTEP, rj, s); else col_read(Y, rm * MSTEP, rj, s); } \
     /* raw(c + 2) -> LDS in slots 2..7 (its requests are a chunk old), then the six requests for raw(c + 3) in slots 10..17: BEHIND the weights of position 3 and as \
        far ahead of the next weights as the registers allow -- loads return in order, a weight fragment from L2 must not queue behind a halo pixel from HBM */    \
     if constexpr ((DABL & 2) == 0) {                                                                                                                \
@@ -572,8 +604,8 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams 
   int ph = 0;  // c % 3
 #pragma unroll 1
   for (int c = 0; c < nC; ++c) {
-    const int d0 = ph == 2 ? -2 * RC_BYTES : RC_BYTES;   // tile (c + 1) - tile c
-    const int d2 = ph == 0 ? -2 * RC_BYTES : RC_BYTES;   // tile (c + 3) - tile (c + 2)
+    const int d0 = ph == 2 ? -2 * RCB : RCB;   // tile (c + 1) - tile c
+    const int d2 = ph == 0 ? -2 * RCB : RCB;   // tile (c + 3) - tile (c + 2)
     if (c < 16) WINO4_STAMP(8 + 2 * c);
     WD_SLOT6(0) WD_SLOT6(6) WD_SLOT6(12) WD_SLOT6(18) WD_SLOT6(24) WD_SLOT6(30) WD_SLOT6(36) WD_SLOT6(42)
     if (c < 16) WINO4_STAMP(9 + 2 * c);
@@ -583,7 +615,7 @@ __global__ __launch_bounds__(W4_NT, 1) void wino4d_f2x2_kernel(const ConvParams 
 #undef WD_SLOT6
 #undef WD_SLOT
   WINO4_STAMP(1);
-  wino4_epilogue<STAMP>(p, P, acc, wsm, bimg, oy0, ox0, n0);
+  wino4_epilogue<STAMP, HALF>(p, P, acc, wsm, bimg2, oy2, ox2, n0);
 }
 
 // 3x3 / stride 1 / pad 1, split-f16 scheme, one fp32 NHWC input, fp32 NHWC output, Winograd weights present
@@ -619,6 +651,14 @@ void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant) {
       default: break;
     }
 #endif
+    // Half-patch geometry where the square patches would waste half a patch row: 1 <= Ho mod 16 <= 8 (the decoders' 40 x 40 maps; PF_WINO_HALF=0: square patches always)
+    static const int half_env = [] { const char* e = getenv("PF_WINO_HALF"); return e ? atoi(e) : 1; }();
+    const int rem = p.Ho % W_PY;
+    if (half_env && rem >= 1 && rem <= 8 && !p.stamps) {
+      const int nhalf = p.B * ((p.Ho + 7) / 8) * tilesX;
+      hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 0, true>), dim3(((nhalf + 1) / 2) * tilesN * p.groups), dim3(W4_NT), 0, s, p);
+      return;
+    }
     if (p.stamps) hipLaunchKernelGGL(wino4d_f2x2_kernel<true>, grid, dim3(W4_NT), 0, s, p);
     else hipLaunchKernelGGL(wino4d_f2x2_kernel<false>, grid, dim3(W4_NT), 0, s, p);
     return;

@@ -691,6 +691,10 @@ WINO_CASES = [
     ("odd23x37", 2, 23, 37, 64, 128),
     ("one_tile_row", 1, 1, 33, 128, 64),
     ("cin96_six_chunks", 1, 18, 16, 96, 64),
+    # r06: maps with 1 <= H mod 16 <= 8 run wino256x64d in its HALF-PATCH geometry (two 8 x 16 half patches per block: rcu40, rcu20, odd23x37, one_tile_row and
+    # cin96_six_chunks above already do); an ODD number of half patches (1 x 5 x 3: the last block's second half is dead) and two images sharing a block
+    ("half_odd40", 1, 40, 40, 64, 64),
+    ("half_pairs_across_images", 3, 8, 40, 64, 128),
 ]
 
 
