@@ -362,218 +362,6 @@ __global__ __launch_bounds__(256, 2) void sr_attention_f16_kernel(const float* _
   }  // query tiles
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// "Image" form (r06): K and V of a (batch, head) in the split-f16 kernel's OPERAND IMAGE in global memory -- both planes, K scaled and row-major, V transposed in
-// the MFMA k order -- as 1 KB MFMA fragments (lane l at byte 16 l: exactly what a wave's ds_read_b128 / LDS-DMA piece is).  Made ONCE per (batch, head) by
-// kv_image_kernel; the attention blocks then take it by LDS-DMA (global_load_lds_dwordx4: no staging registers, no split, no transposing 2-byte LDS writes) while
-// their query rows are already in flight.  In sr_attention_f16_kernel every block fetched, scaled, split and transposed the head's K / V itself, and asked for its
-// queries only behind that staging's barrier: a block was a chain of two memory round trips and ~2 us of VALU / LDS-store work before its first MFMA
-// (a launch of 256 tiny blocks took 12 us at N = 100: profiles/r02_tune_attn_qt.txt).  Same operand values, same MFMA order: bit-identical outputs.
-//   image of one (batch, head), M kv rows, NKB = ceil(M / 32), NCH = ceil(M / 16):
-//     K part: piece ((c * 4 + t) * 2 + plane), c < NKB, t < 4:  lane (l31, hi), element e  =  16 K[32 c + l31][16 t + 8 hi + e]  (rows >= M: 0)
-//     V part: piece ((cc * 2 + j) * 2 + plane), cc < NCH, j < 2: lane (l31, hi), element e  =  16 V[16 cc + (e & 3) + 8 (e >> 2) + 4 hi][32 j + l31]  (rows >= M: 0)
-__host__ __device__ constexpr int at_img_k_pieces(int M) { return ((M + 31) / 32) * 4 * 2; }
-__host__ __device__ constexpr int at_img_pieces(int M) { return at_img_k_pieces(M) + ((M + 15) / 16) * 2 * 2; }
-size_t sr_attention_image_bytes(int B, int M, int heads) { return (size_t)B * heads * at_img_pieces(M) * 1024; }
-
-// one wave per fragment PAIR (hi and lo plane of one (c, t) / (cc, j)); grid (pairs, heads, B)
-__global__ __launch_bounds__(64) void kv_image_kernel(const float* __restrict__ kv, unsigned char* __restrict__ img, int M, int heads) {
-  const int C = heads * HD;
-  const int b = blockIdx.z, h = blockIdx.y, pair = blockIdx.x;
-  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
-  const int kpairs = at_img_k_pieces(M) / 2;
-  const float* kvb = kv + (long)b * M * 2 * C + h * HD;
-  unsigned char* dst = img + ((size_t)(b * heads + h) * at_img_pieces(M) + 2 * pair) * 1024 + lane * 16;
-  float a[8];
-  if (pair < kpairs) {
-    const int c = pair >> 2, t = pair & 3, row = 32 * c + l31;
-    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-    if (row < M) {
-      v0 = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * C + 16 * t + 8 * hi);
-      v1 = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * C + 16 * t + 8 * hi + 4);
-    }
-    a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
-  } else {
-    const int vp = pair - kpairs, cc = vp >> 1, j = vp & 1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int row = 16 * cc + (e & 3) + 8 * (e >> 2) + 4 * hi;
-      a[e] = row < M ? kvb[(long)row * 2 * C + C + 32 * j + l31] : 0.f;
-    }
-  }
-  unsigned hh[4], ll[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {   // the staging arithmetic of sr_attention_f16_kernel, element for element
-    const float c0 = __builtin_amdgcn_fmed3f(a[2 * e] * AT_KV_SCALE, -65504.f, 65504.f), c1 = __builtin_amdgcn_fmed3f(a[2 * e + 1] * AT_KV_SCALE, -65504.f, 65504.f);
-    const float h0 = (float)(_Float16)c0, h1 = (float)(_Float16)c1;
-    hh[e] = at_pack(h0, h1);
-    ll[e] = at_pack(c0 - h0, c1 - h1);
-  }
-  *reinterpret_cast<at_u32x4*>(dst) = at_u32x4{hh[0], hh[1], hh[2], hh[3]};
-  *reinterpret_cast<at_u32x4*>(dst + 1024) = at_u32x4{ll[0], ll[1], ll[2], ll[3]};
-}
-
-__global__ __launch_bounds__(256, 2) void sr_attention_img_kernel(const float* __restrict__ q, const unsigned char* __restrict__ img,
-                                                                  float* __restrict__ out, unsigned short* __restrict__ out_sb, size_t sb_plane, int N, int M, int heads, int QT) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_img[];
-  const int C = heads * HD;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int nchunk = (M + 15) >> 4, npieces = at_img_pieces(M), kbytes = at_img_k_pieces(M) * 1024;
-
-  // ---- the head's operand image -> LDS by LDS-DMA: piece p = wave + 4 i goes to the same piece of the buffer (wave-uniform base + lane x 16 = the DMA's addressing).
-  //      Inline asm as in cnx_mlp.hip: hipcc does not count an asm load (and would otherwise wait for the DMA in front of the first ds_read of the same array):
-  //      the explicit s_waitcnt in front of the barrier below orders it.
-  {
-    const unsigned char* src = img + (size_t)(b * heads + h) * npieces * 1024 + lane * 16;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem_img;
-    for (int pc = wave; pc < npieces; pc += 4) {
-      unsigned keep;
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)pc * 1024u);
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src + (size_t)pc * 1024), "s"(dst) : "memory");
-    }
-  }
-  bool waited = false;
-  for (int qt = 0; qt < QT; ++qt) {
-  // ---- this lane's query row (clamped; out-of-range rows are computed but not stored): B fragments of S^T = K Q^T.  Requested BEFORE the wait for the image
-  const int q0 = (blockIdx.x * QT + qt) * 128 + wave * 32;
-  const bool live = q0 < N;   // wave-uniform; a dead wave still takes part in the one barrier
-  const int qrow = q0 + l31;
-  const int qr = qrow < N ? qrow : N - 1;
-  const float* qp = q + ((long)b * N + (live ? qr : 0)) * C + h * HD + 8 * hi;
-  at_u32x4 qh[4], ql[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float4 v0 = *reinterpret_cast<const float4*>(qp + 16 * t), v1 = *reinterpret_cast<const float4*>(qp + 16 * t + 4);
-    const float a[8] = {v0.x * AT_QS, v0.y * AT_QS, v0.z * AT_QS, v0.w * AT_QS, v1.x * AT_QS, v1.y * AT_QS, v1.z * AT_QS, v1.w * AT_QS};
-    at_split8(a, qh[t], ql[t]);
-  }
-  if (!waited) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    waited = true;
-  }
-  if (!live) break;   // no barrier below
-
-  // ---- S^T[kv][q] * 16: kv blocks of 32 rows (rows past M are zeros in the image and masked below)
-  f32x16 sacc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sacc[c][e] = 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (32 * c < M) {  // block-uniform
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const unsigned char* fr = smem_img + ((c * 4 + t) * 2) * 1024 + lane * 16;
-        const at_u32x4 kh = *reinterpret_cast<const at_u32x4*>(fr);
-        const at_u32x4 kl = *reinterpret_cast<const at_u32x4*>(fr + 1024);
-        sacc[c] = at_mfma(kh, ql[t], sacc[c]);
-        sacc[c] = at_mfma(kl, qh[t], sacc[c]);
-        sacc[c] = at_mfma(kh, qh[t], sacc[c]);
-      }
-    }
-  }
-
-  // ---- softmax over kv for query column (lane & 31): as sr_attention_f16_kernel
-  constexpr float L2E = 1.4426950408889634f / (AT_KV_SCALE * AT_Q_SCALE);
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (32 * c + 32 <= M) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[c][r]);
-    } else if (32 * c < M) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (kvi < M) mx = fmaxf(mx, sacc[c][r]);
-      }
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const float mx2 = mx * L2E - AT_P_EXP;
-  float sum = 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (32 * c + 32 <= M) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pexp = __builtin_amdgcn_exp2f(fmaf(sacc[c][r], L2E, -mx2));
-        sacc[c][r] = pexp;
-        sum += pexp;
-      }
-    } else if (32 * c < M) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float pexp = kvi < M ? __builtin_amdgcn_exp2f(fmaf(sacc[c][r], L2E, -mx2)) : 0.f;
-        sacc[c][r] = pexp;
-        sum += pexp;
-      }
-    }
-  }
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / (sum * AT_KV_SCALE);  // also undoes the scale of V
-
-  // ---- O^T[d][q] * 16 = sum_kv V^T[d][kv] P^T[kv][q]
-  f32x16 oacc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[j][e] = 0.f;
-#pragma unroll
-  for (int cc = 0; cc < 8; ++cc) {
-    if (cc < nchunk) {  // block-uniform
-      float pe[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pe[e] = sacc[cc >> 1][8 * (cc & 1) + e];
-      at_u32x4 ph, pl;
-      at_split8(pe, ph, pl);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned char* fr = smem_img + kbytes + ((cc * 2 + j) * 2) * 1024 + lane * 16;
-        const at_u32x4 vh = *reinterpret_cast<const at_u32x4*>(fr);
-        const at_u32x4 vl = *reinterpret_cast<const at_u32x4*>(fr + 1024);
-        oacc[j] = at_mfma(vh, pl, oacc[j]);
-        oacc[j] = at_mfma(vl, ph, oacc[j]);
-        oacc[j] = at_mfma(vh, ph, oacc[j]);
-      }
-    }
-  }
-
-  if (qrow < N) {
-    const size_t o0 = ((size_t)b * N + qrow) * C + h * HD;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 v = make_float4(oacc[j][4 * g] * inv, oacc[j][4 * g + 1] * inv, oacc[j][4 * g + 2] * inv, oacc[j][4 * g + 3] * inv);
-        const size_t o = o0 + 32 * j + 8 * g + 4 * hi;
-        if (out) *reinterpret_cast<float4*>(out + o) = v;
-        if (out_sb) store_sb4(out_sb, sb_plane, o, v);
-      }
-  }
-  }  // query tiles
-}
-
-// K / V image of the whole batch, then the attention blocks (img: sr_attention_image_bytes(B, M, heads) of caller scratch)
-void launch_sr_attention_img(const float* q, const float* kv, unsigned char* img, float* out, int B, int N, int M, int heads, hipStream_t s, unsigned short* out_sb, size_t sb_plane) {
-  hipLaunchKernelGGL(kv_image_kernel, dim3(at_img_pieces(M) / 2, heads, B), dim3(64), 0, s, kv, img, M, heads);
-  static const int qt_env = [] { const char* e = getenv("PF_ATTN_QT"); return e ? atoi(e) : 0; }();
-  const int tiles = (N + 127) / 128;
-  int QT = 1;
-  if (qt_env > 0) QT = qt_env;
-  else while (QT < 8 && QT * 2 <= tiles && (long)((tiles + 2 * QT - 1) / (2 * QT)) * heads * B >= 300) QT *= 2;
-  const dim3 gridq((tiles + QT - 1) / QT, heads, B);
-  static const bool lds_ok = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(sr_attention_img_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess; }();
-  (void)lds_ok;   // 64 pieces (M = 128) = exactly 64 KB
-  hipLaunchKernelGGL(sr_attention_img_kernel, gridq, dim3(256), (size_t)at_img_pieces(M) * 1024, s, q, img, out, out_sb, sb_plane, N, M, heads, QT);
-}
-
 static int g_attn_variant = -1;  // PF_ATTN_VARIANT: 1 = split-f16 MFMA (default), 0 = exact fp32 MFMA
 void launch_sr_attention_variant(int variant, const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s, unsigned short* out_sb, size_t sb_plane) {
   const dim3 grid((N + 127) / 128, heads, B);

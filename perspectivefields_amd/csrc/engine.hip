@@ -249,7 +249,6 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
-  int attn_img = 1, attn_img_min_b = 8;   // PF_ATTN_IMG / PF_ATTN_IMG_MIN_B: attention on the K / V operand image (attn.hip) from this batch size on
   int s3_split = 1;          // PF_S3_SPLIT: MiT stage 3 on two half-batches / two streams (mit(), "the stage-3 split")
   int side_stream_mode = 1;  // 1 (default): the q projection of a MiT block runs on a second stream next to the sr conv + kv GEMM (both consume LayerNorm-1's
                              // output, attention joins them) -- small launches that each fill a fraction of the chip: +0.6 % (3 x A/B on one box, profiles/
@@ -964,14 +963,12 @@ struct pf_engine {
       float* srb = c.alloc(Mkv * C);
       const Ten srn = S ? Ten(nullptr, c.alloc_sb(Mkv * C)) : Ten(srb);  // LN(sr conv): in place, or planes only
       float* kvb = c.alloc(Mkv * 2 * C);
-      const size_t kvimg_bytes = kvh * kvw <= 112 ? sr_attention_image_bytes(B, kvh * kvw, heads_n) : 0;   // (<= 64 KB of LDS per block; every stage has 100 kv rows)
-      unsigned char* kvimg = kvimg_bytes ? reinterpret_cast<unsigned char*>(c.alloc((kvimg_bytes + 3) / 4)) : nullptr;
       float* hb = c.alloc(M * 4 * C);
       const Ten h2 = c.ten(M * 4 * C, !S, S);
       // One transformer block on `B` images starting at token row 0 of the given buffers (Block.forward, mix_transformers.py:198-202).  gate_B: the batch the
       // row-block gate is taken for (the whole batch, also when the block is issued for one half of it -- see the stage-3 split below)
       auto one_block = [&](Ctx& c, MitBlock& mb, int blk, int B, long M, long Mkv, float*& x, float*& xalt, const Ten& xn, float* qb, const Ten& ab, float* srb, const Ten& srn,
-                           float* kvb, float* hb, const Ten& h2, int gate_B, bool may_fork, unsigned char* kvimg) {
+                           float* kvb, float* hb, const Ten& h2, int gate_B, bool may_fork) {
         // x += proj(attn(LN1(x)))            (Block.forward :199; Attention.forward :108-141)
         // row-block form of the block's linear layers (stage 3 at batch >= ~14): q, kv, proj, fc1, fc2
         // one 64-row block per CU: the form pays only when the last round of blocks nearly fills the 256 CUs (same-box A/Bs, profiles/r04_rb_linear.md: B = 32 -> 224 blocks
@@ -1058,10 +1055,7 @@ struct pf_engine {
         }
         if (!c.dry) {
           ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
-          // K / V operand image (attn.hip, r06) from batch attn_img_min_b on: one more (tiny) launch, attention blocks without staging; below it the extra launch
-          // costs more latency than the staging it removes
-          if (attn_img && nterms == NT_F16X3 && B >= attn_img_min_b && kvimg) launch_sr_attention_img(qb, kvb, kvimg, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
-          else launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
+          launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
         }
         const bool pf_fused = use_rb && (rb_chain & 64) && mb.rpf.w;  // x += proj(attn); hidden = fc1(LN2(x)) in one launch (rb_chain.hip)
         if (pf_fused) {
@@ -1126,9 +1120,9 @@ struct pf_engine {
         float* none = nullptr;
         for (MitBlock& mb : st.blocks) {
           ++blk;
-          one_block(c, mb, blk, Bh, Mh, Mkvh, x, none, xn, qb, ab, srb, srn, kvb, hb, h2, B, false, kvimg);
+          one_block(c, mb, blk, Bh, Mh, Mkvh, x, none, xn, qb, ab, srb, srn, kvb, hb, h2, B, false);
           one_block(c2, mb, blk, Bh, Mh, Mkvh, x2, none, Ten(xn.f ? xn.f + Mh * C : nullptr), qb + Mh * C, Ten(ab.f + Mh * C), srb + Mkvh * C, Ten(srn.f ? srn.f + Mkvh * C : nullptr),
-                    kvb + Mkvh * 2 * C, hb + Mh * 4 * C, Ten(h2.f + Mh * 4 * C), B, false, kvimg ? kvimg + kvimg_bytes / 2 : nullptr);
+                    kvb + Mkvh * 2 * C, hb + Mh * 4 * C, Ten(h2.f + Mh * 4 * C), B, false);
         }
         (void)hipEventRecord(ev_join, side);
         (void)hipStreamWaitEvent(c.s, ev_join, 0);
@@ -1136,7 +1130,7 @@ struct pf_engine {
         for (MitBlock& mb : st.blocks) {
           if (blk >= 0) tap(c, fmt("mit.s%d.b%d", s + 1, blk), x, B, Ho, Wo, C);  // the previous block's output (token stream, pre stage norm)
           ++blk;
-          one_block(c, mb, blk, B, M, Mkv, x, xalt, xn, qb, ab, srb, srn, kvb, hb, h2, B, true, kvimg);
+          one_block(c, mb, blk, B, M, Mkv, x, xalt, xn, qb, ab, srb, srn, kvb, hb, h2, B, true);
         }
       }
       c.release(mk);
@@ -1486,8 +1480,6 @@ int pf_create(pf_handle* out, int device, int arch) {
 #endif
   if (const char* v = getenv("PF_SIDE_STREAM")) e->side_stream_mode = atoi(v);
   if (const char* v = getenv("PF_S3_SPLIT")) e->s3_split = atoi(v);
-  if (const char* v = getenv("PF_ATTN_IMG")) e->attn_img = atoi(v);
-  if (const char* v = getenv("PF_ATTN_IMG_MIN_B")) e->attn_img_min_b = atoi(v);
   if (const char* v = getenv("PF_SBA_HEADS")) e->sba_heads = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;

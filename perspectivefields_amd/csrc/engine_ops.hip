@@ -541,21 +541,14 @@ int pf_op_sr_attention_variant(int device, int variant, const float* q, const fl
   std::string err;
   int rc = check_device(device, &err);
   if (rc != PF_OK) { g_create_error = err; return rc; }
-  if (M <= 0 || M > 128 || variant < 0 || variant > 2) { g_create_error = "pf_op_sr_attention_variant: kv length must be in 1..128, variant 0, 1 or 2"; return PF_ERR_ARG; }
+  if (M <= 0 || M > 128 || (variant != 0 && variant != 1)) { g_create_error = "pf_op_sr_attention_variant: kv length must be in 1..128, variant 0 or 1"; return PF_ERR_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  unsigned char* img = nullptr;   // variant 2 (the K / V image form): scratch for the image
-  if (variant == 2 && hipMalloc(&img, sr_attention_image_bytes(B, M, heads)) != hipSuccess) { g_create_error = "pf_op_sr_attention_variant: hipMalloc failed"; return PF_ERR_DEVICE; }
-  auto launch = [&] {
-    if (variant == 2) launch_sr_attention_img(q, kv, img, out, B, N, M, heads, s);
-    else launch_sr_attention_variant(variant, q, kv, out, B, N, M, heads, s);
-  };
-  struct Free { unsigned char* p; hipStream_t s; ~Free() { if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); } } } free_img{img, s};
-  launch();
+  launch_sr_attention_variant(variant, q, kv, out, B, N, M, heads, s);
   if (iters > 0 && ms_out) {  // timing loop on the caller's data
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     (void)hipEventRecord(a, s);
-    for (int i = 0; i < iters; ++i) launch();
+    for (int i = 0; i < iters; ++i) launch_sr_attention_variant(variant, q, kv, out, B, N, M, heads, s);
     (void)hipEventRecord(b, s);
     (void)hipEventSynchronize(b);
     float t = 0.f;

@@ -185,12 +185,6 @@ void launch_sr_attention(const float* q, const float* kv, float* out, int B, int
 void launch_sr_attention_variant(int variant, const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s,
                                  unsigned short* out_sb = nullptr, size_t sb_plane = 0);
 
-// "image" form of the split-f16 attention (attn.hip): K / V of every (batch, head) written once as MFMA operand fragments (kv_image_kernel), the attention blocks take
-// them by LDS-DMA; img = sr_attention_image_bytes(B, M, heads) bytes of caller scratch; bit-identical to variant 1
-size_t sr_attention_image_bytes(int B, int M, int heads);
-void launch_sr_attention_img(const float* q, const float* kv, unsigned char* img, float* out, int B, int N, int M, int heads, hipStream_t s,
-                             unsigned short* out_sb = nullptr, size_t sb_plane = 0);
-
 // bilinear x2 (align_corners=False), NHWC
 void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb = nullptr, size_t sb_plane = 0);
 

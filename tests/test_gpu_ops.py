@@ -557,29 +557,6 @@ def test_sr_attention_both_kernels(ops, B, N, heads, M):
     _close(f16, ref, 2e-5, "attention split-f16 (O(1) data)")
 
 
-@pytest.mark.parametrize("B,N,heads,M", [(2, 6400, 1, 100), (1, 1600, 2, 100), (3, 400, 5, 100), (3, 100, 8, 100), (1, 70, 2, 37), (1, 130, 1, 128), (1, 33, 1, 16), (2, 300, 2, 1)])
-def test_sr_attention_image_form_is_bit_identical(ops, B, N, heads, M):
-    """r06 (attn.hip sr_attention_img_kernel; Attention.forward, mix_transformers.py:108-141): K / V written ONCE per (batch, head) as the split-f16 kernel's operand
-    image (kv_image_kernel: scaled, split, V transposed in MFMA k order, as 1 KB fragments), the attention blocks take it by LDS-DMA.  Same operand values in the same
-    MFMA order as the kernel that stages K / V itself: torch.equal, also on peaked rows and saturating magnitudes."""
-    C = heads * 64
-    q = _rand((B, N, C), 26)
-    kv = _rand((B, M, 2 * C), 27)
-    if M >= 100:
-        kv[0, 17, :64] = q[0, 5, :64] * 6.0
-        q[0, 9] *= 30.0
-        kv[0, 40:60, C:] *= 1e-4
-        kv[0, 60:70, C:] *= 300.0
-        kv[0, 3, C:C + 64] = 50000.0     # beyond the +-4094 range of the scaled split: saturates identically
-    a = ops.sr_attention_variant(q.cuda(), kv.cuda(), heads, 1)
-    b = ops.sr_attention_variant(q.cuda(), kv.cuda(), heads, 2)
-    assert torch.isfinite(b).all()
-    assert torch.equal(a, b)
-    _, ms1 = ops.sr_attention_variant(q.cuda(), kv.cuda(), heads, 1, iters=20)
-    _, ms2 = ops.sr_attention_variant(q.cuda(), kv.cuda(), heads, 2, iters=20)
-    print(f"[attention image form B{B} N{N} h{heads} M{M}] staging kernel {1e3 * ms1:.1f} us, image + attention {1e3 * ms2:.1f} us")
-
-
 def test_sr_attention_split_f16_extremes(ops):
     """peaked rows (|logit| ~ 100), tiny and large K / V magnitudes, V beyond the +-4094 range of the scaled split
     (saturates: finite output)"""
