@@ -312,8 +312,11 @@ struct pf_engine {
                              // at least rb_min_blocks row blocks: bit mask 1 q, 2 kv, 4 proj, 8 fc1, 16 fc2, 32 the whole key / value branch as one launch (rb_chain.hip; overrides 2), 64 proj + norm2 + fc1 as one launch (overrides 4, 8) (0 = none)
   int rb_min_blocks = 192;   // default for 256 CUs; pf_create rescales it to 3/4 of the device's CU count
   int num_cus = 256;         // hipDeviceProp_t::multiProcessorCount (partitioned / smaller gfx950 configurations: CPX / DPX modes)
-  int wino_min_hw = 40;      // PF_WINO=<n>: 3x3 / stride-1 convs with Cin, Cout multiples of 64 on maps of at least n x n run as Winograd F(2x2, 3x3) (wino.hip; split-f16
-                             // scheme only; 0 = never).  Their inputs' window ends at 65504 / 4 (the input transform adds four values)
+  int wino_min_hw = 20;      // PF_WINO=<n>: 3x3 / stride-1 convs with Cin, Cout multiples of 64 on maps of at least n x n run as Winograd F(2x2, 3x3) (wino.hip; split-f16
+                             // scheme only; 0 = never).  Their inputs' window ends at 65504 / 4 (the input transform adds four values).  r06: 20 instead of 40 -- with the
+                             // half-patch geometry the 20 x 20 RCU convs run 1.45x faster than on the direct tile (profiles/r06_wino_gate.txt; r05's square patches: equal)
+  int wino_min_blocks = 96;  // PF_WINO_MIN_BLOCKS: ... and only launches of at least this many blocks (one block per CU, 512 registers per wave: at batch 1 the 40 x 40 maps
+                             // give 64 blocks and the direct tile, with more and smaller blocks, is 18 % faster there)
   int wino_tile = -1;        // tile id of the Winograd kernel in use
   unsigned* d_sat = nullptr; // pf_set_saturation_counter: caller-owned device counter of the always-on saturation watch (ConvParams::sat); nullptr = off
   float static_window_max = 0.f;  // largest STATIC bound of a tensor that never reaches HBM (the hidden maps of the fused block MLPs), pf_static_window_max
@@ -844,7 +847,8 @@ struct pf_engine {
     }
     if (!conv_tile_usable(p, tile)) tile = conv_default_tile(p);
     // Winograd form where it exists and the map is large enough (the tile table knows the direct tiles only); never while tuning (tune_conv times the direct tiles)
-    if (wino_min_hw > 0 && wino_tile >= 0 && !(c.tuning && c.tune_scratch) && p.Ho >= wino_min_hw && p.Wo >= wino_min_hw && conv_tile_usable(p, wino_tile)) tile = wino_tile;
+    if (wino_min_hw > 0 && wino_tile >= 0 && !(c.tuning && c.tune_scratch) && p.Ho >= wino_min_hw && p.Wo >= wino_min_hw && conv_tile_usable(p, wino_tile) &&
+        conv_wino_blocks(p) >= wino_min_blocks) tile = wino_tile;
     if (c.dbg && c.dbg->range) {
       const int q = c.dbg->seq++;
       for (int g = 0; g < ngroups; ++g) {
@@ -1463,6 +1467,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_WINO")) e->wino_min_hw = atoi(v);
+  if (const char* v = getenv("PF_WINO_MIN_BLOCKS")) e->wino_min_blocks = atoi(v);
   {
     const char* wt = getenv("PF_WINO_TILE");  // "wino256x64d" (default: 4 waves, B fragments computed in registers, hand-placed slots), or "wino256x64c" (its compiler-scheduled form)
     for (int t = 0; t < conv_num_tiles(); ++t) if (strcmp(conv_tile_name(t), wt ? wt : "wino256x64d") == 0) e->wino_tile = t;

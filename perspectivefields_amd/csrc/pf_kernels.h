@@ -159,6 +159,7 @@ const char* conv_tile_name(int tile_id);
 // Winograd F(2x2, 3x3) kernel (wino.hip; tiles "wino256x64d" / "wino256x64c" of the split family)
 bool conv_wino_ok(const ConvParams& p);
 void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant = 0);  // 0: "wino256x64c", 1: "wino256x64d"
+int conv_wino_blocks(const ConvParams& p);   // grid size of the shipped Winograd kernel for this launch (all groups; the half-patch geometry where it applies)
 void wino_pack_weights(const float* packed /*[Cout][3][KWCp], k = (kx, ci)*/, int Cout, int Cin, int KWCp, std::vector<unsigned short>* planes, std::vector<float>* inv_scale);
 
 // rows x C LayerNorm (biased variance), y may alias x

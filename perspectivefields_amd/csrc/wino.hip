@@ -629,6 +629,17 @@ bool conv_wino_ok(const ConvParams& p) {
   return true;
 }
 
+static bool wino_half_geometry(const ConvParams& p) {
+  static const int half_env = [] { const char* e = getenv("PF_WINO_HALF"); return e ? atoi(e) : 1; }();
+  const int rem = p.Ho % W_PY;
+  return half_env && rem >= 1 && rem <= 8;
+}
+int conv_wino_blocks(const ConvParams& p) {
+  const int tilesN = p.Cout / W_BN, tilesX = (p.Wo + W_PX - 1) / W_PX;
+  if (wino_half_geometry(p)) return ((p.B * ((p.Ho + 7) / 8) * tilesX + 1) / 2) * tilesN * p.groups;
+  return p.B * ((p.Ho + W_PY - 1) / W_PY) * tilesX * tilesN * p.groups;
+}
+
 void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant) {
   const int tilesN = p.Cout / W_BN, tilesX = (p.Wo + W_PX - 1) / W_PX, tilesY = (p.Ho + W_PY - 1) / W_PY;
   const dim3 grid(p.B * tilesY * tilesX * tilesN * p.groups);
@@ -652,9 +663,7 @@ void launch_conv_wino(const ConvParams& p, hipStream_t s, int variant) {
     }
 #endif
     // Half-patch geometry where the square patches would waste half a patch row: 1 <= Ho mod 16 <= 8 (the decoders' 40 x 40 maps; PF_WINO_HALF=0: square patches always)
-    static const int half_env = [] { const char* e = getenv("PF_WINO_HALF"); return e ? atoi(e) : 1; }();
-    const int rem = p.Ho % W_PY;
-    if (half_env && rem >= 1 && rem <= 8 && !p.stamps) {
+    if (wino_half_geometry(p) && !p.stamps) {
       const int nhalf = p.B * ((p.Ho + 7) / 8) * tilesX;
       hipLaunchKernelGGL((wino4d_f2x2_kernel<false, 0, true>), dim3(((nhalf + 1) / 2) * tilesN * p.groups), dim3(W4_NT), 0, s, p);
       return;
