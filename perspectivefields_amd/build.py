@@ -70,6 +70,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     hipcc = _hipcc()
+    # objects of translation units that no longer exist (a deleted or renamed .hip) must not linger next to the library that travels to the GPU box
+    keep = {src.replace(".hip", ".o") for src in SOURCES}
+    for f in os.listdir(LIBDIR):
+        if f.endswith(".o") and f not in keep:
+            os.remove(os.path.join(LIBDIR, f))
     objs = []
     procs = []
     for src in SOURCES:
