@@ -285,6 +285,11 @@ int pf_op_rb_linear(int device, const float* d_x, long rows, int tokens, int K, 
  * C = 320; weights in the reference's shapes.  iters > 0 additionally times `iters` launches (x is then garbage). */
 int pf_op_rb_proj_fc1(int device, const float* d_attn, float* d_x, int B, int tokens, int C, const float* h_proj_w, const float* h_proj_b, const float* h_ln2_gamma,
                       const float* h_ln2_beta, float eps, const float* h_fc1_w, const float* h_fc1_b, float* d_hidden, int iters, float* ms_out, void* stream);
+/* The attention half of a one-head, 64-channel MiT block (stage 1 of MiT-B3) as ONE kernel (attn_block.hip): y = x + proj(softmax((LayerNorm_1(x) Wq^T + bq) K^T / 8) V)
+ * -- Block.forward, mix_transformers.py:199, with Attention.forward :108-141 (q :110, softmax :133-134, proj :137-138).  x, y: (B, N, 64) token rows (y may alias x),
+ * kv: (B, M, 128) keys | values of the spatially reduced tokens (1 <= M <= 128); weights in the reference's shapes.  iters > 0 additionally times `iters` launches. */
+int pf_op_mit_attn64(int device, const float* d_x, const float* d_kv, float* d_y, int B, int N, int M, const float* h_ln1_gamma, const float* h_ln1_beta, float eps,
+                     const float* h_q_w, const float* h_q_b, const float* h_proj_w, const float* h_proj_b, int iters, float* ms_out, void* stream);
 /* The key / value branch of a MiT block with 2 x 2 spatial reduction in one launch (rb_chain.hip): kv = Linear_kv(LayerNorm(Conv2d_2x2s2(LayerNorm_1(x)))),
  * mix_transformers.py:119-127 (norm1 of :199 applied to the gathered source tokens).  x: (B, 2 Hr, 2 Wr, C) NHWC token map, C = 320; weights in the reference's shapes
  * (sr [C][C][2][2], kv [2C][C]); kv out: (B, Hr Wr, 2C).  iters > 0 additionally times `iters` launches. */

@@ -71,7 +71,8 @@ struct RbLin { unsigned short* w = nullptr; size_t bytes = 0; float* inv = nullp
 // the key / value branch of a stage-3 block as one launch (rb_chain.hip): combined weight stream (conv as GEMM, then kv) + the two layers' scales / biases
 struct RbSrKv { unsigned short* w = nullptr; size_t bytes = 0; float *sr_inv = nullptr, *sr_b = nullptr, *kv_inv = nullptr, *kv_b = nullptr; };
 struct RbProjFc1 { unsigned short* w = nullptr; size_t bytes = 0; };  // combined weight stream of rb_proj_fc1_kernel (scales / biases: rproj, rfc1)
-struct MitBlock { LNW n1, n2, srn; RbLin rq, rkv, rproj, rfc1, rfc2; RbSrKv rsrkv; RbProjFc1 rpf; ConvW qln /*q with norm1 folded (used next to rsrkv: no LayerNorm-1 launch)*/; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */ };
+struct MitBlock { LNW n1, n2, srn; RbLin rq, rkv, rproj, rfc1, rfc2; RbSrKv rsrkv; RbProjFc1 rpf; ConvW qln /*q with norm1 folded (used next to rsrkv: no LayerNorm-1 launch)*/; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */
+                  unsigned short* a64_w = nullptr; float* a64_tab = nullptr; /* fused attention half of a one-head, 64-channel block (attn_block.hip), when built */ };
 struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
 struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
@@ -249,6 +250,7 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
+  int attn64 = 1;            // PF_ATTN64: the attention half of the one-head stage-1 blocks (q, attention, proj, residual) as one kernel (attn_block.hip)
   int s3_split = 1;          // PF_S3_SPLIT: MiT stage 3 on two half-batches / two streams (mit(), "the stage-3 split")
   int side_stream_mode = 1;  // 1 (default): the q projection of a MiT block runs on a second stream next to the sr conv + kv GEMM (both consume LayerNorm-1's
                              // output, attention joins them) -- small launches that each fill a fraction of the chip: +0.6 % (3 x A/B on one box, profiles/
@@ -667,6 +669,14 @@ struct pf_engine {
             mb.qln.sat_limit = 8188.f;
           }
         }
+        if (attn64 && split_bf16 && mit_attn64_supported(C, MIT_HEADS[s], 100) && MIT_SR[s] > 1) {
+          std::vector<unsigned short> wfr;
+          std::vector<float> tab;
+          attn64_pack(get(b + ".norm1.weight", {C}).data.data(), get(b + ".norm1.bias", {C}).data.data(), get(b + ".attn.q.weight", {C, C}).data.data(), get(b + ".attn.q.bias", {C}).data.data(),
+                      get(b + ".attn.proj.weight", {C, C}).data.data(), get(b + ".attn.proj.bias", {C}).data.data(), &wfr, &tab);
+          mb.a64_w = upload_u16(wfr);
+          mb.a64_tab = upload(tab);
+        }
         if (fuse_mit_mlp && mit_mlp_preferred(C)) {
           std::vector<unsigned short> wpk;
           std::vector<float> tab2;
@@ -977,6 +987,7 @@ struct pf_engine {
         // row-block form of the block's linear layers (stage 3 at batch >= ~14): q, kv, proj, fc1, fc2
         // one 64-row block per CU: the form pays only when the last round of blocks nearly fills the 256 CUs (same-box A/Bs, profiles/r04_rb_linear.md: B = 32 -> 224 blocks
         // +1.2 %, B = 64 -> 448 +1.2 %; B = 48 -> 336 -0.4 %, B = 24 -> 168 -0.9 %, B = 16 -> 112 -4.5 %)
+        const bool fuse64 = attn64 && mb.a64_w && nterms == NT_F16X3 && !S && !c.tuning && sr > 1;
         const long rb_blocks = (long)gate_B * ((N + 63) / 64);
         const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && rb_blocks >= rb_min_blocks && (rb_blocks % num_cus == 0 || rb_blocks % num_cus >= num_cus * 3 / 4);
         if (sr > 1 && use_rb && (rb_chain & 32) && mb.rsrkv.w && mb.qln.ln_s && fuse_ln) {
@@ -1002,6 +1013,17 @@ struct pf_engine {
             a.kv = kvb; a.B = B; a.Hr = kvh; a.Wr = kvw; a.bpi = (kvh * kvw + 31) / 32; a.sat = d_sat;
             ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * Mkv * (double)C * (sr * sr * C + 2 * C), (int)Mkv, 3 * C, sr * sr * C + 2 * C, sr);
             launch_rb_srkv(a, C, c.s);
+          }
+        } else if (sr > 1 && fuse64) {
+          // one head of 64 channels (stage 1): q, the attention core, proj and the residual run as ONE kernel below (attn_block.hip); norm1's output is still needed by
+          // the spatial-reduction conv
+          ln(c, mb.n1, x, xn, M);
+          conv(c, mb.sr, xn, B, Ho, Wo, Ten(srb));
+          if (mb.kv.ln_s) {
+            gemm(c, mb.kv, Ten(srb), Mkv, Ten(kvb));  // LayerNorm(sr conv) inside the kv GEMM
+          } else {
+            ln(c, mb.srn, srb, srn, Mkv);
+            gemm(c, mb.kv, srn, Mkv, Ten(kvb));
           }
         } else if (sr > 1) {
           const bool fork = B >= 4 && (may_fork && can_fork(c));  // batch 1-3: a launch already under-fills the chip; the event pair would only add latency
@@ -1052,16 +1074,27 @@ struct pf_engine {
           gemm(c, mb.q, xn, M, Ten(qb));
           gemm(c, mb.kv, xn, M, Ten(kvb));
         }
-        if (B >= 4 && (sr > 1 || (mb.q.ln_s && mb.kv.ln_s)) && (may_fork && can_fork(c))) (void)hipStreamWaitEvent(c.s, ev_join, 0);
+        if (!fuse64 && B >= 4 && (sr > 1 || (mb.q.ln_s && mb.kv.ln_s)) && (may_fork && can_fork(c))) (void)hipStreamWaitEvent(c.s, ev_join, 0);
         if (c.dbg && c.dbg->range) {
-          range_in(c, fmt("attention s%d.b%d q", s + 1, blk), qb, (size_t)M * C);
+          if (!fuse64) range_in(c, fmt("attention s%d.b%d q", s + 1, blk), qb, (size_t)M * C);   // (fused: q never leaves the registers; the kernel watches it against the same window)
           range_in(c, fmt("attention s%d.b%d kv", s + 1, blk), kvb, (size_t)Mkv * 2 * C);
         }
+        if (fuse64) {
+          range_in(c, fmt("mit_attn64 s%d.b%d x (LN-fused)", s + 1, blk), x, (size_t)M * C);
+          if (!c.dry) {
+            MitAttn64Args a;
+            a.x = x; a.kv = kvb; a.y = x; a.wfr = mb.a64_w; a.tab = mb.a64_tab; a.B = B; a.N = (int)N; a.M = kvh * kvw; a.ln_eps = mb.n1.eps; a.sat = d_sat; a.sat_limit = mb.proj.sat_limit;
+            // work = q + proj (2 x 2 M C C) + QK^T + PV (4 M C kv)
+            ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (double)C + 4.0 * M * C * (kvh * kvw));
+            launch_mit_attn64(a, num_cus, c.s);
+          }
+        }
+        const bool pf_fused = !fuse64 && use_rb && (rb_chain & 64) && mb.rpf.w;  // x += proj(attn); hidden = fc1(LN2(x)) in one launch (rb_chain.hip)
+        if (!fuse64) {
         if (!c.dry) {
           ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (kvh * kvw));  // QK^T + PV
           launch_sr_attention(qb, kvb, ab.f, B, (int)N, kvh * kvw, heads_n, c.s, ab.s.p, ab.s.plane);
         }
-        const bool pf_fused = use_rb && (rb_chain & 64) && mb.rpf.w;  // x += proj(attn); hidden = fc1(LN2(x)) in one launch (rb_chain.hip)
         if (pf_fused) {
           range_in(c, fmt("rb_proj_fc1 s%d.b%d attn", s + 1, blk), ab.f, (size_t)M * C);
           if (!c.dry) {
@@ -1074,6 +1107,7 @@ struct pf_engine {
           }
         } else if (use_rb && (rb_chain & 4)) rb_linear(c, mb.rproj, ab.f, M, (int)N, x, nullptr, ACT_NONE, x);
         else gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
+        }  // !fuse64
         // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
         if (fused_mlp && mb.mlp_w) {                  // norm2 + fc1 + depthwise 3x3 + GELU + fc2 + residual in one kernel, x -> xalt
           range_in(c, fmt("mit_mlp s%d.b%d x (LN-fused)", s + 1, blk), x, (size_t)M * C);
@@ -1485,6 +1519,7 @@ int pf_create(pf_handle* out, int device, int arch) {
 #endif
   if (const char* v = getenv("PF_SIDE_STREAM")) e->side_stream_mode = atoi(v);
   if (const char* v = getenv("PF_S3_SPLIT")) e->s3_split = atoi(v);
+  if (const char* v = getenv("PF_ATTN64")) e->attn64 = atoi(v);
   if (const char* v = getenv("PF_SBA_HEADS")) e->sba_heads = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;

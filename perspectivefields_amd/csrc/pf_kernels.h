@@ -186,6 +186,22 @@ void launch_sr_attention(const float* q, const float* kv, float* out, int B, int
 void launch_sr_attention_variant(int variant, const float* q, const float* kv, float* out, int B, int N, int M, int heads, hipStream_t s,
                                  unsigned short* out_sb = nullptr, size_t sb_plane = 0);
 
+// The attention half of a one-head, 64-channel MiT block as one kernel (attn_block.hip): y = x + proj(softmax((LN1(x) Wq^T + bq) K^T / 8) V); y may alias x
+struct MitAttn64Args {
+  const float* x = nullptr;            // [B][N][64] token rows
+  const float* kv = nullptr;           // [B][M][128] keys | values of the spatially reduced tokens
+  float* y = nullptr;                  // [B][N][64]
+  const unsigned short* wfr = nullptr; // attn64_pack: q and proj fragments
+  const float* tab = nullptr;          // attn64_pack: LayerNorm-1 gamma / beta, inverse scales, biases
+  int B = 0, N = 0, M = 0, QT = 1;
+  float ln_eps = 1e-6f;
+  unsigned* sat = nullptr;             // saturation watch: q against the attention window (8188), y against sat_limit
+  float sat_limit = 65504.f;
+};
+bool mit_attn64_supported(int C, int heads, int kv_rows);
+void launch_mit_attn64(const MitAttn64Args& a, int num_cus, hipStream_t s);
+void attn64_pack(const float* ln_g, const float* ln_b, const float* q_w, const float* q_b, const float* p_w, const float* p_b, std::vector<unsigned short>* wfr, std::vector<float>* tab);
+
 // bilinear x2 (align_corners=False), NHWC
 void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb = nullptr, size_t sb_plane = 0);
 

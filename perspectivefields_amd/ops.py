@@ -176,6 +176,22 @@ def rb_srkv(x, ln1_g, ln1_b, eps1, sr_w, sr_b, srn_g, srn_b, eps2, kv_w, kv_b, i
     return ms.value if iters > 0 else kv
 
 
+def mit_attn64(x, kv, ln_gamma, ln_beta, eps, q_w, q_b, proj_w, proj_b, iters=0, inplace=False):
+    """y = x + proj(softmax((LN1(x) Wq^T + bq) K^T / 8) V) for (B, N, 64) token rows and (B, M, 128) keys | values in one launch (attn_block.hip).
+    iters > 0: returns (y, avg ms per launch)."""
+    import torch
+
+    lib = load_library()
+    x, kv = x.contiguous(), kv.contiguous()
+    B, N, C = x.shape
+    y = x if inplace else torch.empty_like(x)
+    ms = ctypes.c_float()
+    g, b, qw, qb, pw, pb = (_np(t) for t in (ln_gamma, ln_beta, q_w, q_b, proj_w, proj_b))
+    _check(lib.pf_op_mit_attn64(x.device.index, x.data_ptr(), kv.data_ptr(), y.data_ptr(), B, N, kv.shape[1], _hp(g), _hp(b), eps, _hp(qw), _hp(qb), _hp(pw), _hp(pb),
+                                iters, ctypes.byref(ms), _stream_ptr()), None, "pf_op_mit_attn64")
+    return (y, ms.value) if iters > 0 else y
+
+
 def mit_mlp(x, fc1_w, fc1_b, ln_gamma, ln_beta, eps, dw_w, dw_b, fc2_w, fc2_b, iters=0):
     """One MiT block Mlp in one kernel: x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))).  x: (B, Hs, Ws, C) on the GPU, C = 64 or 128.
     iters > 0: returns the average ms per launch instead."""

@@ -557,6 +557,36 @@ def test_sr_attention_both_kernels(ops, B, N, heads, M):
     _close(f16, ref, 2e-5, "attention split-f16 (O(1) data)")
 
 
+@pytest.mark.parametrize("B,N,M", [(2, 6400, 100), (3, 100, 100), (1, 70, 37), (1, 33, 16), (2, 300, 1), (1, 1000, 128)])
+def test_mit_attn64_block(ops, B, N, M):
+    """r06 (attn_block.hip): the attention half of a one-head MiT block -- LayerNorm-1, q projection, softmax(q k^T / 8) v, output projection, residual
+    (mix_transformers.py:199 with :108-141) -- in ONE kernel, every intermediate in registers (transposed products with a permuted contraction index).  Oracle: torch fp64;
+    rows with offsets and an outlier channel (LayerNorm), a dominating key (softmax max path), ragged tiles, in-place update."""
+    C = 64
+    x = _rand((B, N, C), 40) * 2.0 + 0.5
+    x[0, 3] += 40.0
+    x[0, 5, 7] = 300.0
+    kv = _rand((B, M, 2 * C), 41)
+    g, be = 1.0 + 0.2 * _rand((C,), 42), 0.1 * _rand((C,), 43)
+    qw, qb = _rand((C, C), 44, 1.0 / 8.0), 0.1 * _rand((C,), 45)
+    pw, pb = _rand((C, C), 46, 1.0 / 8.0), 0.1 * _rand((C,), 47)
+    xd = x.double()
+    xn = F.layer_norm(xd, (C,), g.double(), be.double(), 1e-6)
+    q = xn @ qw.double().t() + qb.double()
+    if M >= 100:
+        kv[0, 17, :C] = q[0, 9].float() * 3.0     # one key dominates a row
+    k, v = kv.double()[..., :C], kv.double()[..., C:]
+    a = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    ref = xd + (a @ v) @ pw.double().t() + pb.double()
+    got = ops.mit_attn64(x.cuda(), kv.cuda(), g, be, 1e-6, qw, qb, pw, pb)
+    err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+    _, ms = ops.mit_attn64(x.cuda(), kv.cuda(), g, be, 1e-6, qw, qb, pw, pb, iters=10)
+    print(f"[mit_attn64 B{B} N{N} M{M}] max |err| / max |ref| {err:.2e}; {1e3 * ms:.1f} us per launch")
+    _close(got, ref, 3e-5, "mit_attn64")
+    xin = x.cuda().clone()
+    assert torch.equal(ops.mit_attn64(xin, kv.cuda(), g, be, 1e-6, qw, qb, pw, pb, inplace=True), got)   # in place: a block reads and writes its own rows only
+
+
 def test_sr_attention_split_f16_extremes(ops):
     """peaked rows (|logit| ~ 100), tiny and large K / V magnitudes, V beyond the +-4094 range of the scaled split
     (saturates: finite output)"""
