@@ -573,6 +573,10 @@ def main(argv=None):
         try:
             pi = min(Bl - 1, 3)
             line["parity"] = parity_check(args.version, resized, sizes[pi], out, index=pi)
+            if Bl - 1 != pi:   # ... and the LAST image of the batch (another block / wave of every launch); the GPU suite holds the full-batch evidence
+                last = parity_check(args.version, resized, sizes[Bl - 1], out, index=Bl - 1)
+                line["parity"]["second_image"] = {k: last[k] for k in ("image_index", "up_1_minus_cos_max", "latitude_l1_deg", "paramnet_max_abs_delta", "ok") if k in last}
+                line["parity"]["ok"] = bool(line["parity"]["ok"] and last["ok"])
             line["parity_checked"] = bool(line["parity"]["ok"])
         except Exception as e:  # the checker failing must not hide the measurement
             line["parity"] = {"error": repr(e)}
