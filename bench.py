@@ -573,8 +573,9 @@ def main(argv=None):
         try:
             pi = min(Bl - 1, 3)
             line["parity"] = parity_check(args.version, resized, sizes[pi], out, index=pi)
-            if Bl - 1 != pi:   # ... and the LAST image of the batch (another block / wave of every launch); the GPU suite holds the full-batch evidence
-                last = parity_check(args.version, resized, sizes[Bl - 1], out, index=Bl - 1)
+            if Bl - 2 > pi:   # ... and one from the END of the batch (another block / wave of every launch; Bl - 2: with four distinct images tiled over the batch it is not
+                               # image `pi` again); the GPU suite holds the full-batch evidence
+                last = parity_check(args.version, resized, sizes[Bl - 2], out, index=Bl - 2)
                 line["parity"]["second_image"] = {k: last[k] for k in ("image_index", "up_1_minus_cos_max", "latitude_l1_deg", "paramnet_max_abs_delta", "ok") if k in last}
                 line["parity"]["ok"] = bool(line["parity"]["ok"] and last["ok"])
             line["parity_checked"] = bool(line["parity"]["ok"])
