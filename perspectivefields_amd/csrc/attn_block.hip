@@ -320,8 +320,13 @@ void launch_mit_attn64(const MitAttn64Args& a, int num_cus, hipStream_t s) {
   QT = QT < 1 ? 1 : (QT > 8 ? 8 : QT);
   p.QT = QT;
   const size_t lds = ((size_t)2 * p.M * AB_KS + (size_t)2 * AB_C * AB_VS) * sizeof(unsigned short) + AB_WBYTES + AB_TAB * sizeof(float);
-  static const bool attr = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(mit_attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess; }();
-  (void)attr;
+  {  // > 64 KB of dynamic LDS needs the attribute, once per device of the process (a handle is bound to one device; a process may hold several)
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !done[dev])
+      done[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(mit_attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) == hipSuccess;
+  }
   const dim3 grid((tiles + 8 * QT - 1) / (8 * QT), p.B);
   hipLaunchKernelGGL(mit_attn64_kernel, grid, dim3(512), lds, s, p);
 }
