@@ -565,3 +565,19 @@ def test_resize_transform_all_dtypes():
             assert np.array_equal(got, want)
         if ref_rt is not None:
             assert np.array_equal(got, ref_rt(320, 320).apply_image(img)), (shape, dt)
+
+
+def test_verify_trained_script_without_weights(tmp_path):
+    """scripts/verify_trained.py (the first-contact kit for trained checkpoints): without PF_WEIGHTS_DIR it lists the expected checkpoint files of the zoo and exits 2;
+    it imports cleanly on a CPU box (no GPU work before the checks)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "PF_WEIGHTS_DIR"}
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "verify_trained.py")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2, r.stderr[-500:]
+    assert "paramnet_360cities_edina_rpf.pth" in r.stdout and "Paramnet-360Cities-edina-centered" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "verify_trained.py")], capture_output=True, text=True, timeout=300, env=dict(env, PF_WEIGHTS_DIR=str(tmp_path)))
+    # an (empty) weights directory: on a box without a GPU the script says so (2); on a GPU box every version is reported as "checkpoint not in PF_WEIGHTS_DIR" (0)
+    assert (r.returncode == 2 and "no GPU visible" in r.stdout) or (r.returncode == 0 and "not in PF_WEIGHTS_DIR" in r.stdout), (r.returncode, r.stdout[-300:])
