@@ -290,10 +290,6 @@ int pf_op_rb_proj_fc1(int device, const float* d_attn, float* d_x, int B, int to
  * kv: (B, M, 128) keys | values of the spatially reduced tokens (1 <= M <= 128); weights in the reference's shapes.  iters > 0 additionally times `iters` launches. */
 int pf_op_mit_attn64(int device, const float* d_x, const float* d_kv, float* d_y, int B, int N, int M, const float* h_ln1_gamma, const float* h_ln1_beta, float eps,
                      const float* h_q_w, const float* h_q_b, const float* h_proj_w, const float* h_proj_b, int iters, float* ms_out, void* stream);
-/* The same for TWO heads of 64 channels (stage 2 of MiT-B3, C = 128): one head resident at a time, the first head's partial result in a scratch map (attn_block.hip).
- * x, y: (B, N, 128) (y may alias x), kv: (B, M, 256). */
-int pf_op_mit_attn128(int device, const float* d_x, const float* d_kv, float* d_y, int B, int N, int M, const float* h_ln1_gamma, const float* h_ln1_beta, float eps,
-                      const float* h_q_w, const float* h_q_b, const float* h_proj_w, const float* h_proj_b, int iters, float* ms_out, void* stream);
 /* The key / value branch of a MiT block with 2 x 2 spatial reduction in one launch (rb_chain.hip): kv = Linear_kv(LayerNorm(Conv2d_2x2s2(LayerNorm_1(x)))),
  * mix_transformers.py:119-127 (norm1 of :199 applied to the gathered source tokens).  x: (B, 2 Hr, 2 Wr, C) NHWC token map, C = 320; weights in the reference's shapes
  * (sr [C][C][2][2], kv [2C][C]); kv out: (B, Hr Wr, 2C).  iters > 0 additionally times `iters` launches. */

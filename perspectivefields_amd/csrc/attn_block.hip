@@ -331,334 +331,6 @@ void launch_mit_attn64(const MitAttn64Args& a, int num_cus, hipStream_t s) {
   hipLaunchKernelGGL(mit_attn64_kernel, grid, dim3(512), lds, s, p);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------------------
-// TWO heads of 64 channels (stage 2 of MiT-B3: 40 x 40 = 1600 tokens, C = 128, spatial reduction 4 -> 100 key / value rows).  K / V of both heads (127 KB) and the two
-// 128 x 128 matrices (128 KB) do not fit the CU's 160 KB together, so the block walks its tiles TWICE, one head resident at a time:
-//   pass h: stage K_h, V_h, the 64 rows of Wq that make q_h (32 KB) and the 64 columns of Wproj that consume O_h (32 KB); per tile: LayerNorm_1 (again: 128 values per
-//           row), q_h, the attention of head h, the PARTIAL projection  Wproj[:, head h] O_h  over all 128 output channels;
-//   pass 0 writes  x + bias + partial_0  into `tmp` (the engine's otherwise unused attention-output buffer), pass 1 adds partial_1 to it and writes y (= x in place:
-//   pass 1 reads x only for the LayerNorm, and only its own rows).
-// Same register-only chain of transposed products with the permuted contraction index as the one-head kernel above; 4 passes over a 26 MB map instead of the 7 of the
-// three launches it replaces (q: 2, attention: 2, proj: 3).
-namespace {
-constexpr int A2_C = 128;                                  // channels
-constexpr int A2_WQ = 8 * 2 * 2 * 1024;                    // per head: [chunk 8][n tile 2][plane 2] fragments of Wq's 64 rows of that head
-constexpr int A2_WP = 4 * 4 * 2 * 1024;                    // per head: [chunk 4 of the head's 64 columns][n tile 4][plane 2] fragments of Wproj
-constexpr int A2_WHEAD = A2_WQ + A2_WP;                    // 64 KB per head
-constexpr int A2_TAB = 6 * A2_C;
-}  // namespace
-
-__global__ __launch_bounds__(512, 1) void mit_attn128x2_kernel(const MitAttn64Args p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_ab[];
-  const int M = p.M, N = p.N;
-  unsigned short* Kh = reinterpret_cast<unsigned short*>(smem_ab);
-  unsigned short* Kl = Kh + M * AB_KS;
-  unsigned short* VTh = Kl + M * AB_KS;
-  unsigned short* VTl = VTh + AB_C * AB_VS;
-  const unsigned char* Wf = reinterpret_cast<const unsigned char*>(VTl + AB_C * AB_VS);
-  const float* tabs = reinterpret_cast<const float*>(Wf + A2_WHEAD);
-  const int b = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int nchunk = (M + 15) >> 4;
-  const float* t_g = tabs, *t_b = tabs + A2_C, *t_qi = tabs + 2 * A2_C, *t_qb = tabs + 3 * A2_C, *t_pi = tabs + 4 * A2_C, *t_pb = tabs + 5 * A2_C;
-  auto wq = [&](int c, int nt, int plane) { return *reinterpret_cast<const ab_u32x4*>(Wf + (((c * 2 + nt) * 2 + plane) * 1024) + lane * 16); };
-  auto wp = [&](int t, int nt, int plane) { return *reinterpret_cast<const ab_u32x4*>(Wf + A2_WQ + (((t * 4 + nt) * 2 + plane) * 1024) + lane * 16); };
-
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    if (h) __syncthreads();   // every wave is done with head 0's operands
-    // ---- stage K_h (row-major, permuted pieces), V_h (transposed, permuted kv order, zero beyond M), the head's weight fragments, the tables
-    const float* kvb = p.kv + (long)b * M * 2 * A2_C + h * AB_C;
-    for (int i = tid; i < M * (AB_C / 4); i += 512) {
-      const int row = i >> 4, c4 = i & 15;
-      const float4 v = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * A2_C + c4 * 4);
-      const float a[4] = {v.x * AB_KV_SCALE, v.y * AB_KV_SCALE, v.z * AB_KV_SCALE, v.w * AB_KV_SCALE};
-      float hh[4], ll[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float c = __builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);
-        hh[e] = (float)(_Float16)c;
-        ll[e] = c - hh[e];
-      }
-      const int pos = (c4 & ~3) + (((c4 & 1) << 1) | ((c4 >> 1) & 1));
-      *reinterpret_cast<uint2*>(Kh + row * AB_KS + pos * 4) = make_uint2(ab_pack(hh[0], hh[1]), ab_pack(hh[2], hh[3]));
-      *reinterpret_cast<uint2*>(Kl + row * AB_KS + pos * 4) = make_uint2(ab_pack(ll[0], ll[1]), ab_pack(ll[2], ll[3]));
-    }
-    for (int i = tid; i < nchunk * 16 * (AB_C / 4); i += 512) {
-      const int row = i >> 4, c4 = i & 15;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < M) v = *reinterpret_cast<const float4*>(kvb + (long)row * 2 * A2_C + A2_C + c4 * 4);
-      const float a[4] = {v.x * AB_KV_SCALE, v.y * AB_KV_SCALE, v.z * AB_KV_SCALE, v.w * AB_KV_SCALE};
-      const int o = row & 15;
-      const int pos = (row & ~15) + 8 * ((o >> 2) & 1) + (o & 3) + 4 * (o >> 3);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float c = __builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);
-        const _Float16 hv = (_Float16)c;
-        const _Float16 lv = (_Float16)(c - (float)hv);
-        VTh[(c4 * 4 + e) * AB_VS + pos] = __builtin_bit_cast(unsigned short, hv);
-        VTl[(c4 * 4 + e) * AB_VS + pos] = __builtin_bit_cast(unsigned short, lv);
-      }
-    }
-    {
-      const ab_u32x4* src = reinterpret_cast<const ab_u32x4*>(reinterpret_cast<const unsigned char*>(p.wfr) + (size_t)h * A2_WHEAD);
-      for (int i = tid; i < A2_WHEAD / 16; i += 512) reinterpret_cast<ab_u32x4*>(const_cast<unsigned char*>(Wf))[i] = src[i];
-    }
-    if (h == 0)
-      for (int i = tid; i < A2_TAB / 4; i += 512) reinterpret_cast<float4*>(const_cast<float*>(tabs))[i] = reinterpret_cast<const float4*>(p.tab)[i];
-    __syncthreads();
-
-    for (int qt = 0; qt < p.QT; ++qt) {
-      const int q0 = ((blockIdx.x * p.QT + qt) * 8 + wave) * 32;
-      if (q0 >= N) break;  // wave-uniform; no barrier inside the tile loop
-      const int qrow = q0 + l31;
-      const int qr = qrow < N ? qrow : N - 1;
-      const size_t rowoff = ((size_t)b * N + qr) * A2_C + 4 * hi;
-      // ---- the row in the accumulator layout: xr[nt][g] = channels 32 nt + 8 g + 4 hi .. + 3, nt < 4
-      float4 xr[4][4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xr[nt][g] = *reinterpret_cast<const float4*>(p.x + rowoff + 32 * nt + 8 * g);
-      float s = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) s += (xr[nt][g].x + xr[nt][g].y) + (xr[nt][g].z + xr[nt][g].w);
-      s += __shfl_xor(s, 32, 64);
-      const float mu = s * (1.0f / A2_C);
-      float ss = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 v = xr[nt][g];
-          const float4 d = make_float4(v.x - mu, v.y - mu, v.z - mu, v.w - mu);
-          ss = fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, fmaf(d.w, d.w, ss))));
-        }
-      ss += __shfl_xor(ss, 32, 64);
-      const float rs = 1.0f / sqrtf(ss * (1.0f / A2_C) + p.ln_eps);
-      // ---- q_h^T = Wq[head h] LN(x)^T over 8 chunks: the B fragment of chunk c = 2 nt + gp is formed and used at once (no 64-register fragment array)
-      ab_f32x16 qacc[2];
-#pragma unroll
-      for (int nq = 0; nq < 2; ++nq)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) qacc[nq][e] = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          float a[8];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int g = 2 * gp + u, n = 32 * nt + 8 * g + 4 * hi;
-            const float4 gm = *reinterpret_cast<const float4*>(t_g + n), be = *reinterpret_cast<const float4*>(t_b + n);
-            const float4 v = xr[nt][g];
-            a[4 * u] = fmaf((v.x - mu) * rs, gm.x, be.x); a[4 * u + 1] = fmaf((v.y - mu) * rs, gm.y, be.y); a[4 * u + 2] = fmaf((v.z - mu) * rs, gm.z, be.z); a[4 * u + 3] = fmaf((v.w - mu) * rs, gm.w, be.w);
-          }
-          ab_u32x4 bh, bl;
-          ab_split8(a, bh, bl);
-          const int c = 2 * nt + gp;
-#pragma unroll
-          for (int nq = 0; nq < 2; ++nq) qacc[nq] = ab_mma3(wq(c, nq, 0), wq(c, nq, 1), bh, bl, qacc[nq]);
-        }
-      // ---- q_h = acc / S + bias (channels 64 h + 32 nq + 8 g + 4 hi + e), watched, x d^-0.5 x 64, split: chunk t = 2 nq + (g >> 1) of S^T = K Q^T
-      ab_u32x4 qh[4], ql[4];
-#pragma unroll
-      for (int nq = 0; nq < 2; ++nq)
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          float a[8];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int g = 2 * gp + u, n = 64 * h + 32 * nq + 8 * g + 4 * hi;
-            const float4 iv = *reinterpret_cast<const float4*>(t_qi + n), bb = *reinterpret_cast<const float4*>(t_qb + n);
-            const float q0v = fmaf(qacc[nq][4 * g], iv.x, bb.x), q1v = fmaf(qacc[nq][4 * g + 1], iv.y, bb.y), q2v = fmaf(qacc[nq][4 * g + 2], iv.z, bb.z), q3v = fmaf(qacc[nq][4 * g + 3], iv.w, bb.w);
-            if (p.sat) sat_watch4(p.sat, 8188.f, q0v, q1v, q2v, q3v);
-            a[4 * u] = q0v * AB_QS; a[4 * u + 1] = q1v * AB_QS; a[4 * u + 2] = q2v * AB_QS; a[4 * u + 3] = q3v * AB_QS;
-          }
-          ab_split8(a, qh[2 * nq + gp], ql[2 * nq + gp]);
-        }
-      // ---- S^T, softmax, O^T of head h: as mit_attn64_kernel
-      ab_f32x16 sacc[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[c][e] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (32 * c < M) {
-          const int krow = min(c * 32 + l31, M - 1);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const ab_u32x4 kh = *reinterpret_cast<const ab_u32x4*>(Kh + krow * AB_KS + 16 * t + 8 * hi);
-            const ab_u32x4 kl = *reinterpret_cast<const ab_u32x4*>(Kl + krow * AB_KS + 16 * t + 8 * hi);
-            sacc[c] = ab_mma3(kh, kl, qh[t], ql[t], sacc[c]);
-          }
-        }
-      }
-      constexpr float L2E = 1.4426950408889634f / (AB_KV_SCALE * AB_Q_SCALE);
-      float mx = -3.0e38f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (32 * c + 32 <= M) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[c][r]);
-        } else if (32 * c < M) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (kvi < M) mx = fmaxf(mx, sacc[c][r]);
-          }
-        }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mx2 = mx * L2E - AB_P_EXP;
-      float sum = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (32 * c + 32 <= M) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float pexp = __builtin_amdgcn_exp2f(fmaf(sacc[c][r], L2E, -mx2));
-            sacc[c][r] = pexp;
-            sum += pexp;
-          }
-        } else if (32 * c < M) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kvi = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float pexp = kvi < M ? __builtin_amdgcn_exp2f(fmaf(sacc[c][r], L2E, -mx2)) : 0.f;
-            sacc[c][r] = pexp;
-            sum += pexp;
-          }
-        }
-      }
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.0f / (sum * AB_KV_SCALE);
-      ab_f32x16 oacc[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[j][e] = 0.f;
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        if (cc < nchunk) {
-          float pe[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pe[e] = sacc[cc >> 1][8 * (cc & 1) + e];
-          ab_u32x4 ph, pl;
-          ab_split8(pe, ph, pl);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const ab_u32x4 vh = *reinterpret_cast<const ab_u32x4*>(VTh + (32 * j + l31) * AB_VS + 16 * cc + 8 * hi);
-            const ab_u32x4 vl = *reinterpret_cast<const ab_u32x4*>(VTl + (32 * j + l31) * AB_VS + 16 * cc + 8 * hi);
-            oacc[j] = ab_mma3(vh, vl, ph, pl, oacc[j]);
-          }
-        }
-      }
-      // ---- partial projection over the head's 64 columns: chunk t = 2 j + gp, all four output tiles
-      ab_f32x16 yacc[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) yacc[nt][e] = 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          float a[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) a[u] = oacc[j][8 * gp + u] * inv;
-          ab_u32x4 oh, ol;
-          ab_split8(a, oh, ol);
-          const int t = 2 * j + gp;
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) yacc[nt] = ab_mma3(wp(t, nt, 0), wp(t, nt, 1), oh, ol, yacc[nt]);
-        }
-      // ---- pass 0: tmp = x + bias + partial_0; pass 1: y = tmp + partial_1
-      if (qrow < N) {
-        const size_t o0 = ((size_t)b * N + qrow) * A2_C + 4 * hi;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n = 32 * nt + 8 * g + 4 * hi;
-            const float4 iv = *reinterpret_cast<const float4*>(t_pi + n);
-            // the residual row is read AGAIN here (an L2 hit) rather than held in 64 registers through the attention phase: the kernel sits at its 256-register cap
-            float4 r = *reinterpret_cast<const float4*>((h == 0 ? p.x : p.tmp) + o0 + 32 * nt + 8 * g);
-            if (h == 0) {
-              const float4 bb = *reinterpret_cast<const float4*>(t_pb + n);
-              r = make_float4(r.x + bb.x, r.y + bb.y, r.z + bb.z, r.w + bb.w);
-            }
-            const float4 w = make_float4(fmaf(yacc[nt][4 * g], iv.x, r.x), fmaf(yacc[nt][4 * g + 1], iv.y, r.y), fmaf(yacc[nt][4 * g + 2], iv.z, r.z), fmaf(yacc[nt][4 * g + 3], iv.w, r.w));
-            if (h == 0) {
-              *reinterpret_cast<float4*>(p.tmp + o0 + 32 * nt + 8 * g) = w;
-            } else {
-              if (p.sat) sat_watch4(p.sat, p.sat_limit, w.x, w.y, w.z, w.w);
-              *reinterpret_cast<float4*>(p.y + o0 + 32 * nt + 8 * g) = w;
-            }
-          }
-      }
-    }
-  }
-}
-
-bool mit_attn128_supported(int C, int heads, int kv_rows) { return C == A2_C && heads == 2 && kv_rows >= 1 && kv_rows <= 128; }
-
-void launch_mit_attn128(const MitAttn64Args& a, int num_cus, hipStream_t s) {
-  MitAttn64Args p = a;
-  const int tiles = (p.N + 31) / 32;
-  int QT = (int)(((long)tiles * p.B + 8L * num_cus - 1) / (8L * num_cus));
-  QT = QT < 1 ? 1 : (QT > 8 ? 8 : QT);
-  p.QT = QT;
-  const size_t lds = ((size_t)2 * p.M * AB_KS + (size_t)2 * AB_C * AB_VS) * sizeof(unsigned short) + A2_WHEAD + A2_TAB * sizeof(float);
-  {
-    static bool done[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !done[dev])
-      done[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(mit_attn128x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess;
-  }
-  const dim3 grid((tiles + 8 * QT - 1) / (8 * QT), p.B);
-  hipLaunchKernelGGL(mit_attn128x2_kernel, grid, dim3(512), lds, s, p);
-}
-
-// Host side of the two-head kernel: per head h, the fragments of Wq's rows 64 h .. 64 h + 63 ([chunk c < 8][n tile < 2][plane]) and of Wproj's columns 64 h .. 64 h + 63
-// ([chunk t < 4][n tile < 4][plane]), permuted contraction index as above; tables over the 128 channels
-void attn128_pack(const float* ln_g, const float* ln_b, const float* q_w, const float* q_b, const float* p_w, const float* p_b, std::vector<unsigned short>* wfr, std::vector<float>* tab) {
-  const pf_host::F16Planes qs = pf_host::split_f16x2(std::vector<float>(q_w, q_w + (size_t)A2_C * A2_C), A2_C), ps = pf_host::split_f16x2(std::vector<float>(p_w, p_w + (size_t)A2_C * A2_C), A2_C);
-  const size_t n_all = (size_t)A2_C * A2_C;
-  wfr->assign((size_t)2 * A2_WHEAD / 2, 0);
-  for (int h = 0; h < 2; ++h) {
-    unsigned short* base = wfr->data() + (size_t)h * (A2_WHEAD / 2);
-    for (int c = 0; c < 8; ++c)
-      for (int nt = 0; nt < 2; ++nt)
-        for (int plane = 0; plane < 2; ++plane)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
-              const int n = 64 * h + 32 * nt + (lane & 31), k = 16 * c + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-              base[((((size_t)c * 2 + nt) * 2 + plane) * 64 + lane) * 8 + j] = qs.planes[plane * n_all + (size_t)n * A2_C + k];
-            }
-    unsigned short* bp = base + A2_WQ / 2;
-    for (int t = 0; t < 4; ++t)
-      for (int nt = 0; nt < 4; ++nt)
-        for (int plane = 0; plane < 2; ++plane)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
-              const int n = 32 * nt + (lane & 31), k = 64 * h + 16 * t + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-              bp[((((size_t)t * 4 + nt) * 2 + plane) * 64 + lane) * 8 + j] = ps.planes[plane * n_all + (size_t)n * A2_C + k];
-            }
-  }
-  tab->resize(A2_TAB);
-  for (int n = 0; n < A2_C; ++n) {
-    (*tab)[n] = ln_g[n]; (*tab)[A2_C + n] = ln_b[n];
-    (*tab)[2 * A2_C + n] = qs.inv_scale[n]; (*tab)[3 * A2_C + n] = q_b[n];
-    (*tab)[4 * A2_C + n] = ps.inv_scale[n]; (*tab)[5 * A2_C + n] = p_b[n];
-  }
-}
-
 // Host side: LayerNorm-1 table, and both 64 x 64 matrices as split-f16 planes (per-output-channel power-of-two scale, host_pack.h split_f16x2) in MFMA fragment order
 // with the PERMUTED contraction index: fragment (matrix, chunk c, n tile, plane), lane (l31, hi), element j  =  Ws[32 nt + l31][16 c + 8 (j >> 2) + 4 hi + (j & 3)]
 void attn64_pack(const float* ln_g, const float* ln_b, const float* q_w, const float* q_b, const float* p_w, const float* p_b, std::vector<unsigned short>* wfr, std::vector<float>* tab) {

@@ -72,8 +72,7 @@ struct RbLin { unsigned short* w = nullptr; size_t bytes = 0; float* inv = nullp
 struct RbSrKv { unsigned short* w = nullptr; size_t bytes = 0; float *sr_inv = nullptr, *sr_b = nullptr, *kv_inv = nullptr, *kv_b = nullptr; };
 struct RbProjFc1 { unsigned short* w = nullptr; size_t bytes = 0; };  // combined weight stream of rb_proj_fc1_kernel (scales / biases: rproj, rfc1)
 struct MitBlock { LNW n1, n2, srn; RbLin rq, rkv, rproj, rfc1, rfc2; RbSrKv rsrkv; RbProjFc1 rpf; ConvW qln /*q with norm1 folded (used next to rsrkv: no LayerNorm-1 launch)*/; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */
-                  unsigned short* a64_w = nullptr; float* a64_tab = nullptr; /* fused attention half of a one-head, 64-channel block (attn_block.hip), when built */
-                  unsigned short* a128_w = nullptr; float* a128_tab = nullptr; /* ... of a two-head, 128-channel block */ };
+                  unsigned short* a64_w = nullptr; float* a64_tab = nullptr; /* fused attention half of a one-head, 64-channel block (attn_block.hip), when built */ };
 struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
 struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
@@ -251,7 +250,6 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
-  int attn128 = 1;           // PF_ATTN128: ... and of the two-head stage-2 blocks (one head resident at a time)
   int attn64 = 1;            // PF_ATTN64: the attention half of the one-head stage-1 blocks (q, attention, proj, residual) as one kernel (attn_block.hip)
   int s3_split = 1;          // PF_S3_SPLIT: MiT stage 3 on two half-batches / two streams (mit(), "the stage-3 split")
   int side_stream_mode = 1;  // 1 (default): the q projection of a MiT block runs on a second stream next to the sr conv + kv GEMM (both consume LayerNorm-1's
@@ -679,14 +677,6 @@ struct pf_engine {
           mb.a64_w = upload_u16(wfr);
           mb.a64_tab = upload(tab);
         }
-        if (attn64 >= 1 && attn128 && split_bf16 && mit_attn128_supported(C, MIT_HEADS[s], 100) && MIT_SR[s] > 1) {
-          std::vector<unsigned short> wfr;
-          std::vector<float> tab;
-          attn128_pack(get(b + ".norm1.weight", {C}).data.data(), get(b + ".norm1.bias", {C}).data.data(), get(b + ".attn.q.weight", {C, C}).data.data(), get(b + ".attn.q.bias", {C}).data.data(),
-                       get(b + ".attn.proj.weight", {C, C}).data.data(), get(b + ".attn.proj.bias", {C}).data.data(), &wfr, &tab);
-          mb.a128_w = upload_u16(wfr);
-          mb.a128_tab = upload(tab);
-        }
         if (fuse_mit_mlp && mit_mlp_preferred(C)) {
           std::vector<unsigned short> wpk;
           std::vector<float> tab2;
@@ -997,7 +987,7 @@ struct pf_engine {
         // row-block form of the block's linear layers (stage 3 at batch >= ~14): q, kv, proj, fc1, fc2
         // one 64-row block per CU: the form pays only when the last round of blocks nearly fills the 256 CUs (same-box A/Bs, profiles/r04_rb_linear.md: B = 32 -> 224 blocks
         // +1.2 %, B = 64 -> 448 +1.2 %; B = 48 -> 336 -0.4 %, B = 24 -> 168 -0.9 %, B = 16 -> 112 -4.5 %)
-        const bool fuse64 = attn64 && (mb.a64_w || (mb.a128_w && ab.f)) && nterms == NT_F16X3 && !S && !c.tuning && sr > 1;   // (the name covers both fused forms: one head / two heads)
+        const bool fuse64 = attn64 && mb.a64_w && nterms == NT_F16X3 && !S && !c.tuning && sr > 1;
         const long rb_blocks = (long)gate_B * ((N + 63) / 64);
         const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && rb_blocks >= rb_min_blocks && (rb_blocks % num_cus == 0 || rb_blocks % num_cus >= num_cus * 3 / 4);
         if (sr > 1 && use_rb && (rb_chain & 32) && mb.rsrkv.w && mb.qln.ln_s && fuse_ln) {
@@ -1093,11 +1083,10 @@ struct pf_engine {
           range_in(c, fmt("mit_attn64 s%d.b%d x (LN-fused)", s + 1, blk), x, (size_t)M * C);
           if (!c.dry) {
             MitAttn64Args a;
-            a.x = x; a.kv = kvb; a.y = x; a.B = B; a.N = (int)N; a.M = kvh * kvw; a.ln_eps = mb.n1.eps; a.sat = d_sat; a.sat_limit = mb.proj.sat_limit;
+            a.x = x; a.kv = kvb; a.y = x; a.wfr = mb.a64_w; a.tab = mb.a64_tab; a.B = B; a.N = (int)N; a.M = kvh * kvw; a.ln_eps = mb.n1.eps; a.sat = d_sat; a.sat_limit = mb.proj.sat_limit;
             // work = q + proj (2 x 2 M C C) + QK^T + PV (4 M C kv)
             ProfScope ps(c.prof, c.s, PC_ATTN, 4.0 * M * C * (double)C + 4.0 * M * C * (kvh * kvw));
-            if (mb.a64_w) { a.wfr = mb.a64_w; a.tab = mb.a64_tab; launch_mit_attn64(a, num_cus, c.s); }
-            else { a.wfr = mb.a128_w; a.tab = mb.a128_tab; a.tmp = ab.f; launch_mit_attn128(a, num_cus, c.s); }   // two heads: the attention-output buffer is the scratch of the first head's partial result
+            launch_mit_attn64(a, num_cus, c.s);
           }
         }
         const bool pf_fused = !fuse64 && use_rb && (rb_chain & 64) && mb.rpf.w;  // x += proj(attn); hidden = fc1(LN2(x)) in one launch (rb_chain.hip)
@@ -1531,7 +1520,6 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_SIDE_STREAM")) e->side_stream_mode = atoi(v);
   if (const char* v = getenv("PF_S3_SPLIT")) e->s3_split = atoi(v);
   if (const char* v = getenv("PF_ATTN64")) e->attn64 = atoi(v);
-  if (const char* v = getenv("PF_ATTN128")) e->attn128 = atoi(v);
   if (const char* v = getenv("PF_SBA_HEADS")) e->sba_heads = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;

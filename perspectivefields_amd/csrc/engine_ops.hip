@@ -225,45 +225,6 @@ int pf_op_mit_attn64(int device, const float* x, const float* kv, float* y, int 
   return rc;
 }
 
-int pf_op_mit_attn128(int device, const float* x, const float* kv, float* y, int B, int N, int M, const float* ln_g, const float* ln_b, float eps, const float* q_w, const float* q_b,
-                      const float* p_w, const float* p_b, int iters, float* ms_out, void* stream) {
-  std::string err;
-  int rc = check_device(device, &err);
-  if (rc != PF_OK) { g_create_error = err; return rc; }
-  if (!x || !kv || !y || !ln_g || !ln_b || !q_w || !q_b || !p_w || !p_b || B <= 0 || N <= 0 || !mit_attn128_supported(128, 2, M)) {
-    g_create_error = "pf_op_mit_attn128: all operands required; 1 <= kv rows <= 128";
-    return PF_ERR_ARG;
-  }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  TmpDev tmp;
-  std::vector<unsigned short> wfr;
-  std::vector<float> tab;
-  attn128_pack(ln_g, ln_b, q_w, q_b, p_w, p_b, &wfr, &tab);
-  float* scratch = nullptr;
-  if (hipMalloc(&scratch, (size_t)B * N * 128 * 4) != hipSuccess) { g_create_error = "pf_op_mit_attn128: hipMalloc failed"; return PF_ERR_DEVICE; }
-  MitAttn64Args a;
-  a.x = x; a.kv = kv; a.y = y; a.tmp = scratch; a.wfr = tmp.up_u16(wfr); a.tab = tmp.up(tab); a.B = B; a.N = N; a.M = M; a.ln_eps = eps;
-  int cus = 256;
-  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
-  launch_mit_attn128(a, cus, s);
-  if (iters > 0 && ms_out) {
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, s);
-    for (int i = 0; i < iters; ++i) launch_mit_attn128(a, cus, s);
-    (void)hipEventRecord(e1, s);
-    (void)hipEventSynchronize(e1);
-    float t = 0.f;
-    (void)hipEventElapsedTime(&t, e0, e1);
-    *ms_out = t / iters;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  }
-  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
-  tmp.sync_free(s);
-  (void)hipFree(scratch);
-  return rc;
-}
-
 int pf_op_rb_srkv(int device, const float* x, int B, int Hr, int Wr, int C, const float* ln1_g, const float* ln1_b, float eps1, const float* sr_w, const float* sr_b,
                   const float* srn_g, const float* srn_b, float eps2, const float* kv_w, const float* kv_b, float* kv, int iters, float* ms_out, void* stream) {
   std::string err;

@@ -197,13 +197,8 @@ struct MitAttn64Args {
   float ln_eps = 1e-6f;
   unsigned* sat = nullptr;             // saturation watch: q against the attention window (8188), y against sat_limit
   float sat_limit = 65504.f;
-  float* tmp = nullptr;                // two-head form only: [B][N][128] scratch for the first head's partial result
 };
 bool mit_attn64_supported(int C, int heads, int kv_rows);
-// the same for TWO heads of 64 channels (C = 128, stage 2), one head resident at a time (attn_block.hip); x / y: [B][N][128], kv: [B][M][256], a.tmp required
-bool mit_attn128_supported(int C, int heads, int kv_rows);
-void launch_mit_attn128(const MitAttn64Args& a, int num_cus, hipStream_t s);
-void attn128_pack(const float* ln_g, const float* ln_b, const float* q_w, const float* q_b, const float* p_w, const float* p_b, std::vector<unsigned short>* wfr, std::vector<float>* tab);
 void launch_mit_attn64(const MitAttn64Args& a, int num_cus, hipStream_t s);
 void attn64_pack(const float* ln_g, const float* ln_b, const float* q_w, const float* q_b, const float* p_w, const float* p_b, std::vector<unsigned short>* wfr, std::vector<float>* tab);
 

@@ -177,7 +177,7 @@ def rb_srkv(x, ln1_g, ln1_b, eps1, sr_w, sr_b, srn_g, srn_b, eps2, kv_w, kv_b, i
 
 
 def mit_attn64(x, kv, ln_gamma, ln_beta, eps, q_w, q_b, proj_w, proj_b, iters=0, inplace=False):
-    """y = x + proj(softmax((LN1(x) Wq^T + bq) K^T / 8) V) per head of 64 channels for (B, N, C) token rows and (B, M, 2C) keys | values, C = 64 (one head) or 128 (two heads), in one launch (attn_block.hip).
+    """y = x + proj(softmax((LN1(x) Wq^T + bq) K^T / 8) V) for (B, N, 64) token rows and (B, M, 128) keys | values in one launch (attn_block.hip).
     iters > 0: returns (y, avg ms per launch)."""
     import torch
 
@@ -187,9 +187,8 @@ def mit_attn64(x, kv, ln_gamma, ln_beta, eps, q_w, q_b, proj_w, proj_b, iters=0,
     y = x if inplace else torch.empty_like(x)
     ms = ctypes.c_float()
     g, b, qw, qb, pw, pb = (_np(t) for t in (ln_gamma, ln_beta, q_w, q_b, proj_w, proj_b))
-    fn = {64: lib.pf_op_mit_attn64, 128: lib.pf_op_mit_attn128}[C]   # one head of 64 channels / two heads of 64 (attn_block.hip)
-    _check(fn(x.device.index, x.data_ptr(), kv.data_ptr(), y.data_ptr(), B, N, kv.shape[1], _hp(g), _hp(b), eps, _hp(qw), _hp(qb), _hp(pw), _hp(pb),
-              iters, ctypes.byref(ms), _stream_ptr()), None, "pf_op_mit_attn")
+    _check(lib.pf_op_mit_attn64(x.device.index, x.data_ptr(), kv.data_ptr(), y.data_ptr(), B, N, kv.shape[1], _hp(g), _hp(b), eps, _hp(qw), _hp(qb), _hp(pw), _hp(pb),
+                                iters, ctypes.byref(ms), _stream_ptr()), None, "pf_op_mit_attn64")
     return (y, ms.value) if iters > 0 else y
 
 
