@@ -290,6 +290,11 @@ int pf_op_rb_proj_fc1(int device, const float* d_attn, float* d_x, int B, int to
  * kv: (B, M, 128) keys | values of the spatially reduced tokens (1 <= M <= 128); weights in the reference's shapes.  iters > 0 additionally times `iters` launches. */
 int pf_op_mit_attn64(int device, const float* d_x, const float* d_kv, float* d_y, int B, int N, int M, const float* h_ln1_gamma, const float* h_ln1_beta, float eps,
                      const float* h_q_w, const float* h_q_b, const float* h_proj_w, const float* h_proj_b, int iters, float* ms_out, void* stream);
+/* The 7 x 7 convolutions that read the normalised image, as one specialised kernel (stem7.hip): conv 7x7 / stride 2 (the low-level encoder, perspectivefields.py:70-83: eval
+ * BatchNorm folded by the caller into weight / bias, relu = 1) or stride 4 (MiT's first patch embedding + its LayerNorm, mix_transformers.py:205-246: ln gamma / beta given),
+ * pad 3, 3 -> 64 channels.  x: (B, H, W, 4) NHWC4 with channel 3 = 0; y: (B, Ho, Wo, 64); weight in the reference's shape (64, 3, 7, 7).  iters > 0 also times launches. */
+int pf_op_stem7x7(int device, const float* d_x, float* d_y, int B, int H, int W, int stride, const float* h_weight, const float* h_bias, int relu, const float* h_ln_gamma,
+                  const float* h_ln_beta, float eps, int iters, float* ms_out, void* stream);
 /* The key / value branch of a MiT block with 2 x 2 spatial reduction in one launch (rb_chain.hip): kv = Linear_kv(LayerNorm(Conv2d_2x2s2(LayerNorm_1(x)))),
  * mix_transformers.py:119-127 (norm1 of :199 applied to the gathered source tokens).  x: (B, 2 Hr, 2 Wr, C) NHWC token map, C = 320; weights in the reference's shapes
  * (sr [C][C][2][2], kv [2C][C]); kv out: (B, Hr Wr, 2C).  iters > 0 additionally times `iters` launches. */

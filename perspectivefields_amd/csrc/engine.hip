@@ -250,6 +250,8 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
+  int stem7 = 1;             // PF_STEM7: the two 7 x 7 convs on the normalised image (low-level encoder; first patch embedding + its LayerNorm) as the specialised kernel of stem7.hip
+  unsigned short* ll_s7_w = nullptr; float* ll_s7_tab = nullptr; unsigned short* pe_s7_w = nullptr; float* pe_s7_tab = nullptr;
   int attn64 = 1;            // PF_ATTN64: the attention half of the one-head stage-1 blocks (q, attention, proj, residual) as one kernel (attn_block.hip)
   int s3_split = 1;          // PF_S3_SPLIT: MiT stage 3 on two half-batches / two streams (mit(), "the stage-3 split")
   int side_stream_mode = 1;  // 1 (default): the q projection of a MiT block runs on a second stream next to the sr conv + kv GEMM (both consume LayerNorm-1's
@@ -616,6 +618,13 @@ struct pf_engine {
       const std::string pe = "backbone.patch_embed" + std::to_string(s + 1);
       stages[s].pe = make_conv(pe + ".proj.weight", pe + ".proj.bias", C, cin, MIT_PK[s], MIT_PS[s], MIT_PP[s]);
       stages[s].pen = make_ln(pe + ".norm", C, 1e-5f);  // nn.LayerNorm default eps (mix_transformers.py:224)
+      if (s == 0 && stem7 && split_bf16 && stem7x7_supported(cin, C, MIT_PK[s], MIT_PS[s], MIT_PP[s])) {   // conv + LayerNorm of the first patch embedding as one kernel (stem7.hip)
+        std::vector<unsigned short> wfr;
+        std::vector<float> tab;
+        stem7x7_pack(get(pe + ".proj.weight", {C, cin, 7, 7}).data.data(), nullptr, get(pe + ".proj.bias", {C}).data.data(), get(pe + ".norm.weight", {C}).data.data(),
+                     get(pe + ".norm.bias", {C}).data.data(), &wfr, &tab);
+        pe_s7_w = upload_u16(wfr); pe_s7_tab = upload(tab);
+      }
       for (int i = 0; i < MIT_DEPTHS[s]; ++i) {
         const std::string b = "backbone.block" + std::to_string(s + 1) + "." + std::to_string(i);
         MitBlock mb;
@@ -705,6 +714,12 @@ struct pf_engine {
         bias[n] = (float)((double)be[n] - (double)mu[n] * sc[n]);
       }
       ll = make_conv("ll_enc.conv1.weight", "", LL_CH, 3, 7, 2, 3, sc.data(), &bias);
+      if (stem7 && split_bf16 && stem7x7_supported(3, LL_CH, 7, 2, 3)) {
+        std::vector<unsigned short> wfr;
+        std::vector<float> tab;
+        stem7x7_pack(get("ll_enc.conv1.weight", {LL_CH, 3, 7, 7}).data.data(), sc.data(), bias.data(), nullptr, nullptr, &wfr, &tab);
+        ll_s7_w = upload_u16(wfr); ll_s7_tab = upload(tab);
+      }
       auto it = host.find("ll_enc.bn1.num_batches_tracked");
       if (it != host.end()) it->second.used = true;
     }
@@ -939,6 +954,18 @@ struct pf_engine {
     launch_rb_linear(a, r.K, c.s);
   }
 
+  // conv 7x7 on the normalised image (+ ReLU or + LayerNorm) as one launch of stem7.hip
+  void stem(Ctx& c, const unsigned short* wfr, const float* tab, const float* x4, float* y, int B, int H, int W, int stride, bool relu, bool lnorm, float eps, float sat_limit, const char* what) {
+    range_in(c, fmt("stem7x7 s%d %s x", stride, what), x4, (size_t)B * H * W * 4);
+    if (c.dry) return;
+    Stem7Args a;
+    a.x = x4; a.y = y; a.wfr = wfr; a.tab = tab; a.B = B; a.H = H; a.W = W; a.stride = stride; a.Ho = (H + 6 - 7) / stride + 1; a.Wo = (W + 6 - 7) / stride + 1;
+    a.relu = relu ? 1 : 0; a.ln = lnorm ? 1 : 0; a.ln_eps = eps; a.sat = lnorm ? nullptr : d_sat; a.sat_limit = sat_limit;
+    const long M = (long)B * a.Ho * a.Wo;
+    ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * M * 64.0 * 147.0, (int)M, 64, 147, 7);
+    launch_stem7x7(a, num_cus, c.s);
+  }
+
   // MiT-B3 forward_features (mix_transformers.py:449-485); feats[s] = NHWC stage outputs.
   // With `sba` every tensor that only feeds GEMMs (LayerNorm outputs, attention output, the GELU'd hidden map) is
   // written as split planes by its producer and never exists in fp32.
@@ -966,8 +993,12 @@ struct pf_engine {
         (void)hipEventRecord(ev_ll, side2);
         ll_forked = true;
       }
-      conv(c, st.pe, cur, B, H, W, Ten(x));
-      ln(c, st.pen, x, Ten(x), M);
+      if (s == 0 && pe_s7_w && nterms == NT_F16X3 && !c.tuning && cur.f) {
+        stem(c, pe_s7_w, pe_s7_tab, cur.f, x, B, H, W, MIT_PS[s], false, true, st.pen.eps, 65504.f, "patch_embed1 + norm");
+      } else {
+        conv(c, st.pe, cur, B, H, W, Ten(x));
+        ln(c, st.pen, x, Ten(x), M);
+      }
       const size_t mk = c.mark();
       const int kvh = Ho / sr, kvw = Wo / sr;
       const long Mkv = (long)B * kvh * kvw;
@@ -1365,6 +1396,7 @@ struct pf_engine {
     mit(c, B, x0, feats, &llf);
     if (!c.dry && c.prof) c.prof->mark(PH_LL, c.s);
     if (ll_forked) (void)hipStreamWaitEvent(c.s, ev_ll, 0);
+    else if (ll_s7_w && nterms == NT_F16X3 && !c.tuning && llf.f && !llf.s.p) stem(c, ll_s7_w, ll_s7_tab, x0, llf.f, B, NET, NET, 2, true, false, 0.f, ll.sat_limit, "low-level encoder");
     else conv(c, ll, Ten(x0), B, NET, NET, llf, ACT_RELU);  // BN folded (perspectivefields.py:79-83)
     tap(c, "ll", llf.f, B, NET / 2, NET / 2, LL_CH);
     const bool pf = pred_fused();
@@ -1520,6 +1552,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_SIDE_STREAM")) e->side_stream_mode = atoi(v);
   if (const char* v = getenv("PF_S3_SPLIT")) e->s3_split = atoi(v);
   if (const char* v = getenv("PF_ATTN64")) e->attn64 = atoi(v);
+  if (const char* v = getenv("PF_STEM7")) e->stem7 = atoi(v);
   if (const char* v = getenv("PF_SBA_HEADS")) e->sba_heads = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;

@@ -225,6 +225,43 @@ int pf_op_mit_attn64(int device, const float* x, const float* kv, float* y, int 
   return rc;
 }
 
+int pf_op_stem7x7(int device, const float* x, float* y, int B, int H, int W, int stride, const float* w, const float* bias, int relu, const float* ln_g, const float* ln_b, float eps,
+                  int iters, float* ms_out, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (!x || !y || !w || B <= 0 || H <= 0 || W <= 0 || !stem7x7_supported(3, 64, 7, stride, 3) || ((ln_g == nullptr) != (ln_b == nullptr))) {
+    g_create_error = "pf_op_stem7x7: x, y, weight required; stride 2 or 4; LayerNorm gamma and beta together";
+    return PF_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  std::vector<unsigned short> wfr;
+  std::vector<float> tab;
+  stem7x7_pack(w, nullptr, bias, ln_g, ln_b, &wfr, &tab);
+  Stem7Args a;
+  a.x = x; a.y = y; a.wfr = tmp.up_u16(wfr); a.tab = tmp.up(tab); a.B = B; a.H = H; a.W = W; a.stride = stride;
+  a.Ho = (H + 6 - 7) / stride + 1; a.Wo = (W + 6 - 7) / stride + 1; a.relu = relu; a.ln = ln_g ? 1 : 0; a.ln_eps = eps;
+  int cus = 256;
+  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+  launch_stem7x7(a, cus, s);
+  if (iters > 0 && ms_out) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) launch_stem7x7(a, cus, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms_out = t / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
 int pf_op_rb_srkv(int device, const float* x, int B, int Hr, int Wr, int C, const float* ln1_g, const float* ln1_b, float eps1, const float* sr_w, const float* sr_b,
                   const float* srn_g, const float* srn_b, float eps2, const float* kv_w, const float* kv_b, float* kv, int iters, float* ms_out, void* stream) {
   std::string err;

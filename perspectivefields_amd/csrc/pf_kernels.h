@@ -202,6 +202,22 @@ bool mit_attn64_supported(int C, int heads, int kv_rows);
 void launch_mit_attn64(const MitAttn64Args& a, int num_cus, hipStream_t s);
 void attn64_pack(const float* ln_g, const float* ln_b, const float* q_w, const float* q_b, const float* p_w, const float* p_b, std::vector<unsigned short>* wfr, std::vector<float>* tab);
 
+// The two 7 x 7 convolutions on the normalised image (stem7.hip): conv 7x7 / stride 2 or 4 / pad 3, 3 (stored as 4) -> 64 channels, + bias (folded BatchNorm), + ReLU or
+// + LayerNorm over the 64 channels, one kernel
+struct Stem7Args {
+  const float* x = nullptr;            // [B][H][W][4] normalised image (channel 3 = 0)
+  float* y = nullptr;                  // [B][Ho][Wo][64]
+  const unsigned short* wfr = nullptr; // stem7x7_pack: weight fragments
+  const float* tab = nullptr;          // stem7x7_pack: inverse scales, bias, LayerNorm gamma / beta
+  int B = 0, H = 0, W = 0, Ho = 0, Wo = 0, stride = 2, relu = 0, ln = 0, QT = 1;
+  float ln_eps = 1e-5f;
+  unsigned* sat = nullptr;
+  float sat_limit = 65504.f;
+};
+bool stem7x7_supported(int Cin, int Cout, int K, int stride, int pad);
+void launch_stem7x7(const Stem7Args& a, int num_cus, hipStream_t s);
+void stem7x7_pack(const float* w, const double* out_scale, const float* bias, const float* ln_g, const float* ln_b, std::vector<unsigned short>* wfr, std::vector<float>* tab);
+
 // bilinear x2 (align_corners=False), NHWC
 void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb = nullptr, size_t sb_plane = 0);
 

@@ -192,6 +192,24 @@ def mit_attn64(x, kv, ln_gamma, ln_beta, eps, q_w, q_b, proj_w, proj_b, iters=0,
     return (y, ms.value) if iters > 0 else y
 
 
+def stem7x7(x4, weight, bias, stride, relu=False, ln_gamma=None, ln_beta=None, eps=1e-5, iters=0):
+    """conv 7x7 / stride 2 or 4 / pad 3, 3 -> 64 channels (+ ReLU, or + LayerNorm over the 64 channels) on an NHWC4 image (B, H, W, 4) in one launch (stem7.hip).
+    iters > 0: returns (y, avg ms per launch)."""
+    import torch
+
+    lib = load_library()
+    x4 = x4.contiguous()
+    B, H, W, _ = x4.shape
+    Ho, Wo = (H + 6 - 7) // stride + 1, (W + 6 - 7) // stride + 1
+    y = torch.empty((B, Ho, Wo, 64), dtype=torch.float32, device=x4.device)
+    ms = ctypes.c_float()
+    w, b = _np(weight), _np(bias)
+    g, be = (_np(ln_gamma), _np(ln_beta)) if ln_gamma is not None else (None, None)
+    _check(lib.pf_op_stem7x7(x4.device.index, x4.data_ptr(), y.data_ptr(), B, H, W, stride, _hp(w), _hp(b), 1 if relu else 0, _hp(g), _hp(be), float(eps), iters, ctypes.byref(ms),
+                             _stream_ptr()), None, "pf_op_stem7x7")
+    return (y, ms.value) if iters > 0 else y
+
+
 def mit_mlp(x, fc1_w, fc1_b, ln_gamma, ln_beta, eps, dw_w, dw_b, fc2_w, fc2_b, iters=0):
     """One MiT block Mlp in one kernel: x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))).  x: (B, Hs, Ws, C) on the GPU, C = 64 or 128.
     iters > 0: returns the average ms per launch instead."""

@@ -587,6 +587,26 @@ def test_mit_attn64_block(ops, B, N, M):
     assert torch.equal(ops.mit_attn64(xin, kv.cuda(), g, be, 1e-6, qw, qb, pw, pb, inplace=True), got)   # in place: a block reads and writes its own rows only
 
 
+@pytest.mark.parametrize("B,H,W,stride,ln", [(2, 320, 320, 2, False), (2, 320, 320, 4, True), (1, 37, 53, 2, False), (3, 20, 9, 4, True), (1, 7, 7, 4, True)])
+def test_stem7x7(ops, B, H, W, stride, ln):
+    """r06 (stem7.hip): the two 7 x 7 convs that read the normalised image -- the low-level encoder (stride 2, BatchNorm folded, ReLU: perspectivefields.py:70-83) and the
+    first patch embedding (stride 4 + LayerNorm eps 1e-5: mix_transformers.py:205-246) -- as one specialised kernel.  Oracle: torch fp64; image-range inputs (|x| <= 130),
+    odd sizes (borders, ragged last tile)."""
+    x = (_rand((B, H, W, 3), 60) * 60.0)
+    x4 = torch.cat([x, torch.zeros(B, H, W, 1)], dim=-1)
+    w = _rand((64, 3, 7, 7), 61, 1.0 / math.sqrt(147))
+    b = 0.1 * _rand((64,), 62)
+    g, be = (1.0 + 0.2 * _rand((64,), 63), 0.1 * _rand((64,), 64)) if ln else (None, None)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=stride, padding=3).permute(0, 2, 3, 1)
+    ref = F.layer_norm(ref, (64,), g.double(), be.double(), 1e-5) if ln else torch.relu(ref)
+    got = ops.stem7x7(x4.cuda(), w, b, stride, relu=not ln, ln_gamma=g, ln_beta=be, eps=1e-5)
+    assert tuple(got.shape) == tuple(ref.shape)
+    err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+    _, ms = ops.stem7x7(x4.cuda(), w, b, stride, relu=not ln, ln_gamma=g, ln_beta=be, eps=1e-5, iters=10)
+    print(f"[stem7x7 B{B} {H}x{W} s{stride} {'LN' if ln else 'ReLU'}] max |err| / max |ref| {err:.2e}; {1e3 * ms:.1f} us per launch")
+    _close(got, ref, 2e-5 if ln else 2e-5 * 60.0, "stem7x7")
+
+
 def test_sr_attention_split_f16_extremes(ops):
     """peaked rows (|logit| ~ 100), tiny and large K / V magnitudes, V beyond the +-4094 range of the scaled split
     (saturates: finite output)"""
