@@ -42,21 +42,21 @@ __device__ __forceinline__ s7_f32x16 s7_mfma(const s7_u32x4 a, const s7_u32x4 b,
 }  // namespace
 
 template <bool LN>
-__global__ __launch_bounds__(256, 2) void stem7x7_kernel(const Stem7Args p) {
+__global__ __launch_bounds__(512, 2) void stem7x7_kernel(const Stem7Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_s7[];
   const unsigned char* Wf = smem_s7;
   const float* tabs = reinterpret_cast<const float*>(smem_s7 + S7_WBYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  for (int i = tid; i < S7_WBYTES / 16; i += 256) reinterpret_cast<s7_u32x4*>(smem_s7)[i] = reinterpret_cast<const s7_u32x4*>(p.wfr)[i];
-  for (int i = tid; i < S7_TAB / 4; i += 256) reinterpret_cast<float4*>(const_cast<float*>(tabs))[i] = reinterpret_cast<const float4*>(p.tab)[i];
+  for (int i = tid; i < S7_WBYTES / 16; i += 512) reinterpret_cast<s7_u32x4*>(smem_s7)[i] = reinterpret_cast<const s7_u32x4*>(p.wfr)[i];
+  for (int i = tid; i < S7_TAB / 4; i += 512) reinterpret_cast<float4*>(const_cast<float*>(tabs))[i] = reinterpret_cast<const float4*>(p.tab)[i];
   __syncthreads();
   const float* t_inv = tabs, *t_bias = tabs + S7_N, *t_g = tabs + 2 * S7_N, *t_b = tabs + 3 * S7_N;
   const long Mtot = (long)p.B * p.Ho * p.Wo;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((long)p.B * p.H * p.W * 16), 0x00020000);
 
   for (int qt = 0; qt < p.QT; ++qt) {
-    const long m0 = (((long)blockIdx.x * p.QT + qt) * 4 + wave) * 32;
+    const long m0 = (((long)blockIdx.x * p.QT + qt) * 8 + wave) * 32;
     if (m0 >= Mtot) break;  // wave-uniform; no barrier below
     const long m = m0 + l31;
     const long mc = m < Mtot ? m : Mtot - 1;  // pixels past the end: a valid pixel, computed and not stored
@@ -148,13 +148,13 @@ bool stem7x7_supported(int Cin, int Cout, int K, int stride, int pad) { return C
 void launch_stem7x7(const Stem7Args& a, int num_cus, hipStream_t s) {
   Stem7Args p = a;
   const long Mtot = (long)p.B * p.Ho * p.Wo, tiles = (Mtot + 31) / 32;
-  int QT = (int)((tiles + 8L * num_cus - 1) / (8L * num_cus));   // two blocks of four waves per CU, one round
+  int QT = (int)((tiles + 16L * num_cus - 1) / (16L * num_cus));   // two blocks of eight waves per CU (four waves per SIMD cover the gather's latency), one round
   QT = QT < 1 ? 1 : (QT > 32 ? 32 : QT);
   p.QT = QT;
   const size_t lds = S7_WBYTES + S7_TAB * sizeof(float);
-  const dim3 grid((unsigned)((tiles + 4L * QT - 1) / (4L * QT)));
-  if (p.ln) hipLaunchKernelGGL(stem7x7_kernel<true>, grid, dim3(256), lds, s, p);
-  else hipLaunchKernelGGL(stem7x7_kernel<false>, grid, dim3(256), lds, s, p);
+  const dim3 grid((unsigned)((tiles + 8L * QT - 1) / (8L * QT)));
+  if (p.ln) hipLaunchKernelGGL(stem7x7_kernel<true>, grid, dim3(512), lds, s, p);
+  else hipLaunchKernelGGL(stem7x7_kernel<false>, grid, dim3(512), lds, s, p);
 }
 
 // Host side: w [64][3][7][7] (x out_scale[n] when given: the folded BatchNorm) -> Ws[n][k], k = (ky * 8 + kx) * 4 + c (kx = 7 and c = 3: zeros), split-f16 planes
