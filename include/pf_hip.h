@@ -295,6 +295,9 @@ int pf_op_mit_attn64(int device, const float* d_x, const float* d_kv, float* d_y
  * pad 3, 3 -> 64 channels.  x: (B, H, W, 4) NHWC4 with channel 3 = 0; y: (B, Ho, Wo, 64); weight in the reference's shape (64, 3, 7, 7).  iters > 0 also times launches. */
 int pf_op_stem7x7(int device, const float* d_x, float* d_y, int B, int H, int W, int stride, const float* h_weight, const float* h_bias, int relu, const float* h_ln_gamma,
                   const float* h_ln_beta, float eps, int iters, float* ms_out, void* stream);
+/* y = x W^T + b (+ res) for a 128 -> 128 nn.Linear over many rows (thin_linear.hip; the q / output projections of the MiT stage-2 blocks, mix_transformers.py:110,
+ * :137-138): x, res, y (rows, 128) device fp32 (y may alias res), weight (128, 128) / bias (128) host, the reference's shapes.  iters > 0 also times launches. */
+int pf_op_thin128(int device, const float* d_x, long rows, const float* h_weight, const float* h_bias, const float* d_res, float* d_y, int iters, float* ms_out, void* stream);
 /* The key / value branch of a MiT block with 2 x 2 spatial reduction in one launch (rb_chain.hip): kv = Linear_kv(LayerNorm(Conv2d_2x2s2(LayerNorm_1(x)))),
  * mix_transformers.py:119-127 (norm1 of :199 applied to the gathered source tokens).  x: (B, 2 Hr, 2 Wr, C) NHWC token map, C = 320; weights in the reference's shapes
  * (sr [C][C][2][2], kv [2C][C]); kv out: (B, Hr Wr, 2C).  iters > 0 additionally times `iters` launches. */

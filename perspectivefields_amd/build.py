@@ -18,13 +18,13 @@ ASAN = os.environ.get("PF_ASAN", "0") == "1"
 _VARIANT = ("_tune" if os.environ.get("PF_TUNING_BUILD", "0") == "1" else "") + ("_asan" if ASAN else "") + os.environ.get("PF_LIB_SUFFIX", "")
 LIBDIR = os.path.join(HERE, "lib" + _VARIANT)
 LIB = os.path.join(LIBDIR, "libpf_hip.so")
-SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sbf.hip", "igemm_sbh.hip", "wino.hip", "attn.hip", "attn_block.hip", "stem7.hip", "elem.hip", "dw7.hip", "dw7_pk.hip", "cnx_mlp.hip", "mit_mlp.hip", "rb_gemm.hip", "rb_chain.hip", "engine.hip", "engine_ops.hip"]
+SOURCES = ["igemm.hip", "igemm_sb.hip", "igemm_sbf.hip", "igemm_sbh.hip", "wino.hip", "attn.hip", "attn_block.hip", "stem7.hip", "thin_linear.hip", "elem.hip", "dw7.hip", "dw7_pk.hip", "cnx_mlp.hip", "mit_mlp.hip", "rb_gemm.hip", "rb_chain.hip", "engine.hip", "engine_ops.hip"]
 # dw7.hip: the scalar one-channel-per-lane kernel must not be SLP-vectorised (see the file header)
 # NO_PK_F32_FLAGS: these units are compiled without the packed-fp32 feature (pf_kernels.h PF_NO_PK_F32 says why); the x86 host pass prints an "ignoring feature"
 # line per function for it, filtered below
 NO_PK_F32_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {"dw7.hip": ["-fno-slp-vectorize"], "dw7_pk.hip": ["-fno-slp-vectorize"],
-               "attn_block.hip": NO_PK_F32_FLAGS, "stem7.hip": NO_PK_F32_FLAGS, "cnx_mlp.hip": NO_PK_F32_FLAGS, "mit_mlp.hip": NO_PK_F32_FLAGS, "rb_gemm.hip": NO_PK_F32_FLAGS, "rb_chain.hip": NO_PK_F32_FLAGS}
+               "attn_block.hip": NO_PK_F32_FLAGS, "stem7.hip": NO_PK_F32_FLAGS, "thin_linear.hip": NO_PK_F32_FLAGS, "cnx_mlp.hip": NO_PK_F32_FLAGS, "mit_mlp.hip": NO_PK_F32_FLAGS, "rb_gemm.hip": NO_PK_F32_FLAGS, "rb_chain.hip": NO_PK_F32_FLAGS}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 # PF_TUNING_BUILD=1: also compile the measured-and-rejected kernel variants and the ablation (no-load / no-store) kernels that
 # the scripts under scripts/ can select; the product build carries the default path and its parity alternatives only

@@ -72,7 +72,8 @@ struct RbLin { unsigned short* w = nullptr; size_t bytes = 0; float* inv = nullp
 struct RbSrKv { unsigned short* w = nullptr; size_t bytes = 0; float *sr_inv = nullptr, *sr_b = nullptr, *kv_inv = nullptr, *kv_b = nullptr; };
 struct RbProjFc1 { unsigned short* w = nullptr; size_t bytes = 0; };  // combined weight stream of rb_proj_fc1_kernel (scales / biases: rproj, rfc1)
 struct MitBlock { LNW n1, n2, srn; RbLin rq, rkv, rproj, rfc1, rfc2; RbSrKv rsrkv; RbProjFc1 rpf; ConvW qln /*q with norm1 folded (used next to rsrkv: no LayerNorm-1 launch)*/; ConvW q, kv, proj, sr, fc1, fc2; DwW dw; unsigned short* mlp_w = nullptr; float* mlp_tab = nullptr; /* fused Mlp (mit_mlp.hip), when built */
-                  unsigned short* a64_w = nullptr; float* a64_tab = nullptr; /* fused attention half of a one-head, 64-channel block (attn_block.hip), when built */ };
+                  unsigned short* a64_w = nullptr; float* a64_tab = nullptr; /* fused attention half of a one-head, 64-channel block (attn_block.hip), when built */
+                  unsigned short* tq_w = nullptr; float* tq_tab = nullptr; unsigned short* tp_w = nullptr; float* tp_tab = nullptr; /* 128 -> 128 q / proj in the thin form (thin_linear.hip), when built */ };
 struct MitStage { ConvW pe; LNW pen, norm; std::vector<MitBlock> blocks; };
 struct Head {
   ConvW lin[4], proc[4], fold[4], r1c1[4], r1c2[4], r2c1[4], r2c2[4], conv0, conv1, predcls;
@@ -250,6 +251,7 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
+  int thin128 = 1;           // PF_THIN128: the 128 -> 128 q / output projections of the MiT stage-2 blocks in the transposed, register-epilogue form (thin_linear.hip)
   int stem7 = 1;             // PF_STEM7: the two 7 x 7 convs on the normalised image (low-level encoder; first patch embedding + its LayerNorm) as the specialised kernel of stem7.hip
   unsigned short* ll_s7_w = nullptr; float* ll_s7_tab = nullptr; unsigned short* pe_s7_w = nullptr; float* pe_s7_tab = nullptr;
   int attn64 = 1;            // PF_ATTN64: the attention half of the one-head stage-1 blocks (q, attention, proj, residual) as one kernel (attn_block.hip)
@@ -686,6 +688,14 @@ struct pf_engine {
           mb.a64_w = upload_u16(wfr);
           mb.a64_tab = upload(tab);
         }
+        if (thin128 && split_bf16 && thin128_supported(C, C) && MIT_SR[s] > 1) {   // stage 2: q (on norm1's output, which the spatial-reduction conv needs anyway) and proj + residual
+          std::vector<unsigned short> wfr;
+          std::vector<float> tab;
+          thin128_pack(get(b + ".attn.q.weight", {C, C}).data.data(), get(b + ".attn.q.bias", {C}).data.data(), &wfr, &tab);
+          mb.tq_w = upload_u16(wfr); mb.tq_tab = upload(tab);
+          thin128_pack(get(b + ".attn.proj.weight", {C, C}).data.data(), get(b + ".attn.proj.bias", {C}).data.data(), &wfr, &tab);
+          mb.tp_w = upload_u16(wfr); mb.tp_tab = upload(tab);
+        }
         if (fuse_mit_mlp && mit_mlp_preferred(C)) {
           std::vector<unsigned short> wpk;
           std::vector<float> tab2;
@@ -954,6 +964,16 @@ struct pf_engine {
     launch_rb_linear(a, r.K, c.s);
   }
 
+  // a 128 -> 128 linear layer (+ residual) in the thin form (thin_linear.hip)
+  void thin(Ctx& c, const unsigned short* wfr, const float* tab, const float* x, const float* res, float* y, long M, float sat_limit, const char* what) {
+    range_in(c, fmt("thin128 %s x", what), x, (size_t)M * 128);
+    if (c.dry) return;
+    ThinLinArgs a;
+    a.x = x; a.res = res; a.y = y; a.wfr = wfr; a.tab = tab; a.M = M; a.sat = d_sat; a.sat_limit = sat_limit;
+    ProfScope ps(c.prof, c.s, PC_IGEMM_SB, 2.0 * M * 128.0 * 128.0, (int)M, 128, 128, 1);
+    launch_thin128(a, num_cus, c.s);
+  }
+
   // conv 7x7 on the normalised image (+ ReLU or + LayerNorm) as one launch of stem7.hip
   void stem(Ctx& c, const unsigned short* wfr, const float* tab, const float* x4, float* y, int B, int H, int W, int stride, bool relu, bool lnorm, float eps, float sat_limit, const char* what) {
     range_in(c, fmt("stem7x7 s%d %s x", stride, what), x4, (size_t)B * H * W * 4);
@@ -1018,6 +1038,7 @@ struct pf_engine {
         // row-block form of the block's linear layers (stage 3 at batch >= ~14): q, kv, proj, fc1, fc2
         // one 64-row block per CU: the form pays only when the last round of blocks nearly fills the 256 CUs (same-box A/Bs, profiles/r04_rb_linear.md: B = 32 -> 224 blocks
         // +1.2 %, B = 64 -> 448 +1.2 %; B = 48 -> 336 -0.4 %, B = 24 -> 168 -0.9 %, B = 16 -> 112 -4.5 %)
+        const bool thin_q = mb.tq_w && nterms == NT_F16X3 && !S && !c.tuning && xn.f;   // (thin_linear.hip; the same conditions hold for the projection below)
         const bool fuse64 = attn64 && mb.a64_w && nterms == NT_F16X3 && !S && !c.tuning && sr > 1;
         const long rb_blocks = (long)gate_B * ((N + 63) / 64);
         const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && rb_blocks >= rb_min_blocks && (rb_blocks % num_cus == 0 || rb_blocks % num_cus >= num_cus * 3 / 4);
@@ -1074,10 +1095,10 @@ struct pf_engine {
             (void)hipStreamWaitEvent(side, ev_fork, 0);
             Ctx c2 = c;
             c2.s = side;
-            gemm(c2, mb.q, xn, M, Ten(qb));
+            if (thin_q) thin(c2, mb.tq_w, mb.tq_tab, xn.f, nullptr, qb, M, mb.q.sat_limit, "q"); else gemm(c2, mb.q, xn, M, Ten(qb));
             (void)hipEventRecord(ev_join, side);
           } else {
-            gemm(c, mb.q, xn, M, Ten(qb));
+            if (thin_q) thin(c, mb.tq_w, mb.tq_tab, xn.f, nullptr, qb, M, mb.q.sat_limit, "q"); else gemm(c, mb.q, xn, M, Ten(qb));
           }
           conv(c, mb.sr, xn, B, Ho, Wo, Ten(srb));
           if (use_rb && (rb_chain & 2)) {  // measured slower than the LDS tile on these 3 200 rows (50 row blocks: 20.6 vs 12.7 us, profiles/r04_rb_linear.md)
@@ -1137,6 +1158,7 @@ struct pf_engine {
             launch_rb_proj_fc1(a, C, c.s);
           }
         } else if (use_rb && (rb_chain & 4)) rb_linear(c, mb.rproj, ab.f, M, (int)N, x, nullptr, ACT_NONE, x);
+        else if (thin_q && mb.tp_w && ab.f) thin(c, mb.tp_w, mb.tp_tab, ab.f, x, x, M, mb.proj.sat_limit, "proj");
         else gemm(c, mb.proj, ab, M, Ten(x), ACT_NONE, x);
         }  // !fuse64
         // x += fc2(gelu(dwconv(fc1(LN2(x)))))   (:200; Mlp.forward :49-56)
@@ -1553,6 +1575,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_S3_SPLIT")) e->s3_split = atoi(v);
   if (const char* v = getenv("PF_ATTN64")) e->attn64 = atoi(v);
   if (const char* v = getenv("PF_STEM7")) e->stem7 = atoi(v);
+  if (const char* v = getenv("PF_THIN128")) e->thin128 = atoi(v);
   if (const char* v = getenv("PF_SBA_HEADS")) e->sba_heads = atoi(v) != 0;
   if (const char* v = getenv("PF_AUTOTUNE")) e->autotune = atoi(v) != 0;
   if (const char* v = getenv("PF_SPLIT_BF16")) e->split_bf16 = atoi(v) != 0;

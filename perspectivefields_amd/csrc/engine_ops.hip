@@ -262,6 +262,38 @@ int pf_op_stem7x7(int device, const float* x, float* y, int B, int H, int W, int
   return rc;
 }
 
+int pf_op_thin128(int device, const float* x, long rows, const float* w, const float* bias, const float* res, float* y, int iters, float* ms_out, void* stream) {
+  std::string err;
+  int rc = check_device(device, &err);
+  if (rc != PF_OK) { g_create_error = err; return rc; }
+  if (!x || !y || !w || rows <= 0) { g_create_error = "pf_op_thin128: x, y, weight required"; return PF_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TmpDev tmp;
+  std::vector<unsigned short> wfr;
+  std::vector<float> tab;
+  thin128_pack(w, bias, &wfr, &tab);
+  ThinLinArgs a;
+  a.x = x; a.res = res; a.y = y; a.wfr = tmp.up_u16(wfr); a.tab = tmp.up(tab); a.M = rows;
+  int cus = 256;
+  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+  launch_thin128(a, cus, s);
+  if (iters > 0 && ms_out) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) launch_thin128(a, cus, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms_out = t / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  rc = hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_DEVICE;
+  tmp.sync_free(s);
+  return rc;
+}
+
 int pf_op_rb_srkv(int device, const float* x, int B, int Hr, int Wr, int C, const float* ln1_g, const float* ln1_b, float eps1, const float* sr_w, const float* sr_b,
                   const float* srn_g, const float* srn_b, float eps2, const float* kv_w, const float* kv_b, float* kv, int iters, float* ms_out, void* stream) {
   std::string err;

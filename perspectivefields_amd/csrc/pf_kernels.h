@@ -218,6 +218,22 @@ bool stem7x7_supported(int Cin, int Cout, int K, int stride, int pad);
 void launch_stem7x7(const Stem7Args& a, int num_cus, hipStream_t s);
 void stem7x7_pack(const float* w, const double* out_scale, const float* bias, const float* ln_g, const float* ln_b, std::vector<unsigned short>* wfr, std::vector<float>* tab);
 
+// y = x W^T + b (+ res) for 128 -> 128 layers over many rows (thin_linear.hip): weights in LDS, rows as the MFMA's B operand, register epilogue; y may alias res
+struct ThinLinArgs {
+  const float* x = nullptr;            // [M][128]
+  const float* res = nullptr;          // [M][128] or nullptr
+  float* y = nullptr;                  // [M][128]
+  const unsigned short* wfr = nullptr; // thin128_pack
+  const float* tab = nullptr;
+  long M = 0;
+  int QT = 1;
+  unsigned* sat = nullptr;
+  float sat_limit = 65504.f;
+};
+bool thin128_supported(int K, int N);
+void launch_thin128(const ThinLinArgs& a, int num_cus, hipStream_t s);
+void thin128_pack(const float* w, const float* bias, std::vector<unsigned short>* wfr, std::vector<float>* tab);
+
 // bilinear x2 (align_corners=False), NHWC
 void launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t s, unsigned short* y_sb = nullptr, size_t sb_plane = 0);
 

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "pf_op_rb_proj_fc1": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _c.c_int, _c.POINTER(_c.c_float), _P]),
     "pf_op_mit_attn64": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_float, _P, _P, _P, _P, _c.c_int, _c.POINTER(_c.c_float), _P]),
     "pf_op_stem7x7": (_c.c_int, [_c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_int, _P, _P, _c.c_float, _c.c_int, _c.POINTER(_c.c_float), _P]),
+    "pf_op_thin128": (_c.c_int, [_c.c_int, _P, _c.c_long, _P, _P, _P, _P, _c.c_int, _c.POINTER(_c.c_float), _P]),
     "pf_op_rb_srkv": (_c.c_int, [_c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_float, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _c.c_int, _c.POINTER(_c.c_float), _P]),
     "pf_op_linear_ln": (_c.c_int, [_c.c_int, _P, _c.c_long, _c.c_int, _P, _P, _P, _P, _c.c_float, _c.c_int, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P]),
     "pf_op_dwconv3x3_gelu_cfg": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_long, _c.c_int, _P]),

@@ -210,6 +210,21 @@ def stem7x7(x4, weight, bias, stride, relu=False, ln_gamma=None, ln_beta=None, e
     return (y, ms.value) if iters > 0 else y
 
 
+def thin128(x, weight, bias, res=None, iters=0, inplace=False):
+    """x W^T + b (+ res) for a 128 -> 128 layer over (..., 128) rows in the transposed, register-epilogue form (thin_linear.hip).  inplace: y aliases res.
+    iters > 0: returns (y, avg ms per launch)."""
+    import torch
+
+    lib = load_library()
+    x = x.contiguous()
+    rows = x.numel() // 128
+    y = res if (inplace and res is not None) else torch.empty_like(x)
+    ms = ctypes.c_float()
+    w, b = _np(weight), _np(bias)
+    _check(lib.pf_op_thin128(x.device.index, x.data_ptr(), rows, _hp(w), _hp(b), _dp(res), y.data_ptr(), iters, ctypes.byref(ms), _stream_ptr()), None, "pf_op_thin128")
+    return (y, ms.value) if iters > 0 else y
+
+
 def mit_mlp(x, fc1_w, fc1_b, ln_gamma, ln_beta, eps, dw_w, dw_b, fc2_w, fc2_b, iters=0):
     """One MiT block Mlp in one kernel: x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))).  x: (B, Hs, Ws, C) on the GPU, C = 64 or 128.
     iters > 0: returns the average ms per launch instead."""

@@ -607,6 +607,25 @@ def test_stem7x7(ops, B, H, W, stride, ln):
     _close(got, ref, 2e-5 if ln else 2e-5 * 60.0, "stem7x7")
 
 
+@pytest.mark.parametrize("rows,res", [(51200, False), (51200, True), (1600, True), (70, False), (33, True)])
+def test_thin128_linear(ops, rows, res):
+    """r06 (thin_linear.hip): the 128 -> 128 projections of the MiT stage-2 blocks (q: mix_transformers.py:110; proj + residual: :137-138, :199) in the transposed,
+    register-epilogue form.  Oracle: torch fp64; rows with offsets and an outlier channel, ragged last tile, in place on the residual."""
+    x = _rand((rows, 128), 70) * 2.0 + 0.3
+    x[3] += 40.0
+    x[5, 77] = 300.0
+    w, b = _rand((128, 128), 71, 1.0 / math.sqrt(128)), 0.1 * _rand((128,), 72)
+    r = _rand((rows, 128), 73) if res else None
+    ref = x.double() @ w.double().t() + b.double() + (r.double() if res else 0.0)
+    got = ops.thin128(x.cuda(), w, b, r.cuda() if res else None)
+    _, ms = ops.thin128(x.cuda(), w, b, r.cuda() if res else None, iters=10)
+    print(f"[thin128 rows {rows} res {res}] max |err| / max |ref| {float((got.double().cpu() - ref).abs().max() / ref.abs().max()):.2e}; {1e3 * ms:.1f} us per launch")
+    _close(got, ref, 2e-5, "thin128")
+    if res:
+        rin = r.cuda().clone()
+        assert torch.equal(ops.thin128(x.cuda(), w, b, rin, inplace=True), got)
+
+
 def test_sr_attention_split_f16_extremes(ops):
     """peaked rows (|logit| ~ 100), tiny and large K / V magnitudes, V beyond the +-4094 range of the scaled split
     (saturates: finite output)"""
