@@ -187,6 +187,7 @@ __device__ __forceinline__ void at_split8(const float (&a)[8], at_u32x4& h, at_u
   for (int e = 0; e < 4; ++e) split2_f16(a[2 * e], a[2 * e + 1], hh[e], ll[e]);
   h = at_u32x4{hh[0], hh[1], hh[2], hh[3]};
   l = at_u32x4{ll[0], ll[1], ll[2], ll[3]};
+  split_f16_mfma_pad(l);  // register-direct MFMA operand: sb_split.h
 }
 __device__ __forceinline__ f32x16 at_mfma(const at_u32x4 a, const at_u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(at_f16x8, a), __builtin_bit_cast(at_f16x8, b), c, 0, 0, 0);

@@ -49,6 +49,7 @@ __device__ __forceinline__ void ab_split8(const float (&a)[8], ab_u32x4& h, ab_u
   for (int e = 0; e < 4; ++e) split2_f16(a[2 * e], a[2 * e + 1], hh[e], ll[e]);
   h = ab_u32x4{hh[0], hh[1], hh[2], hh[3]};
   l = ab_u32x4{ll[0], ll[1], ll[2], ll[3]};
+  split_f16_mfma_pad(l);  // register-direct MFMA operand: sb_split.h
 }
 __device__ __forceinline__ ab_f32x16 ab_mfma(const ab_u32x4 a, const ab_u32x4 b, const ab_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ab_f16x8, a), __builtin_bit_cast(ab_f16x8, b), c, 0, 0, 0);

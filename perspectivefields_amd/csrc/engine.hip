@@ -251,7 +251,7 @@ struct pf_engine {
   bool fuse_ln = true;       // PF_FUSE_LN=0: run every LayerNorm as its own kernel.  Default: a LayerNorm whose only consumers are 1x1 layers (MiT norm2 -> fc1,
                              // sr norm -> kv, stage-4 norm1 -> q / kv; ConvNeXt norm -> pwconv1) is folded into them (ConvParams::ln): gamma / beta go into the
                              // weights / bias at finalize, the row statistics are accumulated by the GEMM's own staging threads
-  int thin128 = 1;           // PF_THIN128: the 128 -> 128 q / output projections of the MiT stage-2 blocks in the transposed, register-epilogue form (thin_linear.hip)
+  int thin128 = 25600;       // PF_THIN128 (0 = off, n = from n token rows up; 64 KB of weights per block is a prologue that 1 600 rows -- one image -- do not repay: B = 1 -1 %, B >= 16 +0.2 %): the 128 -> 128 q / output projections of the MiT stage-2 blocks in the transposed, register-epilogue form (thin_linear.hip)
   int stem7 = 1;             // PF_STEM7: the two 7 x 7 convs on the normalised image (low-level encoder; first patch embedding + its LayerNorm) as the specialised kernel of stem7.hip
   unsigned short* ll_s7_w = nullptr; float* ll_s7_tab = nullptr; unsigned short* pe_s7_w = nullptr; float* pe_s7_tab = nullptr;
   int attn64 = 1;            // PF_ATTN64: the attention half of the one-head stage-1 blocks (q, attention, proj, residual) as one kernel (attn_block.hip)
@@ -1038,7 +1038,7 @@ struct pf_engine {
         // row-block form of the block's linear layers (stage 3 at batch >= ~14): q, kv, proj, fc1, fc2
         // one 64-row block per CU: the form pays only when the last round of blocks nearly fills the 256 CUs (same-box A/Bs, profiles/r04_rb_linear.md: B = 32 -> 224 blocks
         // +1.2 %, B = 64 -> 448 +1.2 %; B = 48 -> 336 -0.4 %, B = 24 -> 168 -0.9 %, B = 16 -> 112 -4.5 %)
-        const bool thin_q = mb.tq_w && nterms == NT_F16X3 && !S && !c.tuning && xn.f;   // (thin_linear.hip; the same conditions hold for the projection below)
+        const bool thin_q = mb.tq_w && M >= thin128 && nterms == NT_F16X3 && !S && !c.tuning && xn.f;   // (thin_linear.hip; the same conditions hold for the projection below)
         const bool fuse64 = attn64 && mb.a64_w && nterms == NT_F16X3 && !S && !c.tuning && sr > 1;
         const long rb_blocks = (long)gate_B * ((N + 63) / 64);
         const bool use_rb = rb_chain && mb.rq.w && nterms == NT_F16X3 && !S && !c.tuning && rb_blocks >= rb_min_blocks && (rb_blocks % num_cus == 0 || rb_blocks % num_cus >= num_cus * 3 / 4);

@@ -71,6 +71,48 @@ def packed_src1_high_forms(lib):
     return hits
 
 
+_MFMA = re.compile(r"(v_mfma\S+|v_smfmac\S+)\s+([av])\[(\d+):(\d+)\],\s*([av])\[(\d+):(\d+)\],\s*([av])\[(\d+):(\d+)\],")
+_VDEF = re.compile(r"^(v_\S+)\s+v(?:\[(\d+):(\d+)\]|(\d+))")
+
+
+def valu_write_then_mfma_read(lib, states_needed=2):
+    """MFMAs that read, as their A or B operand, a VGPR a VALU instruction wrote fewer than `states_needed` wait states earlier, per kernel:
+    [(mangled kernel name, the VALU instruction, the MFMA, states in between)].  hipcc pads this hazard for its own instructions and not for what an inline-asm
+    statement writes (sb_split.h split_f16_mfma_pad; profiles/r06_asm_mfma_hazard.md: one state -- an s_waitcnt -- between a v_fma_mixhi_f16 and the MFMA gave the
+    matrix core the register's old contents).  Every instruction counts one state, `s_nop N` counts N + 1; the library is expected to contain none."""
+    hits = []
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co); f.flush()
+            p = subprocess.Popen([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", f.name], stdout=subprocess.PIPE, text=True)
+            cur, hist = None, []
+            for line in p.stdout:
+                if line.endswith(">:\n"):
+                    cur, hist = line.split("<")[1][:-3], []
+                    continue
+                ins = line.split("//")[0].strip()
+                if not ins:
+                    continue
+                m = _MFMA.search(ins)
+                if m:
+                    srcs = [(m.group(5), int(m.group(6)), int(m.group(7))), (m.group(8), int(m.group(9)), int(m.group(10)))]
+                    states = 0
+                    for prev in reversed(hist):
+                        if states >= states_needed:
+                            break
+                        d = _VDEF.match(prev)
+                        if d and not prev.startswith(("v_mfma", "v_smfmac", "v_cmp", "v_nop")):
+                            lo = int(d.group(2) or d.group(4)); hi = int(d.group(3) or d.group(4))
+                            if any(s[0] == "v" and not (hi < s[1] or s[2] < lo) for s in srcs):
+                                hits.append((cur, prev, ins, states))
+                        n = re.match(r"s_nop (\d+)", prev)
+                        states += int(n.group(1)) + 1 if n else 1
+                hist.append(ins)
+                del hist[:-8]
+            p.wait()
+    return hits
+
+
 def blocks_per_cu(r):
     """Resident blocks per CU of a kernel: 512 VGPRs per SIMD lane in granules of 8 (at most 8 waves per SIMD), 4 SIMDs, 160 KB of LDS."""
     waves_per_simd = min(8, 512 // max(8, (r["vgpr"] + 7) // 8 * 8))

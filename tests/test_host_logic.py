@@ -444,6 +444,26 @@ def test_no_packed_fp32_src1_high_half_forms_in_the_default_path():
     assert not hits, hits[:8]
 
 
+def test_no_valu_write_within_two_states_of_an_mfma_read():
+    """ISA scan of the built library (no GPU): no MFMA reads, as A or B, a VGPR that a VALU instruction wrote fewer than two wait states earlier.  hipcc pads that
+    hazard for the instructions it emits; the v_fma_mix pair of the split (inline asm, sb_split.h) it cannot see, and the kernels that feed the split straight into
+    an MFMA from registers (attention, fused block, 7 x 7 stem, thin linear) pass the low part through split_f16_mfma_pad.  Found in r06 by the op test of
+    thin128_kernel<false>: one s_waitcnt between the asm and the MFMA, 32 output columns wrong (profiles/r06_asm_mfma_hazard.md)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    from perspectivefields_amd import build as _b
+
+    lib = _b.build(verbose=False)
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    hits = kr.valu_write_then_mfma_read(lib)
+    assert not hits, hits[:8]
+
+
 def test_kernel_resources_static():
     """Static check of the built library (no GPU): every kernel is there for gfx950, fits the 160 KB LDS, and the kernels
     of the default path do not spill (scripts/kernel_resources.py reads the AMDGPU metadata of the embedded code objects)."""
