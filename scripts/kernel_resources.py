@@ -75,6 +75,37 @@ _MFMA = re.compile(r"(v_mfma\S+|v_smfmac\S+)\s+([av])\[(\d+):(\d+)\],\s*([av])\[
 _VDEF = re.compile(r"^(v_\S+)\s+v(?:\[(\d+):(\d+)\]|(\d+))")
 
 
+def scan_valu_write_then_mfma_read(lines, states_needed=2):
+    """The scan of valu_write_then_mfma_read() over the lines of one llvm-objdump -d listing."""
+    hits = []
+    cur, hist = None, []
+    for line in lines:
+        line = line.rstrip("\n")
+        if line.endswith(">:"):
+            cur, hist = line.split("<")[1][:-2], []
+            continue
+        ins = line.split("//")[0].strip()
+        if not ins:
+            continue
+        m = _MFMA.search(ins)
+        if m:
+            srcs = [(m.group(5), int(m.group(6)), int(m.group(7))), (m.group(8), int(m.group(9)), int(m.group(10)))]
+            states = 0
+            for prev in reversed(hist):
+                if states >= states_needed:
+                    break
+                d = _VDEF.match(prev)
+                if d and not prev.startswith(("v_mfma", "v_smfmac", "v_cmp", "v_nop")):
+                    lo = int(d.group(2) or d.group(4)); hi = int(d.group(3) or d.group(4))
+                    if any(s[0] == "v" and not (hi < s[1] or s[2] < lo) for s in srcs):
+                        hits.append((cur, prev, ins, states))
+                n = re.match(r"s_nop (\d+)", prev)
+                states += int(n.group(1)) + 1 if n else 1
+        hist.append(ins)
+        del hist[:-8]
+    return hits
+
+
 def valu_write_then_mfma_read(lib, states_needed=2):
     """MFMAs that read, as their A or B operand, a VGPR a VALU instruction wrote fewer than `states_needed` wait states earlier, per kernel:
     [(mangled kernel name, the VALU instruction, the MFMA, states in between)].  hipcc pads this hazard for its own instructions and not for what an inline-asm
@@ -85,30 +116,7 @@ def valu_write_then_mfma_read(lib, states_needed=2):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
             f.write(co); f.flush()
             p = subprocess.Popen([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", f.name], stdout=subprocess.PIPE, text=True)
-            cur, hist = None, []
-            for line in p.stdout:
-                if line.endswith(">:\n"):
-                    cur, hist = line.split("<")[1][:-3], []
-                    continue
-                ins = line.split("//")[0].strip()
-                if not ins:
-                    continue
-                m = _MFMA.search(ins)
-                if m:
-                    srcs = [(m.group(5), int(m.group(6)), int(m.group(7))), (m.group(8), int(m.group(9)), int(m.group(10)))]
-                    states = 0
-                    for prev in reversed(hist):
-                        if states >= states_needed:
-                            break
-                        d = _VDEF.match(prev)
-                        if d and not prev.startswith(("v_mfma", "v_smfmac", "v_cmp", "v_nop")):
-                            lo = int(d.group(2) or d.group(4)); hi = int(d.group(3) or d.group(4))
-                            if any(s[0] == "v" and not (hi < s[1] or s[2] < lo) for s in srcs):
-                                hits.append((cur, prev, ins, states))
-                        n = re.match(r"s_nop (\d+)", prev)
-                        states += int(n.group(1)) + 1 if n else 1
-                hist.append(ins)
-                del hist[:-8]
+            hits += scan_valu_write_then_mfma_read(p.stdout, states_needed)
             p.wait()
     return hits
 

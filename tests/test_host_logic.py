@@ -464,6 +464,29 @@ def test_no_valu_write_within_two_states_of_an_mfma_read():
     assert not hits, hits[:8]
 
 
+def test_hazard_scan_flags_the_listing_that_failed():
+    """The scanner itself: the listing of thin128_kernel<false> that returned 32 wrong columns (one s_waitcnt between the asm's v_fma_mixhi_f16 and the MFMA) is flagged,
+    the same listing with the pad is not, and neither is a write to a register the MFMA does not read."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    head = ["0000000000001000 <_ZN2pf14thin128_kernelILb0EEEvNS_11ThinLinArgsE>:",
+            "\tv_cvt_pk_f16_f32 v121, v3, v5 // 000000001000: D2680079",
+            "\tv_fma_mixlo_f16 v3, v3, 1.0, -v121 op_sel_hi:[0,0,1] // 000000001008:",
+            "\tv_fma_mixhi_f16 v3, v5, 1.0, -v121 op_sel:[0,0,1] op_sel_hi:[0,0,1] // 000000001010:"]
+    mfma = "\tv_mfma_f32_32x32x16_f16 v[48:63], v[110:113], v[0:3], 0 // 000000001020:"
+    bad = kr.scan_valu_write_then_mfma_read(head + ["\ts_waitcnt lgkmcnt(7) // 000000001018:", mfma])
+    assert len(bad) == 1 and bad[0][0].startswith("_ZN2pf14thin128") and bad[0][1].startswith("v_fma_mixhi_f16 v3") and bad[0][3] == 1, bad
+    assert kr.scan_valu_write_then_mfma_read(head + [mfma])[0][3] == 0
+    assert not kr.scan_valu_write_then_mfma_read(head + ["\ts_nop 1", mfma])
+    assert not kr.scan_valu_write_then_mfma_read(head + ["\ts_waitcnt lgkmcnt(7)", "\tds_read_b128 v[4:7], v71", mfma])
+    assert not kr.scan_valu_write_then_mfma_read(head + [mfma.replace("v[0:3]", "v[4:7]")])
+    assert kr.scan_valu_write_then_mfma_read(head[:1] + ["\tv_mov_b32_e32 v111, 0", "\ts_nop 0", mfma])   # the A operand counts too
+
+
 def test_kernel_resources_static():
     """Static check of the built library (no GPU): every kernel is there for gfx950, fits the 160 KB LDS, and the kernels
     of the default path do not spill (scripts/kernel_resources.py reads the AMDGPU metadata of the embedded code objects)."""
