@@ -326,6 +326,7 @@ struct pf_engine {
   int wino_tile = -1;        // tile id of the Winograd kernel in use
   unsigned* d_sat = nullptr; // pf_set_saturation_counter: caller-owned device counter of the always-on saturation watch (ConvParams::sat); nullptr = off
   float static_window_max = 0.f;  // largest STATIC bound of a tensor that never reaches HBM (the hidden maps of the fused block MLPs), pf_static_window_max
+  int mit_mlp128 = 4;        // PF_MIT_MLP_128 (0 = never, n = from a batch of n images up): the one-kernel Mlp at MiT stage 2 (mit_mlp.hip, C = 128; 25 blocks per image: B = 1 -1.1 %, 2 -0.4 %, 4 +0.7 %, 8 +1.1 %, 32 +0.6 %)
   bool fuse_mit_mlp = true;  // PF_FUSE_MIT_MLP=0: the Mlp of MiT stages 1 / 2 as LayerNorm-fused fc1 + depthwise 3x3 / GELU + fc2 instead of the one-kernel form
                              // (mit_mlp.hip: hidden map in LDS / registers only); split-f16 scheme only
   bool fuse_cnx_mlp = true;  // PF_FUSE_CNX_MLP=0: ConvNeXt blocks of the 96- and 192-channel stages as LayerNorm-fused pwconv1 + pwconv2 GEMMs instead of
@@ -645,7 +646,7 @@ struct pf_engine {
         mb.fc1 = make_linear(b + ".mlp.fc1", 4 * C, C, nullptr, b + ".norm2", 1e-6f);
         mb.dw = make_dw(b + ".mlp.dwconv.dwconv", 4 * C, 3);
         mb.fc2 = make_linear(b + ".mlp.fc2", C, 4 * C);
-        if (fuse_mit_mlp && mit_mlp_preferred(C)) note_static(mlp_hidden_bound(b + ".norm2", b + ".mlp.fc1", b + ".mlp.dwconv.dwconv", C), 65504.f);  // hidden map of the fused Mlp (LDS / registers only)
+        if (fuse_mit_mlp && mit_mlp_preferred(C, mit_mlp128)) note_static(mlp_hidden_bound(b + ".norm2", b + ".mlp.fc1", b + ".mlp.dwconv.dwconv", C), 65504.f);  // hidden map of the fused Mlp (LDS / registers only)
         mb.q.sat_limit = 8188.f; mb.kv.sat_limit = 4094.f;  // the attention kernel's windows (attn.hip: q x 8, k / v x 16 inside the kernel)
         mb.fc1.sat_limit = mb.dw.in_limit;                   // fc1's output goes through the depthwise 3x3 before fc2 contracts it
         if (rb_chain && split_bf16 && rb_linear_supported(C, C) && MIT_SR[s] > 1) {  // stage 3: the row-block form of the block's linear layers
@@ -696,7 +697,7 @@ struct pf_engine {
           thin128_pack(get(b + ".attn.proj.weight", {C, C}).data.data(), get(b + ".attn.proj.bias", {C}).data.data(), &wfr, &tab);
           mb.tp_w = upload_u16(wfr); mb.tp_tab = upload(tab);
         }
-        if (fuse_mit_mlp && mit_mlp_preferred(C)) {
+        if (fuse_mit_mlp && mit_mlp_preferred(C, mit_mlp128)) {
           std::vector<unsigned short> wpk;
           std::vector<float> tab2;
           mit_mlp_pack(get(b + ".mlp.fc1.weight", {4 * C, C}).data.data(), get(b + ".mlp.fc1.bias", {4 * C}).data.data(), get(b + ".norm2.weight", {C}).data.data(),
@@ -1001,7 +1002,7 @@ struct pf_engine {
       const long N = (long)Ho * Wo, M = (long)B * N;
       float* x = c.alloc(M * C);  // token stream, updated in place by the residual epilogues
       // the fused Mlp (mit_mlp.hip) reads the halo rows of neighbouring blocks: it writes a second buffer and the two swap roles
-      const bool fused_mlp = !st.blocks.empty() && st.blocks[0].mlp_w && nterms == NT_F16X3;
+      const bool fused_mlp = !st.blocks.empty() && st.blocks[0].mlp_w && nterms == NT_F16X3 && (C != 128 || B >= mit_mlp128);
       float* xalt = fused_mlp ? c.alloc(M * C) : nullptr;
       const SbT xs = S ? c.alloc_sb(M * C) : SbT();  // split copy of the stage output (next patch embed + decoder)
       if (s == 2 && llf && B >= 4 && side_stream_mode >= 2 && can_fork(c)) {  // PF_SIDE_STREAM=2 (measured: no gain)  // the low-level encoder conv (a full-chip launch of its own) next to the small launches of stages 3 / 4
@@ -1554,6 +1555,7 @@ int pf_create(pf_handle* out, int device, int arch) {
   if (const char* v = getenv("PF_FUSE_LN")) e->fuse_ln = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_CNX_MLP")) e->fuse_cnx_mlp = atoi(v) != 0;
   if (const char* v = getenv("PF_FUSE_MIT_MLP")) e->fuse_mit_mlp = atoi(v) != 0;
+  if (const char* v = getenv("PF_MIT_MLP_128")) e->mit_mlp128 = atoi(v);
   if (const char* v = getenv("PF_WINO")) e->wino_min_hw = atoi(v);
   if (const char* v = getenv("PF_WINO_MIN_BLOCKS")) e->wino_min_blocks = atoi(v);
   {

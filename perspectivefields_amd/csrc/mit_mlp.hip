@@ -256,12 +256,9 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
 
 bool mit_mlp_supported(int C) { return C == 64 || C == 128; }
 // the engine uses it at stage 1 (C = 64: 162 us vs ~260 us as three kernels); the C = 128 instantiation (one block per CU: 96 KB of LDS, 240 VGPRs) measured
-// 175 us vs ~165 us and is left off (PF_MIT_MLP_128=1), profiles/r02_mit_mlp.md
-bool mit_mlp_preferred(int C) {
-  const char* e = getenv("PF_MIT_MLP_128");  // read per call (weight build time only)
-  const int with128 = e ? atoi(e) : 0;
-  return C == 64 || (C == 128 && with128);
-}
+// 175 us vs ~165 us in r02 (profiles/r02_mit_mlp.md) and stayed off until r06, when the same-box A/B at the final kernels read +0.6 % (B = 32), +0.7 % (B = 64), +1.1 % (B = 8), +0.7 % (B = 4),
+// -0.4 % at B = 2 and -1.1 % at B = 1 (25 blocks per image): on from a batch of `with128` images up (Engine::mit_mlp128, PF_MIT_MLP_128; profiles/r06_mit_mlp128_ab.log)
+bool mit_mlp_preferred(int C, int with128) { return C == 64 || (C == 128 && with128 > 0); }
 int mit_mlp_chunk_bytes(int C) { return C == 64 ? MitMlpCfg<64>::CHUNK_BYTES : MitMlpCfg<128>::CHUNK_BYTES; }
 
 void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const float* tab2, int B, int Hs, int Ws, int C, float eps, hipStream_t s, unsigned* sat, float sat_limit) {

@@ -299,7 +299,7 @@ void launch_cnx_mlp(const float* d, float* y, const unsigned short* wpk, const f
 // Fused MiT block Mlp (mit_mlp.hip): y = x + fc2(GELU(dwconv3x3(fc1(LayerNorm(x))))) for C = 64 / 128; x and y are different buffers.
 // wpk / tab2: packed by mit_mlp_pack (engine.hip), one chunk of mit_mlp_chunk_bytes(C) per 32 hidden units
 bool mit_mlp_supported(int C);
-bool mit_mlp_preferred(int C);  // the stages where the engine uses it
+bool mit_mlp_preferred(int C, int with128);  // the stages for which the engine builds its weights (with128 = Engine::mit_mlp128: smallest batch that takes the C = 128 form, 0 = never)
 int mit_mlp_chunk_bytes(int C);
 void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const float* tab2, int B, int Hs, int Ws, int C, float eps, hipStream_t s, unsigned* sat = nullptr, float sat_limit = 65504.f);
 // Row-block linear layers (rb_gemm.hip, rb_common.h): blocks of 64 token rows of one image, weights streamed from L2 into registers in MFMA fragment order
