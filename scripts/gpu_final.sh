@@ -8,7 +8,7 @@ echo "== pytest -m gpu"; timeout 1700 python -m pytest tests -q -m gpu -p no:cac
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/smoke.log
 echo "== bench"; timeout 900 python bench.py --steps 10 --warmup 3 2>&1 | tail -1 | tee gpurun_out/bench.json | cut -c1-300
 echo "== bench noevents"; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_noevents.json | cut -c1-160
-echo "== bench r05 defaults (PF_WINO=40 PF_WINO_HALF=0 PF_S3_SPLIT=0 PF_ATTN64=0 PF_STEM7=0 PF_THIN128=0: square Winograd patches from 40 x 40 maps on, stage 1 with separate q / attention / proj launches)"; PF_WINO=40 PF_WINO_HALF=0 PF_S3_SPLIT=0 PF_ATTN64=0 PF_STEM7=0 PF_THIN128=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_r05_defaults.json | cut -c1-160
+echo "== bench r05 defaults (PF_WINO=40 PF_WINO_HALF=0 PF_S3_SPLIT=0 PF_ATTN64=0 PF_STEM7=0 PF_THIN128=0 PF_MIT_MLP_128=0: square Winograd patches from 40 x 40 maps on, stage 1 with separate q / attention / proj launches)"; PF_WINO=40 PF_WINO_HALF=0 PF_S3_SPLIT=0 PF_ATTN64=0 PF_STEM7=0 PF_THIN128=0 PF_MIT_MLP_128=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_r05_defaults.json | cut -c1-160
 echo "== bench r04 path (PF_WINO=0: direct halo tiles for every 3x3 conv)"; PF_WINO=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_nowino.json | cut -c1-160
 echo "== bench batch 64 (stage-3 split on / off)"; for m in 1 0; do PF_S3_SPLIT=$m timeout 300 python bench.py --batch 64 --steps 8 --warmup 2 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_b64_split$m.json | cut -c1-160; done
 echo "== bench noevents (again)"; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --events-in-timed 0 2>&1 | tail -1 | tee gpurun_out/bench_noevents2.json | cut -c1-160
