@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, C <= 96 ? 3 : 1) void cnx_mlp_kernel(const flo
       split4_f16(v[2 * s + 1], h1, l1);
       xh[s] = u32x4{h0.x, h0.y, h1.x, h1.y};
       xl[s] = u32x4{l0.x, l0.y, l1.x, l1.y};
+      split_f16_mfma_pad(xl[s]);  // register-direct MFMA operand: sb_split.h
     }
   }
 
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256, C <= 96 ? 3 : 1) void cnx_mlp_kernel(const flo
       split4_f16(hv[1], h1, l1);
       hh[u] = u32x4{h0.x, h0.y, h1.x, h1.y};
       hl[u] = u32x4{l0.x, l0.y, l1.x, l1.y};
+      split_f16_mfma_pad(hl[u]);  // register-direct MFMA operand: sb_split.h
     }
     // GEMM 2 (transposed): acc2[q][channels 32 x rows 32] += W2 chunk (A operand) x hidden (B operand)
     if (PRIO) __builtin_amdgcn_s_setprio(1);

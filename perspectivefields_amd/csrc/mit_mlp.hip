@@ -40,8 +40,12 @@ template <int C> struct MitMlpCfg {
   static constexpr int CHUNK_BYTES = ((USED_BYTES + 1023) / 1024) * 1024;      // stride of a chunk in global memory and of a buffer in LDS
 };
 
-template <int C, int TY, int TX>
-__global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const float* __restrict__ x, float* __restrict__ y, const unsigned short* __restrict__ wpk,
+// SB (r06, C = 128): ONE weight buffer instead of two -- the W1 part of a chunk is dead after GEMM 1 and its W2 part is not needed before GEMM 2, so at barrier (A) of chunk t
+// the block requests W2 of chunk t (into the W2 region GEMM 2 of chunk t - 1 has left) and W1 + tables of chunk t + 1 (into the W1 region GEMM 1 of chunk t has left; the
+// tables, which the depthwise phase of chunk t still reads, alternate between two 1.6 KB slots).  Same DMA volume, same request point, same single wait in front of barrier
+// (B) as the double-buffered form; LDS 95 -> 63 KB, i.e. TWO blocks per CU at C = 128 (240 VGPRs fit two waves per SIMD).
+template <int C, int TY, int TX, bool SB = false>
+__global__ __launch_bounds__(256, (C <= 64 || SB) ? 2 : 1) void mit_mlp_kernel(const float* __restrict__ x, float* __restrict__ y, const unsigned short* __restrict__ wpk,
                                                                       const float* __restrict__ tab2, int B, int Hs, int Ws, float eps, unsigned* sat, float sat_limit) {
   typedef MitMlpCfg<C> Cfg;
   constexpr int H = 4 * C, S1 = Cfg::S1, Q = Cfg::Q, NCH = H / 32;
@@ -52,9 +56,11 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
   static_assert(NINT % 32 == 0 && RT2 * Q == 8 && TX % SP == 0 && TY * (TX / SP) == 32 && NCH % 2 == 0, "geometry");
   constexpr int CHUNK = Cfg::CHUNK_BYTES;
   constexpr int HBUF_BYTES = RT1 * 32 * HS * 4, H2_BYTES = NINT * 64 * 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CHUNK + HBUF_BYTES + H2_BYTES];
-  float* Hbuf = reinterpret_cast<float*>(smem + 2 * CHUNK);                          // [RT1 * 32][HS] hidden values of the halo pixels (one chunk)
-  unsigned short* H2 = reinterpret_cast<unsigned short*>(smem + 2 * CHUNK + HBUF_BYTES);  // [2 planes][NINT][32] fp16, 64-byte rows, XOR piece swizzle
+  constexpr int TABB = Cfg::TAB_FLOATS * 4;
+  constexpr int WREG = SB ? Cfg::W1_BYTES + Cfg::W2_BYTES + 2 * TABB : 2 * CHUNK;     // SB: [W1 | W2 | tables of even chunks | tables of odd chunks]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[WREG + HBUF_BYTES + H2_BYTES];
+  float* Hbuf = reinterpret_cast<float*>(smem + WREG);                          // [RT1 * 32][HS] hidden values of the halo pixels (one chunk)
+  unsigned short* H2 = reinterpret_cast<unsigned short*>(smem + WREG + HBUF_BYTES);  // [2 planes][NINT][32] fp16, 64-byte rows, XOR piece swizzle
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int tilesX = (Ws + TX - 1) / TX, tilesY = (Hs + TY - 1) / TY;
@@ -79,7 +85,24 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
       }
     }
   };
-  dma_w(0, 0);
+  // SB: one piece of a chunk (nbytes from byte `from` of chunk t) to LDS offset `to`
+  auto dma_piece = [&](int t, int from, int nbytes, int to) {
+    const char* src = reinterpret_cast<const char*>(wpk) + (size_t)t * CHUNK + from + tid * 16;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(to + wave * 1024));
+    for (int j = 0; 4096 * j < nbytes; ++j) {
+      if (tid * 16 + 4096 * j < nbytes) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src + 4096 * j), "s"(dst + 4096u * j) : "memory");
+      }
+    }
+  };
+  auto dma_w1_tab = [&](int t) {   // W1 + tables of chunk t
+    dma_piece(t, 0, Cfg::W1_BYTES, 0);
+    dma_piece(t, Cfg::W1_BYTES + Cfg::W2_BYTES, TABB, Cfg::W1_BYTES + Cfg::W2_BYTES + (t & 1) * TABB);
+  };
+  auto dma_w2 = [&](int t) { dma_piece(t, Cfg::W1_BYTES, Cfg::W2_BYTES, Cfg::W1_BYTES); };
+  if constexpr (SB) dma_w1_tab(0); else dma_w(0, 0);
 
   // ---- this wave's GEMM-1 rows (halo pixels): split-f16 fragments + LayerNorm statistics, held for the whole kernel
   u32x4 xh[T1][S1], xl[T1][S1];
@@ -121,6 +144,7 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
       split4_f16(v[2 * s + 1], h1, l1);
       xh[k][s] = u32x4{h0.x, h0.y, h1.x, h1.y};
       xl[k][s] = u32x4{l0.x, l0.y, l1.x, l1.y};
+      split_f16_mfma_pad(xl[k][s]);  // register-direct MFMA operand: sb_split.h
     }
   }
 
@@ -143,10 +167,10 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
 
   auto step = [&](int t, auto bufc) {
     constexpr int BUF = decltype(bufc)::value;
-    const unsigned char* cb = smem + BUF * CHUNK;
+    const unsigned char* cb = smem + (SB ? 0 : BUF * CHUNK);
     const unsigned short* w1f = reinterpret_cast<const unsigned short*>(cb) + lane * 8;
     const unsigned short* w2f = reinterpret_cast<const unsigned short*>(cb + Cfg::W1_BYTES) + lane * 8;
-    const float* tb = reinterpret_cast<const float*>(cb + Cfg::W1_BYTES + Cfg::W2_BYTES);  // inv1[32], cs1[32], b1[32], taps [9][32], dw bias [32]
+    const float* tb = reinterpret_cast<const float*>(cb + Cfg::W1_BYTES + Cfg::W2_BYTES + (SB ? BUF * TABB : 0));  // inv1[32], cs1[32], b1[32], taps [9][32], dw bias [32]
     // ---- GEMM 1 (transposed): hidden[32] x rows[32] per owned row tile, then LayerNorm correction + bias, zero outside the image, -> Hbuf
 #pragma unroll
     for (int k = 0; k < T1; ++k) {
@@ -176,7 +200,12 @@ __global__ __launch_bounds__(256, C <= 64 ? 2 : 1) void mit_mlp_kernel(const flo
       }
     }
     __syncthreads();  // (A) hidden values of the whole halo tile in Hbuf; every wave is past GEMM 2 of the previous chunk
-    if (t + 1 < NCH) dma_w(t + 1, 1 - BUF);  // that buffer was last read by chunk t - 1
+    if constexpr (SB) {
+      dma_w2(t);                           // the W2 region was last read by GEMM 2 of chunk t - 1; needed behind barrier (B)
+      if (t + 1 < NCH) dma_w1_tab(t + 1);  // the W1 region by GEMM 1 of this chunk; the tables go to the other slot
+    } else {
+      if (t + 1 < NCH) dma_w(t + 1, 1 - BUF);  // that buffer was last read by chunk t - 1
+    }
     // ---- depthwise 3x3 + bias + GELU for SP pixels x 4 hidden units; fp16 split -> H2 (B operand of GEMM 2)
     {
       typedef float mm_f2 __attribute__((ext_vector_type(2)));
@@ -267,7 +296,10 @@ void launch_mit_mlp(const float* x, float* y, const unsigned short* wpk, const f
     hipLaunchKernelGGL((mit_mlp_kernel<64, 8, 16>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps, sat, sat_limit);
   } else if (C == 128) {
     const dim3 grid((unsigned)(B * ((Hs + 7) / 8) * ((Ws + 7) / 8)));
-    hipLaunchKernelGGL((mit_mlp_kernel<128, 8, 8>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps, sat, sat_limit);
+    const char* e = getenv("PF_MIT_MLP_SB");   // read per launch (four per forward): tests switch it inside one process
+    const int sb = e ? atoi(e) : 1;            // 0: the double-buffered form (one block per CU)
+    if (sb) hipLaunchKernelGGL((mit_mlp_kernel<128, 8, 8, true>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps, sat, sat_limit);
+    else hipLaunchKernelGGL((mit_mlp_kernel<128, 8, 8>), grid, dim3(256), 0, s, x, y, wpk, tab2, B, Hs, Ws, eps, sat, sat_limit);
   }
 }
 

@@ -62,7 +62,8 @@ __device__ __forceinline__ void split2_f16(const float a0, const float a1, unsig
   asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(c0), "v"(h));
   asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(c1), "v"(h));
 }
-// A low part that feeds an MFMA straight from REGISTERS (attn.hip, attn_block.hip, stem7.hip, thin_linear.hip; every other user writes it to LDS first) passes
+// A low part that feeds an MFMA straight from REGISTERS (attn.hip, attn_block.hip, stem7.hip, thin_linear.hip, the row fragments of cnx_mlp.hip / mit_mlp.hip and cnx_mlp's
+// hidden map; every other user writes it to LDS first) passes
 // through this.  hipcc pads the VALU-write -> MFMA-operand-read wait states (two) for the instructions IT emits; what an asm statement writes is invisible to its
 // hazard pass beyond one boundary state, and a v_fma_mixhi_f16 one issue slot ahead of the MFMA that reads its register hands the matrix core the register's OLD
 // contents (r06: thin128_kernel<false>, columns 0 - 31 wrong by ~0.7, found by its op test; profiles/r06_asm_mfma_hazard.md).  The s_nop sits INSIDE an asm that

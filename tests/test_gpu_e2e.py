@@ -201,7 +201,7 @@ def test_fused_layernorm_agrees_with_layernorm_kernels(monkeypatch, case):
         assert c <= 1e-6 and e <= 1e-5 and d <= 5e-5
 
 
-@pytest.mark.parametrize("env", ["PF_FUSE_CNX_MLP=0", "PF_FUSE_MIT_MLP=0", "PF_SIDE_STREAM=0", "PF_SIDE_STREAM=2", "PF_CNX_MLP_192=0", "PF_MIT_MLP_128=0", "PF_MIT_MLP_128=1", "PF_SBA_HEADS=1",
+@pytest.mark.parametrize("env", ["PF_FUSE_CNX_MLP=0", "PF_FUSE_MIT_MLP=0", "PF_SIDE_STREAM=0", "PF_SIDE_STREAM=2", "PF_CNX_MLP_192=0", "PF_MIT_MLP_128=0", "PF_MIT_MLP_128=1", "PF_MIT_MLP_SB=0", "PF_SBA_HEADS=1",
                                  "PF_WINO=0", "PF_WINO_TILE=wino256x64c", "PF_WINO_HALF=0", "PF_ATTN64=0", "PF_STEM7=0", "PF_THIN128=1"])   # (PF_THIN128=1: the thin 128 -> 128 projections of stage 2 from one row up -- the default takes them from 25 600 rows, i.e. batch 16)   the direct halo tile on the 80^2 / 40^2 256 -> 256 shapes (split-f16 mode), the compiler-scheduled Winograd form, square Winograd patches on the 40^2 / 20^2 maps, stage 1 with separate q / attention / proj launches, the 7 x 7 image convs on the implicit-GEMM tiles
 def test_fused_block_mlps_and_stream_modes_agree(monkeypatch, env):
     """The one-kernel block MLPs (cnx_mlp.hip / mit_mlp.hip: hidden map on the chip), their second-stage instantiations, the side-stream modes against the default engine on a batch of 6 (so that the batch >= 4 side-stream fork is active): same mathematics, other roundings / launch

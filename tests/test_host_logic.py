@@ -521,7 +521,7 @@ def test_kernel_resources_static():
         "pf::dwconv3x3_gelu_direct_kernel<32, 8, 8, 0>", "pf::layernorm_kernel<64, 2>",
         # r02: multi-column depthwise 3x3 (the three shipped forms) and the fused-LayerNorm GEMM forms of the 4-wave tiles
         "pf::dwconv3x3_gelu_mc_kernel<64, 2, 40, 2, 2, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 4, 8, 1, 1, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 4, 8, 2, 1, false>", "pf::dwconv3x3_gelu_mc_kernel<64, 5, 16, 1, 2, false>",
-        "pf::cnx_mlp_kernel<96, 0>", "pf::mit_mlp_kernel<64, 8, 16>",  # fused block MLPs (hidden map on chip)
+        "pf::cnx_mlp_kernel<96, 0>", "pf::mit_mlp_kernel<64, 8, 16, false>", "pf::mit_mlp_kernel<128, 8, 8, true>",  # fused block MLPs (hidden map on chip)
         "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23, true>", "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 2, 23, true>", "pf::igemm_sb_kernel<128, 256, 2, 4, 0, false, 1, 23, true>",
     ]
     # r03: the 128 x 64 halo tile with the two-buffer DMA weight ring keeps the 128-VGPR cap (four resident blocks) at the price of 8 registers spilled around the
@@ -542,7 +542,8 @@ def test_kernel_resources_static():
              "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 1, 23, true>": 5, "pf::igemm_sb_kernel<64, 64, 2, 2, 0, false, 2, 23, true>": 4,
              "pf::igemm_sb_kernel<128, 32, 4, 1, 0, false, 1, 23, false>": 5, "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23, false>": 3,
              "pf::igemm_sb_kernel<128, 128, 2, 2, 0, false, 1, 23, true>": 3, "pf::igemm_sb_kernel<128, 256, 2, 4, 0, false, 1, 23, true>": 2,
-             "pf::igemm_sbh_kernel<16, 16, 64, 4, 2, 0, 1, 23, false, false, false>": 2, "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 23, false, false, false>": 4}
+             "pf::igemm_sbh_kernel<16, 16, 64, 4, 2, 0, 1, 23, false, false, false>": 2, "pf::igemm_sbh_kernel<8, 16, 64, 2, 2, 0, 1, 23, false, false, false>": 4,
+             "pf::mit_mlp_kernel<128, 8, 8, true>": 2}   # r06: the single-weight-buffer form exists for the second resident block
     for k, n in floor.items():
         assert blocks_per_cu(by[k]) >= n, (k, by[k], blocks_per_cu(by[k]), n)
 
